@@ -1,0 +1,88 @@
+"""ctypes binding of libgmesh_hip.so (C ABI: include/gmesh_hip.h).
+
+The HIP library is the product path: there is NO CPU fallback.  If the shared object is missing or a
+symbol declared in the header cannot be resolved, importing/using this module fails loudly.
+"""
+import ctypes as C
+import os
+import re
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "libgmesh_hip.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "gmesh_hip.h")
+_lib = None
+
+vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/gmesh_hip.h one to one
+SIGNATURES = {
+    "gm_abi_version": (i32, []),
+    "gm_last_error": (C.c_char_p, []),
+    "gm_geom_bytes": (sz, [i32]),
+    "gm_image_bytes": (sz, [i32, i32]),
+    "gm_binning_bytes": (sz, [i64]),
+    "gm_forward_0": (i32, [vp, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, f32, f32, i32,
+                           vp, i32, vp, C.POINTER(i32)]),
+    "gm_forward_1": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp,
+                           f32, f32, i32, vp, vp, i32, vp]),
+    "gm_backward": (i32, [i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp,
+                          vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "gm_mark_visible": (i32, [i32, vp, vp, vp, vp, vp]),
+    "gm_geom_field": (vp, [vp, i32, C.c_char_p]),
+    "gm_image_field": (vp, [vp, i32, i32, C.c_char_p]),
+    "gm_binning_field": (vp, [vp, i64, i32, i32, C.c_char_p]),
+    "gm_knn_workspace_bytes": (sz, [i32]),
+    "gm_knn": (i32, [i32, vp, vp, vp, sz, vp]),
+    "gm_deform": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "gm_sh_colors": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "gm_profile_enable": (None, [i32]),
+    "gm_profile_reset": (None, []),
+    "gm_profile_read": (i32, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]),
+}
+
+
+def header_symbols():
+    """Every function name declared in include/gmesh_hip.h."""
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(gm_[a-z0-9_]+)\s*\(", txt)))
+
+
+def build(verbose=False):
+    """Compile csrc/*.hip for gfx950 into csrc/libgmesh_hip.so (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j8"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise RuntimeError("building libgmesh_hip.so failed")
+    return SO_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise ImportError(
+                "gaussianmesh_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C gaussianmesh_amd/csrc`). There is no CPU fallback." % SO_PATH)
+        l = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)          # AttributeError if the symbol is absent -> loud failure
+            fn.restype = res
+            fn.argtypes = args
+        if l.gm_abi_version() != 1:
+            raise ImportError("libgmesh_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+class GmeshError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        raise GmeshError("libgmesh_hip: error %d: %s" % (rc, lib().gm_last_error().decode()))

@@ -1,0 +1,281 @@
+// gm_api.hip -- extern "C" entry points of libgmesh_hip.so (include/gmesh_hip.h) and host orchestration.
+//
+// Orchestration replaces CudaRasterizer::Rasterizer::{forward_0, forward_1, backward, markVisible}
+// (cuda_rasterizer/rasterizer_impl.cu:338-413, 416-511, 515-609, 141-153).
+#include "gm_common.h"
+#include "../../include/gmesh_hip.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+namespace gm {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  set_error("HIP error %d (%s) at %s:%d in %s", (int)e, hipGetErrorString(e), file, line, what);
+  return GM_ERR_HIP;
+}
+
+// ---- per-stage profiling -------------------------------------------------------------------
+static const char* kStageNames[ST_COUNT] = {"preprocess", "depth_sort", "scan", "duplicate", "tile_sort", "ranges",
+                                            "render", "render_bwd", "preprocess_bwd", "deform", "sh_colors"};
+struct EvPair { hipEvent_t a, b; int st; };
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<EvPair> g_pending;
+static double g_ms[ST_COUNT];
+static int64_t g_n[ST_COUNT];
+
+StageScope::StageScope(Stage st_, hipStream_t s_) : st(st_), s(s_), rec(nullptr) {
+  if (!g_prof_on) return;
+  EvPair* p = new EvPair;
+  p->st = st;
+  if (hipEventCreate(&p->a) != hipSuccess || hipEventCreate(&p->b) != hipSuccess) { delete p; return; }
+  hipEventRecord(p->a, s);
+  rec = p;
+}
+StageScope::~StageScope() {
+  if (!rec) return;
+  EvPair* p = reinterpret_cast<EvPair*>(rec);
+  hipEventRecord(p->b, s);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_pending.push_back(*p);
+  delete p;
+}
+static void drain_profile() {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& p : g_pending) {
+    float ms = 0.f;
+    if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      g_ms[p.st] += ms;
+      g_n[p.st] += 1;
+    }
+    hipEventDestroy(p.a);
+    hipEventDestroy(p.b);
+  }
+  g_pending.clear();
+}
+
+static int check_raster_args(const RasterArgs& a) {
+  if (a.P < 0 || a.W <= 0 || a.H <= 0) { set_error("invalid sizes P=%d W=%d H=%d", a.P, a.W, a.H); return GM_ERR_INVALID_ARG; }
+  if ((a.shs == nullptr) == (a.colors_precomp == nullptr)) {
+    set_error("provide exactly one of shs / colors_precomp"); return GM_ERR_INVALID_ARG;
+  }
+  const bool sr = a.scales != nullptr && a.rotations != nullptr;
+  if ((a.scales != nullptr) != (a.rotations != nullptr) || sr == (a.cov3D_precomp != nullptr)) {
+    set_error("provide exactly one of (scales, rotations) / cov3D_precomp"); return GM_ERR_INVALID_ARG;
+  }
+  if (a.shs && (a.D < 0 || a.D > 3 || a.M < (a.D + 1) * (a.D + 1))) {
+    set_error("SH degree %d needs M >= %d coefficients (got %d); degree must be 0..3", a.D, (a.D + 1) * (a.D + 1), a.M);
+    return GM_ERR_INVALID_ARG;
+  }
+  if (a.P > 0 && (!a.means3D || !a.opacities || !a.viewmatrix || !a.projmatrix || !a.cam_pos)) {
+    set_error("null required input"); return GM_ERR_INVALID_ARG;
+  }
+  return 0;
+}
+
+}  // namespace gm
+
+using namespace gm;
+
+extern "C" {
+
+int gm_abi_version(void) { return GM_ABI_VERSION; }
+const char* gm_last_error(void) { return g_err; }
+
+size_t gm_geom_bytes(int P) {
+  GeomState g = GeomState::from(nullptr, (size_t)(P > 0 ? P : 1));
+  return (size_t)g.end + 256;
+}
+size_t gm_image_bytes(int W, int H) {
+  ImageState s = ImageState::from(nullptr, W > 0 ? W : 1, H > 0 ? H : 1);
+  return (size_t)s.end + 256;
+}
+size_t gm_binning_bytes(int64_t R) {
+  BinningState b = BinningState::from(nullptr, (size_t)(R > 0 ? R : 1));
+  return (size_t)b.end + 256;
+}
+
+#define FILL_ARGS(a)                                                                                            \
+  RasterArgs a;                                                                                                 \
+  a.P = P; a.D = D; a.M = M; a.W = width; a.H = height; a.background = background; a.means3D = means3D;        \
+  a.shs = shs; a.colors_precomp = colors_precomp; a.opacities = opacities; a.scales = scales;                  \
+  a.rotations = rotations; a.cov3D_precomp = cov3D_precomp; a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; \
+  a.cam_pos = cam_pos; a.scale_modifier = scale_modifier; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;        \
+  a.prefiltered = prefiltered; a.debug = debug; a.stream = reinterpret_cast<hipStream_t>(stream);
+
+int gm_forward_0(void* geom_buffer, int P, int D, int M, const float* background, int width, int height,
+                 const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                 const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                 const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                 float tan_fovy, int prefiltered, int* radii, int debug, void* stream, int* num_rendered) {
+  FILL_ARGS(a)
+  if (int rc = check_raster_args(a)) return rc;
+  if (!num_rendered) { set_error("num_rendered is null"); return GM_ERR_INVALID_ARG; }
+  *num_rendered = 0;
+  if (P == 0) return GM_OK;
+  if (!geom_buffer) { set_error("geom_buffer is null"); return GM_ERR_INVALID_ARG; }
+  GeomState g = GeomState::from(geom_buffer, (size_t)P);
+  if (int rc = launch_preprocess(a, g, radii)) return rc;
+  {  // order Gaussians by (depth bits, id): 4 radix passes over P
+    StageScope sc(ST_DEPTH_SORT, a.stream);
+    if (int rc = radix_sort_pairs(g.depth_key, g.order, g.hist, g.digit_total, (size_t)P, 32, true, debug, a.stream)) return rc;
+  }
+  if (int rc = launch_tile_count_scan(g, P, debug, a.stream)) return rc;
+  uint32_t r = 0;
+  GM_HIP(hipMemcpyAsync(&r, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, a.stream));
+  GM_HIP(hipStreamSynchronize(a.stream));   // the one host sync of a forward (reference: rasterizer_impl.cu:411)
+  if (r > 0x7FFFFFFFu) { set_error("num_rendered overflows int32 (%u)", r); return GM_ERR_INVALID_ARG; }
+  *num_rendered = (int)r;
+  return GM_OK;
+}
+
+int gm_forward_1(void* geom_buffer, void* binning_buffer, void* image_buffer, int P, int D, int M, int num_rendered,
+                 const float* background, int width, int height, const float* means3D, const float* shs,
+                 const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                 const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color, int* radii,
+                 int debug, void* stream) {
+  FILL_ARGS(a)
+  if (int rc = check_raster_args(a)) return rc;
+  if (!image_buffer || !out_color || !background) { set_error("null image_buffer / out_color / background"); return GM_ERR_INVALID_ARG; }
+  if (num_rendered < 0) { set_error("negative num_rendered"); return GM_ERR_INVALID_ARG; }
+  if (P > 0 && (!geom_buffer || (num_rendered > 0 && !binning_buffer))) { set_error("null scratch buffer"); return GM_ERR_INVALID_ARG; }
+  ImageState img = ImageState::from(image_buffer, width, height);
+  const int tiles = ((width + GM_TILE - 1) / GM_TILE) * ((height + GM_TILE - 1) / GM_TILE);
+  GeomState g = GeomState::from(geom_buffer, (size_t)(P > 0 ? P : 1));
+  BinningState b = BinningState::from(binning_buffer, (size_t)num_rendered);
+  int slot = 0;
+  if (P > 0 && num_rendered > 0) {
+    if (int rc = launch_duplicate(g, b, P, width, height, radii, debug, a.stream)) return rc;
+    const int bits = tile_bits(tiles);
+    {
+      StageScope sc(ST_TILE_SORT, a.stream);
+      if (int rc = radix_sort_pairs(b.keys, b.vals, b.hist, b.digit_total, (size_t)num_rendered, bits, false, debug, a.stream)) return rc;
+    }
+    slot = sort_final_slot(bits);
+  }
+  if (int rc = launch_tile_ranges(b, slot, img, num_rendered, tiles, debug, a.stream)) return rc;
+  return launch_render_fwd(g, b.vals[slot], img, width, height, background, out_color, debug, a.stream);
+}
+
+int gm_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                const float* campos, float tan_fovx, float tan_fovy, const int* radii, void* geom_buffer,
+                void* binning_buffer, void* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
+                float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                float* dL_dscale, float* dL_drot, int debug, void* stream) {
+  const float* opacities = reinterpret_cast<const float*>(1);   // not used by backward; satisfies the shared check
+  const float* cam_pos = campos;
+  const int prefiltered = 0;
+  FILL_ARGS(a)
+  if (int rc = check_raster_args(a)) return rc;
+  if (P == 0) return GM_OK;
+  if (!geom_buffer || !image_buffer || !dL_dpix || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor ||
+      !dL_dmean3D || !dL_dcov3D || (shs && !dL_dsh) || (scales && (!dL_dscale || !dL_drot))) {
+    set_error("gm_backward: null buffer"); return GM_ERR_INVALID_ARG;
+  }
+  GeomState g = GeomState::from(geom_buffer, (size_t)P);
+  ImageState img = ImageState::from(image_buffer, width, height);
+  BinningState b = BinningState::from(binning_buffer, (size_t)(R > 0 ? R : 0));
+  const int tiles = ((width + GM_TILE - 1) / GM_TILE) * ((height + GM_TILE - 1) / GM_TILE);
+  const int slot = sort_final_slot(tile_bits(tiles));
+  GM_HIP(hipMemsetAsync(dL_dmean2D, 0, sizeof(float) * 3 * (size_t)P, a.stream));
+  GM_HIP(hipMemsetAsync(dL_dconic, 0, sizeof(float) * 4 * (size_t)P, a.stream));
+  GM_HIP(hipMemsetAsync(dL_dopacity, 0, sizeof(float) * (size_t)P, a.stream));
+  GM_HIP(hipMemsetAsync(dL_dcolor, 0, sizeof(float) * 3 * (size_t)P, a.stream));
+  if (R > 0) {
+    if (!binning_buffer) { set_error("gm_backward: null binning buffer"); return GM_ERR_INVALID_ARG; }
+    if (int rc = launch_render_bwd(g, b.vals[slot], img, width, height, background, dL_dpix, dL_dmean2D, dL_dconic,
+                                   dL_dopacity, dL_dcolor, debug, a.stream)) return rc;
+  }
+  return launch_preprocess_bwd(a, g, radii, dL_dmean2D, dL_dconic, dL_dmean3D, dL_dcolor, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+}
+
+int gm_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                    void* stream) {
+  (void)projmatrix;
+  if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) { set_error("gm_mark_visible: bad args"); return GM_ERR_INVALID_ARG; }
+  return launch_mark_visible(P, means3D, viewmatrix, present, reinterpret_cast<hipStream_t>(stream));
+}
+
+void* gm_geom_field(void* geom_buffer, int P, const char* name) {
+  GeomState g = GeomState::from(geom_buffer, (size_t)(P > 0 ? P : 1));
+  if (!strcmp(name, "splat")) return g.splat;
+  if (!strcmp(name, "radii")) return g.radii;
+  if (!strcmp(name, "tiles_touched")) return g.tiles_touched;
+  if (!strcmp(name, "cov3D")) return g.cov3D;
+  if (!strcmp(name, "clamped")) return g.clamped;
+  if (!strcmp(name, "order")) return g.order[0];
+  if (!strcmp(name, "counters")) return g.counters;
+  return nullptr;
+}
+void* gm_image_field(void* image_buffer, int W, int H, const char* name) {
+  ImageState s = ImageState::from(image_buffer, W, H);
+  if (!strcmp(name, "final_T")) return s.final_T;
+  if (!strcmp(name, "n_contrib")) return s.n_contrib;
+  if (!strcmp(name, "ranges")) return s.ranges;
+  return nullptr;
+}
+void* gm_binning_field(void* binning_buffer, int64_t R, int W, int H, const char* name) {
+  BinningState b = BinningState::from(binning_buffer, (size_t)(R > 0 ? R : 0));
+  const int tiles = ((W + GM_TILE - 1) / GM_TILE) * ((H + GM_TILE - 1) / GM_TILE);
+  const int slot = sort_final_slot(tile_bits(tiles));
+  if (!strcmp(name, "point_list")) return b.vals[slot];
+  if (!strcmp(name, "tile_keys")) return b.keys[slot];
+  return nullptr;
+}
+
+size_t gm_knn_workspace_bytes(int P) { return knn_workspace_bytes(P); }
+int gm_knn(int P, const float* points, float* meanDists, void* workspace, size_t workspace_bytes, void* stream) {
+  if (P < 0 || (P > 0 && (!points || !meanDists || !workspace))) { set_error("gm_knn: bad args"); return GM_ERR_INVALID_ARG; }
+  return launch_knn(P, points, meanDists, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
+}
+
+int gm_deform(int N, const int* tri, const float* w, const float* dV, const float* Rv, const float* Sv,
+              const float* cov, const float* pos, float* pos_out, float* cov_out, float* rot_out, float* cov6_out,
+              void* stream) {
+  if (N < 0 || (N > 0 && (!tri || !w || !dV || !Rv || !Sv || !cov || !pos || !pos_out || !cov_out || !rot_out))) {
+    set_error("gm_deform: bad args"); return GM_ERR_INVALID_ARG;
+  }
+  return launch_deform(N, tri, w, dV, Rv, Sv, cov, pos, pos_out, cov_out, rot_out, cov6_out, reinterpret_cast<hipStream_t>(stream));
+}
+
+int gm_sh_colors(int N, int deg, int M, const float* pos, const float* campos, const float* rot, const float* shs,
+                 float* rgb, void* stream) {
+  if (N < 0 || deg < 0 || deg > 3 || M < (deg + 1) * (deg + 1) || (N > 0 && (!pos || !campos || !shs || !rgb))) {
+    set_error("gm_sh_colors: bad args"); return GM_ERR_INVALID_ARG;
+  }
+  return launch_sh_colors(N, deg, M, pos, campos, rot, shs, rgb, reinterpret_cast<hipStream_t>(stream));
+}
+
+void gm_profile_enable(int on) { g_prof_on = on != 0; }
+void gm_profile_reset(void) {
+  drain_profile();
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (int i = 0; i < ST_COUNT; i++) { g_ms[i] = 0; g_n[i] = 0; }
+}
+int gm_profile_read(const char* stage, double* total_ms, int64_t* launches) {
+  drain_profile();
+  for (int i = 0; i < ST_COUNT; i++)
+    if (!strcmp(stage, kStageNames[i])) {
+      if (total_ms) *total_ms = g_ms[i];
+      if (launches) *launches = g_n[i];
+      return GM_OK;
+    }
+  set_error("unknown stage '%s'", stage);
+  return GM_ERR_INVALID_ARG;
+}
+
+}  // extern "C"

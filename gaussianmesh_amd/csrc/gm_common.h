@@ -1,0 +1,182 @@
+// gm_common.h -- internal declarations shared by the translation units of libgmesh_hip.so.
+// Target: gfx950 (MI355X, CDNA4), wave64.  No CUDA compatibility layer, no dual paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+
+#define GM_TILE 16              // tile edge (pixels); reference cuda_rasterizer/config.h:15-16
+#define GM_WAVE 64
+
+namespace gm {
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define GM_HIP(call)                                                            \
+  do {                                                                          \
+    hipError_t _e = (call);                                                     \
+    if (_e != hipSuccess) return gm::hip_fail(_e, #call, __FILE__, __LINE__);   \
+  } while (0)
+
+// after a kernel launch: always check the launch error; in debug mode also synchronise
+// (reference CHECK_CUDA, cuda_rasterizer/auxiliary.h:165-172)
+#define GM_LAUNCH_CHECK(debug, stream)                                          \
+  do {                                                                          \
+    GM_HIP(hipGetLastError());                                                  \
+    if (debug) GM_HIP(hipStreamSynchronize(stream));                            \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// per-stage timing (gm_profile_*)
+enum Stage {
+  ST_PREPROCESS = 0, ST_DEPTH_SORT, ST_SCAN, ST_DUPLICATE, ST_TILE_SORT, ST_RANGES, ST_RENDER,
+  ST_RENDER_BWD, ST_PREPROCESS_BWD, ST_DEFORM, ST_SH_COLORS, ST_COUNT
+};
+struct StageScope {            // records start/stop events on `s` if profiling is enabled
+  StageScope(Stage st, hipStream_t s);
+  ~StageScope();
+  Stage st; hipStream_t s; void* rec;
+};
+
+// ---------------------------------------------------------------------------------------------
+// scratch layouts.  Bump allocation inside caller-owned byte buffers, 256-byte aligned absolute
+// addresses (reference: obtain<T>() with 128-byte alignment, rasterizer_impl.h:21-27).
+template <typename T>
+static inline T* carve(char*& p, size_t count) {
+  uintptr_t a = (reinterpret_cast<uintptr_t>(p) + 255) & ~uintptr_t(255);
+  T* out = reinterpret_cast<T*>(a);
+  p = reinterpret_cast<char*>(out + count);
+  return out;
+}
+
+#define GM_SORT_ITEMS 4096      // keys per workgroup per radix pass (256 threads x 16)
+#define GM_SCAN_ITEMS 2048      // elements per workgroup in the tiles_touched scan
+
+static inline size_t sort_blocks(size_t n) { return (n + GM_SORT_ITEMS - 1) / GM_SORT_ITEMS; }
+
+struct GeomState {              // per-Gaussian state (P-sized)
+  float4* splat;                // [P][3]: {x,y,con.x,con.y} {con.z,opacity,r,g} {b,depth,0,0}
+  int* radii;                   // internal radii when the caller passes none
+  uint32_t* tiles_touched;      // [P]
+  float* cov3D;                 // [P][6] (computed from scale/rot)
+  uint8_t* clamped;             // [P] bit ch = SH colour channel ch was clamped at 0
+  uint32_t* depth_key[2];       // [P] ping-pong keys of the depth sort (float bits of view z)
+  uint32_t* order[2];           // [P] ping-pong payload; order[0] = Gaussian ids sorted by (depth, id)
+  uint32_t* hist;               // [256][sort_blocks(P)] radix histograms of the depth sort
+  uint32_t* digit_total;        // [256]
+  uint32_t* block_sums;         // [ceil(P/GM_SCAN_ITEMS)] tiles_touched partial sums (sorted order)
+  uint32_t* counters;           // [16] device scalars: [0] = num_rendered
+  static GeomState from(void* buf, size_t P) {
+    char* p = reinterpret_cast<char*>(buf);
+    GeomState g;
+    g.splat = carve<float4>(p, 3 * P);
+    g.radii = carve<int>(p, P);
+    g.tiles_touched = carve<uint32_t>(p, P);
+    g.cov3D = carve<float>(p, 6 * P);
+    g.clamped = carve<uint8_t>(p, P);
+    g.depth_key[0] = carve<uint32_t>(p, P);
+    g.depth_key[1] = carve<uint32_t>(p, P);
+    g.order[0] = carve<uint32_t>(p, P);
+    g.order[1] = carve<uint32_t>(p, P);
+    g.hist = carve<uint32_t>(p, 256 * sort_blocks(P));
+    g.digit_total = carve<uint32_t>(p, 256);
+    g.block_sums = carve<uint32_t>(p, (P + GM_SCAN_ITEMS - 1) / GM_SCAN_ITEMS + 1);
+    g.counters = carve<uint32_t>(p, 16);
+    g.end = p;
+    return g;
+  }
+  char* end;
+};
+
+struct ImageState {             // per-pixel / per-tile state
+  float* final_T;               // [H*W]
+  uint32_t* n_contrib;          // [H*W]
+  uint2* ranges;                // [tiles]
+  static ImageState from(void* buf, int W, int H) {
+    char* p = reinterpret_cast<char*>(buf);
+    const size_t N = (size_t)W * H;
+    const size_t T = (size_t)((W + GM_TILE - 1) / GM_TILE) * ((H + GM_TILE - 1) / GM_TILE);
+    ImageState s;
+    s.final_T = carve<float>(p, N);
+    s.n_contrib = carve<uint32_t>(p, N);
+    s.ranges = carve<uint2>(p, T);
+    s.end = p;
+    return s;
+  }
+  char* end;
+};
+
+struct BinningState {           // per-instance state (R-sized)
+  uint32_t* keys[2];            // [R] tile id per instance, ping-pong
+  uint32_t* vals[2];            // [R] Gaussian id per instance, ping-pong
+  uint32_t* hist;               // [256][sort_blocks(R)]
+  uint32_t* digit_total;        // [256]
+  static BinningState from(void* buf, size_t R) {
+    char* p = reinterpret_cast<char*>(buf);
+    BinningState b;
+    const size_t Rp = R ? R : 1;
+    b.keys[0] = carve<uint32_t>(p, Rp);
+    b.keys[1] = carve<uint32_t>(p, Rp);
+    b.vals[0] = carve<uint32_t>(p, Rp);
+    b.vals[1] = carve<uint32_t>(p, Rp);
+    b.hist = carve<uint32_t>(p, 256 * sort_blocks(Rp));
+    b.digit_total = carve<uint32_t>(p, 256);
+    b.end = p;
+    return b;
+  }
+  char* end;
+};
+
+static inline int tile_bits(int tiles) {      // bits needed to hold tile ids 0..tiles-1 (>=1)
+  int b = 1;
+  while ((1 << b) < tiles) b++;
+  return b;
+}
+// which ping-pong slot holds the result after sorting `bits` bits in 8-bit passes, starting in slot 0
+static inline int sort_final_slot(int bits) { return ((bits + 7) / 8) & 1; }
+
+// ---------------------------------------------------------------------------------------------
+// host launchers implemented in the other translation units (all stream-ordered, return GM_* codes)
+struct RasterArgs {
+  int P, D, M, W, H;
+  const float *background, *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
+  const float *viewmatrix, *projmatrix, *cam_pos;
+  float scale_modifier, tan_fovx, tan_fovy;
+  int prefiltered, debug;
+  hipStream_t stream;
+};
+
+int launch_preprocess(const RasterArgs& a, GeomState& g, int* radii);
+int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
+int launch_preprocess_bwd(const RasterArgs& a, GeomState& g, const int* radii, const float* dL_dmean2D,
+                          const float* dL_dconic, float* dL_dmean3D, const float* dL_dcolor, float* dL_dcov3D,
+                          float* dL_dsh, float* dL_dscale, float* dL_drot);
+
+// stable LSD radix sort of (u32 key, u32 value) pairs on key bits [0, bits), 8 bits per pass, ping-pong
+// between slot 0 and slot 1.  n_dev (optional) = device pointer to the element count; n_max = host upper bound
+// used for grid sizing.  iota_values: pass 1 synthesises values = index instead of reading vals[0].
+int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], uint32_t* hist, uint32_t* digit_total, size_t n,
+                     int bits, bool iota_values, int debug, hipStream_t s);
+
+int launch_tile_count_scan(GeomState& g, int P, int debug, hipStream_t s);          // -> counters[0] = num_rendered
+int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, const int* radii, int debug, hipStream_t s);
+int launch_tile_ranges(BinningState& b, int slot, ImageState& img, int R, int tiles, int debug, hipStream_t s);
+int launch_render_fwd(const GeomState& g, const uint32_t* point_list, ImageState& img, int W, int H,
+                      const float* background, float* out_color, int debug, hipStream_t s);
+int launch_render_bwd(const GeomState& g, const uint32_t* point_list, ImageState& img, int W, int H,
+                      const float* background, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
+                      float* dL_dopacity, float* dL_dcolor, int debug, hipStream_t s);
+
+int launch_deform(int N, const int* tri, const float* w, const float* dV, const float* Rv, const float* Sv,
+                  const float* cov, const float* pos, float* pos_out, float* cov_out, float* rot_out, float* cov6_out,
+                  hipStream_t s);
+int launch_sh_colors(int N, int deg, int M, const float* pos, const float* campos, const float* rot,
+                     const float* shs, float* rgb, hipStream_t s);
+int launch_knn(int P, const float* points, float* meanDists, void* ws, size_t ws_bytes, hipStream_t s);
+size_t knn_workspace_bytes(int P);
+
+}  // namespace gm

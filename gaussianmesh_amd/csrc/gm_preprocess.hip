@@ -1,0 +1,423 @@
+// gm_preprocess.hip -- per-Gaussian kernels: forward preprocess, markVisible, backward preprocess.
+//
+// Replaces (reference, RAST = gaussian_renderer/diff_gaussian_rasterizater/cuda_rasterizer):
+//   RAST/forward.cu:155-256   preprocessCUDA (fwd)  + computeCov3D :118-152, computeCov2D :74-113,
+//                             computeColorFromSH :20-71, in_frustum RAST/auxiliary.h:138-163
+//   RAST/rasterizer_impl.cu:54-66 checkFrustum
+//   RAST/backward.cu:144-274  computeCov2DCUDA, :346-396 preprocessCUDA (bwd), :20-139 SH bwd, :278-341 cov3D bwd
+//
+// ARITHMETIC CONTRACT: this file is compiled with FMA contraction OFF and evaluates
+// every expression in the association order of the reference's C source (GLM column-major products
+// expanded by hand), with correctly rounded division / sqrt (hipcc default) and ndc2Pix in double.
+// The CPU oracle follows the same contract, so radii, tile rectangles, depth keys and everything
+// derived from them (instance lists, ranges) are bit-identical between the two.
+//
+// One thread per Gaussian, 256-thread workgroups.  The kernel is HBM-streaming bound (236 B in,
+// ~90 B out per Gaussian at SH degree 3); the camera matrices are wave-uniform and read through
+// the scalar cache.
+#include "gm_common.h"
+#pragma clang fp contract(off)
+#include "gm_sh.h"
+
+namespace gm {
+
+struct V3 { float x, y, z; };
+
+__device__ __forceinline__ V3 xform4x3(const V3 p, const float* __restrict__ m) {
+  V3 o;
+  o.x = m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12];
+  o.y = m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13];
+  o.z = m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14];
+  return o;
+}
+
+__device__ __forceinline__ float ndc2pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
+
+__device__ __forceinline__ void get_rect(float px, float py, int r, int gx, int gy, int& x0, int& y0, int& x1, int& y1) {
+  x0 = min(gx, max(0, (int)((px - r) / GM_TILE)));
+  y0 = min(gy, max(0, (int)((py - r) / GM_TILE)));
+  x1 = min(gx, max(0, (int)((px + r + GM_TILE - 1) / GM_TILE)));
+  y1 = min(gy, max(0, (int)((py + r + GM_TILE - 1) / GM_TILE)));
+}
+
+// GLM-argument-order rotation entries: Rg[3*c+r] = column c, row r of glm::mat3 R (forward.cu:134-138)
+__device__ __forceinline__ void quat_cols(float r, float x, float y, float z, float* Rg) {
+  Rg[0] = 1.f - 2.f * (y * y + z * z); Rg[1] = 2.f * (x * y - r * z); Rg[2] = 2.f * (x * z + r * y);
+  Rg[3] = 2.f * (x * y + r * z); Rg[4] = 1.f - 2.f * (x * x + z * z); Rg[5] = 2.f * (y * z - r * x);
+  Rg[6] = 2.f * (x * z - r * y); Rg[7] = 2.f * (y * z + r * x); Rg[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+// T = W*J (two non-zero GLM columns), clamped t and clamp masks.  forward.cu:80-99 / backward.cu:166-192
+__device__ __forceinline__ void cov2d_T(V3 mean, float fx, float fy, float tanx, float tany, const float* __restrict__ v,
+                                        V3& t, float* T0, float* T1, float& xmul, float& ymul) {
+  t = xform4x3(mean, v);
+  const float limx = 1.3f * tanx, limy = 1.3f * tany;
+  const float txtz = t.x / t.z, tytz = t.y / t.z;
+  t.x = fminf(limx, fmaxf(-limx, txtz)) * t.z;
+  t.y = fminf(limy, fmaxf(-limy, tytz)) * t.z;
+  xmul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+  ymul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+  const float j00 = fx / t.z, j02 = -(fx * t.x) / (t.z * t.z);
+  const float j11 = fy / t.z, j12 = -(fy * t.y) / (t.z * t.z);
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    T0[i] = (v[4 * i] * j00 + v[4 * i + 1] * 0.0f) + v[4 * i + 2] * j02;
+    T1[i] = (v[4 * i] * 0.0f + v[4 * i + 1] * j11) + v[4 * i + 2] * j12;
+  }
+}
+
+// cov = T^T Vrk^T T; entries [0][0], [0][1], [1][1]; no low-pass.  forward.cu:101-106
+__device__ __forceinline__ void cov2d_from_T(const float* T0, const float* T1, const float* c, float& a, float& b, float& cc) {
+  const float V[9] = {c[0], c[1], c[2], c[1], c[3], c[4], c[2], c[4], c[5]};
+  float A0[3], A1[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    A0[k] = (T0[0] * V[0 + k] + T0[1] * V[3 + k]) + T0[2] * V[6 + k];
+    A1[k] = (T1[0] * V[0 + k] + T1[1] * V[3 + k]) + T1[2] * V[6 + k];
+  }
+  a = (A0[0] * T0[0] + A0[1] * T0[1]) + A0[2] * T0[2];
+  b = (A1[0] * T0[0] + A1[1] * T0[1]) + A1[2] * T0[2];
+  cc = (A1[0] * T1[0] + A1[1] * T1[1]) + A1[2] * T1[2];
+}
+
+struct PreArgs {
+  int P, D, M, W, H, gx, gy;
+  const float *means, *scales, *rots, *opac, *shs, *cov3D_pre, *colors_pre, *view, *proj, *campos;
+  float mod, tanx, tany, fx, fy;
+  float4* splat; int* radii_int; int* radii_out; uint32_t* tiles; float* cov3D; uint8_t* clamped; uint32_t* depth_key;
+};
+
+__global__ __launch_bounds__(256) void preprocess_fwd_kernel(const PreArgs a) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.P) return;
+  int radius_i = 0;
+  uint32_t tiles = 0, dkey = 0xFFFFFFFFu;
+  do {
+    const V3 p = {a.means[3 * (size_t)idx], a.means[3 * (size_t)idx + 1], a.means[3 * (size_t)idx + 2]};
+    const float* pm = a.proj;
+    const float hx = pm[0] * p.x + pm[4] * p.y + pm[8] * p.z + pm[12];
+    const float hy = pm[1] * p.x + pm[5] * p.y + pm[9] * p.z + pm[13];
+    const float hw = pm[3] * p.x + pm[7] * p.y + pm[11] * p.z + pm[15];
+    const float p_w = 1.0f / (hw + 0.0000001f);
+    const float prx = hx * p_w, pry = hy * p_w;
+    const V3 pv = xform4x3(p, a.view);
+    if (pv.z <= 0.2f) break;                        // in_frustum, auxiliary.h:153
+    float c3[6];
+    if (a.cov3D_pre) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) c3[k] = a.cov3D_pre[6 * (size_t)idx + k];
+    } else {                                        // computeCov3D, forward.cu:118-152
+      const float4 q = reinterpret_cast<const float4*>(a.rots)[idx];
+      float Rg[9], Mc[9];
+      quat_cols(q.x, q.y, q.z, q.w, Rg);
+      const float s[3] = {a.mod * a.scales[3 * (size_t)idx], a.mod * a.scales[3 * (size_t)idx + 1],
+                          a.mod * a.scales[3 * (size_t)idx + 2]};
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) Mc[3 * c + k] = s[k] * Rg[3 * c + k];
+#define SIG(u, w) (Mc[3 * u + 0] * Mc[3 * w + 0] + Mc[3 * u + 1] * Mc[3 * w + 1] + Mc[3 * u + 2] * Mc[3 * w + 2])
+      c3[0] = SIG(0, 0); c3[1] = SIG(0, 1); c3[2] = SIG(0, 2); c3[3] = SIG(1, 1); c3[4] = SIG(1, 2); c3[5] = SIG(2, 2);
+#undef SIG
+#pragma unroll
+      for (int k = 0; k < 6; k++) a.cov3D[6 * (size_t)idx + k] = c3[k];
+    }
+    V3 t; float T0[3], T1[3], xm, ym, ca, cb, cc;
+    cov2d_T(p, a.fx, a.fy, a.tanx, a.tany, a.view, t, T0, T1, xm, ym);
+    cov2d_from_T(T0, T1, c3, ca, cb, cc);
+    ca += 0.3f; cc += 0.3f;
+    const float det = ca * cc - cb * cb;
+    if (det == 0.0f) break;
+    const float det_inv = 1.f / det;
+    const float conx = cc * det_inv, cony = -cb * det_inv, conz = ca * det_inv;
+    const float mid = 0.5f * (ca + cc);
+    const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+    const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+    const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+    const float pix = ndc2pix(prx, a.W), piy = ndc2pix(pry, a.H);
+    int x0, y0, x1, y1;
+    get_rect(pix, piy, (int)my_radius, a.gx, a.gy, x0, y0, x1, y1);
+    if ((x1 - x0) * (y1 - y0) == 0) break;
+    float col[3];
+    uint8_t clampbits = 0;
+    if (a.colors_pre) {
+      col[0] = a.colors_pre[3 * (size_t)idx]; col[1] = a.colors_pre[3 * (size_t)idx + 1]; col[2] = a.colors_pre[3 * (size_t)idx + 2];
+    } else {                                        // computeColorFromSH, forward.cu:20-71
+      float dx = p.x - a.campos[0], dy = p.y - a.campos[1], dz = p.z - a.campos[2];
+      const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+      dx = dx / len; dy = dy / len; dz = dz / len;
+      float sh[48];
+      const int ncoef = (a.D + 1) * (a.D + 1);
+      load_sh(a.shs, idx, a.M, ncoef, sh);
+#pragma unroll
+      for (int ch = 0; ch < 3; ch++) {
+        float r = sh_channel(a.D, [&](int i) { return sh[3 * i + ch]; }, dx, dy, dz);
+        r += 0.5f;
+        if (r < 0) clampbits |= (uint8_t)(1u << ch);
+        col[ch] = fmaxf(r, 0.0f);
+      }
+    }
+    a.clamped[idx] = clampbits;
+    a.splat[3 * (size_t)idx + 0] = make_float4(pix, piy, conx, cony);
+    a.splat[3 * (size_t)idx + 1] = make_float4(conz, a.opac[idx], col[0], col[1]);
+    a.splat[3 * (size_t)idx + 2] = make_float4(col[2], pv.z, 0.f, 0.f);
+    radius_i = (int)my_radius;
+    tiles = (uint32_t)((y1 - y0) * (x1 - x0));
+    dkey = __float_as_uint(pv.z);
+  } while (0);
+  a.radii_int[idx] = radius_i;
+  if (a.radii_out) a.radii_out[idx] = radius_i;
+  a.tiles[idx] = tiles;
+  a.depth_key[idx] = dkey;
+}
+
+int launch_preprocess(const RasterArgs& r, GeomState& g, int* radii) {
+  StageScope sc(ST_PREPROCESS, r.stream);
+  PreArgs a;
+  a.P = r.P; a.D = r.D; a.M = r.M; a.W = r.W; a.H = r.H;
+  a.gx = (r.W + GM_TILE - 1) / GM_TILE; a.gy = (r.H + GM_TILE - 1) / GM_TILE;
+  a.means = r.means3D; a.scales = r.scales; a.rots = r.rotations; a.opac = r.opacities; a.shs = r.shs;
+  a.cov3D_pre = r.cov3D_precomp; a.colors_pre = r.colors_precomp; a.view = r.viewmatrix; a.proj = r.projmatrix;
+  a.campos = r.cam_pos; a.mod = r.scale_modifier; a.tanx = r.tan_fovx; a.tany = r.tan_fovy;
+  a.fy = r.H / (2.0f * r.tan_fovy); a.fx = r.W / (2.0f * r.tan_fovx);   // rasterizer_impl.cu:359-360
+  a.splat = g.splat; a.radii_int = g.radii; a.radii_out = radii; a.tiles = g.tiles_touched; a.cov3D = g.cov3D;
+  a.clamped = g.clamped; a.depth_key = g.depth_key[0];
+  if (r.P > 0) hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((r.P + 255) / 256), dim3(256), 0, r.stream, a);
+  GM_LAUNCH_CHECK(r.debug, r.stream);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float* __restrict__ means,
+                                                           const float* __restrict__ view, uint8_t* __restrict__ present) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= P) return;
+  const V3 p = {means[3 * (size_t)idx], means[3 * (size_t)idx + 1], means[3 * (size_t)idx + 2]};
+  const V3 pv = xform4x3(p, view);
+  present[idx] = (pv.z <= 0.2f) ? 0 : 1;
+}
+
+int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s) {
+  if (P > 0) hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, view, present);
+  GM_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward: computeCov2DCUDA + preprocessCUDA(bwd) fused, one thread per Gaussian.  Every gradient
+// output row is written by its thread (zeros for culled Gaussians) so no memset is needed for them.
+struct PreBwdArgs {
+  int P, D, M, W, H;
+  const float *means, *shs, *scales, *rots, *cov3D, *view, *proj, *campos;
+  const int* radii; const uint8_t* clamped;
+  float mod, tanx, tany, fx, fy;
+  const float *dL_dmean2D, *dL_dconic, *dL_dcolor;
+  float *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
+};
+
+__global__ __launch_bounds__(256) void preprocess_bwd_kernel(const PreBwdArgs a) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.P) return;
+  const int ncoef = (a.D + 1) * (a.D + 1);
+  float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool visible = a.radii[idx] > 0;
+  if (visible) {
+    const V3 mean = {a.means[3 * (size_t)idx], a.means[3 * (size_t)idx + 1], a.means[3 * (size_t)idx + 2]};
+    float c3[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) c3[k] = a.cov3D[6 * (size_t)idx + k];
+    {  // ---- computeCov2DCUDA, backward.cu:144-274
+      const float4 dc4 = reinterpret_cast<const float4*>(a.dL_dconic)[idx];
+      const float dcx = dc4.x, dcy = dc4.y, dcz = dc4.w;
+      V3 t; float T0[3], T1[3], xm, ym, ca, cb, cc;
+      cov2d_T(mean, a.fx, a.fy, a.tanx, a.tany, a.view, t, T0, T1, xm, ym);
+      cov2d_from_T(T0, T1, c3, ca, cb, cc);
+      ca += 0.3f; cc += 0.3f;
+      const float denom = ca * cc - cb * cb;
+      float dL_da = 0, dL_db = 0, dL_dc = 0;
+      const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+      if (denom2inv != 0) {
+        dL_da = denom2inv * (-cc * cc * dcx + 2 * cb * cc * dcy + (denom - ca * cc) * dcz);
+        dL_dc = denom2inv * (-ca * ca * dcz + 2 * ca * cb * dcy + (denom - ca * cc) * dcx);
+        dL_db = denom2inv * 2 * (cb * cc * dcx - (denom + 2 * cb * cb) * dcy + ca * cb * dcz);
+        dcov[0] = (T0[0] * T0[0] * dL_da + T0[0] * T1[0] * dL_db + T1[0] * T1[0] * dL_dc);
+        dcov[3] = (T0[1] * T0[1] * dL_da + T0[1] * T1[1] * dL_db + T1[1] * T1[1] * dL_dc);
+        dcov[5] = (T0[2] * T0[2] * dL_da + T0[2] * T1[2] * dL_db + T1[2] * T1[2] * dL_dc);
+        dcov[1] = 2 * T0[0] * T0[1] * dL_da + (T0[0] * T1[1] + T0[1] * T1[0]) * dL_db + 2 * T1[0] * T1[1] * dL_dc;
+        dcov[2] = 2 * T0[0] * T0[2] * dL_da + (T0[0] * T1[2] + T0[2] * T1[0]) * dL_db + 2 * T1[0] * T1[2] * dL_dc;
+        dcov[4] = 2 * T0[2] * T0[1] * dL_da + (T0[1] * T1[2] + T0[2] * T1[1]) * dL_db + 2 * T1[1] * T1[2] * dL_dc;
+      }
+      const float V[9] = {c3[0], c3[1], c3[2], c3[1], c3[3], c3[4], c3[2], c3[4], c3[5]};
+#define VR(cc_, rr_) V[3 * (cc_) + (rr_)]
+      const float dT00 = 2 * (T0[0] * VR(0, 0) + T0[1] * VR(0, 1) + T0[2] * VR(0, 2)) * dL_da + (T1[0] * VR(0, 0) + T1[1] * VR(0, 1) + T1[2] * VR(0, 2)) * dL_db;
+      const float dT01 = 2 * (T0[0] * VR(1, 0) + T0[1] * VR(1, 1) + T0[2] * VR(1, 2)) * dL_da + (T1[0] * VR(1, 0) + T1[1] * VR(1, 1) + T1[2] * VR(1, 2)) * dL_db;
+      const float dT02 = 2 * (T0[0] * VR(2, 0) + T0[1] * VR(2, 1) + T0[2] * VR(2, 2)) * dL_da + (T1[0] * VR(2, 0) + T1[1] * VR(2, 1) + T1[2] * VR(2, 2)) * dL_db;
+      const float dT10 = 2 * (T1[0] * VR(0, 0) + T1[1] * VR(0, 1) + T1[2] * VR(0, 2)) * dL_dc + (T0[0] * VR(0, 0) + T0[1] * VR(0, 1) + T0[2] * VR(0, 2)) * dL_db;
+      const float dT11 = 2 * (T1[0] * VR(1, 0) + T1[1] * VR(1, 1) + T1[2] * VR(1, 2)) * dL_dc + (T0[0] * VR(1, 0) + T0[1] * VR(1, 1) + T0[2] * VR(1, 2)) * dL_db;
+      const float dT12 = 2 * (T1[0] * VR(2, 0) + T1[1] * VR(2, 1) + T1[2] * VR(2, 2)) * dL_dc + (T0[0] * VR(2, 0) + T0[1] * VR(2, 1) + T0[2] * VR(2, 2)) * dL_db;
+#undef VR
+      const float* v = a.view;
+      const float dJ00 = v[0] * dT00 + v[4] * dT01 + v[8] * dT02;
+      const float dJ02 = v[2] * dT00 + v[6] * dT01 + v[10] * dT02;
+      const float dJ11 = v[1] * dT10 + v[5] * dT11 + v[9] * dT12;
+      const float dJ12 = v[2] * dT10 + v[6] * dT11 + v[10] * dT12;
+      const float tz = 1.f / t.z, tz2 = tz * tz, tz3 = tz2 * tz;
+      const float dtx = xm * -a.fx * tz2 * dJ02;
+      const float dty = ym * -a.fy * tz2 * dJ12;
+      const float dtz = -a.fx * tz2 * dJ00 - a.fy * tz2 * dJ11 + (2 * a.fx * t.x) * tz3 * dJ02 + (2 * a.fy * t.y) * tz3 * dJ12;
+      dmean[0] = v[0] * dtx + v[1] * dty + v[2] * dtz;     // transformVec4x3Transpose
+      dmean[1] = v[4] * dtx + v[5] * dty + v[6] * dtz;
+      dmean[2] = v[8] * dtx + v[9] * dty + v[10] * dtz;
+    }
+    {  // ---- projection part, backward.cu:370-387
+      const float* pr = a.proj;
+      const float hw = pr[3] * mean.x + pr[7] * mean.y + pr[11] * mean.z + pr[15];
+      const float m_w = 1.0f / (hw + 0.0000001f);
+      const float mul1 = (pr[0] * mean.x + pr[4] * mean.y + pr[8] * mean.z + pr[12]) * m_w * m_w;
+      const float mul2 = (pr[1] * mean.x + pr[5] * mean.y + pr[9] * mean.z + pr[13]) * m_w * m_w;
+      const float gxx = a.dL_dmean2D[3 * (size_t)idx], gyy = a.dL_dmean2D[3 * (size_t)idx + 1];
+      dmean[0] += (pr[0] * m_w - pr[3] * mul1) * gxx + (pr[1] * m_w - pr[3] * mul2) * gyy;
+      dmean[1] += (pr[4] * m_w - pr[7] * mul1) * gxx + (pr[5] * m_w - pr[7] * mul2) * gyy;
+      dmean[2] += (pr[8] * m_w - pr[11] * mul1) * gxx + (pr[9] * m_w - pr[11] * mul2) * gyy;
+    }
+    if (a.shs) {  // ---- computeColorFromSH backward, backward.cu:20-139
+      const float ox = mean.x - a.campos[0], oy = mean.y - a.campos[1], oz = mean.z - a.campos[2];
+      const float len = sqrtf(ox * ox + oy * oy + oz * oz);
+      const float x = ox / len, y = oy / len, z = oz / len;
+      float sh[48];
+      load_sh(a.shs, idx, a.M, ncoef, sh);
+      const uint8_t cl = a.clamped[idx];
+      float dRGB[3], wgt[16];
+#pragma unroll
+      for (int ch = 0; ch < 3; ch++) dRGB[ch] = a.dL_dcolor[3 * (size_t)idx + ch] * (((cl >> ch) & 1) ? 0.f : 1.f);
+      float ddx[3] = {0, 0, 0}, ddy[3] = {0, 0, 0}, ddz[3] = {0, 0, 0};
+#define S(i, ch) sh[3 * (i) + (ch)]
+      wgt[0] = SH_C0;
+      if (a.D > 0) {
+        wgt[1] = -SH_C1 * y; wgt[2] = SH_C1 * z; wgt[3] = -SH_C1 * x;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) { ddx[ch] = -SH_C1 * S(3, ch); ddy[ch] = -SH_C1 * S(1, ch); ddz[ch] = SH_C1 * S(2, ch); }
+        if (a.D > 1) {
+          const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+          wgt[4] = SH_C2[0] * xy; wgt[5] = SH_C2[1] * yz; wgt[6] = SH_C2[2] * (2.f * zz - xx - yy);
+          wgt[7] = SH_C2[3] * xz; wgt[8] = SH_C2[4] * (xx - yy);
+#pragma unroll
+          for (int ch = 0; ch < 3; ch++) {
+            ddx[ch] += SH_C2[0] * y * S(4, ch) + SH_C2[2] * 2.f * -x * S(6, ch) + SH_C2[3] * z * S(7, ch) + SH_C2[4] * 2.f * x * S(8, ch);
+            ddy[ch] += SH_C2[0] * x * S(4, ch) + SH_C2[1] * z * S(5, ch) + SH_C2[2] * 2.f * -y * S(6, ch) + SH_C2[4] * 2.f * -y * S(8, ch);
+            ddz[ch] += SH_C2[1] * y * S(5, ch) + SH_C2[2] * 2.f * 2.f * z * S(6, ch) + SH_C2[3] * x * S(7, ch);
+          }
+          if (a.D > 2) {
+            wgt[9] = SH_C3[0] * y * (3.f * xx - yy); wgt[10] = SH_C3[1] * xy * z;
+            wgt[11] = SH_C3[2] * y * (4.f * zz - xx - yy); wgt[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+            wgt[13] = SH_C3[4] * x * (4.f * zz - xx - yy); wgt[14] = SH_C3[5] * z * (xx - yy);
+            wgt[15] = SH_C3[6] * x * (xx - 3.f * yy);
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+              ddx[ch] += (SH_C3[0] * S(9, ch) * 3.f * 2.f * xy + SH_C3[1] * S(10, ch) * yz + SH_C3[2] * S(11, ch) * -2.f * xy +
+                          SH_C3[3] * S(12, ch) * -3.f * 2.f * xz + SH_C3[4] * S(13, ch) * (-3.f * xx + 4.f * zz - yy) +
+                          SH_C3[5] * S(14, ch) * 2.f * xz + SH_C3[6] * S(15, ch) * 3.f * (xx - yy));
+              ddy[ch] += (SH_C3[0] * S(9, ch) * 3.f * (xx - yy) + SH_C3[1] * S(10, ch) * xz +
+                          SH_C3[2] * S(11, ch) * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * S(12, ch) * -3.f * 2.f * yz +
+                          SH_C3[4] * S(13, ch) * -2.f * xy + SH_C3[5] * S(14, ch) * -2.f * yz + SH_C3[6] * S(15, ch) * -3.f * 2.f * xy);
+              ddz[ch] += (SH_C3[1] * S(10, ch) * xy + SH_C3[2] * S(11, ch) * 4.f * 2.f * yz +
+                          SH_C3[3] * S(12, ch) * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * S(13, ch) * 4.f * 2.f * xz +
+                          SH_C3[5] * S(14, ch) * (xx - yy));
+            }
+          }
+        }
+      }
+#undef S
+      float* dsh = a.dL_dsh + (size_t)idx * a.M * 3;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        if (i < a.M) {
+          const bool on = i < ncoef;
+#pragma unroll
+          for (int ch = 0; ch < 3; ch++) dsh[3 * i + ch] = on ? wgt[i] * dRGB[ch] : 0.f;
+        }
+      }
+      for (int i = 16; i < a.M; i++)
+        for (int ch = 0; ch < 3; ch++) dsh[3 * i + ch] = 0.f;
+      const float ddir[3] = {ddx[0] * dRGB[0] + ddx[1] * dRGB[1] + ddx[2] * dRGB[2],
+                             ddy[0] * dRGB[0] + ddy[1] * dRGB[1] + ddy[2] * dRGB[2],
+                             ddz[0] * dRGB[0] + ddz[1] * dRGB[1] + ddz[2] * dRGB[2]};
+      // dnormvdv, auxiliary.h:106-116
+      const float sum2 = ox * ox + oy * oy + oz * oz;
+      const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+      dmean[0] += ((+sum2 - ox * ox) * ddir[0] - oy * ox * ddir[1] - oz * ox * ddir[2]) * invsum32;
+      dmean[1] += (-ox * oy * ddir[0] + (sum2 - oy * oy) * ddir[1] - oz * oy * ddir[2]) * invsum32;
+      dmean[2] += (-ox * oz * ddir[0] - oy * oz * ddir[1] + (sum2 - oz * oz) * ddir[2]) * invsum32;
+    }
+  } else if (a.shs) {
+    float* dsh = a.dL_dsh + (size_t)idx * a.M * 3;
+    for (int i = 0; i < a.M * 3; i++) dsh[i] = 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) a.dL_dmean3D[3 * (size_t)idx + k] = dmean[k];
+#pragma unroll
+  for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = dcov[k];
+  if (a.scales) {  // ---- computeCov3D backward, backward.cu:278-341
+    float dsc[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0};
+    if (visible) {
+      const float4 q = reinterpret_cast<const float4*>(a.rots)[idx];
+      const float r = q.x, x = q.y, y = q.z, z = q.w;
+      float Rg[9], Mc[9];
+      quat_cols(r, x, y, z, Rg);
+      const float s[3] = {a.mod * a.scales[3 * (size_t)idx], a.mod * a.scales[3 * (size_t)idx + 1], a.mod * a.scales[3 * (size_t)idx + 2]};
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) Mc[3 * c + k] = s[k] * Rg[3 * c + k];
+      const float* d = dcov;
+      const float dS[9] = {d[0], 0.5f * d[1], 0.5f * d[2], 0.5f * d[1], d[3], 0.5f * d[4], 0.5f * d[2], 0.5f * d[4], d[5]};
+      float dM[9];
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+          dM[3 * j + i] = (2.0f * Mc[0 + i]) * dS[3 * j + 0] + (2.0f * Mc[3 + i]) * dS[3 * j + 1] + (2.0f * Mc[6 + i]) * dS[3 * j + 2];
+      float Rt[9], dMt[9];
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++) { Rt[3 * c + rr] = Rg[3 * rr + c]; dMt[3 * c + rr] = dM[3 * rr + c]; }
+#pragma unroll
+      for (int c = 0; c < 3; c++) dsc[c] = Rt[3 * c + 0] * dMt[3 * c + 0] + Rt[3 * c + 1] * dMt[3 * c + 1] + Rt[3 * c + 2] * dMt[3 * c + 2];
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++) dMt[3 * c + rr] *= s[c];
+#define DM(c_, r_) dMt[3 * (c_) + (r_)]
+      dq[0] = 2 * z * (DM(0, 1) - DM(1, 0)) + 2 * y * (DM(2, 0) - DM(0, 2)) + 2 * x * (DM(1, 2) - DM(2, 1));
+      dq[1] = 2 * y * (DM(1, 0) + DM(0, 1)) + 2 * z * (DM(2, 0) + DM(0, 2)) + 2 * r * (DM(1, 2) - DM(2, 1)) - 4 * x * (DM(2, 2) + DM(1, 1));
+      dq[2] = 2 * x * (DM(1, 0) + DM(0, 1)) + 2 * r * (DM(2, 0) - DM(0, 2)) + 2 * z * (DM(1, 2) + DM(2, 1)) - 4 * y * (DM(2, 2) + DM(0, 0));
+      dq[3] = 2 * r * (DM(0, 1) - DM(1, 0)) + 2 * x * (DM(2, 0) + DM(0, 2)) + 2 * y * (DM(1, 2) + DM(2, 1)) - 4 * z * (DM(1, 1) + DM(0, 0));
+#undef DM
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) a.dL_dscale[3 * (size_t)idx + k] = dsc[k];
+    reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(dq[0], dq[1], dq[2], dq[3]);
+  }
+}
+
+int launch_preprocess_bwd(const RasterArgs& r, GeomState& g, const int* radii, const float* dL_dmean2D,
+                          const float* dL_dconic, float* dL_dmean3D, const float* dL_dcolor, float* dL_dcov3D,
+                          float* dL_dsh, float* dL_dscale, float* dL_drot) {
+  StageScope sc(ST_PREPROCESS_BWD, r.stream);
+  PreBwdArgs a;
+  a.P = r.P; a.D = r.D; a.M = r.M; a.W = r.W; a.H = r.H;
+  a.means = r.means3D; a.shs = r.shs; a.scales = r.scales; a.rots = r.rotations;
+  a.cov3D = r.cov3D_precomp ? r.cov3D_precomp : g.cov3D;
+  a.view = r.viewmatrix; a.proj = r.projmatrix; a.campos = r.cam_pos;
+  a.radii = radii ? radii : g.radii; a.clamped = g.clamped;
+  a.mod = r.scale_modifier; a.tanx = r.tan_fovx; a.tany = r.tan_fovy;
+  a.fy = r.H / (2.0f * r.tan_fovy); a.fx = r.W / (2.0f * r.tan_fovx);
+  a.dL_dmean2D = dL_dmean2D; a.dL_dconic = dL_dconic; a.dL_dcolor = dL_dcolor;
+  a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot;
+  if (r.P > 0) hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((r.P + 255) / 256), dim3(256), 0, r.stream, a);
+  GM_LAUNCH_CHECK(r.debug, r.stream);
+  return 0;
+}
+
+}  // namespace gm

@@ -1,0 +1,330 @@
+// gm_render.hip -- per-tile alpha blending, forward and backward.
+//
+// Replaces (reference, RAST = gaussian_renderer/diff_gaussian_rasterizater/cuda_rasterizer):
+//   RAST/forward.cu:261-374   renderCUDA (forward)
+//   RAST/backward.cu:399-557  renderCUDA (backward)
+//
+// CDNA4 mapping (DESIGN.md "blend"): the reference gives each 16x16 tile to a 256-thread block that
+// stages 256-entry batches in shared memory behind two block barriers and lets every pixel thread
+// re-read the batch from LDS (and the colour from global memory).  Here a tile is processed by
+// 4/PPL independent wave64s, each owning 64*PPL pixels (PPL pixels per lane, in registers):
+//   * a wave gathers 64 list entries at a time (lane j <- entry j: one 4-byte id + three 16-byte
+//     splat loads) into registers, double-buffered so the next batch's HBM/L2 latency hides under
+//     the current batch's arithmetic;
+//   * entry j is broadcast to all lanes with v_readlane_b32 into SGPRs (the entry is wave-uniform),
+//     so the inner loop has no LDS traffic, no s_barrier and no per-pixel global colour read;
+//   * "is every pixel done" is a wave vote (__all) instead of __syncthreads_count; an entry that no
+//     pixel of the wave accepts is skipped with one __any.
+// Discrete semantics are the reference's: skip power>0, skip alpha<1/255, stop (without applying the
+// entry) when T(1-alpha)<1e-4, n_contrib = 1-based list position of the last accepted entry.
+// FMA contraction is allowed here and exp() is v_exp_f32 on power*log2(e); see DESIGN.md for the
+// tolerance argument.
+#include "gm_common.h"
+#include <cstdlib>
+
+namespace gm {
+
+#define LOG2E 1.4426950408889634f
+
+__device__ __forceinline__ float bcast(float v, int j) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+}
+
+struct Batch {      // lane j holds list entry j of the current 64-entry batch
+  float4 a;         // x, y, conic.x, conic.y
+  float4 b;         // conic.z, opacity, r, g
+  float c;          // b
+  uint32_t id;
+};
+
+__device__ __forceinline__ Batch load_batch(const uint32_t* __restrict__ list, const float4* __restrict__ splat, int e, int n) {
+  Batch t;
+  t.a = make_float4(0.f, 0.f, 0.f, 0.f); t.b = t.a; t.c = 0.f; t.id = 0;
+  if (e >= 0 && e < n) {
+    const uint32_t id = list[e];
+    t.id = id;
+    t.a = splat[3 * (size_t)id];
+    t.b = splat[3 * (size_t)id + 1];
+    t.c = splat[3 * (size_t)id + 2].x;
+  }
+  return t;
+}
+
+template <int PPL>
+__global__ __launch_bounds__(256 / PPL) void render_fwd_kernel(const uint2* __restrict__ ranges,
+                                                               const uint32_t* __restrict__ point_list,
+                                                               const float4* __restrict__ splat, int W, int H, int gx,
+                                                               const float* __restrict__ bg, float* __restrict__ out_color,
+                                                               float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x;
+  const int tx = tile % gx, ty = tile / gx;
+  const uint2 range = ranges[tile];
+  const int n = (int)(range.y - range.x);
+  const uint32_t* list = point_list + range.x;
+
+  const int px = tx * GM_TILE + (lane & 15);
+  const float pixx = (float)px;
+  int py[PPL];
+  float pixy[PPL], T[PPL], Cr[PPL], Cg[PPL], Cb[PPL];
+  uint32_t last[PPL];
+  bool done[PPL];
+#pragma unroll
+  for (int k = 0; k < PPL; k++) {
+    py[k] = ty * GM_TILE + (wave * PPL + k) * 4 + (lane >> 4);
+    pixy[k] = (float)py[k];
+    T[k] = 1.0f; Cr[k] = Cg[k] = Cb[k] = 0.f; last[k] = 0;
+    done[k] = !(px < W && py[k] < H);
+  }
+
+  Batch cur = load_batch(list, splat, lane, n);
+  for (int base = 0; base < n; base += 64) {
+    bool all_done = true;
+#pragma unroll
+    for (int k = 0; k < PPL; k++) all_done = all_done && done[k];
+    if (__all(all_done)) break;
+    const Batch nxt = load_batch(list, splat, base + 64 + lane, n);   // prefetch (all-zero past the end)
+    const int cnt = min(64, n - base);
+    for (int j = 0; j < cnt; j++) {
+      const float sx = bcast(cur.a.x, j), sy = bcast(cur.a.y, j);
+      const float cx = bcast(cur.a.z, j), cy = bcast(cur.a.w, j), cz = bcast(cur.b.x, j);
+      const float op = bcast(cur.b.y, j);
+      const float dx = sx - pixx;
+      float alpha[PPL], testT[PPL];
+      bool valid[PPL], anyv = false;
+#pragma unroll
+      for (int k = 0; k < PPL; k++) {
+        const float dy = sy - pixy[k];
+        const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
+        alpha[k] = fminf(0.99f, op * __builtin_amdgcn_exp2f(power * LOG2E));
+        valid[k] = !done[k] && (power <= 0.0f) && (alpha[k] >= 1.0f / 255.0f);
+        testT[k] = T[k] * (1.0f - alpha[k]);
+        const bool stop = valid[k] && (testT[k] < 0.0001f);
+        done[k] = done[k] || stop;
+        valid[k] = valid[k] && !stop;
+        anyv = anyv || valid[k];
+      }
+      if (__any(anyv)) {
+        const float r = bcast(cur.b.z, j), g = bcast(cur.b.w, j), b = bcast(cur.c, j);
+        const uint32_t contributor = (uint32_t)(base + j + 1);
+#pragma unroll
+        for (int k = 0; k < PPL; k++) {
+          const float w = valid[k] ? alpha[k] * T[k] : 0.0f;
+          Cr[k] += r * w; Cg[k] += g * w; Cb[k] += b * w;
+          T[k] = valid[k] ? testT[k] : T[k];
+          last[k] = valid[k] ? contributor : last[k];
+        }
+      }
+    }
+    cur = nxt;
+  }
+
+  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+  const size_t HW = (size_t)H * W;
+#pragma unroll
+  for (int k = 0; k < PPL; k++) {
+    if (px < W && py[k] < H) {
+      const size_t pid = (size_t)W * py[k] + px;
+      final_T[pid] = T[k];
+      n_contrib[pid] = last[k];
+      out_color[pid] = Cr[k] + T[k] * bg0;
+      out_color[HW + pid] = Cg[k] + T[k] * bg1;
+      out_color[2 * HW + pid] = Cb[k] + T[k] * bg2;
+    }
+  }
+}
+
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+int launch_render_fwd(const GeomState& g, const uint32_t* point_list, ImageState& img, int W, int H,
+                      const float* background, float* out_color, int debug, hipStream_t s) {
+  StageScope sc(ST_RENDER, s);
+  static const int ppl = env_int("GM_RENDER_PPL", 2);
+  const int gx = (W + GM_TILE - 1) / GM_TILE, gy = (H + GM_TILE - 1) / GM_TILE;
+  const int tiles = gx * gy;
+  if (tiles > 0) {
+    switch (ppl) {
+      case 1:
+        hipLaunchKernelGGL(render_fwd_kernel<1>, dim3(tiles), dim3(256), 0, s, img.ranges, point_list, g.splat, W, H, gx,
+                           background, out_color, img.final_T, img.n_contrib);
+        break;
+      case 4:
+        hipLaunchKernelGGL(render_fwd_kernel<4>, dim3(tiles), dim3(64), 0, s, img.ranges, point_list, g.splat, W, H, gx,
+                           background, out_color, img.final_T, img.n_contrib);
+        break;
+      default:
+        hipLaunchKernelGGL(render_fwd_kernel<2>, dim3(tiles), dim3(128), 0, s, img.ranges, point_list, g.splat, W, H, gx,
+                           background, out_color, img.final_T, img.n_contrib);
+    }
+  }
+  GM_LAUNCH_CHECK(debug, s);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave64 sum: row scans with DPP row_shr, then row_bcast 15 / 31; total lands in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int sh = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
+  return v + __int_as_float(sh);
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+  v = dpp_add<0x111, 0xf>(v);   // row_shr:1
+  v = dpp_add<0x112, 0xf>(v);   // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);   // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);   // row_shr:8
+  v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1,3
+  v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2,3
+  return v;
+}
+
+template <int PPL>
+__global__ __launch_bounds__(256 / PPL) void render_bwd_kernel(const uint2* __restrict__ ranges,
+                                                               const uint32_t* __restrict__ point_list,
+                                                               const float4* __restrict__ splat, int W, int H, int gx,
+                                                               const float* __restrict__ bg, const float* __restrict__ final_T,
+                                                               const uint32_t* __restrict__ n_contrib,
+                                                               const float* __restrict__ dL_dpix, float* __restrict__ dL_dmean2D,
+                                                               float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
+                                                               float* __restrict__ dL_dcolor) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x;
+  const int tx = tile % gx, ty = tile / gx;
+  const uint2 range = ranges[tile];
+  const int n = (int)(range.y - range.x);
+  if (n == 0) return;
+  const uint32_t* list = point_list + range.x;
+  const size_t HW = (size_t)H * W;
+  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+  const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+
+  const int px = tx * GM_TILE + (lane & 15);
+  const float pixx = (float)px;
+  float pixy[PPL], T[PPL], T_final[PPL], last_alpha[PPL], bg_dot[PPL];
+  float dpr[PPL], dpg[PPL], dpb[PPL], lcr[PPL], lcg[PPL], lcb[PPL], arr[PPL], arg_[PPL], arb[PPL];
+  int last[PPL];
+  int max_last = 0;
+#pragma unroll
+  for (int k = 0; k < PPL; k++) {
+    const int py = ty * GM_TILE + (wave * PPL + k) * 4 + (lane >> 4);
+    pixy[k] = (float)py;
+    const bool inside = px < W && py < H;
+    const size_t pid = inside ? (size_t)W * py + px : 0;
+    T_final[k] = inside ? final_T[pid] : 0.f;
+    T[k] = T_final[k];
+    last[k] = inside ? (int)n_contrib[pid] : 0;
+    dpr[k] = inside ? dL_dpix[pid] : 0.f;
+    dpg[k] = inside ? dL_dpix[HW + pid] : 0.f;
+    dpb[k] = inside ? dL_dpix[2 * HW + pid] : 0.f;
+    bg_dot[k] = bg0 * dpr[k] + bg1 * dpg[k] + bg2 * dpb[k];
+    last_alpha[k] = 0.f; lcr[k] = lcg[k] = lcb[k] = 0.f; arr[k] = arg_[k] = arb[k] = 0.f;
+    max_last = max(max_last, last[k]);
+  }
+  // entries at list positions >= max over the wave of n_contrib are never used: start there
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) max_last = max(max_last, __shfl_xor(max_last, d));
+  const int start = max_last;           // number of list entries this wave has to visit (positions start-1 .. 0)
+
+  // batch b covers list positions start-1-b*64-j (j = lane), i.e. back to front
+  Batch cur = load_batch(list, splat, start - 1 - lane, n);
+  for (int base = 0; base < start; base += 64) {
+    const Batch nxt = load_batch(list, splat, start - 1 - (base + 64) - lane, n);
+    const int cnt = min(64, start - base);
+    for (int j = 0; j < cnt; j++) {
+      const int pos = start - 1 - base - j;          // 0-based list position == reference `contributor`
+      const float sx = bcast(cur.a.x, j), sy = bcast(cur.a.y, j);
+      const float cx = bcast(cur.a.z, j), cy = bcast(cur.a.w, j), cz = bcast(cur.b.x, j);
+      const float op = bcast(cur.b.y, j);
+      const float dx = sx - pixx;
+      float G[PPL], alpha[PPL], dy[PPL];
+      bool valid[PPL], anyv = false;
+#pragma unroll
+      for (int k = 0; k < PPL; k++) {
+        dy[k] = sy - pixy[k];
+        const float power = -0.5f * (cx * dx * dx + cz * dy[k] * dy[k]) - cy * dx * dy[k];
+        G[k] = __builtin_amdgcn_exp2f(power * LOG2E);
+        alpha[k] = fminf(0.99f, op * G[k]);
+        valid[k] = (pos < last[k]) && (power <= 0.0f) && (alpha[k] >= 1.0f / 255.0f);
+        anyv = anyv || valid[k];
+      }
+      if (!__any(anyv)) continue;
+      const float r = bcast(cur.b.z, j), g = bcast(cur.b.w, j), b = bcast(cur.c, j);
+      const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)cur.id, j);
+      float s_cr = 0.f, s_cg = 0.f, s_cb = 0.f, s_mx = 0.f, s_my = 0.f, s_ca = 0.f, s_cb2 = 0.f, s_cc = 0.f, s_op = 0.f;
+#pragma unroll
+      for (int k = 0; k < PPL; k++) {
+        if (valid[k]) {
+          T[k] = T[k] / (1.f - alpha[k]);
+          const float dchannel_dcolor = alpha[k] * T[k];
+          float dL_dalpha;
+          arr[k] = last_alpha[k] * lcr[k] + (1.f - last_alpha[k]) * arr[k];
+          arg_[k] = last_alpha[k] * lcg[k] + (1.f - last_alpha[k]) * arg_[k];
+          arb[k] = last_alpha[k] * lcb[k] + (1.f - last_alpha[k]) * arb[k];
+          lcr[k] = r; lcg[k] = g; lcb[k] = b;
+          dL_dalpha = (r - arr[k]) * dpr[k] + (g - arg_[k]) * dpg[k] + (b - arb[k]) * dpb[k];
+          s_cr += dchannel_dcolor * dpr[k]; s_cg += dchannel_dcolor * dpg[k]; s_cb += dchannel_dcolor * dpb[k];
+          dL_dalpha *= T[k];
+          last_alpha[k] = alpha[k];
+          dL_dalpha += (-T_final[k] / (1.f - alpha[k])) * bg_dot[k];
+          const float dL_dG = op * dL_dalpha;
+          const float gdx = G[k] * dx, gdy = G[k] * dy[k];
+          const float dG_ddelx = -gdx * cx - gdy * cy;
+          const float dG_ddely = -gdy * cz - gdx * cy;
+          s_mx += dL_dG * dG_ddelx * ddelx_dx;
+          s_my += dL_dG * dG_ddely * ddely_dy;
+          s_ca += -0.5f * gdx * dx * dL_dG;
+          s_cb2 += -0.5f * gdx * dy[k] * dL_dG;
+          s_cc += -0.5f * gdy * dy[k] * dL_dG;
+          s_op += G[k] * dL_dalpha;
+        }
+      }
+      s_cr = wave_sum_to_lane63(s_cr); s_cg = wave_sum_to_lane63(s_cg); s_cb = wave_sum_to_lane63(s_cb);
+      s_mx = wave_sum_to_lane63(s_mx); s_my = wave_sum_to_lane63(s_my);
+      s_ca = wave_sum_to_lane63(s_ca); s_cb2 = wave_sum_to_lane63(s_cb2); s_cc = wave_sum_to_lane63(s_cc);
+      s_op = wave_sum_to_lane63(s_op);
+      if (lane == 63) {
+        atomicAdd(&dL_dcolor[3 * (size_t)gid + 0], s_cr);
+        atomicAdd(&dL_dcolor[3 * (size_t)gid + 1], s_cg);
+        atomicAdd(&dL_dcolor[3 * (size_t)gid + 2], s_cb);
+        atomicAdd(&dL_dmean2D[3 * (size_t)gid + 0], s_mx);
+        atomicAdd(&dL_dmean2D[3 * (size_t)gid + 1], s_my);
+        atomicAdd(&dL_dconic[4 * (size_t)gid + 0], s_ca);
+        atomicAdd(&dL_dconic[4 * (size_t)gid + 1], s_cb2);
+        atomicAdd(&dL_dconic[4 * (size_t)gid + 3], s_cc);
+        atomicAdd(&dL_dopacity[gid], s_op);
+      }
+    }
+    cur = nxt;
+  }
+}
+
+int launch_render_bwd(const GeomState& g, const uint32_t* point_list, ImageState& img, int W, int H,
+                      const float* background, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
+                      float* dL_dopacity, float* dL_dcolor, int debug, hipStream_t s) {
+  StageScope sc(ST_RENDER_BWD, s);
+  static const int ppl = env_int("GM_RENDER_BWD_PPL", 4);
+  const int gx = (W + GM_TILE - 1) / GM_TILE, gy = (H + GM_TILE - 1) / GM_TILE;
+  const int tiles = gx * gy;
+  if (tiles > 0) {
+    switch (ppl) {
+      case 1:
+        hipLaunchKernelGGL(render_bwd_kernel<1>, dim3(tiles), dim3(256), 0, s, img.ranges, point_list, g.splat, W, H, gx,
+                           background, img.final_T, img.n_contrib, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
+        break;
+      case 2:
+        hipLaunchKernelGGL(render_bwd_kernel<2>, dim3(tiles), dim3(128), 0, s, img.ranges, point_list, g.splat, W, H, gx,
+                           background, img.final_T, img.n_contrib, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
+        break;
+      default:
+        hipLaunchKernelGGL(render_bwd_kernel<4>, dim3(tiles), dim3(64), 0, s, img.ranges, point_list, g.splat, W, H, gx,
+                           background, img.final_T, img.n_contrib, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
+    }
+  }
+  GM_LAUNCH_CHECK(debug, s);
+  return 0;
+}
+
+}  // namespace gm

@@ -1,0 +1,87 @@
+"""Mesh-driven deformation of bound Gaussians (edit tool), tensor-in form.
+
+Mirrors edittool/__init__.py of the reference:
+  SingleObjectDeform (:40-131): attribute names gaussian_pos, gaussian_cov, gaussian_o, gaussian_feature,
+  gaussian_deform_pos / gaussian_deform_cov / gaussian_deform_rot, gaussian_triangles, weight_g_pos, vertex.
+  deform_gaussian(deform_mesh_path) of the reference reads an OBJ and calls pyACAP.GetRS; pyACAP is an external
+  binary that is not in the reference tree, so here the per-vertex (R, S) are an explicit input:
+      obj.deform(V1, R, S)   # V1 [Vm,3] deformed vertices, R/S [Vm,3,3]
+The arithmetic (gather, barycentric blend, RS cov RS^T, x + dx) runs in one HIP kernel (csrc/gm_deform.hip).
+"""
+import torch
+
+from . import _lib
+
+
+def _f(t):
+    return t.detach().contiguous().float()
+
+
+def deform_tensors(tri, w, dV, Rv, Sv, cov, pos):
+    """gm_deform: returns (pos' [N,3], cov' [N,3,3], rot [N,3,3], cov6 [N,6])."""
+    lib = _lib.lib()
+    device = pos.device
+    if device.type != "cuda":
+        raise _lib.GmeshError("deform needs tensors on a HIP (cuda) device; there is no CPU path")
+    tri = tri.detach().contiguous().to(torch.int32)
+    w, dV, Rv, Sv, cov, pos = (_f(t) for t in (w, dV, Rv, Sv, cov, pos))
+    N = pos.shape[0]
+    f = dict(dtype=torch.float32, device=device)
+    pos_o = torch.empty((N, 3), **f); cov_o = torch.empty((N, 3, 3), **f); rot_o = torch.empty((N, 3, 3), **f)
+    cov6 = torch.empty((N, 6), **f)
+    with torch.cuda.device(device):
+        _lib.check(lib.gm_deform(N, tri.data_ptr(), w.data_ptr(), dV.data_ptr(), Rv.data_ptr(), Sv.data_ptr(), cov.data_ptr(),
+                                 pos.data_ptr(), pos_o.data_ptr(), cov_o.data_ptr(), rot_o.data_ptr(), cov6.data_ptr(),
+                                 torch.cuda.current_stream(device).cuda_stream))
+    return pos_o, cov_o, rot_o, cov6
+
+
+def sh_colors(pos, campos, shs, rot=None, deg=3):
+    """gm_sh_colors: max(SH_deg(rot^T normalize(pos - campos)) + 0.5, 0)  (edittool/__init__.py:442-448)."""
+    lib = _lib.lib()
+    device = pos.device
+    pos, campos, shs = _f(pos), _f(campos), _f(shs)
+    rot = None if rot is None else _f(rot)
+    N, M = shs.shape[0], shs.shape[1]
+    rgb = torch.empty((N, 3), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        _lib.check(lib.gm_sh_colors(N, int(deg), M, pos.data_ptr(), campos.data_ptr(), None if rot is None else rot.data_ptr(),
+                                    shs.data_ptr(), rgb.data_ptr(), torch.cuda.current_stream(device).cuda_stream))
+    return rgb
+
+
+class SingleObjectDeform:
+    """Tensor-in counterpart of edittool.SingleObjectDeform.
+
+    gaussian_pos [N,3], gaussian_cov [N,3,3], gaussian_o [N,1], gaussian_feature [N,16,3],
+    gaussian_triangles int [N,3] (vertex ids of the bound face), weights [N,3] (barycentric, from
+    get_barycentric_coordinate), vertex [Vm,3] rest vertices."""
+
+    def __init__(self, gaussian_pos, gaussian_cov, gaussian_o, gaussian_feature, gaussian_triangles, weights, vertex,
+                 name=None):
+        self.name = name
+        self.gaussian_pos = _f(gaussian_pos)
+        self.gaussian_cov = _f(gaussian_cov)
+        self.gaussian_o = _f(gaussian_o)
+        self.gaussian_feature = _f(gaussian_feature)
+        self.gaussian_triangles = gaussian_triangles.detach().contiguous().to(torch.int32)
+        self.coord = _f(weights)
+        self.weight_g_pos = self.coord.unsqueeze(2)
+        self.weight_g_rs = self.coord.unsqueeze(2).unsqueeze(3)
+        self.vertex = _f(vertex)
+        self.number_gaussian = self.gaussian_pos.shape[0]
+        self.gaussian_deform_pos = self.gaussian_pos
+        self.gaussian_deform_cov = self.gaussian_cov
+        self.gaussian_deform_rot = torch.eye(3, device=self.gaussian_pos.device).expand(self.number_gaussian, 3, 3).contiguous()
+        self.gaussian_deform_cov6 = None
+
+    def get_name(self):
+        return self.name
+
+    def deform(self, deform_vertex, cur_rot, cur_shear):
+        dV = _f(deform_vertex) - self.vertex
+        pos, cov, rot, cov6 = deform_tensors(self.gaussian_triangles, self.coord, dV, cur_rot.reshape(-1, 3, 3),
+                                             cur_shear.reshape(-1, 3, 3), self.gaussian_cov, self.gaussian_pos)
+        self.gaussian_deform_pos, self.gaussian_deform_cov, self.gaussian_deform_rot = pos, cov, rot
+        self.gaussian_deform_cov6 = cov6
+        return pos, cov, rot

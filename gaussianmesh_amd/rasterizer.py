@@ -1,0 +1,200 @@
+"""Operator API of the differentiable Gaussian rasterizer on PyTorch-ROCm tensors.
+
+Mirrors gaussian_renderer/diff_gaussian_rasterizater/__init__.py of the reference:
+  GaussianRasterizationSettings (:6-18), _RasterizeGaussians fwd/bwd (:23-124), GaussianRasterizer (:126-174),
+  NewGaussianRasterizer (:280-328; same op with the SH stride M forced to 16,
+  rasterize_points_deformed.py:157,230).
+Same names, argument order, shapes, dtypes and error behaviour; tensors are torch tensors on a HIP device and
+the work is done by libgmesh_hip.so through its C ABI (include/gmesh_hip.h).  Jittor's nn.Module.execute is
+provided as an alias of forward.
+"""
+import ctypes as C
+from typing import NamedTuple
+
+import torch
+from torch import nn
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _prep(t, device):
+    """contiguous float32 on `device`, or None for an absent / empty optional input."""
+    if t is None or t.numel() == 0:
+        return None
+    if t.device != device:
+        raise ValueError("rasterizer input on %s but means3D on %s" % (t.device, device))
+    return t.detach().contiguous().float()
+
+
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def rasterize_forward(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                      projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug,
+                      force_M=None):
+    """RasterizeGaussiansCUDA of the reference bridge (rasterize_points.py:88-274): returns
+    (num_rendered, color[3,H,W], radii[P], geomBuffer, binningBuffer, imgBuffer)."""
+    lib = _lib.lib()
+    device = means3D.device
+    if device.type != "cuda":
+        raise _lib.GmeshError("gaussianmesh_amd rasterizer needs tensors on a HIP (cuda) device; there is no CPU path")
+    means3D = _prep(means3D, device)
+    P = 0 if means3D is None else means3D.shape[0]
+    sh, colors, scales, rotations, cov3D_precomp = (_prep(t, device) for t in (sh, colors, scales, rotations, cov3D_precomp))
+    opacity = _prep(opacity, device)
+    bg, viewmatrix, projmatrix, campos = (_prep(t, device) for t in (bg, viewmatrix, projmatrix, campos))
+    H, W = int(image_height), int(image_width)
+    M = 0
+    if sh is not None:
+        M = sh.shape[1] if sh.dim() == 3 else sh.numel() // (3 * max(P, 1))
+    if force_M is not None and sh is not None:
+        if M != force_M:
+            raise ValueError("NewGaussianRasterizer expects shs of shape [P,%d,3]" % force_M)
+    stream = _stream(device)
+    with torch.cuda.device(device):
+        color = torch.empty((3, H, W), dtype=torch.float32, device=device)
+        radii = torch.zeros((P,), dtype=torch.int32, device=device)
+        geom = torch.empty((lib.gm_geom_bytes(P),), dtype=torch.uint8, device=device)
+        img = torch.empty((lib.gm_image_bytes(W, H),), dtype=torch.uint8, device=device)
+        R = C.c_int(0)
+        _lib.check(lib.gm_forward_0(_ptr(geom), P, int(degree), M, _ptr(bg), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),
+                                    _ptr(opacity), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),
+                                    _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
+                                    int(bool(prefiltered)), _ptr(radii), int(bool(debug)), stream, C.byref(R)))
+        num_rendered = R.value
+        binning = torch.empty((lib.gm_binning_bytes(num_rendered),), dtype=torch.uint8, device=device)
+        _lib.check(lib.gm_forward_1(_ptr(geom), _ptr(binning), _ptr(img), P, int(degree), M, num_rendered, _ptr(bg), W, H,
+                                    _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales),
+                                    float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
+                                    _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
+                                    int(bool(prefiltered)), _ptr(color), _ptr(radii), int(bool(debug)), stream))
+    return num_rendered, color, radii, geom, binning, img
+
+
+def rasterize_backward(bg, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
+                       tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos, geom, num_rendered, binning, img, debug):
+    """RasterizeGaussiansBackwardCUDA of the reference bridge (rasterize_points.py:276-401): returns
+    (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)."""
+    lib = _lib.lib()
+    device = means3D.device
+    means3D = _prep(means3D, device)
+    P = means3D.shape[0]
+    sh, colors, scales, rotations, cov3D_precomp = (_prep(t, device) for t in (sh, colors, scales, rotations, cov3D_precomp))
+    bg, viewmatrix, projmatrix, campos = (_prep(t, device) for t in (bg, viewmatrix, projmatrix, campos))
+    dpix = _prep(dL_dout_color, device)
+    H, W = dpix.shape[1], dpix.shape[2]
+    M = sh.shape[1] if sh is not None else 0
+    f = dict(dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        dmeans2D = torch.empty((P, 3), **f); dconic = torch.empty((P, 2, 2), **f); dopac = torch.empty((P, 1), **f)
+        dcolors = torch.empty((P, 3), **f); dmeans3D = torch.empty((P, 3), **f); dcov3D = torch.empty((P, 6), **f)
+        dsh = torch.empty((P, M, 3), **f) if sh is not None else None
+        dscales = torch.empty((P, 3), **f) if scales is not None else None
+        drots = torch.empty((P, 4), **f) if scales is not None else None
+        _lib.check(lib.gm_backward(P, int(degree), M, int(num_rendered), _ptr(bg), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),
+                                   _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
+                                   _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), _ptr(radii), _ptr(geom),
+                                   _ptr(binning), _ptr(img), _ptr(dpix), _ptr(dmeans2D), _ptr(dconic), _ptr(dopac),
+                                   _ptr(dcolors), _ptr(dmeans3D), _ptr(dcov3D), _ptr(dsh), _ptr(dscales), _ptr(drots),
+                                   int(bool(debug)), _stream(device)))
+    return dmeans2D, dcolors, dopac, dmeans3D, dcov3D, dsh, dscales, drots
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """rasterize_points.py:39-58 mark_visible -> bool [P]."""
+    lib = _lib.lib()
+    device = means3D.device
+    means3D, viewmatrix, projmatrix = (_prep(t, device) for t in (means3D, viewmatrix, projmatrix))
+    P = 0 if means3D is None else means3D.shape[0]
+    present = torch.zeros((P,), dtype=torch.uint8, device=device)
+    if P:
+        with torch.cuda.device(device):
+            _lib.check(lib.gm_mark_visible(P, _ptr(means3D), _ptr(viewmatrix), _ptr(projmatrix), _ptr(present), _stream(device)))
+    return present.bool()
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+                force_M):
+        rs = raster_settings
+        num_rendered, color, radii, geom, binning, img = rasterize_forward(
+            rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+            rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos,
+            rs.prefiltered, rs.debug, force_M)
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.opacity_shape = opacities.shape
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii):
+        rs = ctx.raster_settings
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
+        g2d, gcol, gop, g3d, gcov, gsh, gsc, grot = rasterize_backward(
+            rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+            rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos, geom, ctx.num_rendered,
+            binning, img, rs.debug)
+        has = lambda t: t is not None and t.numel() > 0
+        return (g3d, g2d, gsh if has(sh) else None, gcol if has(colors_precomp) else None, gop.reshape(ctx.opacity_shape),
+                gsc if has(scales) else None, grot if has(rotations) else None, gcov if has(cov3Ds_precomp) else None,
+                None, None)
+
+
+class GaussianRasterizer(nn.Module):
+    _force_M = None
+
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        with torch.no_grad():
+            rs = self.raster_settings
+            return mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        raster_settings = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        e = lambda: torch.empty(0, device=means3D.device)
+        shs = e() if shs is None else shs
+        colors_precomp = e() if colors_precomp is None else colors_precomp
+        scales = e() if scales is None else scales
+        rotations = e() if rotations is None else rotations
+        cov3D_precomp = e() if cov3D_precomp is None else cov3D_precomp
+        return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                         raster_settings, self._force_M)
+
+    execute = forward      # Jittor spelling used by the reference (nn.Module.execute)
+
+
+class NewGaussianRasterizer(GaussianRasterizer):
+    """Edit-tool variant: identical op, SH stride fixed at 16 coefficients (rasterize_points_deformed.py:157,230)."""
+    _force_M = 16

@@ -1,0 +1,146 @@
+/*
+ * gmesh_hip.h -- C ABI of libgmesh_hip.so: the MI355X (gfx950) implementation of the GaussianMesh
+ * hot path.  Plain pointers and sizes only; every device pointer is a HIP device address, every
+ * call is stream-ordered on `stream` (a hipStream_t passed as void*; NULL = the null stream).
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the reference
+ * repo root; RAST = gaussian_renderer/diff_gaussian_rasterizater/cuda_rasterizer).  The reference
+ * exposes these as C++ static members called from Jittor `jt.code` JIT stubs
+ * (rasterize_points.py:123-190, 197-269, 311-396); INTEGRATION.md shows the stub a maintainer
+ * would write against this header instead.
+ *
+ * Conventions shared by all calls
+ *   - return value: 0 = GM_OK, otherwise a GM_ERR_* code; gm_last_error() gives a thread-local
+ *     human-readable message (replaces the C++ exceptions of RAST/rasterizer_impl.cu:372-375 and
+ *     the CHECK_CUDA macro, RAST/auxiliary.h:165-172).
+ *   - `debug` != 0: synchronise and check for errors after every kernel launch (CHECK_CUDA semantics).
+ *   - ownership: the caller owns every buffer; the library never allocates device memory
+ *     (as in the reference, where python allocates geomBuffer/binningBuffer/imgBuffer,
+ *     rasterize_points.py:118-121, 192-194).  Scratch buffers are opaque; their layout depends only
+ *     on (base address mod 256, P/R/W/H) so the SAME buffers at the SAME addresses must be passed to
+ *     gm_forward_1 and gm_backward after gm_forward_0 (reference: rasterizer_impl.cu:546-548).
+ *   - nullable inputs: shs | colors_precomp (exactly one), (scales,rotations) | cov3D_precomp
+ *     (exactly one), radii (optional output).  NULL means "feature off" for all of them.
+ *   - all float data is IEEE binary32, contiguous, in the layouts of the reference python boundary:
+ *     means3D [P,3], shs [P,M,3], colors_precomp [P,3], opacities [P], scales [P,3],
+ *     rotations [P,4] (r,x,y,z), cov3D_precomp [P,6] (xx,xy,xz,yy,yz,zz),
+ *     viewmatrix/projmatrix 16 floats (the transposed 4x4 of scene/cameras.py:47-49),
+ *     cam_pos 3 floats, background 3 floats, out_color planar [3,H,W].
+ */
+#ifndef GMESH_HIP_H_INCLUDED
+#define GMESH_HIP_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GM_OK 0
+#define GM_ERR_INVALID_ARG 1   /* bad size / null where not allowed / misuse */
+#define GM_ERR_HIP 2           /* a HIP runtime call or kernel failed */
+#define GM_ERR_BUFFER 3        /* a caller-provided buffer is too small */
+
+/* ABI version of this header; bumped on any signature change. */
+#define GM_ABI_VERSION 1
+int gm_abi_version(void);
+const char* gm_last_error(void);
+
+/* Scratch sizes.  Replace CudaRasterizer::required<GeometryState|ImageState|BinningState>(n)
+ * (RAST/rasterizer_impl.h:67-73; python side rasterize_points.py:63-86). */
+size_t gm_geom_bytes(int P);
+size_t gm_image_bytes(int W, int H);
+size_t gm_binning_bytes(int64_t num_rendered);
+
+/* Replaces CudaRasterizer::Rasterizer::forward_0 (RAST/rasterizer.h:31-51, rasterizer_impl.cu:338-413):
+ * per-Gaussian preprocess (cull, cov3D, EWA cov2D, conic, radius, tile rect, SH->RGB) and the
+ * count of (Gaussian, tile) instances.  Performs the ONE host synchronisation of a forward pass
+ * (reference: cudaMemcpy D2H at rasterizer_impl.cu:411) and stores the count in *num_rendered.
+ * radii (int32 [P], may be NULL) receives the screen radius (0 = culled). */
+int gm_forward_0(void* geom_buffer, int P, int D, int M, const float* background, int width, int height,
+                 const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                 const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                 const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                 float tan_fovy, int prefiltered, int* radii, int debug, void* stream, int* num_rendered);
+
+/* Replaces CudaRasterizer::Rasterizer::forward_1 (RAST/rasterizer.h:53-76, rasterizer_impl.cu:416-511):
+ * instance emission, (tile, depth) ordering, tile ranges, front-to-back alpha blend.
+ * binning_buffer must hold gm_binning_bytes(num_rendered), image_buffer gm_image_bytes(W,H). */
+int gm_forward_1(void* geom_buffer, void* binning_buffer, void* image_buffer, int P, int D, int M, int num_rendered,
+                 const float* background, int width, int height, const float* means3D, const float* shs,
+                 const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                 const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color, int* radii,
+                 int debug, void* stream);
+
+/* Replaces CudaRasterizer::Rasterizer::backward (RAST/rasterizer.h:103-132, rasterizer_impl.cu:515-609).
+ * Gradient outputs: dL_dmean2D [P,3] (x,y used), dL_dconic [P,4] (slots 0,1,3 used), dL_dopacity [P],
+ * dL_dcolor [P,3], dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3], dL_dscale [P,3], dL_drot [P,4].
+ * Unlike the reference (which needs them zero-filled by the caller, rasterize_points.py:302-310) the
+ * library zeroes every gradient output itself, so on return they hold exactly this pass's gradients.
+ * dL_dsh may be NULL when shs is NULL; dL_dscale/dL_drot may be NULL when scales is NULL. */
+int gm_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                const float* campos, float tan_fovx, float tan_fovy, const int* radii, void* geom_buffer,
+                void* binning_buffer, void* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
+                float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                float* dL_dscale, float* dL_drot, int debug, void* stream);
+
+/* Replaces CudaRasterizer::Rasterizer::markVisible (RAST/rasterizer.h:24-29, rasterizer_impl.cu:141-153).
+ * present: uint8 [P], 1 if view-space z > 0.2. */
+int gm_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                    void* stream);
+
+/* Read-only views into the opaque scratch buffers (tests / debugging; the reference exposes the
+ * same data as the GeometryState/ImageState/BinningState structs, RAST/rasterizer_impl.h:29-65).
+ * Each returns a device pointer inside the given buffer, or NULL for an unknown name.
+ *   geom:    "splat" float[P][12] = {x,y,conic.x,conic.y | conic.z,opacity,r,g | b,depth,0,0},
+ *            "radii" int32[P] (internal copy), "tiles_touched" uint32[P], "cov3D" float[P][6],
+ *            "clamped" uint8[P] (bit ch set = channel ch clamped), "order" uint32[P] (Gaussian ids by depth)
+ *   image:   "final_T" float[H*W], "n_contrib" uint32[H*W], "ranges" uint32[T][2]
+ *   binning: "point_list" uint32[R], "tile_keys" uint32[R] (sorted tile id per instance) */
+void* gm_geom_field(void* geom_buffer, int P, const char* name);
+void* gm_image_field(void* image_buffer, int W, int H, const char* name);
+void* gm_binning_field(void* binning_buffer, int64_t R, int W, int H, const char* name);
+
+/* Replaces SimpleKNN::knn (scene/simple_knn/cuda_headers/simple_knn.h:18, simple_knn.cu:185-221):
+ * meanDists[i] = mean of the 3 smallest squared distances from point i to the other points.
+ * The reference allocates its temporaries internally (cudaMalloc/thrust); here the caller passes a
+ * workspace of gm_knn_workspace_bytes(P).  Performs one host synchronisation (bounding box readback,
+ * as simple_knn.cu:197,200). */
+size_t gm_knn_workspace_bytes(int P);
+int gm_knn(int P, const float* points, float* meanDists, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Mesh-driven deformation of bound Gaussians; replaces the Jittor tensor algebra of
+ * SingleObjectDeform.deform_gaussian (edittool/__init__.py:116-131), tensor-in form:
+ *   tri int32 [N,3] vertex ids of the bound face, w float [N,3] barycentric weights,
+ *   dV float [Vm,3] = V_deformed - V_rest, Rv / Sv float [Vm,3,3] per-vertex rotation / shear
+ *   (pyACAP GetRS output), cov float [N,3,3] rest covariance, pos float [N,3] rest position.
+ * Outputs: pos_out [N,3], cov_out [N,3,3] (= RS cov RS^T, RS = Rb^T Sb), rot_out [N,3,3] (= Rb^T).
+ * cov6_out (may be NULL): float [N,6] strip_symmetric(cov_out) ready for cov3D_precomp
+ * (edittool/general_utils.py:26-37). */
+int gm_deform(int N, const int* tri, const float* w, const float* dV, const float* Rv, const float* Sv,
+              const float* cov, const float* pos, float* pos_out, float* cov_out, float* rot_out, float* cov6_out,
+              void* stream);
+
+/* View-dependent colour of deformed Gaussians; replaces edittool/__init__.py:442-448:
+ *   dir = normalize(pos - campos); dir_rot = rot^T dir; rgb = max(SH_deg(dir_rot) + 0.5, 0).
+ * rot may be NULL (identity: the train-time convert_SHs_python path, gaussian_renderer/__init__.py:84-89). */
+int gm_sh_colors(int N, int deg, int M, const float* pos, const float* campos, const float* rot, const float* shs,
+                 float* rgb, void* stream);
+
+/* Per-stage GPU timing (HIP events recorded on `stream` around each kernel group).  Off by default.
+ * gm_profile_enable(1) starts collecting, gm_profile_read synchronises the recorded events and returns
+ * accumulated milliseconds and launch count for a stage name ("preprocess","depth_sort","scan",
+ * "duplicate","tile_sort","ranges","render","render_bwd","preprocess_bwd","deform","sh_colors");
+ * gm_profile_reset clears the accumulators. */
+void gm_profile_enable(int on);
+void gm_profile_reset(void);
+int gm_profile_read(const char* stage, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,68 @@
+"""Helpers for the -m gpu tests: run the HIP path through the python operator API / C ABI and expose the
+opaque scratch state as numpy arrays (via gm_*_field)."""
+import numpy as np
+import torch
+
+from gaussianmesh_amd import _lib
+from gaussianmesh_amd import rasterizer as R
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def T(a, rg=False, dtype=torch.float32):
+    t = torch.tensor(np.asarray(a), dtype=dtype, device=dev())
+    if rg:
+        t.requires_grad_(True)
+    return t
+
+
+def settings(cam, bg, D, mod=1.0, debug=False):
+    return R.GaussianRasterizationSettings(
+        image_height=cam["H"], image_width=cam["W"], tanfovx=cam["tanx"], tanfovy=cam["tany"], bg=T(bg),
+        scale_modifier=mod, viewmatrix=T(cam["view"]), projmatrix=T(cam["proj"]), sh_degree=D, campos=T(cam["campos"]),
+        prefiltered=False, debug=debug)
+
+
+def _view(buf, ptr, count, dtype):
+    off = ptr - buf.data_ptr()
+    nbytes = count * torch.tensor([], dtype=dtype).element_size()
+    return buf[off:off + nbytes].view(dtype).cpu().numpy()
+
+
+def forward_state(scene, cam, bg, D=3, use_precomp_cov=False, use_precomp_color=False, mod=1.0, debug=False):
+    """Low-level forward returning colour + every intermediate the oracle also exposes."""
+    lib = _lib.lib()
+    P = scene["means"].shape[0]
+    W, H = cam["W"], cam["H"]
+    sh = None if use_precomp_color else T(scene["shs"])
+    col = T(scene["colors_precomp"]) if use_precomp_color else None
+    sc = None if use_precomp_cov else T(scene["scales"])
+    rot = None if use_precomp_cov else T(scene["rots"])
+    cov = T(scene["cov3D_precomp"]) if use_precomp_cov else None
+    nr, color, radii, geom, binning, img = R.rasterize_forward(
+        T(bg), T(scene["means"]), col, T(scene["opac"]), sc, rot, mod, cov, T(cam["view"]), T(cam["proj"]), cam["tanx"],
+        cam["tany"], H, W, sh, D, T(cam["campos"]), False, debug)
+    torch.cuda.synchronize()
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    out = dict(R=nr, color=color.cpu().numpy(), radii=radii.cpu().numpy(), geom=geom, binning=binning, img=img)
+    if P > 0:
+        gp = lambda n: lib.gm_geom_field(geom.data_ptr(), P, n.encode())
+        out["splat"] = _view(geom, gp("splat"), P * 12, torch.float32).reshape(P, 12)
+        out["tiles"] = _view(geom, gp("tiles_touched"), P, torch.int32).astype(np.uint32)
+        out["cov3D"] = _view(geom, gp("cov3D"), P * 6, torch.float32).reshape(P, 6)
+        out["clamped"] = _view(geom, gp("clamped"), P, torch.uint8)
+        out["order"] = _view(geom, gp("order"), P, torch.int32).astype(np.uint32)
+    ip = lambda n: lib.gm_image_field(img.data_ptr(), W, H, n.encode())
+    out["final_T"] = _view(img, ip("final_T"), W * H, torch.float32)
+    out["n_contrib"] = _view(img, ip("n_contrib"), W * H, torch.int32).astype(np.uint32)
+    out["ranges"] = _view(img, ip("ranges"), tiles * 2, torch.int32).astype(np.uint32).reshape(tiles, 2)
+    if nr > 0:
+        bp = lambda n: lib.gm_binning_field(binning.data_ptr(), nr, W, H, n.encode())
+        out["point_list"] = _view(binning, bp("point_list"), nr, torch.int32).astype(np.uint32)
+        out["tile_keys"] = _view(binning, bp("tile_keys"), nr, torch.int32).astype(np.uint32)
+    else:
+        out["point_list"] = np.zeros(0, np.uint32)
+        out["tile_keys"] = np.zeros(0, np.uint32)
+    return out
