@@ -40,13 +40,13 @@ StageScope::StageScope(Stage st_, hipStream_t s_) : st(st_), s(s_), rec(nullptr)
   EvPair* p = new EvPair;
   p->st = st;
   if (hipEventCreate(&p->a) != hipSuccess || hipEventCreate(&p->b) != hipSuccess) { delete p; return; }
-  hipEventRecord(p->a, s);
+  (void)hipEventRecord(p->a, s);
   rec = p;
 }
 StageScope::~StageScope() {
   if (!rec) return;
   EvPair* p = reinterpret_cast<EvPair*>(rec);
-  hipEventRecord(p->b, s);
+  (void)hipEventRecord(p->b, s);
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_pending.push_back(*p);
   delete p;
@@ -59,14 +59,15 @@ static void drain_profile() {
       g_ms[p.st] += ms;
       g_n[p.st] += 1;
     }
-    hipEventDestroy(p.a);
-    hipEventDestroy(p.b);
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
   }
   g_pending.clear();
 }
 
 static int check_raster_args(const RasterArgs& a) {
   if (a.P < 0 || a.W <= 0 || a.H <= 0) { set_error("invalid sizes P=%d W=%d H=%d", a.P, a.W, a.H); return GM_ERR_INVALID_ARG; }
+  if (a.P == 0) return 0;                       // empty cloud: every per-Gaussian pointer may be null
   if ((a.shs == nullptr) == (a.colors_precomp == nullptr)) {
     set_error("provide exactly one of shs / colors_precomp"); return GM_ERR_INVALID_ARG;
   }

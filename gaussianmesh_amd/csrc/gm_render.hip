@@ -142,7 +142,7 @@ static int env_int(const char* name, int dflt) {
 int launch_render_fwd(const GeomState& g, const uint32_t* point_list, ImageState& img, int W, int H,
                       const float* background, float* out_color, int debug, hipStream_t s) {
   StageScope sc(ST_RENDER, s);
-  static const int ppl = env_int("GM_RENDER_PPL", 2);
+  const int ppl = env_int("GM_RENDER_PPL", 2);          // tuning knob, read per launch
   const int gx = (W + GM_TILE - 1) / GM_TILE, gy = (H + GM_TILE - 1) / GM_TILE;
   const int tiles = gx * gy;
   if (tiles > 0) {
@@ -305,7 +305,7 @@ int launch_render_bwd(const GeomState& g, const uint32_t* point_list, ImageState
                       const float* background, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
                       float* dL_dopacity, float* dL_dcolor, int debug, hipStream_t s) {
   StageScope sc(ST_RENDER_BWD, s);
-  static const int ppl = env_int("GM_RENDER_BWD_PPL", 4);
+  const int ppl = env_int("GM_RENDER_BWD_PPL", 4);      // tuning knob, read per launch
   const int gx = (W + GM_TILE - 1) / GM_TILE, gy = (H + GM_TILE - 1) / GM_TILE;
   const int tiles = gx * gy;
   if (tiles > 0) {

@@ -73,6 +73,7 @@ def test_forward_medium_ragged(oracle, ppl, monkeypatch):
     """C1-like case (10k Gaussians) at a size that is not a multiple of the tile, long lists (multi-batch)."""
     from gpu_utils import forward_state
     from gaussianmesh_amd import scenes
+    monkeypatch.setenv("GM_RENDER_PPL", ppl)          # pixels per lane of the blend kernel (1, 2 or 4 waves' worth)
     sc = scenes.make_cloud(10000, seed=0, scale_lo=0.02, scale_hi=0.25)
     cam = scenes.orbit_camera(2, 9, 250, 130, radius=7.0)
     bg = np.array([1, 1, 1], np.float32)
@@ -110,6 +111,12 @@ def _grads_gpu(sc, cam, bg, dpix, D, use_precomp_cov, use_precomp_color, mod=1.0
 def _rel(a, b):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.mark.parametrize("bwd_ppl", ["1", "2", "4"])
+def test_backward_ppl_variants(oracle, bwd_ppl, monkeypatch):
+    monkeypatch.setenv("GM_RENDER_BWD_PPL", bwd_ppl)
+    test_backward_medium(oracle)
 
 
 @pytest.mark.parametrize("use_precomp_cov,use_precomp_color", MODES)
