@@ -1,0 +1,256 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the GaussianMesh hot path on MI355X.
+
+Workload (BASELINE.json configs[2] = "C3", the configuration the metric is quoted on: 1 M Gaussians @ 1080p):
+1 M Gaussians bound to a 15k-face torus proxy mesh; one STEP = one frame of the edit-tool loop
+(edittool/__init__.py:103-131, 400-475 of the reference):
+    deform (gm_deform: mesh state (V1,R,S) of frame t -> x', Sigma', rot)
+  + view-dependent colour (gm_sh_colors: rotated direction, SH degree 3)
+  + rasterize forward (gm_forward_0/1 with colors_precomp + cov3D_precomp) at 1920x1080.
+All inputs are resident in HBM before the timed region.  With --gpus N every rank renders its own camera of
+the 64-camera orbit (views shard); rank 0 owns the mesh animation and broadcasts the per-frame
+mesh state (0.63 MB) over RCCL, the static cloud is broadcast once before timing.  value = frames of all ranks
+per second (weak scaling).
+
+One JSON line on stdout (rank 0).  Extra objects: "roofline" (dominant kernel, HIP-event timing from
+gm_profile_*), "cpu_baseline" (oracle port on the host cores, N=1 only), "fwd_bwd" (ms/iter of forward +
+backward on the same cloud through the autograd operator, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s measured achievable
+
+STAGES = ["deform", "sh_colors", "preprocess", "depth_sort", "scan", "duplicate", "tile_sort", "ranges", "render"]
+
+
+def build_scene(P, W, H, frames, seed=0):
+    from gaussianmesh_amd import scenes
+    verts, faces = scenes.torus_mesh(100, 75)
+    cl = scenes.bind_cloud_to_mesh(P, verts, faces, seed=seed)
+    cov = scenes.cov3d_from_scale_rot(cl["scales"], cl["rots"]).astype(np.float32)
+    mesh = np.zeros((frames, verts.shape[0], 21), np.float32)
+    for t in range(frames):
+        V1, Rv, Sv = scenes.twist_bend_frame(verts, t, period=frames)
+        mesh[t, :, 0:3] = V1
+        mesh[t, :, 3:12] = Rv.reshape(-1, 9)
+        mesh[t, :, 12:21] = Sv.reshape(-1, 9)
+    return dict(verts=verts.astype(np.float32), tri=cl["tri"], weights=cl["weights"], pos=cl["means"], cov=cov,
+                opac=cl["opac"], shs=cl["shs"], scales=cl["scales"], rots=cl["rots"], mesh=mesh)
+
+
+def algorithmic_bytes(stage, P, V, R, W, H, Vm, M=16):
+    """SURVEY.md 8(d) per-unit figures, split per stage (precomputed colour/cov input mode)."""
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    bits = max(1, int(np.ceil(np.log2(max(T, 2)))))
+    return {
+        "deform": P * (12 + 12 + 36 + 12) + P * (36 + 12 + 36 + 24) + Vm * 84,
+        "sh_colors": P * (12 + 36 + 12 * M) + P * 12,
+        "preprocess": P * (12 + 24 + 4 + 12) + V * 48,
+        "scan": P * 8,
+        "depth_sort": P * (4 + 16 * 4),                 # 4-byte key histogram read + 4 passes x (8 B in + 8 B out)
+        "duplicate": V * 20 + R * 8,
+        "tile_sort": R * (4 + 16 * ((bits + 7) // 8)),
+        "ranges": R * 4 + T * 8,
+        "render": R * 40 + W * H * 12,
+    }[stage]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--cameras", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fwd-bwd", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from gaussianmesh_amd import _lib, scenes
+    from gaussianmesh_amd import rasterizer as Rz
+    from gaussianmesh_amd.deform import deform_tensors, sh_colors
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    lib = _lib.lib()
+
+    P, W, H, F = args.gaussians, args.width, args.height, args.cameras
+    # ---- scene: rank 0 generates, everyone else receives it over RCCL (one-time broadcast of the shared cloud)
+    shapes = dict(tri=((P, 3), torch.int32), weights=((P, 3), torch.float32), pos=((P, 3), torch.float32),
+                  cov=((P, 3, 3), torch.float32), opac=((P, 1), torch.float32), shs=((P, 16, 3), torch.float32),
+                  scales=((P, 3), torch.float32), rots=((P, 4), torch.float32), verts=((7500, 3), torch.float32),
+                  mesh=((F, 7500, 21), torch.float32))
+    g = {}
+    if rank == 0:
+        host = build_scene(P, W, H, F)
+        for k, (shp, dt) in shapes.items():
+            g[k] = torch.tensor(host[k], dtype=dt, device=dev).reshape(shp).contiguous()
+    else:
+        for k, (shp, dt) in shapes.items():
+            g[k] = torch.empty(shp, dtype=dt, device=dev)
+    if world > 1:
+        for k in shapes:
+            if k != "mesh":                      # the animation stays on rank 0; frames are broadcast one at a time
+                dist.broadcast(g[k], src=0)
+    Vm = g["verts"].shape[0]
+    cams = [scenes.orbit_camera(k, F, W, H) for k in range(F)]
+    cam_t = [dict(view=torch.tensor(c["view"], device=dev), proj=torch.tensor(c["proj"], device=dev),
+                  campos=torch.tensor(c["campos"], device=dev), tanx=c["tanx"], tany=c["tany"]) for c in cams]
+    bg = torch.ones(3, device=dev)              # edit tool renders on white (edittool/__init__.py:410)
+    frame_buf = torch.empty((Vm, 21), dtype=torch.float32, device=dev)
+    stats = {}
+
+    def step(i):
+        t = i % F
+        if world > 1:                            # real exchange step: mesh state of frame t from rank 0
+            if rank == 0:
+                frame_buf.copy_(g["mesh"][t])
+            dist.broadcast(frame_buf, src=0)
+            ms = frame_buf
+        else:
+            ms = g["mesh"][t]
+        V1 = ms[:, 0:3].contiguous(); Rv = ms[:, 3:12].contiguous(); Sv = ms[:, 12:21].contiguous()
+        dV = V1 - g["verts"]
+        pos, cov, rot, cov6 = deform_tensors(g["tri"], g["weights"], dV, Rv, Sv, g["cov"], g["pos"])
+        c = cam_t[(rank * (F // max(world, 1)) + i) % F]
+        rgb = sh_colors(pos, c["campos"], g["shs"], rot=rot, deg=3)
+        nr, color, radii, _, _, _ = Rz.rasterize_forward(bg, pos, rgb, g["opac"], None, None, 1.0, cov6, c["view"], c["proj"],
+                                                         c["tanx"], c["tany"], H, W, None, 3, c["campos"], False, False)
+        stats["R"] = nr
+        stats["radii"] = radii
+        return color
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    fps = world * args.steps / elapsed
+
+    out = {
+        "metric": "frames/sec (fwd), 1M Gaussians @1080p, deform+render", "value": fps, "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C3: %d Gaussians bound to 15k-face torus, per-frame mesh deform + SH colour + forward "
+                               "render %dx%d, %d-camera orbit, views sharded by rank" % (P, W, H, F),
+                   "gaussians": P, "width": W, "height": H, "sh_degree": 3, "views_per_step_per_gpu": 1,
+                   "parallelism": "views x%d" % world},
+    }
+
+    if rank == 0:
+        # ---- per-stage HIP-event timing over a second pass of the same steps (events perturb the pipelining a
+        # little, so they are kept out of the region that defines `value`)
+        lib.gm_profile_reset(); lib.gm_profile_enable(1)
+        nprof = min(args.steps, 50)
+        for i in range(nprof):
+            step(args.warmup + i)
+        torch.cuda.synchronize()
+        lib.gm_profile_enable(0)
+        import ctypes as C
+        Rn = int(stats["R"]); V = int((stats["radii"] > 0).sum().item())
+        per = {}
+        for s in STAGES:
+            ms = C.c_double(0); n = C.c_int64(0)
+            lib.gm_profile_read(s.encode(), C.byref(ms), C.byref(n))
+            if n.value:
+                per[s] = ms.value / n.value
+        dom = max(per, key=per.get)
+        ab = algorithmic_bytes(dom, P, V, Rn, W, H, Vm)
+        ach = ab / (per[dom] * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": ab, "avg_ms": per[dom]}
+        out["stage_ms"] = {k: round(v, 4) for k, v in per.items()}
+        out["scene"] = {"P": P, "V": V, "R": Rn}
+        tot_bytes = sum(algorithmic_bytes(s, P, V, Rn, W, H, Vm) for s in per)
+        out["frame_roofline"] = {"algorithmic_bytes": tot_bytes, "achieved": tot_bytes / (elapsed / args.steps) / 1e9,
+                                 "frac": tot_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s"}
+
+    if rank == 0 and world == 1 and not args.no_fwd_bwd:
+        # ---- forward + backward through the autograd operator (train-time input mode: SH + scale/rot)
+        from gaussianmesh_amd import GaussianRasterizer, GaussianRasterizationSettings
+        c = cam_t[0]
+        rs = GaussianRasterizationSettings(H, W, c["tanx"], c["tany"], torch.zeros(3, device=dev), 1.0, c["view"], c["proj"], 3,
+                                           c["campos"], False, False)
+        leaves = [g[k].clone().requires_grad_(True) for k in ("pos", "opac", "shs", "scales", "rots")]
+        m2d = torch.zeros_like(leaves[0], requires_grad=True)
+        wgt = torch.randn((3, H, W), device=dev)
+        rast = GaussianRasterizer(rs)
+
+        def it():
+            for l in leaves + [m2d]:
+                l.grad = None
+            color, _ = rast(leaves[0], m2d, leaves[1], shs=leaves[2], scales=leaves[3], rotations=leaves[4])
+            (color * wgt).sum().backward()
+        for _ in range(3):
+            it()
+        torch.cuda.synchronize()
+        nit = 20
+        t1 = time.perf_counter()
+        for _ in range(nit):
+            it()
+        torch.cuda.synchronize()
+        out["fwd_bwd"] = {"ms_per_iter": 1e3 * (time.perf_counter() - t1) / nit, "iters": nit,
+                          "config": "%d Gaussians, %dx%d, SH3 + scale/rot inputs, loss = sum(w*image)" % (P, W, H)}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # ---- CPU baseline: the oracle port (plain C + OpenMP) on the host cores, bounded sample of the same workload
+        from oracle import oracle as orc
+        nfr = 2
+        hp = {k: g[k].cpu().numpy() for k in ("tri", "weights", "pos", "cov", "opac", "shs", "verts")}
+        mesh0 = g["mesh"][:nfr].cpu().numpy()
+        tc = time.perf_counter()
+        for t in range(nfr):
+            ms = mesh0[t]
+            dV = ms[:, 0:3] - hp["verts"]
+            p2, c2, r2 = orc.deform(hp["tri"], hp["weights"], dV, ms[:, 3:12].reshape(-1, 3, 3), ms[:, 12:21].reshape(-1, 3, 3),
+                                    hp["cov"], hp["pos"])
+            rgb = orc.sh_colors_rotated(p2, cams[t]["campos"], r2, hp["shs"], deg=3)
+            sc = dict(means=p2, opac=hp["opac"], colors_precomp=rgb, cov3D_precomp=scenes.strip_symmetric(c2))
+            orc.forward_fast(sc, cams[t], np.ones(3, np.float32), D=3, use_precomp_cov=True, use_precomp_color=True)
+        cpu_s = time.perf_counter() - tc
+        out["cpu_baseline"] = {"value": nfr / cpu_s, "unit": "frames/s", "cores": orc.num_threads(), "kind": "port",
+                               "sample": "%d frames of the same C3 workload (deform + SH colour + forward) through "
+                                         "oracle/libgm_oracle.so with OpenMP" % nfr}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
