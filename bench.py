@@ -121,6 +121,7 @@ def main():
     bg = torch.ones(3, device=dev)              # edit tool renders on white (edittool/__init__.py:410)
     frame_buf = torch.empty((Vm, 21), dtype=torch.float32, device=dev)
     stats = {}
+    workspace = Rz.RasterWorkspace()
 
     def step(i):
         t = i % F
@@ -137,7 +138,8 @@ def main():
         c = cam_t[(rank * (F // max(world, 1)) + i) % F]
         rgb = sh_colors(pos, c["campos"], g["shs"], rot=rot, deg=3)
         nr, color, radii, _, _, _ = Rz.rasterize_forward(bg, pos, rgb, g["opac"], None, None, 1.0, cov6, c["view"], c["proj"],
-                                                         c["tanx"], c["tany"], H, W, None, 3, c["campos"], False, False)
+                                                         c["tanx"], c["tany"], H, W, None, 3, c["campos"], False, False,
+                                                         workspace=workspace)
         stats["R"] = nr
         stats["radii"] = radii
         return color

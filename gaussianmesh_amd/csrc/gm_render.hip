@@ -13,6 +13,12 @@
 //     the current batch's arithmetic;
 //   * entry j is broadcast to all lanes with v_readlane_b32 into SGPRs (the entry is wave-uniform),
 //     so the inner loop has no LDS traffic, no s_barrier and no per-pixel global colour read;
+//   * while lane j holds entry j it also tests, once per batch and for all 64 entries in parallel, whether
+//     the entry can reach alpha >= 1/255 anywhere inside the wave's pixel rectangle (exact minimum of the
+//     conic's quadratic form over the rectangle, with a rounding margin).  A 64-bit ballot of the survivors
+//     drives the inner loop (s_ff1 over set bits), so entries whose rect merely covers the tile cost ~1 VALU
+//     op instead of ~20 per pixel.  The cull is conservative: a culled entry would have been skipped by every
+//     pixel of the wave (alpha < 1/255), so results and n_contrib are unchanged.
 //   * "is every pixel done" is a wave vote (__all) instead of __syncthreads_count; an entry that no
 //     pixel of the wave accepts is skipped with one __any.
 // Discrete semantics are the reference's: skip power>0, skip alpha<1/255, stop (without applying the
@@ -50,6 +56,41 @@ __device__ __forceinline__ Batch load_batch(const uint32_t* __restrict__ list, c
   return t;
 }
 
+
+// Can entry (centre sx,sy; conic a,b,c; opacity op) reach alpha >= 1/255 at any pixel centre of the rectangle
+// [x0,x1] x [y0,y1]?  alpha >= 1/255  <=>  q(d) = a dx^2 + 2 b dx dy + c dy^2 <= 2 ln(255 op), d = centre - pixel.
+// q is a positive-definite form, so its minimum over the rectangle is 0 if the centre is inside and otherwise
+// lies on one of the four edges (1-D clamped minimum per edge).  The margin covers float rounding of both this
+// test and the per-pixel evaluation (proportional to the magnitude of the cancelling terms).
+__device__ __forceinline__ bool may_touch(float sx, float sy, float a, float b, float c, float op,
+                                          float x0, float x1, float y0, float y1) {
+  if (!(op >= 0.0039f)) return false;                 // op < 1/255 (1/255 = 0.0039216): alpha = op*G < 1/255 everywhere
+  const float dxl = sx - x1, dxh = sx - x0, dyl = sy - y1, dyh = sy - y0;
+  const float thr = 1.3862943611f * __builtin_amdgcn_logf(255.0f * op);   // 2 ln(255 op) = 2 ln2 log2(255 op)
+  const float mx = fmaxf(fabsf(dxl), fabsf(dxh)), my = fmaxf(fabsf(dyl), fabsf(dyh));
+  const float margin = 4e-6f * (a * mx * mx + c * my * my + 2.0f * fabsf(b) * mx * my) + 1e-3f;
+  if (dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f) return true;   // centre inside: q_min = 0 <= thr (op >= 1/255)
+  const float nb_c = -b * __builtin_amdgcn_rcpf(c), nb_a = -b * __builtin_amdgcn_rcpf(a);
+  float qmin;
+  {
+    const float y = fminf(fmaxf(nb_c * dxl, dyl), dyh);
+    qmin = a * dxl * dxl + 2.f * b * dxl * y + c * y * y;
+  }
+  {
+    const float y = fminf(fmaxf(nb_c * dxh, dyl), dyh);
+    qmin = fminf(qmin, a * dxh * dxh + 2.f * b * dxh * y + c * y * y);
+  }
+  {
+    const float x = fminf(fmaxf(nb_a * dyl, dxl), dxh);
+    qmin = fminf(qmin, a * x * x + 2.f * b * x * dyl + c * dyl * dyl);
+  }
+  {
+    const float x = fminf(fmaxf(nb_a * dyh, dxl), dxh);
+    qmin = fminf(qmin, a * x * x + 2.f * b * x * dyh + c * dyh * dyh);
+  }
+  return !(qmin > thr + margin);                       // NaN-safe: keep the entry unless it is provably out of reach
+}
+
 template <int PPL>
 __global__ __launch_bounds__(256 / PPL) void render_fwd_kernel(const uint2* __restrict__ ranges,
                                                                const uint32_t* __restrict__ point_list,
@@ -77,6 +118,10 @@ __global__ __launch_bounds__(256 / PPL) void render_fwd_kernel(const uint2* __re
     done[k] = !(px < W && py[k] < H);
   }
 
+  // pixel-centre rectangle owned by this wave
+  const float rx0 = (float)(tx * GM_TILE), rx1 = rx0 + (float)(GM_TILE - 1);
+  const float ry0 = (float)(ty * GM_TILE + wave * PPL * 4), ry1 = ry0 + (float)(PPL * 4 - 1);
+
   Batch cur = load_batch(list, splat, lane, n);
   for (int base = 0; base < n; base += 64) {
     bool all_done = true;
@@ -84,8 +129,11 @@ __global__ __launch_bounds__(256 / PPL) void render_fwd_kernel(const uint2* __re
     for (int k = 0; k < PPL; k++) all_done = all_done && done[k];
     if (__all(all_done)) break;
     const Batch nxt = load_batch(list, splat, base + 64 + lane, n);   // prefetch (all-zero past the end)
-    const int cnt = min(64, n - base);
-    for (int j = 0; j < cnt; j++) {
+    const bool keep = (base + lane < n) && may_touch(cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, rx0, rx1, ry0, ry1);
+    unsigned long long todo = __ballot(keep);
+    while (todo) {
+      const int j = __ffsll(todo) - 1;
+      todo &= todo - 1;
       const float sx = bcast(cur.a.x, j), sy = bcast(cur.a.y, j);
       const float cx = bcast(cur.a.z, j), cy = bcast(cur.a.w, j), cz = bcast(cur.b.x, j);
       const float op = bcast(cur.b.y, j);
@@ -142,21 +190,21 @@ static int env_int(const char* name, int dflt) {
 int launch_render_fwd(const GeomState& g, const uint32_t* point_list, ImageState& img, int W, int H,
                       const float* background, float* out_color, int debug, hipStream_t s) {
   StageScope sc(ST_RENDER, s);
-  const int ppl = env_int("GM_RENDER_PPL", 2);          // tuning knob, read per launch
+  const int ppl = env_int("GM_RENDER_PPL", 1);          // tuning knob, read per launch
   const int gx = (W + GM_TILE - 1) / GM_TILE, gy = (H + GM_TILE - 1) / GM_TILE;
   const int tiles = gx * gy;
   if (tiles > 0) {
     switch (ppl) {
-      case 1:
-        hipLaunchKernelGGL(render_fwd_kernel<1>, dim3(tiles), dim3(256), 0, s, img.ranges, point_list, g.splat, W, H, gx,
-                           background, out_color, img.final_T, img.n_contrib);
-        break;
       case 4:
         hipLaunchKernelGGL(render_fwd_kernel<4>, dim3(tiles), dim3(64), 0, s, img.ranges, point_list, g.splat, W, H, gx,
                            background, out_color, img.final_T, img.n_contrib);
         break;
-      default:
+      case 2:
         hipLaunchKernelGGL(render_fwd_kernel<2>, dim3(tiles), dim3(128), 0, s, img.ranges, point_list, g.splat, W, H, gx,
+                           background, out_color, img.final_T, img.n_contrib);
+        break;
+      default:
+        hipLaunchKernelGGL(render_fwd_kernel<1>, dim3(tiles), dim3(256), 0, s, img.ranges, point_list, g.splat, W, H, gx,
                            background, out_color, img.final_T, img.n_contrib);
     }
   }
@@ -228,12 +276,17 @@ __global__ __launch_bounds__(256 / PPL) void render_bwd_kernel(const uint2* __re
   for (int d = 32; d >= 1; d >>= 1) max_last = max(max_last, __shfl_xor(max_last, d));
   const int start = max_last;           // number of list entries this wave has to visit (positions start-1 .. 0)
 
+  const float rx0 = (float)(tx * GM_TILE), rx1 = rx0 + (float)(GM_TILE - 1);
+  const float ry0 = (float)(ty * GM_TILE + wave * PPL * 4), ry1 = ry0 + (float)(PPL * 4 - 1);
   // batch b covers list positions start-1-b*64-j (j = lane), i.e. back to front
   Batch cur = load_batch(list, splat, start - 1 - lane, n);
   for (int base = 0; base < start; base += 64) {
     const Batch nxt = load_batch(list, splat, start - 1 - (base + 64) - lane, n);
-    const int cnt = min(64, start - base);
-    for (int j = 0; j < cnt; j++) {
+    const bool keep = (base + lane < start) && may_touch(cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, rx0, rx1, ry0, ry1);
+    unsigned long long todo = __ballot(keep);
+    while (todo) {
+      const int j = __ffsll(todo) - 1;
+      todo &= todo - 1;
       const int pos = start - 1 - base - j;          // 0-based list position == reference `contributor`
       const float sx = bcast(cur.a.x, j), sy = bcast(cur.a.y, j);
       const float cx = bcast(cur.a.z, j), cy = bcast(cur.a.w, j), cz = bcast(cur.b.x, j);

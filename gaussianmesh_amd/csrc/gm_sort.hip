@@ -15,8 +15,10 @@
 //   K1 radix_hist     : workgroup b counts the 256 digit values of its 4096 keys -> hist[digit][b]
 //   K2 radix_scan     : workgroup d exclusive-scans row d of hist in place, writes digit_total[d]
 //   K3 radix_scatter  : workgroup b re-reads its keys, ranks them stably (per-wave match-any with
-//                       64-bit ballots + per-wave digit counters in LDS), and writes key/value to
-//                       exclusive_scan(digit_total)[d] + hist[d][b] + rank.
+//                       64-bit ballots + per-wave digit counters in LDS), sorts the tile by digit inside
+//                       LDS, and streams it out: digit d's run goes to
+//                       exclusive_scan(digit_total)[d] + hist[d][b] + (position in run), so global stores
+//                       are contiguous runs rather than per-lane scatters.
 // A workgroup is 256 threads = 4 waves; wave w owns the contiguous 1024-key slice w of the tile and
 // walks it in 16 rounds of 64 consecutive keys (lane l <-> key round*64+l), so loads are fully
 // coalesced and rank order == index order (stability).
@@ -85,6 +87,10 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const uint32_
                                                                     uint32_t nblk, const uint32_t* __restrict__ digit_total) {
   __shared__ uint32_t wcnt[RS_WAVES][256];   // per-wave running digit counts -> per-wave exclusive offsets
   __shared__ uint32_t gbase[256];            // global base of each digit for this workgroup
+  __shared__ uint32_t dstart[256];           // start of each digit's run inside the locally sorted tile
+  __shared__ uint32_t wsum2[RS_WAVES];
+  __shared__ uint32_t lkey[GM_SORT_ITEMS];   // locally sorted tile (32 KiB with lval)
+  __shared__ uint32_t lval[GM_SORT_ITEMS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
@@ -135,8 +141,10 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const uint32_
     }
     old = __shfl(old, leader < 0 ? 0 : leader);
     rank[r] = old + before;
+    __builtin_amdgcn_wave_barrier();         // keep the per-wave LDS counter updates of successive rounds in order
   }
   __syncthreads();
+  uint32_t dcount;
   {  // turn per-wave counts into per-wave exclusive offsets (thread d handles digit d)
     uint32_t run = 0;
 #pragma unroll
@@ -145,16 +153,46 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const uint32_
       wcnt[w][threadIdx.x] = run;
       run += c;
     }
+    dcount = run;                               // keys of this workgroup with digit == threadIdx.x
+  }
+  {  // dstart[d] = exclusive scan of dcount over digits: position of digit d's run inside the sorted tile
+    uint32_t incl = dcount;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) wsum2[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+#pragma unroll
+    for (int w = 0; w < RS_WAVES; w++) woff += (w < wave) ? wsum2[w] : 0;
+    dstart[threadIdx.x] = woff + incl - dcount;
   }
   __syncthreads();
+  // local scatter into LDS: the tile becomes sorted by digit (stable), so the global stores below are
+  // contiguous runs (one run per digit) instead of 64 unrelated 4-byte writes per wave instruction
 #pragma unroll
   for (int r = 0; r < RS_ROUNDS; r++) {
     const uint32_t idx = wbase + r * 64 + lane;
     if (idx < n) {
       const uint32_t d = (key[r] >> shift) & mask;
-      const uint32_t dst = gbase[d] + wcnt[wave][d] + rank[r];
-      keys_out[dst] = key[r];
-      vals_out[dst] = IOTA ? idx : vals_in[idx];
+      const uint32_t lp = dstart[d] + wcnt[wave][d] + rank[r];
+      lkey[lp] = key[r];
+      lval[lp] = IOTA ? idx : vals_in[idx];
+    }
+  }
+  __syncthreads();
+  const uint32_t tile_n = min((uint32_t)GM_SORT_ITEMS, n - blockIdx.x * GM_SORT_ITEMS);
+#pragma unroll
+  for (int i = 0; i < GM_SORT_ITEMS / RS_THREADS; i++) {
+    const uint32_t lp = i * RS_THREADS + threadIdx.x;
+    if (lp < tile_n) {
+      const uint32_t k = lkey[lp];
+      const uint32_t d = (k >> shift) & mask;
+      const uint32_t dst = gbase[d] + (lp - dstart[d]);
+      keys_out[dst] = k;
+      vals_out[dst] = lval[lp];
     }
   }
 }

@@ -49,9 +49,27 @@ def _stream(device):
     return torch.cuda.current_stream(device).cuda_stream
 
 
+class RasterWorkspace:
+    """Caller-owned scratch (geometry / image / binning byte buffers) that is reused across forward calls and
+    grows geometrically, so a render loop performs no device allocation in steady state (the reference allocates
+    and zero-fills all three buffers on every call, rasterize_points.py:118-121, 192-194).  Only valid while no
+    backward pass still needs the buffers: the autograd operator uses a fresh set whenever a gradient is required."""
+
+    def __init__(self, growth=1.25):
+        self.growth = growth
+        self._bufs = {}
+
+    def get(self, name, nbytes, device):
+        b = self._bufs.get(name)
+        if b is None or b.device != device or b.numel() < nbytes:
+            b = torch.empty((int(nbytes * self.growth) + 256,), dtype=torch.uint8, device=device)
+            self._bufs[name] = b
+        return b
+
+
 def rasterize_forward(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                       projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug,
-                      force_M=None):
+                      force_M=None, workspace=None):
     """RasterizeGaussiansCUDA of the reference bridge (rasterize_points.py:88-274): returns
     (num_rendered, color[3,H,W], radii[P], geomBuffer, binningBuffer, imgBuffer)."""
     lib = _lib.lib()
@@ -73,16 +91,23 @@ def rasterize_forward(bg, means3D, colors, opacity, scales, rotations, scale_mod
     stream = _stream(device)
     with torch.cuda.device(device):
         color = torch.empty((3, H, W), dtype=torch.float32, device=device)
-        radii = torch.zeros((P,), dtype=torch.int32, device=device)
-        geom = torch.empty((lib.gm_geom_bytes(P),), dtype=torch.uint8, device=device)
-        img = torch.empty((lib.gm_image_bytes(W, H),), dtype=torch.uint8, device=device)
+        radii = torch.empty((P,), dtype=torch.int32, device=device)
+        if workspace is not None:
+            geom = workspace.get("geom", lib.gm_geom_bytes(P), device)
+            img = workspace.get("img", lib.gm_image_bytes(W, H), device)
+        else:
+            geom = torch.empty((lib.gm_geom_bytes(P),), dtype=torch.uint8, device=device)
+            img = torch.empty((lib.gm_image_bytes(W, H),), dtype=torch.uint8, device=device)
         R = C.c_int(0)
         _lib.check(lib.gm_forward_0(_ptr(geom), P, int(degree), M, _ptr(bg), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),
                                     _ptr(opacity), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),
                                     _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
                                     int(bool(prefiltered)), _ptr(radii), int(bool(debug)), stream, C.byref(R)))
         num_rendered = R.value
-        binning = torch.empty((lib.gm_binning_bytes(num_rendered),), dtype=torch.uint8, device=device)
+        if workspace is not None:
+            binning = workspace.get("binning", lib.gm_binning_bytes(num_rendered), device)
+        else:
+            binning = torch.empty((lib.gm_binning_bytes(num_rendered),), dtype=torch.uint8, device=device)
         _lib.check(lib.gm_forward_1(_ptr(geom), _ptr(binning), _ptr(img), P, int(degree), M, num_rendered, _ptr(bg), W, H,
                                     _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales),
                                     float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
@@ -133,15 +158,26 @@ def mark_visible(means3D, viewmatrix, projmatrix):
     return present.bool()
 
 
+_WORKSPACES = {}
+
+
+def _shared_workspace(device):
+    ws = _WORKSPACES.get(device)
+    if ws is None:
+        ws = _WORKSPACES[device] = RasterWorkspace()
+    return ws
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
                 force_M):
         rs = raster_settings
+        ws = None if any(ctx.needs_input_grad) else _shared_workspace(means3D.device)   # inference: reuse scratch
         num_rendered, color, radii, geom, binning, img = rasterize_forward(
             rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
             rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos,
-            rs.prefiltered, rs.debug, force_M)
+            rs.prefiltered, rs.debug, force_M, ws)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.opacity_shape = opacities.shape
