@@ -151,10 +151,39 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __rest
   if (i == R - 1) ranges[cur].y = (uint32_t)R;
 }
 
+// Workgroup schedule for the blend kernels: tiles ordered by list length, longest first (LPT), so the
+// multi-thousand-entry tiles start at once and the short ones fill in behind them instead of the reverse.
+// Counting sort on a quarter-octave length class (64 classes); single workgroup, tiles <= a few 10k.
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restrict__ ranges, int tiles, uint32_t* __restrict__ order) {
+  __shared__ uint32_t cnt[64];
+  if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  auto cls = [](uint32_t n) -> uint32_t {
+    if (n == 0) return 63u;
+    const uint32_t lg = 31u - (uint32_t)__clz((int)n);           // floor(log2 n)
+    const uint32_t frac = lg >= 2 ? (n >> (lg - 2)) & 3u : 0u;     // next two bits
+    const uint32_t c = 4u * lg + frac;                             // 0..127 in principle, n < 2^15.75 in practice
+    return c >= 62u ? 0u : 62u - c;                                // long lists -> small class
+  };
+  for (int t = threadIdx.x; t < tiles; t += 1024) atomicAdd(&cnt[cls(ranges[t].y - ranges[t].x)], 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int c = 0; c < 64; c++) { const uint32_t v = cnt[c]; cnt[c] = run; run += v; }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < tiles; t += 1024) {
+    const uint32_t pos = atomicAdd(&cnt[cls(ranges[t].y - ranges[t].x)], 1u);
+    order[pos] = (uint32_t)t;
+  }
+}
+
 int launch_tile_ranges(BinningState& b, int slot, ImageState& img, int R, int tiles, int debug, hipStream_t s) {
   StageScope sc(ST_RANGES, s);
   GM_HIP(hipMemsetAsync(img.ranges, 0, sizeof(uint2) * (size_t)tiles, s));
   if (R > 0) hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, b.keys[slot], R, img.ranges);
+  GM_LAUNCH_CHECK(debug, s);
+  hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, img.ranges, tiles, img.tile_order);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }

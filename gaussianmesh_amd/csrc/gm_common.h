@@ -96,6 +96,7 @@ struct ImageState {             // per-pixel / per-tile state
   float* final_T;               // [H*W]
   uint32_t* n_contrib;          // [H*W]
   uint2* ranges;                // [tiles]
+  uint32_t* tile_order;         // [tiles] tile ids, longest list first (workgroup -> tile schedule)
   static ImageState from(void* buf, int W, int H) {
     char* p = reinterpret_cast<char*>(buf);
     const size_t N = (size_t)W * H;
@@ -104,6 +105,7 @@ struct ImageState {             // per-pixel / per-tile state
     s.final_T = carve<float>(p, N);
     s.n_contrib = carve<uint32_t>(p, N);
     s.ranges = carve<uint2>(p, T);
+    s.tile_order = carve<uint32_t>(p, T);
     s.end = p;
     return s;
   }
