@@ -79,7 +79,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from gaussianmesh_amd import _lib, scenes
+    from gaussianmesh_amd import _lib, multiview, scenes
     from gaussianmesh_amd import rasterizer as Rz
     from gaussianmesh_amd.deform import deform_tensors, sh_colors
 
@@ -110,10 +110,8 @@ def main():
     else:
         for k, (shp, dt) in shapes.items():
             g[k] = torch.empty(shp, dtype=dt, device=dev)
-    if world > 1:
-        for k in shapes:
-            if k != "mesh":                      # the animation stays on rank 0; frames are broadcast one at a time
-                dist.broadcast(g[k], src=0)
+    # the animation ("mesh") stays on rank 0; its frames are broadcast one at a time inside the timed loop
+    multiview.broadcast_cloud({k: v for k, v in g.items() if k != "mesh"}, src=0)
     Vm = g["verts"].shape[0]
     cams = [scenes.orbit_camera(k, F, W, H) for k in range(F)]
     cam_t = [dict(view=torch.tensor(c["view"], device=dev), proj=torch.tensor(c["proj"], device=dev),
@@ -125,17 +123,16 @@ def main():
 
     def step(i):
         t = i % F
-        if world > 1:                            # real exchange step: mesh state of frame t from rank 0
+        if world > 1:                            # real exchange step: mesh state of frame t from rank 0 (RCCL)
             if rank == 0:
                 frame_buf.copy_(g["mesh"][t])
-            dist.broadcast(frame_buf, src=0)
-            ms = frame_buf
+            ms = multiview.broadcast_mesh_state(frame_buf, src=0)
         else:
             ms = g["mesh"][t]
-        V1 = ms[:, 0:3].contiguous(); Rv = ms[:, 3:12].contiguous(); Sv = ms[:, 12:21].contiguous()
+        V1, Rv, Sv = multiview.unpack_mesh_state(ms)
         dV = V1 - g["verts"]
         pos, cov, rot, cov6 = deform_tensors(g["tri"], g["weights"], dV, Rv, Sv, g["cov"], g["pos"])
-        c = cam_t[(rank * (F // max(world, 1)) + i) % F]
+        c = cam_t[multiview.view_for_step(i, F, rank, world)]
         rgb = sh_colors(pos, c["campos"], g["shs"], rot=rot, deg=3)
         nr, color, radii, _, _, _ = Rz.rasterize_forward(bg, pos, rgb, g["opac"], None, None, 1.0, cov6, c["view"], c["proj"],
                                                          c["tanx"], c["tany"], H, W, None, 3, c["campos"], False, False,
@@ -158,10 +155,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = multiview.max_over_ranks(elapsed, dev)
     fps = world * args.steps / elapsed
 
     out = {

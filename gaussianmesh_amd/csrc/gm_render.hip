@@ -355,7 +355,7 @@ static int env_int(const char* name, int dflt) {
 int launch_render_fwd(const GeomState& g, const uint32_t* point_list, ImageState& img, int W, int H,
                       const float* background, float* out_color, int debug, hipStream_t s) {
   StageScope sc(ST_RENDER, s);
-  const int ppl = env_int("GM_RENDER_PPL", 0);          // 0 = cooperative kernel (default); 1/2/4 = independent-wave variants          // tuning knob, read per launch
+  const int ppl = env_int("GM_RENDER_PPL", 1);          // 1/2/4 = pixels per lane of the independent-wave kernel (default 1); 0 = cooperative variant          // tuning knob, read per launch
   const int gx = (W + GM_TILE - 1) / GM_TILE, gy = (H + GM_TILE - 1) / GM_TILE;
   const int tiles = gx * gy;
   if (tiles > 0) {
@@ -368,12 +368,12 @@ int launch_render_fwd(const GeomState& g, const uint32_t* point_list, ImageState
         hipLaunchKernelGGL(render_fwd_kernel<2>, dim3(tiles), dim3(128), 0, s, img.ranges, point_list, img.tile_order, g.splat, W, H, gx,
                            background, out_color, img.final_T, img.n_contrib);
         break;
-      case 1:
-        hipLaunchKernelGGL(render_fwd_kernel<1>, dim3(tiles), dim3(256), 0, s, img.ranges, point_list, img.tile_order, g.splat, W, H, gx,
+      case 0:
+        hipLaunchKernelGGL(render_fwd_coop_kernel, dim3(tiles), dim3(256), 0, s, img.ranges, point_list, img.tile_order, g.splat, W, H, gx,
                            background, out_color, img.final_T, img.n_contrib);
         break;
       default:
-        hipLaunchKernelGGL(render_fwd_coop_kernel, dim3(tiles), dim3(256), 0, s, img.ranges, point_list, img.tile_order, g.splat, W, H, gx,
+        hipLaunchKernelGGL(render_fwd_kernel<1>, dim3(tiles), dim3(256), 0, s, img.ranges, point_list, img.tile_order, g.splat, W, H, gx,
                            background, out_color, img.final_T, img.n_contrib);
     }
   }
@@ -530,12 +530,12 @@ int launch_render_bwd(const GeomState& g, const uint32_t* point_list, ImageState
                       const float* background, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
                       float* dL_dopacity, float* dL_dcolor, int debug, hipStream_t s) {
   StageScope sc(ST_RENDER_BWD, s);
-  const int ppl = env_int("GM_RENDER_BWD_PPL", 4);      // tuning knob, read per launch
+  const int ppl = env_int("GM_RENDER_BWD_PPL", 1);      // tuning knob, read per launch
   const int gx = (W + GM_TILE - 1) / GM_TILE, gy = (H + GM_TILE - 1) / GM_TILE;
   const int tiles = gx * gy;
   if (tiles > 0) {
     switch (ppl) {
-      case 1:
+      default:
         hipLaunchKernelGGL(render_bwd_kernel<1>, dim3(tiles), dim3(256), 0, s, img.ranges, point_list, img.tile_order, g.splat, W, H, gx,
                            background, img.final_T, img.n_contrib, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
         break;
@@ -543,7 +543,7 @@ int launch_render_bwd(const GeomState& g, const uint32_t* point_list, ImageState
         hipLaunchKernelGGL(render_bwd_kernel<2>, dim3(tiles), dim3(128), 0, s, img.ranges, point_list, img.tile_order, g.splat, W, H, gx,
                            background, img.final_T, img.n_contrib, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
         break;
-      default:
+      case 4:
         hipLaunchKernelGGL(render_bwd_kernel<4>, dim3(tiles), dim3(64), 0, s, img.ranges, point_list, img.tile_order, g.splat, W, H, gx,
                            background, img.final_T, img.n_contrib, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
     }

@@ -17,6 +17,18 @@ def _f(t):
     return t.detach().contiguous().float()
 
 
+def barycentric_weights(points, p1, p2, p3):
+    """Host-side (numpy, float64) barycentric weights from sub-triangle areas, as the reference computes them once
+    per object when a mesh is attached (edittool/general_utils.py:73-88 get_barycentric_coordinate)."""
+    import numpy as np
+    e1, e2, e3 = points - p1, points - p2, points - p3
+    s1 = np.linalg.norm(np.cross(e2, e3), axis=1)
+    s2 = np.linalg.norm(np.cross(e1, e3), axis=1)
+    s3 = np.linalg.norm(np.cross(e1, e2), axis=1)
+    s = s1 + s2 + s3
+    return np.stack([s1 / s, s2 / s, s3 / s], axis=1)
+
+
 def deform_tensors(tri, w, dV, Rv, Sv, cov, pos):
     """gm_deform: returns (pos' [N,3], cov' [N,3,3], rot [N,3,3], cov6 [N,6])."""
     lib = _lib.lib()

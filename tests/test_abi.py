@@ -1,0 +1,83 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/gmesh_hip.h declares; size queries and
+argument validation (which run before any HIP call) behave; the product path has no CPU fallback."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_library_exports_every_header_symbol():
+    from gaussianmesh_amd import _lib
+    l = _lib.lib()
+    names = _lib.header_symbols()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(l, n), n
+    assert set(names) == set(_lib.SIGNATURES), "python signatures out of sync with include/gmesh_hip.h"
+    assert l.gm_abi_version() == 1
+
+
+def test_scratch_sizes_scale_linearly():
+    from gaussianmesh_amd import _lib
+    l = _lib.lib()
+    g1, g2 = l.gm_geom_bytes(1_000_000), l.gm_geom_bytes(2_000_000)
+    assert 90e6 < g1 < 120e6 and abs(g2 - 2 * g1) < 1e5        # ~97 B per Gaussian
+    b1 = l.gm_binning_bytes(8_000_000)
+    assert 128e6 <= b1 < 140e6                                   # 16 B per instance + histograms
+    i1 = l.gm_image_bytes(1920, 1080)
+    assert 16.5e6 < i1 < 17e6                                    # 8 B per pixel + tiles
+    assert l.gm_geom_bytes(0) > 0 and l.gm_binning_bytes(0) > 0
+    assert l.gm_knn_workspace_bytes(1000) > 16 * 1000
+
+
+def test_argument_validation_happens_before_any_gpu_work():
+    from gaussianmesh_amd import _lib
+    l = _lib.lib()
+    R = C.c_int(-1)
+    one = 1   # bogus non-null "pointers": validation must reject before dereferencing anything
+    rc = l.gm_forward_0(one, 10, 3, 16, one, 64, 64, one, one, one, one, one, 1.0, one, None, one, one, one, 0.5, 0.5, 0, None, 0, None, C.byref(R))
+    assert rc == 1 and b"exactly one of shs / colors_precomp" in l.gm_last_error()
+    rc = l.gm_forward_0(one, 10, 3, 16, one, 64, 64, one, one, None, one, one, 1.0, one, one, one, one, one, 0.5, 0.5, 0, None, 0, None, C.byref(R))
+    assert rc == 1 and b"scales, rotations" in l.gm_last_error()
+    rc = l.gm_forward_0(one, 10, 3, 9, one, 64, 64, one, one, None, one, one, 1.0, one, None, one, one, one, 0.5, 0.5, 0, None, 0, None, C.byref(R))
+    assert rc == 1 and b"SH degree" in l.gm_last_error()
+    rc = l.gm_forward_0(one, -1, 0, 0, one, 64, 64, one, None, one, one, None, 1.0, None, one, one, one, one, 0.5, 0.5, 0, None, 0, None, C.byref(R))
+    assert rc == 1
+    assert l.gm_knn(5, None, None, None, 0, None) == 1
+    assert l.gm_sh_colors(5, 4, 16, one, one, None, one, one, None) == 1
+
+
+def test_no_cpu_fallback():
+    from gaussianmesh_amd import GaussianRasterizationSettings, GaussianRasterizer, distCUDA2
+    from gaussianmesh_amd._lib import GmeshError
+    from gaussianmesh_amd.deform import deform_tensors
+    P = 8
+    rs = GaussianRasterizationSettings(32, 32, 0.5, 0.5, torch.zeros(3), 1.0, torch.eye(4), torch.eye(4), 0, torch.zeros(3), False, False)
+    m = torch.zeros(P, 3)
+    with pytest.raises(GmeshError):
+        GaussianRasterizer(rs)(m, m, torch.ones(P, 1), colors_precomp=torch.ones(P, 3), cov3D_precomp=torch.ones(P, 6))
+    with pytest.raises(GmeshError):
+        distCUDA2(m)
+    with pytest.raises(GmeshError):
+        deform_tensors(torch.zeros(P, 3, dtype=torch.int32), m, m, torch.zeros(P, 3, 3), torch.zeros(P, 3, 3), torch.zeros(P, 3, 3), m)
+
+
+def test_operator_argument_rules_match_reference():
+    """diff_gaussian_rasterizater/__init__.py:146-150: exactly one of shs/colors and of (scales,rotations)/cov3D."""
+    from gaussianmesh_amd import GaussianRasterizationSettings, GaussianRasterizer, NewGaussianRasterizer
+    rs = GaussianRasterizationSettings(32, 32, 0.5, 0.5, torch.zeros(3), 1.0, torch.eye(4), torch.eye(4), 0, torch.zeros(3), False, False)
+    m = torch.zeros(4, 3); o = torch.ones(4, 1); sh = torch.zeros(4, 16, 3); s = torch.ones(4, 3); q = torch.ones(4, 4)
+    for cls in (GaussianRasterizer, NewGaussianRasterizer):
+        r = cls(rs)
+        assert r.execute.__func__ is r.forward.__func__            # Jittor spelling kept
+        with pytest.raises(Exception, match="SHs or precomputed colors"):
+            r(m, m, o, scales=s, rotations=q)
+        with pytest.raises(Exception, match="SHs or precomputed colors"):
+            r(m, m, o, shs=sh, colors_precomp=m, scales=s, rotations=q)
+        with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+            r(m, m, o, shs=sh, scales=s)
+        with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+            r(m, m, o, shs=sh, scales=s, rotations=q, cov3D_precomp=torch.ones(4, 6))
+    assert GaussianRasterizationSettings._fields == ("image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier",
+                                                     "viewmatrix", "projmatrix", "sh_degree", "campos", "prefiltered", "debug")

@@ -1,0 +1,91 @@
+"""N>1 path on CPU: two gloo ranks shard the views of a deforming cloud; the static cloud is broadcast once and the
+mesh state once per frame (gaussianmesh_amd/multiview.py).  The renderer is pluggable; here it is the CPU oracle
+(tests may use the oracle as a checker / stand-in renderer, the product path cannot)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def test_shard_views_partition():
+    from gaussianmesh_amd.multiview import shard_views, view_for_step
+    for n, w in [(64, 8), (10, 4), (3, 8), (7, 2)]:
+        parts = [shard_views(n, r, w) for r in range(w)]
+        assert sorted(sum(parts, [])) == list(range(n))
+        assert max(map(len, parts)) - min(map(len, parts)) <= 1
+    assert shard_views(64, 3, 8) == list(range(24, 32))         # C4: 8 views per GPU
+    assert [view_for_step(s, 64, 1, 8) for s in range(10)] == [8, 9, 10, 11, 12, 13, 14, 15, 8, 9]
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+    from gaussianmesh_amd import multiview, scenes
+    from oracle import oracle as orc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    N, W, H, views, frames = 400, 48, 32, 4, 2
+    verts, faces = scenes.torus_mesh(12, 8)
+    Vm = verts.shape[0]
+    shapes = dict(tri=((N, 3), torch.int32), weights=((N, 3), torch.float32), pos=((N, 3), torch.float32),
+                  cov=((N, 3, 3), torch.float32), opac=((N, 1), torch.float32), shs=((N, 16, 3), torch.float32),
+                  verts=((Vm, 3), torch.float32))
+    cloud = {k: torch.zeros(s, dtype=d) for k, (s, d) in shapes.items()}
+    if rank == 0:                                               # only rank 0 knows the scene
+        cl = scenes.bind_cloud_to_mesh(N, verts, faces, seed=3)
+        cl["scales"] *= 6
+        cov = scenes.cov3d_from_scale_rot(cl["scales"], cl["rots"]).astype(np.float32)
+        src = dict(tri=cl["tri"], weights=cl["weights"], pos=cl["means"], cov=cov, opac=cl["opac"], shs=cl["shs"], verts=verts)
+        for k in cloud:
+            cloud[k].copy_(torch.tensor(np.asarray(src[k]), dtype=shapes[k][1]).reshape(shapes[k][0]))
+    multiview.broadcast_cloud(cloud, src=0)
+    c = {k: v.numpy() for k, v in cloud.items()}
+
+    def mesh_state_of(t):
+        V1, Rv, Sv = scenes.twist_bend_frame(verts, t + 3, period=16)
+        return torch.tensor(np.concatenate([V1, Rv.reshape(-1, 9), Sv.reshape(-1, 9)], 1), dtype=torch.float32)
+
+    def deform_and_render(state, v):
+        V1, Rv, Sv = (x.numpy() for x in multiview.unpack_mesh_state(state))
+        p, cv, r = orc.deform(c["tri"], c["weights"], V1 - c["verts"], Rv.reshape(-1, 3, 3), Sv.reshape(-1, 3, 3), c["cov"], c["pos"])
+        cam = scenes.orbit_camera(v, views, W, H, radius=6.0)
+        rgb = orc.sh_colors_rotated(p, cam["campos"], r, c["shs"])
+        sc = dict(means=p, opac=c["opac"], colors_precomp=rgb, cov3D_precomp=scenes.strip_symmetric(cv))
+        return orc.forward_fast(sc, cam, np.ones(3, np.float32), use_precomp_cov=True, use_precomp_color=True)[0]
+
+    state = torch.zeros((Vm, 21), dtype=torch.float32)
+    out = multiview.render_trajectory(views, frames, mesh_state_of, deform_and_render, state, src=0)
+    t = multiview.max_over_ranks(float(rank + 1), torch.device("cpu"))
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), tmax=t, **{"%d_%d" % k: v for k, v in out.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_matches_single_process(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = dict(np.load(tmp_path / "rank0.npz")); r1 = dict(np.load(tmp_path / "rank1.npz"))
+    assert float(r0.pop("tmax")) == 2.0 and float(r1.pop("tmax")) == 2.0      # MAX all-reduce over ranks
+    assert sorted(r0) == ["0_0", "0_1", "1_0", "1_1"] and sorted(r1) == ["0_2", "0_3", "1_2", "1_3"]
+    # single-process reference of the same trajectory
+    port2 = _free_port()
+    single = tmp_path / "single"; single.mkdir()
+    mp.spawn(_worker, args=(1, port2, str(single)), nprocs=1, join=True)
+    s = dict(np.load(single / "rank0.npz")); s.pop("tmax")
+    both = {**r0, **r1}
+    assert sorted(both) == sorted(s)
+    for k in s:
+        assert np.array_equal(both[k], s[k]), k
+        assert s[k].std() > 0                                    # something was actually rendered

@@ -1,0 +1,97 @@
+"""Structural properties of the oracle: binning order, fast path == staged path, knn vs a KD-tree, deform invariants."""
+import numpy as np
+import pytest
+
+from helpers import small_scene
+
+
+def test_higher_msb(oracle):
+    # rasterizer_impl.cu:35-50 on the tile counts of 256^2, 1080p and 4K
+    assert [oracle.higher_msb(n) for n in (256, 8160, 32400, 1, 2, 3)] == [9, 13, 15, 1, 2, 2]
+
+
+def test_binning_is_stable_tile_depth_order(oracle):
+    sc, cam = small_scene(P=800, W=100, H=60, seed=2)
+    sc["means"][10:20] = sc["means"][10]           # identical depths -> ties must stay in Gaussian-index order
+    fw = oracle.forward_full(sc, cam, np.zeros(3, np.float32))
+    keys, pl, geo = fw["bins"]["keys"], fw["bins"]["point_list"], fw["geo"]
+    assert (np.diff(keys.astype(np.uint64).view(np.int64)) >= 0).all()
+    same = keys[1:] == keys[:-1]
+    assert (pl[1:][same] > pl[:-1][same]).all()    # ties: ascending Gaussian id
+    assert fw["bins"]["R"] == int(geo["tiles"].sum())
+    rg = fw["bins"]["ranges"]
+    n = (rg[:, 1] - rg[:, 0]).sum()
+    assert n == fw["bins"]["R"]
+    depth_bits = geo["depths"].view(np.uint32)[pl]
+    assert np.array_equal(keys & np.uint64(0xFFFFFFFF), depth_bits.astype(np.uint64))
+
+
+@pytest.mark.parametrize("pre", [False, True])
+def test_fast_forward_equals_staged(oracle, pre):
+    sc, cam = small_scene(P=700, W=90, H=70, seed=5)
+    bg = np.array([1, 0.5, 0.25], np.float32)
+    fw = oracle.forward_full(sc, cam, bg, use_precomp_cov=pre, use_precomp_color=pre)
+    col, radii, R = oracle.forward_fast(sc, cam, bg, use_precomp_cov=pre, use_precomp_color=pre)
+    assert R == fw["bins"]["R"] and np.array_equal(radii, fw["geo"]["radii"]) and np.array_equal(col, fw["color"])
+
+
+def test_linearity_in_background_and_colour(oracle):
+    """Image is affine in (bg, colours) for fixed geometry: C = sum w_i c_i + T bg."""
+    sc, cam = small_scene(P=300, W=48, H=48, seed=6)
+    z = np.zeros(3, np.float32)
+    a = oracle.forward_full(sc, cam, z, use_precomp_color=True)["color"]
+    sc2 = dict(sc); sc2["colors_precomp"] = 2 * sc["colors_precomp"]
+    b = oracle.forward_full(sc2, cam, z, use_precomp_color=True)
+    assert np.allclose(b["color"], 2 * a, atol=1e-6)
+    c = oracle.forward_full(sc, cam, np.ones(3, np.float32), use_precomp_color=True)
+    assert np.allclose(c["color"] - a, c["final_T"].reshape(1, cam["H"], cam["W"]), atol=1e-6)
+
+
+def test_knn_against_kdtree(oracle):
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(0)
+    pts = rng.normal(size=(3000, 3)).astype(np.float32)
+    out = oracle.knn_mean_dist2(pts)
+    d, _ = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=4)
+    assert np.allclose(out, (d[:, 1:] ** 2).mean(1), rtol=1e-5)
+
+
+def test_deform_invariants(oracle):
+    from gaussianmesh_amd import scenes
+    verts, faces = scenes.torus_mesh(20, 12)
+    cl = scenes.bind_cloud_to_mesh(500, verts, faces, seed=1)
+    cov = scenes.cov3d_from_scale_rot(cl["scales"], cl["rots"]).astype(np.float32)
+    Vm = verts.shape[0]
+    I = np.tile(np.eye(3, dtype=np.float32), (Vm, 1, 1))
+    # identity
+    p, c, r = oracle.deform(cl["tri"], cl["weights"], np.zeros((Vm, 3), np.float32), I, I, cov, cl["means"])
+    assert np.array_equal(p, cl["means"]) and np.allclose(c, cov, atol=1e-7) and np.allclose(r, np.eye(3))
+    # rigid motion x -> Q x + t with the reference convention: per-vertex R such that RS = R^T S maps the covariance,
+    # i.e. the blended rotation is stored transposed (edittool/__init__.py:122): pass R = Q^T
+    a = 0.7
+    Q = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    t = np.array([0.3, -0.2, 0.5])
+    V1 = verts @ Q.T + t
+    Rv = np.tile(Q.T.astype(np.float32), (Vm, 1, 1))
+    p, c, r = oracle.deform(cl["tri"], cl["weights"], (V1 - verts).astype(np.float32), Rv, I, cov, cl["means"])
+    assert np.allclose(c, Q @ cov.astype(np.float64) @ Q.T, atol=1e-6)
+    assert np.allclose(r, Q, atol=1e-6)
+    # positions move by the barycentric blend of the vertex displacements
+    tri = cl["tri"]; w = cl["weights"]
+    dV = V1 - verts
+    exp = cl["means"] + (w[:, :, None] * dV[tri]).sum(1)
+    assert np.allclose(p, exp, atol=1e-5)
+    # uniform scale s: R = I, S = s I -> cov * s^2
+    p, c, r = oracle.deform(cl["tri"], cl["weights"], (0.5 * verts).astype(np.float32), I, 1.5 * I, cov, cl["means"])
+    assert np.allclose(c, 2.25 * cov, rtol=1e-6)
+
+
+def test_twist_frames_are_polar_decompositions():
+    from gaussianmesh_amd import scenes
+    verts, _ = scenes.torus_mesh(16, 10)
+    V1, R, S = scenes.twist_bend_frame(verts, t=5, period=64)
+    assert np.allclose(R @ R.transpose(0, 2, 1), np.eye(3), atol=1e-10)
+    assert np.allclose(S, S.transpose(0, 2, 1), atol=1e-10)
+    assert np.allclose(np.linalg.det(R), 1.0)
+    V0, R0, S0 = scenes.twist_bend_frame(verts, t=0)
+    assert np.allclose(V0, verts) and np.allclose(R0, np.eye(3)) and np.allclose(S0, np.eye(3))
