@@ -192,16 +192,13 @@ int gm_backward(int P, int D, int M, int R, const float* background, int width, 
   BinningState b = BinningState::from(binning_buffer, (size_t)(R > 0 ? R : 0));
   const int tiles = ((width + GM_TILE - 1) / GM_TILE) * ((height + GM_TILE - 1) / GM_TILE);
   const int slot = sort_final_slot(tile_bits(tiles));
-  GM_HIP(hipMemsetAsync(dL_dmean2D, 0, sizeof(float) * 3 * (size_t)P, a.stream));
-  GM_HIP(hipMemsetAsync(dL_dconic, 0, sizeof(float) * 4 * (size_t)P, a.stream));
-  GM_HIP(hipMemsetAsync(dL_dopacity, 0, sizeof(float) * (size_t)P, a.stream));
-  GM_HIP(hipMemsetAsync(dL_dcolor, 0, sizeof(float) * 3 * (size_t)P, a.stream));
+  GM_HIP(hipMemsetAsync(g.grad_acc, 0, sizeof(float) * 12 * (size_t)P, a.stream));   // the only zero-fill of a backward
   if (R > 0) {
     if (!binning_buffer) { set_error("gm_backward: null binning buffer"); return GM_ERR_INVALID_ARG; }
-    if (int rc = launch_render_bwd(g, b.vals[slot], img, width, height, background, dL_dpix, dL_dmean2D, dL_dconic,
-                                   dL_dopacity, dL_dcolor, debug, a.stream)) return rc;
+    if (int rc = launch_render_bwd(g, b.vals[slot], img, width, height, background, dL_dpix, debug, a.stream)) return rc;
   }
-  return launch_preprocess_bwd(a, g, radii, dL_dmean2D, dL_dconic, dL_dmean3D, dL_dcolor, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+  return launch_preprocess_bwd(a, g, radii, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
+                               dL_dscale, dL_drot);
 }
 
 int gm_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,

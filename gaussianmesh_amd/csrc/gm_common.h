@@ -70,6 +70,7 @@ struct GeomState {              // per-Gaussian state (P-sized)
   uint32_t* digit_total;        // [256]
   uint32_t* block_sums;         // [ceil(P/GM_SCAN_ITEMS)] tiles_touched partial sums (sorted order)
   uint32_t* counters;           // [16] device scalars: [0] = num_rendered
+  float* grad_acc;              // [P][12] backward accumulators: dcolor rgb | dmean2D xy | dconic x,y,w | dopacity | pad
   static GeomState from(void* buf, size_t P) {
     char* p = reinterpret_cast<char*>(buf);
     GeomState g;
@@ -86,6 +87,7 @@ struct GeomState {              // per-Gaussian state (P-sized)
     g.digit_total = carve<uint32_t>(p, 256);
     g.block_sums = carve<uint32_t>(p, (P + GM_SCAN_ITEMS - 1) / GM_SCAN_ITEMS + 1);
     g.counters = carve<uint32_t>(p, 16);
+    g.grad_acc = carve<float>(p, 12 * P);
     g.end = p;
     return g;
   }
@@ -154,9 +156,9 @@ struct RasterArgs {
 
 int launch_preprocess(const RasterArgs& a, GeomState& g, int* radii);
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
-int launch_preprocess_bwd(const RasterArgs& a, GeomState& g, const int* radii, const float* dL_dmean2D,
-                          const float* dL_dconic, float* dL_dmean3D, const float* dL_dcolor, float* dL_dcov3D,
-                          float* dL_dsh, float* dL_dscale, float* dL_drot);
+int launch_preprocess_bwd(const RasterArgs& a, GeomState& g, const int* radii, float* dL_dmean2D, float* dL_dconic,
+                          float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                          float* dL_dscale, float* dL_drot);   // reads g.grad_acc, writes every gradient output
 
 // stable LSD radix sort of (u32 key, u32 value) pairs on key bits [0, bits), 8 bits per pass, ping-pong
 // between slot 0 and slot 1.  n_dev (optional) = device pointer to the element count; n_max = host upper bound
@@ -170,8 +172,7 @@ int launch_tile_ranges(BinningState& b, int slot, ImageState& img, int R, int ti
 int launch_render_fwd(const GeomState& g, const uint32_t* point_list, ImageState& img, int W, int H,
                       const float* background, float* out_color, int debug, hipStream_t s);
 int launch_render_bwd(const GeomState& g, const uint32_t* point_list, ImageState& img, int W, int H,
-                      const float* background, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
-                      float* dL_dopacity, float* dL_dcolor, int debug, hipStream_t s);
+                      const float* background, const float* dL_dpix, int debug, hipStream_t s);   // accumulates into g.grad_acc
 
 int launch_deform(int N, const int* tri, const float* w, const float* dV, const float* Rv, const float* Sv,
                   const float* cov, const float* pos, float* pos_out, float* cov_out, float* rot_out, float* cov6_out,

@@ -211,7 +211,8 @@ struct PreBwdArgs {
   const float *means, *shs, *scales, *rots, *cov3D, *view, *proj, *campos;
   const int* radii; const uint8_t* clamped;
   float mod, tanx, tany, fx, fy;
-  const float *dL_dmean2D, *dL_dconic, *dL_dcolor;
+  const float* grad_acc;                                   // [P][12] packed accumulators written by render_bwd_kernel
+  float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor;  // API outputs unpacked from grad_acc
   float *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
 };
 
@@ -221,14 +222,22 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(const PreBwdArgs a)
   const int ncoef = (a.D + 1) * (a.D + 1);
   float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const bool visible = a.radii[idx] > 0;
+  // unpack the blend-stage accumulators (all zero for Gaussians no tile ever touched)
+  const float4 acc0 = reinterpret_cast<const float4*>(a.grad_acc)[3 * (size_t)idx];
+  const float4 acc1 = reinterpret_cast<const float4*>(a.grad_acc)[3 * (size_t)idx + 1];
+  const float acc2 = a.grad_acc[12 * (size_t)idx + 8];
+  const float dcol[3] = {acc0.x, acc0.y, acc0.z};
+  a.dL_dcolor[3 * (size_t)idx] = acc0.x; a.dL_dcolor[3 * (size_t)idx + 1] = acc0.y; a.dL_dcolor[3 * (size_t)idx + 2] = acc0.z;
+  a.dL_dmean2D[3 * (size_t)idx] = acc0.w; a.dL_dmean2D[3 * (size_t)idx + 1] = acc1.x; a.dL_dmean2D[3 * (size_t)idx + 2] = 0.f;
+  reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(acc1.y, acc1.z, 0.f, acc1.w);
+  a.dL_dopacity[idx] = acc2;
   if (visible) {
     const V3 mean = {a.means[3 * (size_t)idx], a.means[3 * (size_t)idx + 1], a.means[3 * (size_t)idx + 2]};
     float c3[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) c3[k] = a.cov3D[6 * (size_t)idx + k];
     {  // ---- computeCov2DCUDA, backward.cu:144-274
-      const float4 dc4 = reinterpret_cast<const float4*>(a.dL_dconic)[idx];
-      const float dcx = dc4.x, dcy = dc4.y, dcz = dc4.w;
+      const float dcx = acc1.y, dcy = acc1.z, dcz = acc1.w;
       V3 t; float T0[3], T1[3], xm, ym, ca, cb, cc;
       cov2d_T(mean, a.fx, a.fy, a.tanx, a.tany, a.view, t, T0, T1, xm, ym);
       cov2d_from_T(T0, T1, c3, ca, cb, cc);
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(const PreBwdArgs a)
       const float m_w = 1.0f / (hw + 0.0000001f);
       const float mul1 = (pr[0] * mean.x + pr[4] * mean.y + pr[8] * mean.z + pr[12]) * m_w * m_w;
       const float mul2 = (pr[1] * mean.x + pr[5] * mean.y + pr[9] * mean.z + pr[13]) * m_w * m_w;
-      const float gxx = a.dL_dmean2D[3 * (size_t)idx], gyy = a.dL_dmean2D[3 * (size_t)idx + 1];
+      const float gxx = acc0.w, gyy = acc1.x;
       dmean[0] += (pr[0] * m_w - pr[3] * mul1) * gxx + (pr[1] * m_w - pr[3] * mul2) * gyy;
       dmean[1] += (pr[4] * m_w - pr[7] * mul1) * gxx + (pr[5] * m_w - pr[7] * mul2) * gyy;
       dmean[2] += (pr[8] * m_w - pr[11] * mul1) * gxx + (pr[9] * m_w - pr[11] * mul2) * gyy;
@@ -289,7 +298,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(const PreBwdArgs a)
       const uint8_t cl = a.clamped[idx];
       float dRGB[3], wgt[16];
 #pragma unroll
-      for (int ch = 0; ch < 3; ch++) dRGB[ch] = a.dL_dcolor[3 * (size_t)idx + ch] * (((cl >> ch) & 1) ? 0.f : 1.f);
+      for (int ch = 0; ch < 3; ch++) dRGB[ch] = dcol[ch] * (((cl >> ch) & 1) ? 0.f : 1.f);
       float ddx[3] = {0, 0, 0}, ddy[3] = {0, 0, 0}, ddz[3] = {0, 0, 0};
 #define S(i, ch) sh[3 * (i) + (ch)]
       wgt[0] = SH_C0;
@@ -401,9 +410,9 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(const PreBwdArgs a)
   }
 }
 
-int launch_preprocess_bwd(const RasterArgs& r, GeomState& g, const int* radii, const float* dL_dmean2D,
-                          const float* dL_dconic, float* dL_dmean3D, const float* dL_dcolor, float* dL_dcov3D,
-                          float* dL_dsh, float* dL_dscale, float* dL_drot) {
+int launch_preprocess_bwd(const RasterArgs& r, GeomState& g, const int* radii, float* dL_dmean2D, float* dL_dconic,
+                          float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                          float* dL_dscale, float* dL_drot) {
   StageScope sc(ST_PREPROCESS_BWD, r.stream);
   PreBwdArgs a;
   a.P = r.P; a.D = r.D; a.M = r.M; a.W = r.W; a.H = r.H;
@@ -413,7 +422,8 @@ int launch_preprocess_bwd(const RasterArgs& r, GeomState& g, const int* radii, c
   a.radii = radii ? radii : g.radii; a.clamped = g.clamped;
   a.mod = r.scale_modifier; a.tanx = r.tan_fovx; a.tany = r.tan_fovy;
   a.fy = r.H / (2.0f * r.tan_fovy); a.fx = r.W / (2.0f * r.tan_fovx);
-  a.dL_dmean2D = dL_dmean2D; a.dL_dconic = dL_dconic; a.dL_dcolor = dL_dcolor;
+  a.grad_acc = g.grad_acc;
+  a.dL_dmean2D = dL_dmean2D; a.dL_dconic = dL_dconic; a.dL_dopacity = dL_dopacity; a.dL_dcolor = dL_dcolor;
   a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot;
   if (r.P > 0) hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((r.P + 255) / 256), dim3(256), 0, r.stream, a);
   GM_LAUNCH_CHECK(r.debug, r.stream);

@@ -382,7 +382,20 @@ int launch_render_fwd(const GeomState& g, const uint32_t* point_list, ImageState
 }
 
 // ---------------------------------------------------------------------------------------------
-// wave64 sum: row scans with DPP row_shr, then row_bcast 15 / 31; total lands in lane 63.
+// Backward blend.
+//
+// Per (wave, surviving entry) every lane holds nine partial sums (its pixels' contributions to dL/dcolor rgb,
+// dL/dmean2D xy, dL/dconic x,y,w and dL/dopacity of that Gaussian).  The reference issues nine global atomics per
+// (pixel, entry); here the wave first reduces them, with the gfx950 lane-swap instructions doing a TRANSPOSED
+// reduction of eight values at once:
+//   v_permlane32_swap + add : (q0,q1) -> one register holding q0's 32-lane partials in lanes 0-31 and q1's in 32-63
+//   v_permlane16_swap + add : two such registers -> one register, one value per 16-lane row
+//   row_ror:8 add + select  : two such registers -> one register, one value per 8-lane group
+//   row_half_mirror, quad_perm[3,2,1,0], quad_perm[1,0,3,2] adds: finish inside the 8-lane groups
+// = 18 VALU instructions for eight totals (48 with a plain 6-step DPP tree each), and the eight totals sit in eight
+// different lanes, so ONE global_atomic_add_f32 instruction commits them.  The ninth value takes the plain DPP tree.
+// Accumulation goes to a packed per-Gaussian record grad_acc[P][12] (one cache line instead of four arrays);
+// preprocess_bwd_kernel unpacks it into the API's dL_dmean2D / dL_dconic / dL_dopacity / dL_dcolor.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_add(float v) {
   const int sh = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
@@ -397,6 +410,36 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
   v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2,3
   return v;
 }
+__device__ __forceinline__ float swap32_add(float a, float b) {   // lanes 0-31: a[l]+a[l+32]; lanes 32-63: b[l-32]+b[l]
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float swap16_add(float a, float b) {   // rows: a.r0+a.r1 | b.r0+b.r1 | a.r2+a.r3 | b.r2+b.r3
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// totals of q0..q7; the total of q[slot] is returned in every lane of the 8-lane group with
+// slot == reduce8_slot(lane)
+__device__ __forceinline__ float reduce8(const float* q, int lane) {
+  const float s01 = swap32_add(q[0], q[1]), s23 = swap32_add(q[2], q[3]);
+  const float s45 = swap32_add(q[4], q[5]), s67 = swap32_add(q[6], q[7]);
+  const float ta = swap16_add(s01, s23);            // rows: q0 q2 q1 q3
+  const float tb = swap16_add(s45, s67);            // rows: q4 q6 q5 q7
+  const float x = dpp_add<0x128, 0xf>(ta);          // row_ror:8 -> 8-lane partials, duplicated in both halves
+  const float y = dpp_add<0x128, 0xf>(tb);
+  float u = (lane & 8) ? y : x;
+  u = dpp_add<0x141, 0xf>(u);                       // row_half_mirror
+  u = dpp_add<0x1B, 0xf>(u);                        // quad_perm [3,2,1,0]
+  u = dpp_add<0xB1, 0xf>(u);                        // quad_perm [1,0,3,2]
+  return u;
+}
+__device__ __forceinline__ int reduce8_slot(int lane) {
+  const int r = lane >> 4, h = (lane >> 3) & 1;
+  const int a_idx = (r == 0) ? 0 : (r == 1) ? 2 : (r == 2) ? 1 : 3;
+  return h ? a_idx + 4 : a_idx;                     // h = 1: q4 q6 q5 q7
+}
+
+#define GM_ACC_STRIDE 12   // floats per Gaussian in grad_acc: rgb(0-2) mean2D xy(3-4) conic x,y,w(5-7) opacity(8)
 
 template <int PPL>
 __global__ __launch_bounds__(256 / PPL) void render_bwd_kernel(const uint2* __restrict__ ranges,
@@ -404,9 +447,7 @@ __global__ __launch_bounds__(256 / PPL) void render_bwd_kernel(const uint2* __re
                                                                const uint32_t* __restrict__ tile_order, const float4* __restrict__ splat, int W, int H, int gx,
                                                                const float* __restrict__ bg, const float* __restrict__ final_T,
                                                                const uint32_t* __restrict__ n_contrib,
-                                                               const float* __restrict__ dL_dpix, float* __restrict__ dL_dmean2D,
-                                                               float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
-                                                               float* __restrict__ dL_dcolor) {
+                                                               const float* __restrict__ dL_dpix, float* __restrict__ grad_acc) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tile = (int)tile_order[blockIdx.x];
   const int tx = tile % gx, ty = tile / gx;
@@ -444,7 +485,10 @@ __global__ __launch_bounds__(256 / PPL) void render_bwd_kernel(const uint2* __re
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) max_last = max(max_last, __shfl_xor(max_last, d));
   const int start = max_last;           // number of list entries this wave has to visit (positions start-1 .. 0)
+  if (start == 0) return;
 
+  const int my_slot = reduce8_slot(lane);
+  const bool committer = (lane & 7) == 0;
   const float rx0 = (float)(tx * GM_TILE), rx1 = rx0 + (float)(GM_TILE - 1);
   const float ry0 = (float)(ty * GM_TILE + wave * PPL * 4), ry1 = ry0 + (float)(PPL * 4 - 1);
   // batch b covers list positions start-1-b*64-j (j = lane), i.e. back to front
@@ -478,74 +522,63 @@ __global__ __launch_bounds__(256 / PPL) void render_bwd_kernel(const uint2* __re
       if (!__any(anyv)) continue;
       const float r = bcast(cur.b.z, j), g = bcast(cur.b.w, j), b = bcast(cur.c, j);
       const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)cur.id, j);
-      float s_cr = 0.f, s_cg = 0.f, s_cb = 0.f, s_mx = 0.f, s_my = 0.f, s_ca = 0.f, s_cb2 = 0.f, s_cc = 0.f, s_op = 0.f;
+      float q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, q8 = 0.f;
 #pragma unroll
       for (int k = 0; k < PPL; k++) {
         if (valid[k]) {
-          T[k] = T[k] / (1.f - alpha[k]);
+          const float inv = __builtin_amdgcn_rcpf(1.f - alpha[k]);      // 1/(1-alpha): T recovery and the bg term
+          T[k] = T[k] * inv;
           const float dchannel_dcolor = alpha[k] * T[k];
-          float dL_dalpha;
           arr[k] = last_alpha[k] * lcr[k] + (1.f - last_alpha[k]) * arr[k];
           arg_[k] = last_alpha[k] * lcg[k] + (1.f - last_alpha[k]) * arg_[k];
           arb[k] = last_alpha[k] * lcb[k] + (1.f - last_alpha[k]) * arb[k];
           lcr[k] = r; lcg[k] = g; lcb[k] = b;
-          dL_dalpha = (r - arr[k]) * dpr[k] + (g - arg_[k]) * dpg[k] + (b - arb[k]) * dpb[k];
-          s_cr += dchannel_dcolor * dpr[k]; s_cg += dchannel_dcolor * dpg[k]; s_cb += dchannel_dcolor * dpb[k];
+          float dL_dalpha = (r - arr[k]) * dpr[k] + (g - arg_[k]) * dpg[k] + (b - arb[k]) * dpb[k];
+          q[0] += dchannel_dcolor * dpr[k]; q[1] += dchannel_dcolor * dpg[k]; q[2] += dchannel_dcolor * dpb[k];
           dL_dalpha *= T[k];
           last_alpha[k] = alpha[k];
-          dL_dalpha += (-T_final[k] / (1.f - alpha[k])) * bg_dot[k];
+          dL_dalpha += (-T_final[k] * inv) * bg_dot[k];
           const float dL_dG = op * dL_dalpha;
           const float gdx = G[k] * dx, gdy = G[k] * dy[k];
           const float dG_ddelx = -gdx * cx - gdy * cy;
           const float dG_ddely = -gdy * cz - gdx * cy;
-          s_mx += dL_dG * dG_ddelx * ddelx_dx;
-          s_my += dL_dG * dG_ddely * ddely_dy;
-          s_ca += -0.5f * gdx * dx * dL_dG;
-          s_cb2 += -0.5f * gdx * dy[k] * dL_dG;
-          s_cc += -0.5f * gdy * dy[k] * dL_dG;
-          s_op += G[k] * dL_dalpha;
+          q[3] += dL_dG * dG_ddelx * ddelx_dx;
+          q[4] += dL_dG * dG_ddely * ddely_dy;
+          q[5] += -0.5f * gdx * dx * dL_dG;
+          q[6] += -0.5f * gdx * dy[k] * dL_dG;
+          q[7] += -0.5f * gdy * dy[k] * dL_dG;
+          q8 += G[k] * dL_dalpha;
         }
       }
-      s_cr = wave_sum_to_lane63(s_cr); s_cg = wave_sum_to_lane63(s_cg); s_cb = wave_sum_to_lane63(s_cb);
-      s_mx = wave_sum_to_lane63(s_mx); s_my = wave_sum_to_lane63(s_my);
-      s_ca = wave_sum_to_lane63(s_ca); s_cb2 = wave_sum_to_lane63(s_cb2); s_cc = wave_sum_to_lane63(s_cc);
-      s_op = wave_sum_to_lane63(s_op);
-      if (lane == 63) {
-        atomicAdd(&dL_dcolor[3 * (size_t)gid + 0], s_cr);
-        atomicAdd(&dL_dcolor[3 * (size_t)gid + 1], s_cg);
-        atomicAdd(&dL_dcolor[3 * (size_t)gid + 2], s_cb);
-        atomicAdd(&dL_dmean2D[3 * (size_t)gid + 0], s_mx);
-        atomicAdd(&dL_dmean2D[3 * (size_t)gid + 1], s_my);
-        atomicAdd(&dL_dconic[4 * (size_t)gid + 0], s_ca);
-        atomicAdd(&dL_dconic[4 * (size_t)gid + 1], s_cb2);
-        atomicAdd(&dL_dconic[4 * (size_t)gid + 3], s_cc);
-        atomicAdd(&dL_dopacity[gid], s_op);
-      }
+      const float tot = reduce8(q, lane);
+      q8 = wave_sum_to_lane63(q8);
+      float* acc = grad_acc + (size_t)gid * GM_ACC_STRIDE;
+      if (committer) atomicAdd(acc + my_slot, tot);
+      if (lane == 63) atomicAdd(acc + 8, q8);
     }
     cur = nxt;
   }
 }
 
 int launch_render_bwd(const GeomState& g, const uint32_t* point_list, ImageState& img, int W, int H,
-                      const float* background, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
-                      float* dL_dopacity, float* dL_dcolor, int debug, hipStream_t s) {
+                      const float* background, const float* dL_dpix, int debug, hipStream_t s) {
   StageScope sc(ST_RENDER_BWD, s);
   const int ppl = env_int("GM_RENDER_BWD_PPL", 1);      // tuning knob, read per launch
   const int gx = (W + GM_TILE - 1) / GM_TILE, gy = (H + GM_TILE - 1) / GM_TILE;
   const int tiles = gx * gy;
   if (tiles > 0) {
     switch (ppl) {
-      default:
-        hipLaunchKernelGGL(render_bwd_kernel<1>, dim3(tiles), dim3(256), 0, s, img.ranges, point_list, img.tile_order, g.splat, W, H, gx,
-                           background, img.final_T, img.n_contrib, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
-        break;
       case 2:
         hipLaunchKernelGGL(render_bwd_kernel<2>, dim3(tiles), dim3(128), 0, s, img.ranges, point_list, img.tile_order, g.splat, W, H, gx,
-                           background, img.final_T, img.n_contrib, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
+                           background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc);
         break;
       case 4:
         hipLaunchKernelGGL(render_bwd_kernel<4>, dim3(tiles), dim3(64), 0, s, img.ranges, point_list, img.tile_order, g.splat, W, H, gx,
-                           background, img.final_T, img.n_contrib, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
+                           background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc);
+        break;
+      default:
+        hipLaunchKernelGGL(render_bwd_kernel<1>, dim3(tiles), dim3(256), 0, s, img.ranges, point_list, img.tile_order, g.splat, W, H, gx,
+                           background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc);
     }
   }
   GM_LAUNCH_CHECK(debug, s);
