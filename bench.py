@@ -4,8 +4,8 @@
 Workload (BASELINE.json configs[2] = "C3", the configuration the metric is quoted on: 1 M Gaussians @ 1080p):
 1 M Gaussians bound to a 15k-face torus proxy mesh; one STEP = one frame of the edit-tool loop
 (edittool/__init__.py:103-131, 400-475 of the reference):
-    deform (gm_deform: mesh state (V1,R,S) of frame t -> x', Sigma', rot)
-  + view-dependent colour (gm_sh_colors: rotated direction, SH degree 3)
+    deform + view-dependent colour (gm_deform_shade, one fused pass: mesh state (V1,R,S) of frame t -> x', Sigma',
+    rotated view direction, SH degree 3 -> colors_precomp)
   + rasterize forward (gm_forward_0/1 with colors_precomp + cov3D_precomp) at 1920x1080.
 All inputs are resident in HBM before the timed region.  With --gpus N every rank renders its own camera of
 the 64-camera orbit (views shard); rank 0 owns the mesh animation and broadcasts the per-frame
@@ -36,6 +36,12 @@ def build_scene(P, W, H, frames, seed=0):
     from gaussianmesh_amd import scenes
     verts, faces = scenes.torus_mesh(100, 75)
     cl = scenes.bind_cloud_to_mesh(P, verts, faces, seed=seed)
+    # Memory layout: Gaussians stored grouped by the face they are bound to (as the reference's model creates them:
+    # one per face, then face-splitting densification, scene/mesh_based_gaussian_model.py:183-241, 596-647), so the
+    # per-vertex (dV,R,S) gathers of neighbouring Gaussians hit the same rows.
+    perm = np.argsort(cl["fid"], kind="stable")
+    for k in ("tri", "weights", "means", "opac", "shs", "scales", "rots", "fid"):
+        cl[k] = np.ascontiguousarray(cl[k][perm])
     cov = scenes.cov3d_from_scale_rot(cl["scales"], cl["rots"]).astype(np.float32)
     mesh = np.zeros((frames, verts.shape[0], 21), np.float32)
     for t in range(frames):
@@ -52,7 +58,7 @@ def algorithmic_bytes(stage, P, V, R, W, H, Vm, M=16):
     T = ((W + 15) // 16) * ((H + 15) // 16)
     bits = max(1, int(np.ceil(np.log2(max(T, 2)))))
     return {
-        "deform": P * (12 + 12 + 36 + 12) + P * (36 + 12 + 36 + 24) + Vm * 84,
+        "deform": P * (12 + 12 + 36 + 12 + 12 * M) + P * (12 + 24 + 12) + Vm * 84,     # fused deform + colour
         "sh_colors": P * (12 + 36 + 12 * M) + P * 12,
         "preprocess": P * (12 + 24 + 4 + 12) + V * 48,
         "scan": P * 8,
@@ -81,7 +87,7 @@ def main():
     import torch.distributed as dist
     from gaussianmesh_amd import _lib, multiview, scenes
     from gaussianmesh_amd import rasterizer as Rz
-    from gaussianmesh_amd.deform import deform_tensors, sh_colors
+    from gaussianmesh_amd.deform import deform_shade
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -131,9 +137,8 @@ def main():
             ms = g["mesh"][t]
         V1, Rv, Sv = multiview.unpack_mesh_state(ms)
         dV = V1 - g["verts"]
-        pos, cov, rot, cov6 = deform_tensors(g["tri"], g["weights"], dV, Rv, Sv, g["cov"], g["pos"])
         c = cam_t[multiview.view_for_step(i, F, rank, world)]
-        rgb = sh_colors(pos, c["campos"], g["shs"], rot=rot, deg=3)
+        pos, cov6, rgb = deform_shade(g["tri"], g["weights"], dV, Rv, Sv, g["cov"], g["pos"], g["shs"], c["campos"], deg=3)
         nr, color, radii, _, _, _ = Rz.rasterize_forward(bg, pos, rgb, g["opac"], None, None, 1.0, cov6, c["view"], c["proj"],
                                                          c["tanx"], c["tany"], H, W, None, 3, c["campos"], False, False,
                                                          workspace=workspace)

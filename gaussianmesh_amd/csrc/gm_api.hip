@@ -258,6 +258,18 @@ int gm_sh_colors(int N, int deg, int M, const float* pos, const float* campos, c
   return launch_sh_colors(N, deg, M, pos, campos, rot, shs, rgb, reinterpret_cast<hipStream_t>(stream));
 }
 
+int gm_deform_shade(int N, int deg, int M, const int* tri, const float* w, const float* dV, const float* Rv, const float* Sv,
+                    const float* cov, const float* pos, const float* shs, const float* campos, float* pos_out, float* cov6_out,
+                    float* rgb_out, float* cov_out, float* rot_out, void* stream) {
+  if (N < 0 || deg < 0 || deg > 3 || M < (deg + 1) * (deg + 1) ||
+      (N > 0 && (!tri || !w || !dV || !Rv || !Sv || !cov || !pos || !shs || !campos || !pos_out || !cov6_out || !rgb_out)) ||
+      ((cov_out == nullptr) != (rot_out == nullptr))) {
+    set_error("gm_deform_shade: bad args"); return GM_ERR_INVALID_ARG;
+  }
+  return launch_deform_shade(N, deg, M, tri, w, dV, Rv, Sv, cov, pos, shs, campos, pos_out, cov6_out, rgb_out, cov_out, rot_out,
+                             reinterpret_cast<hipStream_t>(stream));
+}
+
 void gm_profile_enable(int on) { g_prof_on = on != 0; }
 void gm_profile_reset(void) {
   drain_profile();

@@ -37,8 +37,10 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
   return woff + incl - v;
 }
 
+__device__ __forceinline__ uint32_t rect_count(uint2 r) { return (r.y & 0xFFFFu) * (r.y >> 16); }
+
 __global__ __launch_bounds__(BN_THREADS) void tile_block_sums_kernel(const uint32_t* __restrict__ order,
-                                                                      const uint32_t* __restrict__ tiles, int P,
+                                                                      const uint2* __restrict__ rects, int P,
                                                                       uint32_t* __restrict__ block_sums) {
   __shared__ uint32_t wsum[BN_THREADS / 64];
   const int base = blockIdx.x * GM_SCAN_ITEMS + threadIdx.x * BN_PER_THREAD;
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(BN_THREADS) void tile_block_sums_kernel(const uint3
 #pragma unroll
   for (int i = 0; i < BN_PER_THREAD; i++) {
     const int s = base + i;
-    if (s < P) sum += tiles[order[s]];
+    if (s < P) sum += rect_count(rects[order[s]]);
   }
   uint32_t total;
   block_exclusive_scan(sum, wsum, total);
@@ -78,7 +80,7 @@ int launch_tile_count_scan(GeomState& g, int P, int debug, hipStream_t s) {
   StageScope sc(ST_SCAN, s);
   const int nb = (P + GM_SCAN_ITEMS - 1) / GM_SCAN_ITEMS;
   if (nb > 0) {
-    hipLaunchKernelGGL(tile_block_sums_kernel, dim3(nb), dim3(BN_THREADS), 0, s, g.order[0], g.tiles_touched, P, g.block_sums);
+    hipLaunchKernelGGL(tile_block_sums_kernel, dim3(nb), dim3(BN_THREADS), 0, s, g.order[0], g.rect, P, g.block_sums);
     GM_LAUNCH_CHECK(debug, s);
   }
   hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(BN_THREADS), 0, s, g.block_sums, nb, g.counters);
@@ -93,48 +95,68 @@ __device__ __forceinline__ void get_rect(float px, float py, int r, int gx, int 
   y1 = min(gy, max(0, (int)((py + r + GM_TILE - 1) / GM_TILE)));
 }
 
+// Instance emission.  Workgroup b owns sorted positions [b*2048, (b+1)*2048); thread t owns 8 consecutive ones and
+// gathers their tile rectangles (one 8-byte read each, written by preprocess).  After the block scan of the counts each
+// WAVE emits the instances of its own 512 Gaussians: it walks its non-empty items (ballot + s_ff1), broadcasts the
+// item (offset, rect, id) with v_readlane and lets lane l write instance l of the rectangle, so one store instruction
+// covers a whole splat with consecutive addresses.  A splat that covers 100 tiles costs two store instructions instead
+// of serialising one lane for 100 iterations as the reference's per-Gaussian loop does (RAST/rasterizer_impl.cu:98-109).
+// The emitted order (Gaussian order, then rect row-major) is unchanged.
 __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* __restrict__ order,
-                                                                const uint32_t* __restrict__ tiles,
-                                                                const float4* __restrict__ splat,
-                                                                const int* __restrict__ radii, int P, int gx, int gy,
+                                                                const uint2* __restrict__ rects, int P, int gx,
                                                                 const uint32_t* __restrict__ block_sums,
                                                                 uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
   __shared__ uint32_t wsum[BN_THREADS / 64];
+  const int lane = threadIdx.x & 63;
   const int base = blockIdx.x * GM_SCAN_ITEMS + threadIdx.x * BN_PER_THREAD;
-  uint32_t gid[BN_PER_THREAD], cnt[BN_PER_THREAD], sum = 0;
+  uint32_t gid[BN_PER_THREAD], cnt[BN_PER_THREAD], offs[BN_PER_THREAD], sum = 0;
+  uint2 rc[BN_PER_THREAD];
 #pragma unroll
   for (int i = 0; i < BN_PER_THREAD; i++) {
     const int s = base + i;
     gid[i] = s < P ? order[s] : 0u;
-    cnt[i] = s < P ? tiles[gid[i]] : 0u;
+  }
+#pragma unroll
+  for (int i = 0; i < BN_PER_THREAD; i++) {
+    const int s = base + i;
+    rc[i] = s < P ? rects[gid[i]] : make_uint2(0u, 0u);
+    cnt[i] = rect_count(rc[i]);
     sum += cnt[i];
   }
   uint32_t total;
   uint32_t off = block_sums[blockIdx.x] + block_exclusive_scan(sum, wsum, total);
 #pragma unroll
+  for (int i = 0; i < BN_PER_THREAD; i++) { offs[i] = off; off += cnt[i]; }
+#pragma unroll
   for (int i = 0; i < BN_PER_THREAD; i++) {
-    if (cnt[i] == 0) continue;
-    const uint32_t g = gid[i];
-    const float4 s0 = splat[3 * (size_t)g];
-    int x0, y0, x1, y1;
-    get_rect(s0.x, s0.y, radii[g], gx, gy, x0, y0, x1, y1);
-    for (int y = y0; y < y1; y++)
-      for (int x = x0; x < x1; x++) {
-        keys_out[off] = (uint32_t)(y * gx + x);
-        vals_out[off] = g;
-        off++;
+    unsigned long long todo = __ballot(cnt[i] != 0);
+    while (todo) {
+      const int j = __ffsll(todo) - 1;
+      todo &= todo - 1;
+      const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)offs[i], j);
+      const uint32_t rx = (uint32_t)__builtin_amdgcn_readlane((int)rc[i].x, j);
+      const uint32_t ry = (uint32_t)__builtin_amdgcn_readlane((int)rc[i].y, j);
+      const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)gid[i], j);
+      const uint32_t x0 = rx & 0xFFFFu, y0 = rx >> 16, w = ry & 0xFFFFu, n = w * (ry >> 16);
+      const float inv_w = 1.0f / (float)w;
+      for (uint32_t k = lane; k < n; k += 64) {
+        const uint32_t row = (uint32_t)(((float)k + 0.5f) * inv_w);      // exact floor(k / w) for k < 2^22
+        const uint32_t col = k - row * w;
+        keys_out[o + k] = (y0 + row) * (uint32_t)gx + (x0 + col);
+        vals_out[o + k] = g;
       }
+    }
   }
 }
 
 int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, const int* radii, int debug, hipStream_t s) {
   StageScope sc(ST_DUPLICATE, s);
   const int nb = (P + GM_SCAN_ITEMS - 1) / GM_SCAN_ITEMS;
-  const int gx = (W + GM_TILE - 1) / GM_TILE, gy = (H + GM_TILE - 1) / GM_TILE;
-  (void)radii;
+  const int gx = (W + GM_TILE - 1) / GM_TILE;
+  (void)radii; (void)H;
   if (nb > 0)
-    hipLaunchKernelGGL(duplicate_kernel, dim3(nb), dim3(BN_THREADS), 0, s, g.order[0], g.tiles_touched, g.splat, g.radii, P,
-                       gx, gy, g.block_sums, b.keys[0], b.vals[0]);
+    hipLaunchKernelGGL(duplicate_kernel, dim3(nb), dim3(BN_THREADS), 0, s, g.order[0], g.rect, P, gx, g.block_sums, b.keys[0],
+                       b.vals[0]);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }
@@ -151,39 +173,10 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __rest
   if (i == R - 1) ranges[cur].y = (uint32_t)R;
 }
 
-// Workgroup schedule for the blend kernels: tiles ordered by list length, longest first (LPT), so the
-// multi-thousand-entry tiles start at once and the short ones fill in behind them instead of the reverse.
-// Counting sort on a quarter-octave length class (64 classes); single workgroup, tiles <= a few 10k.
-__global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restrict__ ranges, int tiles, uint32_t* __restrict__ order) {
-  __shared__ uint32_t cnt[64];
-  if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
-  __syncthreads();
-  auto cls = [](uint32_t n) -> uint32_t {
-    if (n == 0) return 63u;
-    const uint32_t lg = 31u - (uint32_t)__clz((int)n);           // floor(log2 n)
-    const uint32_t frac = lg >= 2 ? (n >> (lg - 2)) & 3u : 0u;     // next two bits
-    const uint32_t c = 4u * lg + frac;                             // 0..127 in principle, n < 2^15.75 in practice
-    return c >= 62u ? 0u : 62u - c;                                // long lists -> small class
-  };
-  for (int t = threadIdx.x; t < tiles; t += 1024) atomicAdd(&cnt[cls(ranges[t].y - ranges[t].x)], 1u);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t run = 0;
-    for (int c = 0; c < 64; c++) { const uint32_t v = cnt[c]; cnt[c] = run; run += v; }
-  }
-  __syncthreads();
-  for (int t = threadIdx.x; t < tiles; t += 1024) {
-    const uint32_t pos = atomicAdd(&cnt[cls(ranges[t].y - ranges[t].x)], 1u);
-    order[pos] = (uint32_t)t;
-  }
-}
-
 int launch_tile_ranges(BinningState& b, int slot, ImageState& img, int R, int tiles, int debug, hipStream_t s) {
   StageScope sc(ST_RANGES, s);
   GM_HIP(hipMemsetAsync(img.ranges, 0, sizeof(uint2) * (size_t)tiles, s));
   if (R > 0) hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, b.keys[slot], R, img.ranges);
-  GM_LAUNCH_CHECK(debug, s);
-  hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, img.ranges, tiles, img.tile_order);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }

@@ -54,14 +54,20 @@ static inline T* carve(char*& p, size_t count) {
 }
 
 #define GM_SORT_ITEMS 4096      // keys per workgroup per radix pass (256 threads x 16)
-#define GM_SCAN_ITEMS 2048      // elements per workgroup in the tiles_touched scan
+#define GM_SCAN_ITEMS 512       // Gaussians per workgroup in the tiles_touched scan / instance emission (256 threads x 2)
 
-static inline size_t sort_blocks(size_t n) { return (n + GM_SORT_ITEMS - 1) / GM_SORT_ITEMS; }
+#define GM_SORT_SMALL_N (4u << 20)   // below this many keys the radix sort uses 1024-key tiles (more workgroups)
+// number of histogram columns (workgroups) the radix sort uses for n keys
+static inline size_t sort_blocks(size_t n) {
+  const size_t tile = n <= GM_SORT_SMALL_N ? 1024 : GM_SORT_ITEMS;
+  return (n + tile - 1) / tile;
+}
 
 struct GeomState {              // per-Gaussian state (P-sized)
   float4* splat;                // [P][3]: {x,y,con.x,con.y} {con.z,opacity,r,g} {b,depth,0,0}
   int* radii;                   // internal radii when the caller passes none
   uint32_t* tiles_touched;      // [P]
+  uint2* rect;                  // [P] tile rectangle {x0 | y0 << 16, width | height << 16}; width*height = tiles_touched
   float* cov3D;                 // [P][6] (computed from scale/rot)
   uint8_t* clamped;             // [P] bit ch = SH colour channel ch was clamped at 0
   uint32_t* depth_key[2];       // [P] ping-pong keys of the depth sort (float bits of view z)
@@ -77,6 +83,7 @@ struct GeomState {              // per-Gaussian state (P-sized)
     g.splat = carve<float4>(p, 3 * P);
     g.radii = carve<int>(p, P);
     g.tiles_touched = carve<uint32_t>(p, P);
+    g.rect = carve<uint2>(p, P);
     g.cov3D = carve<float>(p, 6 * P);
     g.clamped = carve<uint8_t>(p, P);
     g.depth_key[0] = carve<uint32_t>(p, P);
@@ -98,7 +105,6 @@ struct ImageState {             // per-pixel / per-tile state
   float* final_T;               // [H*W]
   uint32_t* n_contrib;          // [H*W]
   uint2* ranges;                // [tiles]
-  uint32_t* tile_order;         // [tiles] tile ids, longest list first (workgroup -> tile schedule)
   static ImageState from(void* buf, int W, int H) {
     char* p = reinterpret_cast<char*>(buf);
     const size_t N = (size_t)W * H;
@@ -107,7 +113,6 @@ struct ImageState {             // per-pixel / per-tile state
     s.final_T = carve<float>(p, N);
     s.n_contrib = carve<uint32_t>(p, N);
     s.ranges = carve<uint2>(p, T);
-    s.tile_order = carve<uint32_t>(p, T);
     s.end = p;
     return s;
   }
@@ -179,6 +184,9 @@ int launch_deform(int N, const int* tri, const float* w, const float* dV, const 
                   hipStream_t s);
 int launch_sh_colors(int N, int deg, int M, const float* pos, const float* campos, const float* rot,
                      const float* shs, float* rgb, hipStream_t s);
+int launch_deform_shade(int N, int deg, int M, const int* tri, const float* w, const float* dV, const float* Rv, const float* Sv,
+                        const float* cov, const float* pos, const float* shs, const float* campos, float* pos_out,
+                        float* cov6_out, float* rgb_out, float* cov_out, float* rot_out, hipStream_t s);
 int launch_knn(int P, const float* points, float* meanDists, void* ws, size_t ws_bytes, hipStream_t s);
 size_t knn_workspace_bytes(int P);
 

@@ -10,6 +10,8 @@
 #include "gm_common.h"
 #pragma clang fp contract(off)
 #include "gm_sh.h"
+#include "gm_stage.h"
+#include <cstdlib>
 
 namespace gm {
 
@@ -99,6 +101,134 @@ int launch_sh_colors(int N, int deg, int M, const float* pos, const float* campo
                      const float* shs, float* rgb, hipStream_t s) {
   StageScope sc(ST_SH_COLORS, s);
   if (N > 0) hipLaunchKernelGGL(sh_colors_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, deg, M, pos, campos, rot, shs, rgb);
+  GM_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused edit-loop kernel: deform + view-dependent colour in one pass (what ObjectVisualTool.render_gaussian needs per
+// frame: means3D = x', colors_precomp, cov3D_precomp = strip_symmetric(Sigma'); edittool/__init__.py:421-472).
+// Reads 264 B and writes 48 B per Gaussian (+72 B if the caller also wants Sigma' and rot), against
+// 72+108 (deform) + 240+12 (colour) for the two separate kernels.  SH and covariance rows go through LDS
+// (gm_stage.h), results leave through LDS as coalesced 16-byte stores.
+template <int DS_THREADS>
+__global__ __launch_bounds__(DS_THREADS) void deform_shade_kernel(int N, int deg, const int* __restrict__ tri, const float* __restrict__ w,
+                                                                  const float* __restrict__ dV, const float* __restrict__ Rv,
+                                                                  const float* __restrict__ Sv, const float* __restrict__ cov,
+                                                                  const float* __restrict__ pos, const float* __restrict__ shs,
+                                                                  const float* __restrict__ campos, float* __restrict__ pos_out,
+                                                                  float* __restrict__ cov6_out, float* __restrict__ rgb_out,
+                                                                  float* __restrict__ cov_out, float* __restrict__ rot_out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* l_sh = lds;                           // [256][49]
+  float* l_cov = lds + DS_THREADS * 49;        // [256][9]
+  const size_t row0 = (size_t)blockIdx.x * DS_THREADS;
+  const int nrows = min(DS_THREADS, N - (int)row0);
+  stage_rows<48, 49, DS_THREADS>(shs, row0, nrows, l_sh);
+  stage_rows<9, 9, DS_THREADS>(cov, row0, nrows, l_cov);
+  const int t = threadIdx.x;
+  const size_t i = row0 + t;
+  const bool live = t < nrows;
+  float O[9], Rt[9], npos[3], col[3];
+  int t0 = 0, t1 = 0, t2 = 0; float w0 = 0.f, w1 = 0.f, w2 = 0.f, p0 = 0.f, p1 = 0.f, p2 = 0.f;
+  if (live) {
+    t0 = tri[3 * i]; t1 = tri[3 * i + 1]; t2 = tri[3 * i + 2];
+    w0 = w[3 * i]; w1 = w[3 * i + 1]; w2 = w[3 * i + 2];
+    p0 = pos[3 * i]; p1 = pos[3 * i + 1]; p2 = pos[3 * i + 2];
+  }
+  float d[3], Rb[9], Sb[9];
+#pragma unroll
+  for (int k = 0; k < 3; k++) d[k] = (w0 * dV[3 * (size_t)t0 + k] + w1 * dV[3 * (size_t)t1 + k]) + w2 * dV[3 * (size_t)t2 + k];
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    Rb[k] = (w0 * Rv[9 * (size_t)t0 + k] + w1 * Rv[9 * (size_t)t1 + k]) + w2 * Rv[9 * (size_t)t2 + k];
+    Sb[k] = (w0 * Sv[9 * (size_t)t0 + k] + w1 * Sv[9 * (size_t)t1 + k]) + w2 * Sv[9 * (size_t)t2 + k];
+  }
+  __syncthreads();
+  {
+    float RS[9], A[9], C[9];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) Rt[3 * a + b] = Rb[3 * b + a];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) RS[3 * a + b] = (Rt[3 * a] * Sb[b] + Rt[3 * a + 1] * Sb[3 + b]) + Rt[3 * a + 2] * Sb[6 + b];
+#pragma unroll
+    for (int k = 0; k < 9; k++) C[k] = l_cov[t * 9 + k];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) A[3 * a + b] = (RS[3 * a] * C[b] + RS[3 * a + 1] * C[3 + b]) + RS[3 * a + 2] * C[6 + b];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) O[3 * a + b] = (A[3 * a] * RS[3 * b] + A[3 * a + 1] * RS[3 * b + 1]) + A[3 * a + 2] * RS[3 * b + 2];
+    npos[0] = p0 + d[0]; npos[1] = p1 + d[1]; npos[2] = p2 + d[2];
+    float dx = npos[0] - campos[0], dy = npos[1] - campos[1], dz = npos[2] - campos[2];
+    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    dx = dx / len; dy = dy / len; dz = dz / len;
+    // dir_rot = rot^T dir with rot = Rt
+    const float x = (Rt[0] * dx + Rt[3] * dy) + Rt[6] * dz;
+    const float y = (Rt[1] * dx + Rt[4] * dy) + Rt[7] * dz;
+    const float z = (Rt[2] * dx + Rt[5] * dy) + Rt[8] * dz;
+    const float* sh = l_sh + t * 49;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+      const float r = sh_channel(deg, [&](int k) { return sh[3 * k + ch]; }, x, y, z);
+      col[ch] = fmaxf(r + 0.5f, 0.0f);
+    }
+  }
+  __syncthreads();                               // everyone is done reading the staged inputs: reuse LDS for the outputs
+  float* o_pos = lds;                            // [256][3]
+  float* o_rgb = lds + DS_THREADS * 3;           // [256][3]
+  float* o_c6 = lds + DS_THREADS * 6;            // [256][6]  (stride 7 to stay conflict-free)
+  float* o_cov = lds + DS_THREADS * 13;          // [256][9]
+  float* o_rot = lds + DS_THREADS * 22;          // [256][9]
+#pragma unroll
+  for (int k = 0; k < 3; k++) { o_pos[t * 3 + k] = npos[k]; o_rgb[t * 3 + k] = col[k]; }
+  o_c6[t * 7 + 0] = O[0]; o_c6[t * 7 + 1] = O[1]; o_c6[t * 7 + 2] = O[2]; o_c6[t * 7 + 3] = O[4]; o_c6[t * 7 + 4] = O[5]; o_c6[t * 7 + 5] = O[8];
+  if (cov_out) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) { o_cov[t * 9 + k] = O[k]; o_rot[t * 9 + k] = Rt[k]; }
+  }
+  __syncthreads();
+  unstage_rows<3, 3, DS_THREADS>(pos_out, row0, nrows, o_pos);
+  unstage_rows<3, 3, DS_THREADS>(rgb_out, row0, nrows, o_rgb);
+  unstage_rows<6, 7, DS_THREADS>(cov6_out, row0, nrows, o_c6);
+  if (cov_out) {
+    unstage_rows<9, 9, DS_THREADS>(cov_out, row0, nrows, o_cov);
+    unstage_rows<9, 9, DS_THREADS>(rot_out, row0, nrows, o_rot);
+  }
+}
+
+int launch_deform_shade(int N, int deg, int M, const int* tri, const float* w, const float* dV, const float* Rv, const float* Sv,
+                        const float* cov, const float* pos, const float* shs, const float* campos, float* pos_out,
+                        float* cov6_out, float* rgb_out, float* cov_out, float* rot_out, hipStream_t s) {
+  if (N <= 0) return 0;
+  if (M != 16 || !aligned16(shs) || !aligned16(cov) || !aligned16(pos_out) || !aligned16(cov6_out) || !aligned16(rgb_out) ||
+      (cov_out && (!aligned16(cov_out) || !aligned16(rot_out)))) {
+    // general layout: run the two unfused kernels (needs the 72 B/Gaussian intermediates from the caller)
+    if (!cov_out || !rot_out) { set_error("gm_deform_shade: M != 16 or unaligned buffers need cov_out/rot_out"); return 1; }
+    if (int rc = launch_deform(N, tri, w, dV, Rv, Sv, cov, pos, pos_out, cov_out, rot_out, cov6_out, s)) return rc;
+    return launch_sh_colors(N, deg, M, pos_out, campos, rot_out, shs, rgb_out, s);
+  }
+  StageScope sc(ST_DEFORM, s);
+  // 64 Gaussians per workgroup (one wave, 14.5 KiB of LDS): ~11 workgroups per CU sit in different phases
+  // (load / compute / store), which keeps far more bytes in flight than a few 256-thread groups in lock-step
+  const char* e = getenv("GM_DS_THREADS");
+  const int th = e ? atoi(e) : 64;
+  const size_t lds_bytes = sizeof(float) * th * (49 + 9);
+  if (th == 256)
+    hipLaunchKernelGGL(deform_shade_kernel<256>, dim3((N + 255) / 256), dim3(256), lds_bytes, s, N, deg, tri, w, dV, Rv, Sv, cov, pos,
+                       shs, campos, pos_out, cov6_out, rgb_out, cov_out, rot_out);
+  else if (th == 128)
+    hipLaunchKernelGGL(deform_shade_kernel<128>, dim3((N + 127) / 128), dim3(128), lds_bytes, s, N, deg, tri, w, dV, Rv, Sv, cov, pos,
+                       shs, campos, pos_out, cov6_out, rgb_out, cov_out, rot_out);
+  else
+    hipLaunchKernelGGL(deform_shade_kernel<64>, dim3((N + 63) / 64), dim3(64), lds_bytes, s, N, deg, tri, w, dV, Rv, Sv, cov, pos,
+                       shs, campos, pos_out, cov6_out, rgb_out, cov_out, rot_out);
   GM_HIP(hipGetLastError());
   return 0;
 }

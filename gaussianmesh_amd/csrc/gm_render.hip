@@ -103,11 +103,11 @@ __device__ __forceinline__ bool may_touch(float sx, float sy, float a, float b, 
 template <int PPL>
 __global__ __launch_bounds__(256 / PPL) void render_fwd_kernel(const uint2* __restrict__ ranges,
                                                                const uint32_t* __restrict__ point_list,
-                                                               const uint32_t* __restrict__ tile_order, const float4* __restrict__ splat, int W, int H, int gx,
+                                                               const float4* __restrict__ splat, int W, int H, int gx,
                                                                const float* __restrict__ bg, float* __restrict__ out_color,
                                                                float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tile = (int)tile_order[blockIdx.x];
+  const int tile = blockIdx.x;
   const int tx = tile % gx, ty = tile / gx;
   const uint2 range = ranges[tile];
   const int n = (int)(range.y - range.x);
@@ -250,7 +250,7 @@ __device__ __forceinline__ StripTest strip_mask(float sx, float sy, float a, flo
 
 __global__ __launch_bounds__(256) void render_fwd_coop_kernel(const uint2* __restrict__ ranges,
                                                               const uint32_t* __restrict__ point_list,
-                                                              const uint32_t* __restrict__ tile_order, const float4* __restrict__ splat, int W, int H, int gx,
+                                                              const float4* __restrict__ splat, int W, int H, int gx,
                                                               const float* __restrict__ bg, float* __restrict__ out_color,
                                                               float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
   __shared__ float4 la[2][256];
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void render_fwd_coop_kernel(const uint2* __res
   __shared__ int flags[2][4];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile = (int)tile_order[blockIdx.x];
+  const int tile = blockIdx.x;
   const int tx = tile % gx, ty = tile / gx;
   const uint2 range = ranges[tile];
   const int n = (int)(range.y - range.x);
@@ -361,19 +361,19 @@ int launch_render_fwd(const GeomState& g, const uint32_t* point_list, ImageState
   if (tiles > 0) {
     switch (ppl) {
       case 4:
-        hipLaunchKernelGGL(render_fwd_kernel<4>, dim3(tiles), dim3(64), 0, s, img.ranges, point_list, img.tile_order, g.splat, W, H, gx,
+        hipLaunchKernelGGL(render_fwd_kernel<4>, dim3(tiles), dim3(64), 0, s, img.ranges, point_list, g.splat, W, H, gx,
                            background, out_color, img.final_T, img.n_contrib);
         break;
       case 2:
-        hipLaunchKernelGGL(render_fwd_kernel<2>, dim3(tiles), dim3(128), 0, s, img.ranges, point_list, img.tile_order, g.splat, W, H, gx,
+        hipLaunchKernelGGL(render_fwd_kernel<2>, dim3(tiles), dim3(128), 0, s, img.ranges, point_list, g.splat, W, H, gx,
                            background, out_color, img.final_T, img.n_contrib);
         break;
       case 0:
-        hipLaunchKernelGGL(render_fwd_coop_kernel, dim3(tiles), dim3(256), 0, s, img.ranges, point_list, img.tile_order, g.splat, W, H, gx,
+        hipLaunchKernelGGL(render_fwd_coop_kernel, dim3(tiles), dim3(256), 0, s, img.ranges, point_list, g.splat, W, H, gx,
                            background, out_color, img.final_T, img.n_contrib);
         break;
       default:
-        hipLaunchKernelGGL(render_fwd_kernel<1>, dim3(tiles), dim3(256), 0, s, img.ranges, point_list, img.tile_order, g.splat, W, H, gx,
+        hipLaunchKernelGGL(render_fwd_kernel<1>, dim3(tiles), dim3(256), 0, s, img.ranges, point_list, g.splat, W, H, gx,
                            background, out_color, img.final_T, img.n_contrib);
     }
   }
@@ -444,12 +444,12 @@ __device__ __forceinline__ int reduce8_slot(int lane) {
 template <int PPL>
 __global__ __launch_bounds__(256 / PPL) void render_bwd_kernel(const uint2* __restrict__ ranges,
                                                                const uint32_t* __restrict__ point_list,
-                                                               const uint32_t* __restrict__ tile_order, const float4* __restrict__ splat, int W, int H, int gx,
+                                                               const float4* __restrict__ splat, int W, int H, int gx,
                                                                const float* __restrict__ bg, const float* __restrict__ final_T,
                                                                const uint32_t* __restrict__ n_contrib,
                                                                const float* __restrict__ dL_dpix, float* __restrict__ grad_acc) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tile = (int)tile_order[blockIdx.x];
+  const int tile = blockIdx.x;
   const int tx = tile % gx, ty = tile / gx;
   const uint2 range = ranges[tile];
   const int n = (int)(range.y - range.x);
@@ -569,15 +569,15 @@ int launch_render_bwd(const GeomState& g, const uint32_t* point_list, ImageState
   if (tiles > 0) {
     switch (ppl) {
       case 2:
-        hipLaunchKernelGGL(render_bwd_kernel<2>, dim3(tiles), dim3(128), 0, s, img.ranges, point_list, img.tile_order, g.splat, W, H, gx,
+        hipLaunchKernelGGL(render_bwd_kernel<2>, dim3(tiles), dim3(128), 0, s, img.ranges, point_list, g.splat, W, H, gx,
                            background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc);
         break;
       case 4:
-        hipLaunchKernelGGL(render_bwd_kernel<4>, dim3(tiles), dim3(64), 0, s, img.ranges, point_list, img.tile_order, g.splat, W, H, gx,
+        hipLaunchKernelGGL(render_bwd_kernel<4>, dim3(tiles), dim3(64), 0, s, img.ranges, point_list, g.splat, W, H, gx,
                            background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc);
         break;
       default:
-        hipLaunchKernelGGL(render_bwd_kernel<1>, dim3(tiles), dim3(256), 0, s, img.ranges, point_list, img.tile_order, g.splat, W, H, gx,
+        hipLaunchKernelGGL(render_bwd_kernel<1>, dim3(tiles), dim3(256), 0, s, img.ranges, point_list, g.splat, W, H, gx,
                            background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc);
     }
   }

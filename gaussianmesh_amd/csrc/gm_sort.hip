@@ -28,19 +28,34 @@ namespace gm {
 
 #define RS_THREADS 256
 #define RS_WAVES 4
-#define RS_ROUNDS 16                       // rounds of 64 keys per wave: 4 * 16 * 64 = 4096 = GM_SORT_ITEMS
+// ROUNDS = rounds of 64 keys per wave; a workgroup sorts 4 * ROUNDS * 64 keys.  ROUNDS = 16 (4096 keys) for the
+// instance sort; ROUNDS = 4 (1024 keys) for the 1 M-key depth / Morton sorts, which would otherwise run on fewer
+// workgroups than the chip has CUs.
 
+// Digit histogram of one tile.  Keys with equal digits inside a wave are counted once (match-any with eight 64-bit
+// ballots, the peer-group leader adds popcount) instead of one LDS atomic per key: the tile-id digits of the instance
+// sort are so coherent that per-key atomics serialise on a handful of LDS addresses.
+template <int ROUNDS>
 __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n,
                                                                  int shift, uint32_t mask, uint32_t* __restrict__ hist,
                                                                  uint32_t nblk) {
   __shared__ uint32_t h[256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   h[threadIdx.x] = 0;
   __syncthreads();
-  const uint32_t base = blockIdx.x * GM_SORT_ITEMS;
+  const uint32_t wbase = blockIdx.x * (RS_WAVES * ROUNDS * 64) + wave * (ROUNDS * 64);
 #pragma unroll
-  for (int i = 0; i < GM_SORT_ITEMS / RS_THREADS; i++) {
-    const uint32_t idx = base + i * RS_THREADS + threadIdx.x;
-    if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & mask], 1u);
+  for (int r = 0; r < ROUNDS; r++) {
+    const uint32_t idx = wbase + r * 64 + lane;
+    const bool valid = idx < n;
+    const uint32_t d = valid ? (keys[idx] >> shift) & mask : 0u;
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      const uint64_t bal = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? bal : ~bal;
+    }
+    if (valid && lane == __ffsll((unsigned long long)peers) - 1) atomicAdd(&h[d], (uint32_t)__popcll(peers));
   }
   __syncthreads();
   hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
@@ -78,7 +93,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scan_kernel(uint32_t* __rest
   if (threadIdx.x == 0) digit_total[blockIdx.x] = carry_s;
 }
 
-template <bool IOTA>
+template <bool IOTA, int RS_ROUNDS>
 __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                     const uint32_t* __restrict__ vals_in,
                                                                     uint32_t* __restrict__ keys_out,
@@ -89,8 +104,9 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const uint32_
   __shared__ uint32_t gbase[256];            // global base of each digit for this workgroup
   __shared__ uint32_t dstart[256];           // start of each digit's run inside the locally sorted tile
   __shared__ uint32_t wsum2[RS_WAVES];
-  __shared__ uint32_t lkey[GM_SORT_ITEMS];   // locally sorted tile (32 KiB with lval)
-  __shared__ uint32_t lval[GM_SORT_ITEMS];
+  constexpr int TILE_KEYS = RS_WAVES * RS_ROUNDS * 64;
+  __shared__ uint32_t lkey[TILE_KEYS];       // locally sorted tile (32 KiB with lval at 4096 keys)
+  __shared__ uint32_t lval[TILE_KEYS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
@@ -113,7 +129,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const uint32_
   }
   __syncthreads();
 
-  const uint32_t wbase = blockIdx.x * GM_SORT_ITEMS + wave * (RS_ROUNDS * 64);
+  const uint32_t wbase = blockIdx.x * TILE_KEYS + wave * (RS_ROUNDS * 64);
   uint32_t key[RS_ROUNDS], rank[RS_ROUNDS];
 #pragma unroll
   for (int r = 0; r < RS_ROUNDS; r++) {
@@ -183,9 +199,9 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const uint32_
     }
   }
   __syncthreads();
-  const uint32_t tile_n = min((uint32_t)GM_SORT_ITEMS, n - blockIdx.x * GM_SORT_ITEMS);
+  const uint32_t tile_n = min((uint32_t)TILE_KEYS, n - blockIdx.x * TILE_KEYS);
 #pragma unroll
-  for (int i = 0; i < GM_SORT_ITEMS / RS_THREADS; i++) {
+  for (int i = 0; i < TILE_KEYS / RS_THREADS; i++) {
     const uint32_t lp = i * RS_THREADS + threadIdx.x;
     if (lp < tile_n) {
       const uint32_t k = lkey[lp];
@@ -197,29 +213,38 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const uint32_
   }
 }
 
-int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], uint32_t* hist, uint32_t* digit_total, size_t n,
-                     int bits, bool iota_values, int debug, hipStream_t s) {
-  if (n == 0) return 0;
-  if (n > 0xFFFFFFF0ull) { set_error("radix_sort_pairs: n too large"); return 1; }
-  const uint32_t nblk = (uint32_t)sort_blocks(n);
+template <int ROUNDS>
+static int radix_sort_pairs_t(uint32_t* keys[2], uint32_t* vals[2], uint32_t* hist, uint32_t* digit_total, size_t n,
+                              int bits, bool iota_values, int debug, hipStream_t s) {
+  const uint32_t tile_keys = RS_WAVES * ROUNDS * 64;
+  const uint32_t nblk = (uint32_t)((n + tile_keys - 1) / tile_keys);
   int cur = 0;
   for (int shift = 0; shift < bits; shift += 8) {
     const int nb = (bits - shift) < 8 ? (bits - shift) : 8;
     const uint32_t mask = (1u << nb) - 1u;
-    hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(RS_THREADS), 0, s, keys[cur], (uint32_t)n, shift, mask, hist, nblk);
+    hipLaunchKernelGGL(radix_hist_kernel<ROUNDS>, dim3(nblk), dim3(RS_THREADS), 0, s, keys[cur], (uint32_t)n, shift, mask, hist, nblk);
     GM_LAUNCH_CHECK(debug, s);
     hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(RS_THREADS), 0, s, hist, nblk, digit_total);
     GM_LAUNCH_CHECK(debug, s);
     if (iota_values && shift == 0)
-      hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nblk), dim3(RS_THREADS), 0, s, keys[cur], vals[cur], keys[cur ^ 1],
+      hipLaunchKernelGGL((radix_scatter_kernel<true, ROUNDS>), dim3(nblk), dim3(RS_THREADS), 0, s, keys[cur], vals[cur], keys[cur ^ 1],
                          vals[cur ^ 1], (uint32_t)n, shift, mask, hist, nblk, digit_total);
     else
-      hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nblk), dim3(RS_THREADS), 0, s, keys[cur], vals[cur], keys[cur ^ 1],
+      hipLaunchKernelGGL((radix_scatter_kernel<false, ROUNDS>), dim3(nblk), dim3(RS_THREADS), 0, s, keys[cur], vals[cur], keys[cur ^ 1],
                          vals[cur ^ 1], (uint32_t)n, shift, mask, hist, nblk, digit_total);
     GM_LAUNCH_CHECK(debug, s);
     cur ^= 1;
   }
   return 0;
+}
+
+// hist must hold 256 * sort_hist_blocks(n) counters
+int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], uint32_t* hist, uint32_t* digit_total, size_t n,
+                     int bits, bool iota_values, int debug, hipStream_t s) {
+  if (n == 0) return 0;
+  if (n > 0xFFFFFFF0ull) { set_error("radix_sort_pairs: n too large"); return 1; }
+  if (n <= GM_SORT_SMALL_N) return radix_sort_pairs_t<4>(keys, vals, hist, digit_total, n, bits, iota_values, debug, s);
+  return radix_sort_pairs_t<16>(keys, vals, hist, digit_total, n, bits, iota_values, debug, s);
 }
 
 }  // namespace gm

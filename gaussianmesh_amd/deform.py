@@ -62,6 +62,28 @@ def sh_colors(pos, campos, shs, rot=None, deg=3):
     return rgb
 
 
+def deform_shade(tri, w, dV, Rv, Sv, cov, pos, shs, campos, deg=3, want_cov_rot=False):
+    """gm_deform_shade: fused deform + rotated-direction SH colour.  Returns (pos' [N,3], cov6 [N,6], rgb [N,3]) and, with
+    want_cov_rot, also (cov' [N,3,3], rot [N,3,3])."""
+    lib = _lib.lib()
+    device = pos.device
+    if device.type != "cuda":
+        raise _lib.GmeshError("deform_shade needs tensors on a HIP (cuda) device; there is no CPU path")
+    tri = tri.detach().contiguous().to(torch.int32)
+    w, dV, Rv, Sv, cov, pos, shs, campos = (_f(t) for t in (w, dV, Rv, Sv, cov, pos, shs, campos))
+    N, M = pos.shape[0], shs.shape[1]
+    f = dict(dtype=torch.float32, device=device)
+    pos_o = torch.empty((N, 3), **f); cov6 = torch.empty((N, 6), **f); rgb = torch.empty((N, 3), **f)
+    cov_o = torch.empty((N, 3, 3), **f) if want_cov_rot else None
+    rot_o = torch.empty((N, 3, 3), **f) if want_cov_rot else None
+    with torch.cuda.device(device):
+        _lib.check(lib.gm_deform_shade(N, int(deg), M, tri.data_ptr(), w.data_ptr(), dV.data_ptr(), Rv.data_ptr(), Sv.data_ptr(),
+                                       cov.data_ptr(), pos.data_ptr(), shs.data_ptr(), campos.data_ptr(), pos_o.data_ptr(),
+                                       cov6.data_ptr(), rgb.data_ptr(), None if cov_o is None else cov_o.data_ptr(),
+                                       None if rot_o is None else rot_o.data_ptr(), torch.cuda.current_stream(device).cuda_stream))
+    return (pos_o, cov6, rgb, cov_o, rot_o) if want_cov_rot else (pos_o, cov6, rgb)
+
+
 class SingleObjectDeform:
     """Tensor-in counterpart of edittool.SingleObjectDeform.
 
@@ -97,3 +119,12 @@ class SingleObjectDeform:
         self.gaussian_deform_pos, self.gaussian_deform_cov, self.gaussian_deform_rot = pos, cov, rot
         self.gaussian_deform_cov6 = cov6
         return pos, cov, rot
+
+    def deform_and_shade(self, deform_vertex, cur_rot, cur_shear, campos, deg=3):
+        """One fused pass for the render loop: updates gaussian_deform_pos / gaussian_deform_cov6 and returns
+        (means3D, colors_precomp, cov3D_precomp) for NewGaussianRasterizer (edittool/__init__.py:464-472)."""
+        dV = _f(deform_vertex) - self.vertex
+        pos, cov6, rgb = deform_shade(self.gaussian_triangles, self.coord, dV, cur_rot.reshape(-1, 3, 3), cur_shear.reshape(-1, 3, 3),
+                                      self.gaussian_cov, self.gaussian_pos, self.gaussian_feature, campos, deg)
+        self.gaussian_deform_pos, self.gaussian_deform_cov6 = pos, cov6
+        return pos, rgb, cov6

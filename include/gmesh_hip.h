@@ -131,6 +131,14 @@ int gm_deform(int N, const int* tri, const float* w, const float* dV, const floa
 int gm_sh_colors(int N, int deg, int M, const float* pos, const float* campos, const float* rot, const float* shs,
                  float* rgb, void* stream);
 
+/* Fused edit-loop step: gm_deform followed by gm_sh_colors(rot = the deformed rotation) in ONE pass over the cloud
+ * (what ObjectVisualTool.render_gaussian consumes per frame, edittool/__init__.py:421-472): pos_out [N,3],
+ * cov6_out [N,6] (cov3D_precomp), rgb_out [N,3] (colors_precomp).  cov_out / rot_out ([N,3,3] each) are optional
+ * (both or neither) for callers that also want SingleObjectDeform's gaussian_deform_cov / gaussian_deform_rot. */
+int gm_deform_shade(int N, int deg, int M, const int* tri, const float* w, const float* dV, const float* Rv, const float* Sv,
+                    const float* cov, const float* pos, const float* shs, const float* campos, float* pos_out, float* cov6_out,
+                    float* rgb_out, float* cov_out, float* rot_out, void* stream);
+
 /* Per-stage GPU timing (HIP events recorded on `stream` around each kernel group).  Off by default.
  * gm_profile_enable(1) starts collecting, gm_profile_read synchronises the recorded events and returns
  * accumulated milliseconds and launch count for a stage name ("preprocess","depth_sort","scan",

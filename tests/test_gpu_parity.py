@@ -240,3 +240,12 @@ def test_deform_and_sh_colors(oracle):
     rgb_ref = oracle.sh_colors_rotated(p_ref, campos, r_ref, cl["shs"], deg=3)
     rgb = sh_colors(T(p_ref), T(campos), T(cl["shs"]), rot=T(r_ref), deg=3).cpu().numpy()
     assert np.abs(rgb - rgb_ref).max() <= 1e-5
+    # fused kernel == the two separate kernels, bit for bit (same arithmetic, different data movement)
+    from gaussianmesh_amd.deform import deform_shade
+    args = (T(cl["tri"], dtype=torch.int32), T(cl["weights"]), T(dV), T(Rv), T(Sv), T(cov), T(cl["means"]), T(cl["shs"]), T(campos))
+    fp, fc6, frgb, fcov, frot = (x.cpu().numpy() for x in deform_shade(*args, deg=3, want_cov_rot=True))
+    rgb_sep = sh_colors(T(p), T(campos), T(cl["shs"]), rot=T(r), deg=3).cpu().numpy()
+    assert np.array_equal(fp, p) and np.array_equal(fc6, c6) and np.array_equal(fcov, c) and np.array_equal(frot, r)
+    assert np.array_equal(frgb, rgb_sep)
+    fp2, fc62, frgb2 = (x.cpu().numpy() for x in deform_shade(*args, deg=3))
+    assert np.array_equal(fp2, p) and np.array_equal(fc62, c6) and np.array_equal(frgb2, rgb_sep)
