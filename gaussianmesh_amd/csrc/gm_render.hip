@@ -131,6 +131,11 @@ __global__ __launch_bounds__(256 / PPL) void render_fwd_kernel(const uint2* __re
   const float rx0 = (float)(tx * GM_TILE), rx1 = rx0 + (float)(GM_TILE - 1);
   const float ry0 = (float)(ty * GM_TILE + wave * PPL * 4), ry1 = ry0 + (float)(PPL * 4 - 1);
 
+  // wave-private LDS copy of the current batch: survivors are re-read from here as LDS broadcasts (3 LDS
+  // instructions, no VALU issue slots) instead of 9 v_readlane_b32 per survivor
+  __shared__ float4 l_rec[4 / PPL][64][3];
+  float4 (*rec)[3] = l_rec[wave];
+
   Batch cur = load_records(splat, load_id(list, lane, n), lane < n);
   uint32_t id_nxt = load_id(list, 64 + lane, n);
   for (int base = 0; base < n; base += 64) {
@@ -142,37 +147,60 @@ __global__ __launch_bounds__(256 / PPL) void render_fwd_kernel(const uint2* __re
     const Batch nxt = load_records(splat, id_nxt, base + 64 + lane < n);    // records of the next batch
     id_nxt = load_id(list, base + 128 + lane, n);                          // ids of the batch after that
     const bool keep = (base + lane < n) && may_touch(cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, rx0, rx1, ry0, ry1);
+    rec[lane][0] = cur.a; rec[lane][1] = cur.b; rec[lane][2] = make_float4(cur.c, 0.f, 0.f, 0.f);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     unsigned long long todo = __ballot(keep);
+    // Survivors are taken two at a time: the two alpha evaluations (the long dependent chain: quadratic form,
+    // exp, min) are independent and interleave, only the short T/C recurrence is applied in order.  A wave that
+    // is alone on its SIMD at the tail of a 10k-entry tile otherwise issues one dependent instruction every ~6 cycles.
     while (todo) {
-      const int j = __ffsll(todo) - 1;
+      const int j0 = __ffsll(todo) - 1;
       todo &= todo - 1;
-      const float sx = bcast(cur.a.x, j), sy = bcast(cur.a.y, j);
-      const float cx = bcast(cur.a.z, j), cy = bcast(cur.a.w, j), cz = bcast(cur.b.x, j);
-      const float op = bcast(cur.b.y, j);
-      const float dx = sx - pixx;
-      float alpha[PPL], testT[PPL];
-      bool valid[PPL], anyv = false;
+      const bool has1 = todo != 0;
+      const int j1 = has1 ? __ffsll(todo) - 1 : j0;
+      todo &= todo - 1;
+      const float4 A0 = rec[j0][0], B0 = rec[j0][1], A1 = rec[j1][0], B1 = rec[j1][1];
+      const float sx0 = A0.x, sy0 = A0.y, cx0 = A0.z, cy0 = A0.w, cz0 = B0.x, op0 = B0.y;
+      const float sx1 = A1.x, sy1 = A1.y, cx1 = A1.z, cy1 = A1.w, cz1 = B1.x, op1 = B1.y;
+      const float dx0 = sx0 - pixx, dx1 = sx1 - pixx;
+      float alpha0[PPL], alpha1[PPL], t0[PPL], t1[PPL];
+      bool v0[PPL], v1[PPL], anyv = false;
 #pragma unroll
       for (int k = 0; k < PPL; k++) {
-        const float dy = sy - pixy[k];
-        const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
-        alpha[k] = fminf(0.99f, op * __builtin_amdgcn_exp2f(power * LOG2E));
-        valid[k] = !done[k] && (power <= 0.0f) && (alpha[k] >= 1.0f / 255.0f);
-        testT[k] = T[k] * (1.0f - alpha[k]);
-        const bool stop = valid[k] && (testT[k] < 0.0001f);
-        done[k] = done[k] || stop;
-        valid[k] = valid[k] && !stop;
-        anyv = anyv || valid[k];
+        const float dy0 = sy0 - pixy[k], dy1 = sy1 - pixy[k];
+        const float power0 = -0.5f * (cx0 * dx0 * dx0 + cz0 * dy0 * dy0) - cy0 * dx0 * dy0;
+        const float power1 = -0.5f * (cx1 * dx1 * dx1 + cz1 * dy1 * dy1) - cy1 * dx1 * dy1;
+        alpha0[k] = fminf(0.99f, op0 * __builtin_amdgcn_exp2f(power0 * LOG2E));
+        alpha1[k] = fminf(0.99f, op1 * __builtin_amdgcn_exp2f(power1 * LOG2E));
+        // entry j0
+        v0[k] = !done[k] && (power0 <= 0.0f) && (alpha0[k] >= 1.0f / 255.0f);
+        t0[k] = T[k] * (1.0f - alpha0[k]);
+        const bool stop0 = v0[k] && (t0[k] < 0.0001f);
+        done[k] = done[k] || stop0;
+        v0[k] = v0[k] && !stop0;
+        const float Tm = v0[k] ? t0[k] : T[k];
+        // entry j1 (in list order after j0)
+        v1[k] = has1 && !done[k] && (power1 <= 0.0f) && (alpha1[k] >= 1.0f / 255.0f);
+        t1[k] = Tm * (1.0f - alpha1[k]);
+        const bool stop1 = v1[k] && (t1[k] < 0.0001f);
+        done[k] = done[k] || stop1;
+        v1[k] = v1[k] && !stop1;
+        anyv = anyv || v0[k] || v1[k];
       }
       if (__any(anyv)) {
-        const float r = bcast(cur.b.z, j), g = bcast(cur.b.w, j), b = bcast(cur.c, j);
-        const uint32_t contributor = (uint32_t)(base + j + 1);
+        const float r0 = B0.z, g0 = B0.w, b0 = rec[j0][2].x;
+        const float r1 = B1.z, g1 = B1.w, b1 = rec[j1][2].x;
+        const uint32_t c0 = (uint32_t)(base + j0 + 1), c1 = (uint32_t)(base + j1 + 1);
 #pragma unroll
         for (int k = 0; k < PPL; k++) {
-          const float w = valid[k] ? alpha[k] * T[k] : 0.0f;
-          Cr[k] += r * w; Cg[k] += g * w; Cb[k] += b * w;
-          T[k] = valid[k] ? testT[k] : T[k];
-          last[k] = valid[k] ? contributor : last[k];
+          const float w0 = v0[k] ? alpha0[k] * T[k] : 0.0f;
+          const float Tm = v0[k] ? t0[k] : T[k];
+          const float w1 = v1[k] ? alpha1[k] * Tm : 0.0f;
+          Cr[k] += r0 * w0; Cg[k] += g0 * w0; Cb[k] += b0 * w0;
+          Cr[k] += r1 * w1; Cg[k] += g1 * w1; Cb[k] += b1 * w1;
+          T[k] = v1[k] ? t1[k] : Tm;
+          last[k] = v1[k] ? c1 : (v0[k] ? c0 : last[k]);
         }
       }
     }
