@@ -212,7 +212,7 @@ int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t*
 struct PreBwdArgs {
   int P, D, M, W, H;
   const float *means, *shs, *scales, *rots, *cov3D, *view, *proj, *campos;
-  const int* radii; const uint8_t* clamped;
+  const int* radii; const uint8_t* clamped; const float4* splat;
   float mod, tanx, tany, fx, fy;
   const float* grad_acc;                                   // [P][12] packed accumulators written by render_bwd_kernel
   float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor;  // API outputs unpacked from grad_acc
@@ -226,21 +226,33 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(const PreBwdArgs a)
   float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const bool visible = a.radii[idx] > 0;
   // unpack the blend-stage accumulators (all zero for Gaussians no tile ever touched)
+  // grad_acc = dL/dcolor rgb + the moments (1, dx, dy, dx^2, dx dy, dy^2) of h = G dL/dG over all pixels; combine them
+  // with this Gaussian's conic / opacity into the reference's accumulators (backward.cu:538-554)
   const float4 acc0 = reinterpret_cast<const float4*>(a.grad_acc)[3 * (size_t)idx];
   const float4 acc1 = reinterpret_cast<const float4*>(a.grad_acc)[3 * (size_t)idx + 1];
-  const float acc2 = a.grad_acc[12 * (size_t)idx + 8];
+  const float m2yy = a.grad_acc[12 * (size_t)idx + 8];
   const float dcol[3] = {acc0.x, acc0.y, acc0.z};
+  float g2dx = 0.f, g2dy = 0.f, gop = 0.f;
+  if (visible) {
+    const float4 s0 = a.splat[3 * (size_t)idx], s1 = a.splat[3 * (size_t)idx + 1];
+    const float cx = s0.z, cy = s0.w, cz = s1.x, op = s1.y;
+    const float m0 = acc0.w, m1x = acc1.x, m1y = acc1.y;
+    g2dx = -(0.5f * a.W) * (cx * m1x + cy * m1y);
+    g2dy = -(0.5f * a.H) * (cz * m1y + cy * m1x);
+    gop = (m0 != 0.f) ? m0 / op : 0.f;
+  }
+  const float gcx = -0.5f * acc1.z, gcy = -0.5f * acc1.w, gcw = -0.5f * m2yy;
   a.dL_dcolor[3 * (size_t)idx] = acc0.x; a.dL_dcolor[3 * (size_t)idx + 1] = acc0.y; a.dL_dcolor[3 * (size_t)idx + 2] = acc0.z;
-  a.dL_dmean2D[3 * (size_t)idx] = acc0.w; a.dL_dmean2D[3 * (size_t)idx + 1] = acc1.x; a.dL_dmean2D[3 * (size_t)idx + 2] = 0.f;
-  reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(acc1.y, acc1.z, 0.f, acc1.w);
-  a.dL_dopacity[idx] = acc2;
+  a.dL_dmean2D[3 * (size_t)idx] = g2dx; a.dL_dmean2D[3 * (size_t)idx + 1] = g2dy; a.dL_dmean2D[3 * (size_t)idx + 2] = 0.f;
+  reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(gcx, gcy, 0.f, gcw);
+  a.dL_dopacity[idx] = gop;
   if (visible) {
     const V3 mean = {a.means[3 * (size_t)idx], a.means[3 * (size_t)idx + 1], a.means[3 * (size_t)idx + 2]};
     float c3[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) c3[k] = a.cov3D[6 * (size_t)idx + k];
     {  // ---- computeCov2DCUDA, backward.cu:144-274
-      const float dcx = acc1.y, dcy = acc1.z, dcz = acc1.w;
+      const float dcx = gcx, dcy = gcy, dcz = gcw;
       V3 t; float T0[3], T1[3], xm, ym, ca, cb, cc;
       cov2d_T(mean, a.fx, a.fy, a.tanx, a.tany, a.view, t, T0, T1, xm, ym);
       cov2d_from_T(T0, T1, c3, ca, cb, cc);
@@ -287,7 +299,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(const PreBwdArgs a)
       const float m_w = 1.0f / (hw + 0.0000001f);
       const float mul1 = (pr[0] * mean.x + pr[4] * mean.y + pr[8] * mean.z + pr[12]) * m_w * m_w;
       const float mul2 = (pr[1] * mean.x + pr[5] * mean.y + pr[9] * mean.z + pr[13]) * m_w * m_w;
-      const float gxx = acc0.w, gyy = acc1.x;
+      const float gxx = g2dx, gyy = g2dy;
       dmean[0] += (pr[0] * m_w - pr[3] * mul1) * gxx + (pr[1] * m_w - pr[3] * mul2) * gyy;
       dmean[1] += (pr[4] * m_w - pr[7] * mul1) * gxx + (pr[5] * m_w - pr[7] * mul2) * gyy;
       dmean[2] += (pr[8] * m_w - pr[11] * mul1) * gxx + (pr[9] * m_w - pr[11] * mul2) * gyy;
@@ -422,7 +434,7 @@ int launch_preprocess_bwd(const RasterArgs& r, GeomState& g, const int* radii, f
   a.means = r.means3D; a.shs = r.shs; a.scales = r.scales; a.rots = r.rotations;
   a.cov3D = r.cov3D_precomp ? r.cov3D_precomp : g.cov3D;
   a.view = r.viewmatrix; a.proj = r.projmatrix; a.campos = r.cam_pos;
-  a.radii = radii ? radii : g.radii; a.clamped = g.clamped;
+  a.radii = radii ? radii : g.radii; a.clamped = g.clamped; a.splat = g.splat;
   a.mod = r.scale_modifier; a.tanx = r.tan_fovx; a.tany = r.tan_fovy;
   a.fy = r.H / (2.0f * r.tan_fovy); a.fx = r.W / (2.0f * r.tan_fovx);
   a.grad_acc = g.grad_acc;

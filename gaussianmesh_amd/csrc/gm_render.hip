@@ -467,7 +467,7 @@ __device__ __forceinline__ int reduce8_slot(int lane) {
   return h ? a_idx + 4 : a_idx;                     // h = 1: q4 q6 q5 q7
 }
 
-#define GM_ACC_STRIDE 12   // floats per Gaussian in grad_acc: rgb(0-2) mean2D xy(3-4) conic x,y,w(5-7) opacity(8)
+#define GM_ACC_STRIDE 12   // floats per Gaussian in grad_acc: dcolor rgb (0-2), moments of h: 1, dx, dy, dx^2, dx dy, dy^2 (3-8)
 
 template <int PPL>
 __global__ __launch_bounds__(256 / PPL) void render_bwd_kernel(const uint2* __restrict__ ranges,
@@ -485,7 +485,6 @@ __global__ __launch_bounds__(256 / PPL) void render_bwd_kernel(const uint2* __re
   const uint32_t* list = point_list + range.x;
   const size_t HW = (size_t)H * W;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-  const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
 
   const int px = tx * GM_TILE + (lane & 15);
   const float pixx = (float)px;
@@ -519,6 +518,8 @@ __global__ __launch_bounds__(256 / PPL) void render_bwd_kernel(const uint2* __re
   const bool committer = (lane & 7) == 0;
   const float rx0 = (float)(tx * GM_TILE), rx1 = rx0 + (float)(GM_TILE - 1);
   const float ry0 = (float)(ty * GM_TILE + wave * PPL * 4), ry1 = ry0 + (float)(PPL * 4 - 1);
+  __shared__ float4 l_rec[4 / PPL][64][3];       // wave-private LDS copy of the batch (see render_fwd_kernel)
+  float4 (*rec)[3] = l_rec[wave];
   // batch b covers list positions start-1-b*64-j (j = lane), i.e. back to front
   Batch cur = load_records(splat, load_id(list, start - 1 - lane, n), start - 1 - lane >= 0);
   uint32_t id_nxt = load_id(list, start - 1 - 64 - lane, n);
@@ -527,14 +528,16 @@ __global__ __launch_bounds__(256 / PPL) void render_bwd_kernel(const uint2* __re
     const Batch nxt = load_records(splat, id_nxt, start - 1 - (base + 64) - lane >= 0);
     id_nxt = load_id(list, start - 1 - (base + 128) - lane, n);
     const bool keep = (base + lane < start) && may_touch(cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, rx0, rx1, ry0, ry1);
+    rec[lane][0] = cur.a; rec[lane][1] = cur.b; rec[lane][2] = make_float4(cur.c, __uint_as_float(cur.id), 0.f, 0.f);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     unsigned long long todo = __ballot(keep);
     while (todo) {
       const int j = __ffsll(todo) - 1;
       todo &= todo - 1;
       const int pos = start - 1 - base - j;          // 0-based list position == reference `contributor`
-      const float sx = bcast(cur.a.x, j), sy = bcast(cur.a.y, j);
-      const float cx = bcast(cur.a.z, j), cy = bcast(cur.a.w, j), cz = bcast(cur.b.x, j);
-      const float op = bcast(cur.b.y, j);
+      const float4 RA = rec[j][0], RB = rec[j][1];
+      const float sx = RA.x, sy = RA.y, cx = RA.z, cy = RA.w, cz = RB.x, op = RB.y;
       const float dx = sx - pixx;
       float G[PPL], alpha[PPL], dy[PPL];
       bool valid[PPL], anyv = false;
@@ -548,8 +551,13 @@ __global__ __launch_bounds__(256 / PPL) void render_bwd_kernel(const uint2* __re
         anyv = anyv || valid[k];
       }
       if (!__any(anyv)) continue;
-      const float r = bcast(cur.b.z, j), g = bcast(cur.b.w, j), b = bcast(cur.c, j);
-      const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)cur.id, j);
+      const float4 RC = rec[j][2];
+      const float r = RB.z, g = RB.w, b = RC.x;
+      const uint32_t gid = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(RC.y));
+      // per-lane partial sums of: dL/dcolor rgb (q0-2) and the six moments of h = G * dL/dG over the wave's pixels
+      // (q3 = sum h, q4 = sum h dx, q5 = sum h dy, q6 = sum h dx^2, q7 = sum h dx dy, q8 = sum h dy^2).
+      // preprocess_bwd_kernel turns the moments into dL/dopacity, dL/dmean2D and dL/dconic (backward.cu:538-554):
+      //   dL/dopacity = q3 / opacity, dL/dmean2D = -(W/2)(cx q4 + cy q5), -(H/2)(cz q5 + cy q4), dL/dconic = -q6/2, -q7/2, -q8/2
       float q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, q8 = 0.f;
 #pragma unroll
       for (int k = 0; k < PPL; k++) {
@@ -557,32 +565,26 @@ __global__ __launch_bounds__(256 / PPL) void render_bwd_kernel(const uint2* __re
           const float inv = __builtin_amdgcn_rcpf(1.f - alpha[k]);      // 1/(1-alpha): T recovery and the bg term
           T[k] = T[k] * inv;
           const float dchannel_dcolor = alpha[k] * T[k];
-          arr[k] = last_alpha[k] * lcr[k] + (1.f - last_alpha[k]) * arr[k];
-          arg_[k] = last_alpha[k] * lcg[k] + (1.f - last_alpha[k]) * arg_[k];
-          arb[k] = last_alpha[k] * lcb[k] + (1.f - last_alpha[k]) * arb[k];
+          arr[k] += last_alpha[k] * (lcr[k] - arr[k]);                  // accum_rec = la*lc + (1-la)*accum_rec
+          arg_[k] += last_alpha[k] * (lcg[k] - arg_[k]);
+          arb[k] += last_alpha[k] * (lcb[k] - arb[k]);
           lcr[k] = r; lcg[k] = g; lcb[k] = b;
           float dL_dalpha = (r - arr[k]) * dpr[k] + (g - arg_[k]) * dpg[k] + (b - arb[k]) * dpb[k];
           q[0] += dchannel_dcolor * dpr[k]; q[1] += dchannel_dcolor * dpg[k]; q[2] += dchannel_dcolor * dpb[k];
-          dL_dalpha *= T[k];
           last_alpha[k] = alpha[k];
-          dL_dalpha += (-T_final[k] * inv) * bg_dot[k];
-          const float dL_dG = op * dL_dalpha;
-          const float gdx = G[k] * dx, gdy = G[k] * dy[k];
-          const float dG_ddelx = -gdx * cx - gdy * cy;
-          const float dG_ddely = -gdy * cz - gdx * cy;
-          q[3] += dL_dG * dG_ddelx * ddelx_dx;
-          q[4] += dL_dG * dG_ddely * ddely_dy;
-          q[5] += -0.5f * gdx * dx * dL_dG;
-          q[6] += -0.5f * gdx * dy[k] * dL_dG;
-          q[7] += -0.5f * gdy * dy[k] * dL_dG;
-          q8 += G[k] * dL_dalpha;
+          dL_dalpha = dL_dalpha * T[k] - (T_final[k] * inv) * bg_dot[k];
+          const float h = (op * G[k]) * dL_dalpha;                      // G * dL/dG with dL/dG = opacity * dL/dalpha
+          const float hx = h * dx, hy = h * dy[k];
+          q[3] += h; q[4] += hx; q[5] += hy;
+          q[6] += hx * dx; q[7] += hx * dy[k]; q8 += hy * dy[k];
         }
       }
       const float tot = reduce8(q, lane);
       q8 = wave_sum_to_lane63(q8);
-      float* acc = grad_acc + (size_t)gid * GM_ACC_STRIDE;
-      if (committer) atomicAdd(acc + my_slot, tot);
-      if (lane == 63) atomicAdd(acc + 8, q8);
+      // eight totals sit in the lanes with (lane & 7) == 0, the ninth in lane 63: one atomic instruction commits all nine
+      const bool last_lane = lane == 63;
+      if (committer || last_lane)
+        atomicAdd(grad_acc + (size_t)gid * GM_ACC_STRIDE + (last_lane ? 8 : my_slot), last_lane ? q8 : tot);
     }
     cur = nxt;
   }
