@@ -20,6 +20,8 @@ vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 SIGNATURES = {
     "gm_abi_version": (i32, []),
     "gm_last_error": (C.c_char_p, []),
+    "gm_set_tile_culling": (None, [i32]),
+    "gm_get_tile_culling": (i32, []),
     "gm_geom_bytes": (sz, [i32]),
     "gm_image_bytes": (sz, [i32, i32]),
     "gm_binning_bytes": (sz, [i64]),

@@ -13,6 +13,7 @@
 namespace gm {
 
 static thread_local char g_err[512] = "";
+static int g_tile_cull = 1;        // gm_set_tile_culling
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -92,6 +93,8 @@ using namespace gm;
 extern "C" {
 
 int gm_abi_version(void) { return GM_ABI_VERSION; }
+void gm_set_tile_culling(int on) { g_tile_cull = on ? 1 : 0; }
+int gm_get_tile_culling(void) { return g_tile_cull; }
 const char* gm_last_error(void) { return g_err; }
 
 size_t gm_geom_bytes(int P) {
@@ -113,7 +116,7 @@ size_t gm_binning_bytes(int64_t R) {
   a.shs = shs; a.colors_precomp = colors_precomp; a.opacities = opacities; a.scales = scales;                  \
   a.rotations = rotations; a.cov3D_precomp = cov3D_precomp; a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; \
   a.cam_pos = cam_pos; a.scale_modifier = scale_modifier; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;        \
-  a.prefiltered = prefiltered; a.debug = debug; a.stream = reinterpret_cast<hipStream_t>(stream);
+  a.prefiltered = prefiltered; a.debug = debug; a.tile_cull = g_tile_cull; a.stream = reinterpret_cast<hipStream_t>(stream);
 
 int gm_forward_0(void* geom_buffer, int P, int D, int M, const float* background, int width, int height,
                  const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
@@ -158,7 +161,7 @@ int gm_forward_1(void* geom_buffer, void* binning_buffer, void* image_buffer, in
   BinningState b = BinningState::from(binning_buffer, (size_t)num_rendered);
   int slot = 0;
   if (P > 0 && num_rendered > 0) {
-    if (int rc = launch_duplicate(g, b, P, width, height, radii, debug, a.stream)) return rc;
+    if (int rc = launch_duplicate(g, b, P, width, height, a.tile_cull, debug, a.stream)) return rc;
     const int bits = tile_bits(tiles);
     {
       StageScope sc(ST_TILE_SORT, a.stream);

@@ -9,6 +9,7 @@
 // emitted instance stream is already depth-ordered and only needs a stable sort by tile id afterwards.
 // Workgroup b owns sorted positions [b*2048, (b+1)*2048); thread t owns 8 consecutive positions.
 #include "gm_common.h"
+#include "gm_cull.h"
 #pragma clang fp contract(off)
 
 namespace gm {
@@ -37,10 +38,8 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
   return woff + incl - v;
 }
 
-__device__ __forceinline__ uint32_t rect_count(uint2 r) { return (r.y & 0xFFFFu) * (r.y >> 16); }
-
 __global__ __launch_bounds__(BN_THREADS) void tile_block_sums_kernel(const uint32_t* __restrict__ order,
-                                                                      const uint2* __restrict__ rects, int P,
+                                                                      const uint32_t* __restrict__ tiles, int P,
                                                                       uint32_t* __restrict__ block_sums) {
   __shared__ uint32_t wsum[BN_THREADS / 64];
   const int base = blockIdx.x * GM_SCAN_ITEMS + threadIdx.x * BN_PER_THREAD;
@@ -48,7 +47,7 @@ __global__ __launch_bounds__(BN_THREADS) void tile_block_sums_kernel(const uint3
 #pragma unroll
   for (int i = 0; i < BN_PER_THREAD; i++) {
     const int s = base + i;
-    if (s < P) sum += rect_count(rects[order[s]]);
+    if (s < P) sum += tiles[order[s]];
   }
   uint32_t total;
   block_exclusive_scan(sum, wsum, total);
@@ -80,7 +79,7 @@ int launch_tile_count_scan(GeomState& g, int P, int debug, hipStream_t s) {
   StageScope sc(ST_SCAN, s);
   const int nb = (P + GM_SCAN_ITEMS - 1) / GM_SCAN_ITEMS;
   if (nb > 0) {
-    hipLaunchKernelGGL(tile_block_sums_kernel, dim3(nb), dim3(BN_THREADS), 0, s, g.order[0], g.rect, P, g.block_sums);
+    hipLaunchKernelGGL(tile_block_sums_kernel, dim3(nb), dim3(BN_THREADS), 0, s, g.order[0], g.tiles_touched, P, g.block_sums);
     GM_LAUNCH_CHECK(debug, s);
   }
   hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(BN_THREADS), 0, s, g.block_sums, nb, g.counters);
@@ -95,22 +94,25 @@ __device__ __forceinline__ void get_rect(float px, float py, int r, int gx, int 
   y1 = min(gy, max(0, (int)((py + r + GM_TILE - 1) / GM_TILE)));
 }
 
-// Instance emission.  Workgroup b owns sorted positions [b*2048, (b+1)*2048); thread t owns 8 consecutive ones and
-// gathers their tile rectangles (one 8-byte read each, written by preprocess).  After the block scan of the counts each
-// WAVE emits the instances of its own 512 Gaussians: it walks its non-empty items (ballot + s_ff1), broadcasts the
-// item (offset, rect, id) with v_readlane and lets lane l write instance l of the rectangle, so one store instruction
-// covers a whole splat with consecutive addresses.  A splat that covers 100 tiles costs two store instructions instead
-// of serialising one lane for 100 iterations as the reference's per-Gaussian loop does (RAST/rasterizer_impl.cu:98-109).
-// The emitted order (Gaussian order, then rect row-major) is unchanged.
+// Instance emission.  Workgroup b owns sorted positions [b*512, (b+1)*512); thread t owns 2 consecutive ones and
+// gathers their bin records (candidate rectangle + emit mask, written by preprocess) and instance counts.  After the
+// block scan of the counts each WAVE emits the instances of its own Gaussians: it walks its non-empty items (ballot +
+// s_ff1), broadcasts the item with v_readlane and lets lane l handle candidate tile l of the rectangle, writing it at
+// offset + popcount(mask below l) if its mask bit is set: one store instruction covers a whole splat with consecutive
+// addresses, where the reference serialises one lane per Gaussian over its rectangle (RAST/rasterizer_impl.cu:98-109).
+// Rectangles of more than 64 tiles re-run the tile test in 64-tile chunks.  Emitted order = Gaussian order (depth, id),
+// then rectangle row-major - the reference's order restricted to the emitted tiles.
 __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* __restrict__ order,
-                                                                const uint2* __restrict__ rects, int P, int gx,
+                                                                const uint4* __restrict__ bins, const uint32_t* __restrict__ tiles,
+                                                                const float4* __restrict__ splat, int tile_cull, int P, int gx,
                                                                 const uint32_t* __restrict__ block_sums,
                                                                 uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
   __shared__ uint32_t wsum[BN_THREADS / 64];
   const int lane = threadIdx.x & 63;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const int base = blockIdx.x * GM_SCAN_ITEMS + threadIdx.x * BN_PER_THREAD;
   uint32_t gid[BN_PER_THREAD], cnt[BN_PER_THREAD], offs[BN_PER_THREAD], sum = 0;
-  uint2 rc[BN_PER_THREAD];
+  uint4 rc[BN_PER_THREAD];
 #pragma unroll
   for (int i = 0; i < BN_PER_THREAD; i++) {
     const int s = base + i;
@@ -119,8 +121,8 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
 #pragma unroll
   for (int i = 0; i < BN_PER_THREAD; i++) {
     const int s = base + i;
-    rc[i] = s < P ? rects[gid[i]] : make_uint2(0u, 0u);
-    cnt[i] = rect_count(rc[i]);
+    cnt[i] = s < P ? tiles[gid[i]] : 0u;
+    rc[i] = (s < P && cnt[i]) ? bins[gid[i]] : make_uint4(0u, 0u, 0u, 0u);
     sum += cnt[i];
   }
   uint32_t total;
@@ -137,26 +139,52 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
       const uint32_t rx = (uint32_t)__builtin_amdgcn_readlane((int)rc[i].x, j);
       const uint32_t ry = (uint32_t)__builtin_amdgcn_readlane((int)rc[i].y, j);
       const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)gid[i], j);
-      const uint32_t x0 = rx & 0xFFFFu, y0 = rx >> 16, w = ry & 0xFFFFu, n = w * (ry >> 16);
+      const uint32_t x0 = rx & 0xFFFFu, y0 = rx >> 16, w = ry & 0xFFFFu, ncand = w * (ry >> 16);
       const float inv_w = 1.0f / (float)w;
-      for (uint32_t k = lane; k < n; k += 64) {
-        const uint32_t row = (uint32_t)(((float)k + 0.5f) * inv_w);      // exact floor(k / w) for k < 2^22
-        const uint32_t col = k - row * w;
-        keys_out[o + k] = (y0 + row) * (uint32_t)gx + (x0 + col);
-        vals_out[o + k] = g;
+      if (ncand <= 64) {
+        const unsigned long long mask = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)rc[i].w, j) << 32) |
+                                        (uint32_t)__builtin_amdgcn_readlane((int)rc[i].z, j);
+        if ((mask >> lane) & 1ull) {
+          const uint32_t row = (uint32_t)(((float)lane + 0.5f) * inv_w), col = lane - row * w;
+          const uint32_t pos = o + (uint32_t)__popcll(mask & lt_mask);
+          keys_out[pos] = (y0 + row) * (uint32_t)gx + (x0 + col);
+          vals_out[pos] = g;
+        }
+      } else {
+        const float4 s0 = splat[3 * (size_t)g], s1 = splat[3 * (size_t)g + 1];
+        const uint32_t h = ry >> 16;
+        const TileCull tc = tile_cull_setup(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, (float)(x0 * GM_TILE), (float)((x0 + w) * GM_TILE - 1),
+                                            (float)(y0 * GM_TILE), (float)((y0 + h) * GM_TILE - 1));
+        uint32_t run = o;
+        for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
+          const uint32_t k = c0 + lane;
+          const uint32_t row = (uint32_t)(((float)k + 0.5f) * inv_w), col = k - row * w;
+          bool pass = k < ncand;
+          if (pass && tile_cull) {                 // same per-row span as preprocess used for the count
+            int ta, tb;
+            pass = row_tiles(tc, s0.x, s0.y, (int)(y0 + row), (int)x0, (int)(x0 + w), ta, tb) && (int)(x0 + col) >= ta && (int)(x0 + col) <= tb;
+          }
+          const unsigned long long bal = __ballot(pass);
+          if (pass) {
+            const uint32_t pos = run + (uint32_t)__popcll(bal & lt_mask);
+            keys_out[pos] = (y0 + row) * (uint32_t)gx + (x0 + col);
+            vals_out[pos] = g;
+          }
+          run += (uint32_t)__popcll(bal);
+        }
       }
     }
   }
 }
 
-int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, const int* radii, int debug, hipStream_t s) {
+int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, int tile_cull, int debug, hipStream_t s) {
   StageScope sc(ST_DUPLICATE, s);
   const int nb = (P + GM_SCAN_ITEMS - 1) / GM_SCAN_ITEMS;
   const int gx = (W + GM_TILE - 1) / GM_TILE;
-  (void)radii; (void)H;
+  (void)H;
   if (nb > 0)
-    hipLaunchKernelGGL(duplicate_kernel, dim3(nb), dim3(BN_THREADS), 0, s, g.order[0], g.rect, P, gx, g.block_sums, b.keys[0],
-                       b.vals[0]);
+    hipLaunchKernelGGL(duplicate_kernel, dim3(nb), dim3(BN_THREADS), 0, s, g.order[0], g.bin, g.tiles_touched, g.splat, tile_cull,
+                       P, gx, g.block_sums, b.keys[0], b.vals[0]);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }

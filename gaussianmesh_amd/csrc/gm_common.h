@@ -67,7 +67,8 @@ struct GeomState {              // per-Gaussian state (P-sized)
   float4* splat;                // [P][3]: {x,y,con.x,con.y} {con.z,opacity,r,g} {b,depth,0,0}
   int* radii;                   // internal radii when the caller passes none
   uint32_t* tiles_touched;      // [P]
-  uint2* rect;                  // [P] tile rectangle {x0 | y0 << 16, width | height << 16}; width*height = tiles_touched
+  uint4* bin;                   // [P] {x0 | y0 << 16, width | height << 16, mask_lo, mask_hi}: candidate tile rectangle and, for
+                                //     rectangles of <= 64 tiles, the bit mask (row-major) of the tiles actually emitted
   float* cov3D;                 // [P][6] (computed from scale/rot)
   uint8_t* clamped;             // [P] bit ch = SH colour channel ch was clamped at 0
   uint32_t* depth_key[2];       // [P] ping-pong keys of the depth sort (float bits of view z)
@@ -83,7 +84,7 @@ struct GeomState {              // per-Gaussian state (P-sized)
     g.splat = carve<float4>(p, 3 * P);
     g.radii = carve<int>(p, P);
     g.tiles_touched = carve<uint32_t>(p, P);
-    g.rect = carve<uint2>(p, P);
+    g.bin = carve<uint4>(p, P);
     g.cov3D = carve<float>(p, 6 * P);
     g.clamped = carve<uint8_t>(p, P);
     g.depth_key[0] = carve<uint32_t>(p, P);
@@ -156,6 +157,7 @@ struct RasterArgs {
   const float *viewmatrix, *projmatrix, *cam_pos;
   float scale_modifier, tan_fovx, tan_fovy;
   int prefiltered, debug;
+  int tile_cull;                // 1: emit (Gaussian, tile) only if the Gaussian can reach alpha >= 1/255 inside the tile
   hipStream_t stream;
 };
 
@@ -172,7 +174,7 @@ int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], uint32_t* hist, uint3
                      int bits, bool iota_values, int debug, hipStream_t s);
 
 int launch_tile_count_scan(GeomState& g, int P, int debug, hipStream_t s);          // -> counters[0] = num_rendered
-int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, const int* radii, int debug, hipStream_t s);
+int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, int tile_cull, int debug, hipStream_t s);
 int launch_tile_ranges(BinningState& b, int slot, ImageState& img, int R, int tiles, int debug, hipStream_t s);
 int launch_render_fwd(const GeomState& g, const uint32_t* point_list, ImageState& img, int W, int H,
                       const float* background, float* out_color, int debug, hipStream_t s);

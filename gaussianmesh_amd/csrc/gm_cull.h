@@ -1,0 +1,104 @@
+// gm_cull.h -- exact, conservative "can this Gaussian reach alpha >= 1/255 inside this pixel rectangle" test.
+// Used at two granularities: 16x16 tiles when instances are emitted (gm_preprocess.hip / gm_binning.hip) and the
+// 16x4 strip of a wave inside the blend kernels (gm_render.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace gm {
+
+// Can entry (centre sx,sy; conic a,b,c; opacity op) reach alpha >= 1/255 at any pixel centre of the rectangle
+// [x0,x1] x [y0,y1]?  alpha >= 1/255  <=>  q(d) = a dx^2 + 2 b dx dy + c dy^2 <= 2 ln(255 op), d = centre - pixel.
+// q is a positive-definite form, so its minimum over the rectangle is 0 if the centre is inside and otherwise
+// lies on one of the four edges (1-D clamped minimum per edge).  The margin covers float rounding of both this
+// test and the per-pixel evaluation (proportional to the magnitude of the cancelling terms).
+__device__ __forceinline__ bool may_touch(float sx, float sy, float a, float b, float c, float op,
+                                          float x0, float x1, float y0, float y1) {
+  if (!(op >= 0.0039f)) return false;                 // op < 1/255 (1/255 = 0.0039216): alpha = op*G < 1/255 everywhere
+  const float dxl = sx - x1, dxh = sx - x0, dyl = sy - y1, dyh = sy - y0;
+  const float thr = 1.3862943611f * __builtin_amdgcn_logf(255.0f * op);   // 2 ln(255 op) = 2 ln2 log2(255 op)
+  const float mx = fmaxf(fabsf(dxl), fabsf(dxh)), my = fmaxf(fabsf(dyl), fabsf(dyh));
+  const float margin = 4e-6f * (a * mx * mx + c * my * my + 2.0f * fabsf(b) * mx * my) + 1e-3f;
+  if (dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f) return true;   // centre inside: q_min = 0 <= thr (op >= 1/255)
+  const float nb_c = -b * __builtin_amdgcn_rcpf(c), nb_a = -b * __builtin_amdgcn_rcpf(a);
+  float qmin;
+  {
+    const float y = fminf(fmaxf(nb_c * dxl, dyl), dyh);
+    qmin = a * dxl * dxl + 2.f * b * dxl * y + c * y * y;
+  }
+  {
+    const float y = fminf(fmaxf(nb_c * dxh, dyl), dyh);
+    qmin = fminf(qmin, a * dxh * dxh + 2.f * b * dxh * y + c * y * y);
+  }
+  {
+    const float x = fminf(fmaxf(nb_a * dyl, dxl), dxh);
+    qmin = fminf(qmin, a * x * x + 2.f * b * x * dyl + c * dyl * dyl);
+  }
+  {
+    const float x = fminf(fmaxf(nb_a * dyh, dxl), dxh);
+    qmin = fminf(qmin, a * x * x + 2.f * b * x * dyh + c * dyh * dyh);
+  }
+  return !(qmin > thr + margin);                       // NaN-safe: keep the entry unless it is provably out of reach
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Tile-row form of the same test, used when instances are emitted: instead of testing the tiles of the candidate
+// rectangle one by one, compute per tile ROW the pixel-x interval in which the region {alpha >= 1/255} (the ellipse
+// q(d) <= lim) exists inside that row's pixel band.  A tile of the row is hit iff its pixel range meets the
+// interval (both sets are convex and the tile spans the whole band), so this yields exactly the tiles may_touch()
+// would keep (up to the conservative epsilons) at a cost per row instead of per tile.
+// With d = centre - pixel, for fixed dy the ellipse spans dx in (-b dy -+ sqrt(a lim - det dy^2)) / a; over a band the
+// upper end is concave in dy (max at an end point or at dy = -dystar where it equals xext), the lower end convex.
+struct TileCull {
+  float a, b, inv_a, lim, det, dymax, xext, dystar;
+  int mode;          // 0 = nothing reachable, 1 = use row_span, 2 = keep every tile (degenerate conic / NaN)
+};
+
+__device__ __forceinline__ TileCull tile_cull_setup(float sx, float sy, float a, float b, float c, float op,
+                                                    float rx0, float rx1, float ry0, float ry1) {
+  TileCull t;
+  t.a = a; t.b = b; t.inv_a = __builtin_amdgcn_rcpf(a);
+  t.mode = 1;
+  const float mx = fmaxf(fabsf(sx - rx0), fabsf(sx - rx1)), my = fmaxf(fabsf(sy - ry0), fabsf(sy - ry1));
+  const float thr = 1.3862943611f * __builtin_amdgcn_logf(255.0f * op);
+  t.lim = thr + 4e-6f * (a * mx * mx + c * my * my + 2.0f * fabsf(b) * mx * my) + 1e-3f;
+  t.det = a * c - b * b;
+  if (!(op >= 0.0039f) || t.lim <= 0.f) { t.mode = 0; return t; }
+  const float r = t.lim / t.det;
+  t.dymax = sqrtf(a * r) * 1.0001f + 1e-3f;
+  t.xext = sqrtf(c * r) * 1.0001f + 1e-3f;
+  t.dystar = b * sqrtf(r / c);
+  if (!(t.det > 0.f) || !(t.dymax < 1e30f) || !(t.xext < 1e30f) || !(t.dystar == t.dystar)) t.mode = 2;
+  return t;
+}
+
+// pixel-x interval [A, B] reachable inside pixel rows [py0, py1]; false if the band is out of reach
+__device__ __forceinline__ bool row_span(const TileCull& t, float sx, float sy, float py0, float py1, float& A, float& B) {
+  float dyl = fmaxf(sy - py1, -t.dymax), dyh = fminf(sy - py0, t.dymax);
+  if (!(dyl <= dyh)) return false;
+  const float sl = sqrtf(fmaxf(t.a * t.lim - t.det * dyl * dyl, 0.f)), sh = sqrtf(fmaxf(t.a * t.lim - t.det * dyh * dyh, 0.f));
+  float hi = fmaxf(-t.b * dyl + sl, -t.b * dyh + sh) * t.inv_a;
+  float lo = fminf(-t.b * dyl - sl, -t.b * dyh - sh) * t.inv_a;
+  if (-t.dystar >= dyl && -t.dystar <= dyh) hi = t.xext;
+  if (t.dystar >= dyl && t.dystar <= dyh) lo = -t.xext;
+  hi = fminf(hi, t.xext); lo = fmaxf(lo, -t.xext);
+  const float eps = 2e-3f + 1e-4f * (fabsf(hi) + fabsf(lo));
+  A = sx - hi - eps; B = sx - lo + eps;
+  return true;
+}
+
+// tiles [ta, tb] (inclusive, clamped to [x0, x1)) of tile row ty that are emitted; false if none
+__device__ __forceinline__ bool row_tiles(const TileCull& t, float sx, float sy, int ty, int x0, int x1, int& ta, int& tb) {
+  if (t.mode == 0) return false;
+  ta = x0; tb = x1 - 1;
+  if (t.mode == 2) return true;
+  float A, B;
+  const float py0 = (float)(ty * 16);
+  if (!row_span(t, sx, sy, py0, py0 + 15.f, A, B)) return false;
+  // tile tx covers pixel centres [16 tx, 16 tx + 15]
+  const float fa = ceilf((A - 15.f) * 0.0625f), fb = floorf(B * 0.0625f);
+  ta = max(x0, (int)fmaxf(fa, -1e9f)); tb = min(x1 - 1, (int)fminf(fb, 1e9f));
+  return ta <= tb;
+}
+
+}  // namespace gm

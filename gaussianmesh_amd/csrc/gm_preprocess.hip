@@ -18,6 +18,7 @@
 #include "gm_common.h"
 #pragma clang fp contract(off)
 #include "gm_sh.h"
+#include "gm_cull.h"
 
 namespace gm {
 
@@ -84,7 +85,7 @@ struct PreArgs {
   int P, D, M, W, H, gx, gy;
   const float *means, *scales, *rots, *opac, *shs, *cov3D_pre, *colors_pre, *view, *proj, *campos;
   float mod, tanx, tany, fx, fy;
-  float4* splat; int* radii_int; int* radii_out; uint32_t* tiles; uint2* rect; float* cov3D; uint8_t* clamped; uint32_t* depth_key;
+  float4* splat; int* radii_int; int* radii_out; uint32_t* tiles; uint4* bin; int tile_cull; float* cov3D; uint8_t* clamped; uint32_t* depth_key;
 };
 
 __global__ __launch_bounds__(256) void preprocess_fwd_kernel(const PreArgs a) {
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(const PreArgs a) {
   if (idx >= a.P) return;
   int radius_i = 0;
   uint32_t tiles = 0, dkey = 0xFFFFFFFFu;
-  uint2 rect = make_uint2(0u, 0u);
+  uint4 bin = make_uint4(0u, 0u, 0u, 0u);
   do {
     const V3 p = {a.means[3 * (size_t)idx], a.means[3 * (size_t)idx + 1], a.means[3 * (size_t)idx + 2]};
     const float* pm = a.proj;
@@ -163,14 +164,35 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(const PreArgs a) {
     a.splat[3 * (size_t)idx + 1] = make_float4(conz, a.opac[idx], col[0], col[1]);
     a.splat[3 * (size_t)idx + 2] = make_float4(col[2], pv.z, 0.f, 0.f);
     radius_i = (int)my_radius;
-    tiles = (uint32_t)((y1 - y0) * (x1 - x0));
-    rect = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)(x1 - x0) | ((uint32_t)(y1 - y0) << 16));
+    // Instances to emit.  The reference emits one per tile of the rectangle (rasterizer_impl.cu:98-109).  With
+    // tile_cull the tiles the Gaussian cannot reach with alpha >= 1/255 are dropped here: every pixel of such a
+    // tile skips the entry anyway (forward.cu:344), so images and gradients are unchanged while the instance
+    // count - and with it the sort, the tile lists and the blend work - shrinks by ~2-3x.
+    const int rw = x1 - x0, rh = y1 - y0, ncand = rw * rh;
+    unsigned long long mask = 0ull;
+    if (!a.tile_cull) {
+      tiles = (uint32_t)ncand;
+      mask = ncand >= 64 ? ~0ull : ((1ull << ncand) - 1ull);
+    } else {
+      const TileCull tc = tile_cull_setup(pix, piy, conx, cony, conz, a.opac[idx], (float)(x0 * GM_TILE), (float)(x1 * GM_TILE - 1),
+                                          (float)(y0 * GM_TILE), (float)(y1 * GM_TILE - 1));
+      uint32_t cnt = 0;
+      for (int ry = 0; ry < rh; ry++) {            // per tile row: the span of tiles the alpha >= 1/255 region reaches
+        int ta, tb;
+        if (!row_tiles(tc, pix, piy, y0 + ry, x0, x1, ta, tb)) continue;
+        const int len = tb - ta + 1, bit0 = ry * rw + (ta - x0);
+        cnt += (uint32_t)len;
+        if (ncand <= 64) mask |= (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << bit0;
+      }
+      tiles = cnt;
+    }
+    bin = make_uint4((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)rw | ((uint32_t)rh << 16), (uint32_t)mask, (uint32_t)(mask >> 32));
     dkey = __float_as_uint(pv.z);
   } while (0);
   a.radii_int[idx] = radius_i;
   if (a.radii_out) a.radii_out[idx] = radius_i;
   a.tiles[idx] = tiles;
-  a.rect[idx] = rect;
+  a.bin[idx] = bin;
   a.depth_key[idx] = dkey;
 }
 
@@ -183,7 +205,7 @@ int launch_preprocess(const RasterArgs& r, GeomState& g, int* radii) {
   a.cov3D_pre = r.cov3D_precomp; a.colors_pre = r.colors_precomp; a.view = r.viewmatrix; a.proj = r.projmatrix;
   a.campos = r.cam_pos; a.mod = r.scale_modifier; a.tanx = r.tan_fovx; a.tany = r.tan_fovy;
   a.fy = r.H / (2.0f * r.tan_fovy); a.fx = r.W / (2.0f * r.tan_fovx);   // rasterizer_impl.cu:359-360
-  a.splat = g.splat; a.radii_int = g.radii; a.radii_out = radii; a.tiles = g.tiles_touched; a.rect = g.rect; a.cov3D = g.cov3D;
+  a.splat = g.splat; a.radii_int = g.radii; a.radii_out = radii; a.tiles = g.tiles_touched; a.bin = g.bin; a.tile_cull = r.tile_cull; a.cov3D = g.cov3D;
   a.clamped = g.clamped; a.depth_key = g.depth_key[0];
   if (r.P > 0) hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((r.P + 255) / 256), dim3(256), 0, r.stream, a);
   GM_LAUNCH_CHECK(r.debug, r.stream);

@@ -26,6 +26,7 @@
 // FMA contraction is allowed here and exp() is v_exp_f32 on power*log2(e); see DESIGN.md for the
 // tolerance argument.
 #include "gm_common.h"
+#include "gm_cull.h"
 #include <cstdlib>
 
 namespace gm {
@@ -65,40 +66,6 @@ __device__ __forceinline__ Batch load_records(const float4* __restrict__ splat, 
   return t;
 }
 
-
-// Can entry (centre sx,sy; conic a,b,c; opacity op) reach alpha >= 1/255 at any pixel centre of the rectangle
-// [x0,x1] x [y0,y1]?  alpha >= 1/255  <=>  q(d) = a dx^2 + 2 b dx dy + c dy^2 <= 2 ln(255 op), d = centre - pixel.
-// q is a positive-definite form, so its minimum over the rectangle is 0 if the centre is inside and otherwise
-// lies on one of the four edges (1-D clamped minimum per edge).  The margin covers float rounding of both this
-// test and the per-pixel evaluation (proportional to the magnitude of the cancelling terms).
-__device__ __forceinline__ bool may_touch(float sx, float sy, float a, float b, float c, float op,
-                                          float x0, float x1, float y0, float y1) {
-  if (!(op >= 0.0039f)) return false;                 // op < 1/255 (1/255 = 0.0039216): alpha = op*G < 1/255 everywhere
-  const float dxl = sx - x1, dxh = sx - x0, dyl = sy - y1, dyh = sy - y0;
-  const float thr = 1.3862943611f * __builtin_amdgcn_logf(255.0f * op);   // 2 ln(255 op) = 2 ln2 log2(255 op)
-  const float mx = fmaxf(fabsf(dxl), fabsf(dxh)), my = fmaxf(fabsf(dyl), fabsf(dyh));
-  const float margin = 4e-6f * (a * mx * mx + c * my * my + 2.0f * fabsf(b) * mx * my) + 1e-3f;
-  if (dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f) return true;   // centre inside: q_min = 0 <= thr (op >= 1/255)
-  const float nb_c = -b * __builtin_amdgcn_rcpf(c), nb_a = -b * __builtin_amdgcn_rcpf(a);
-  float qmin;
-  {
-    const float y = fminf(fmaxf(nb_c * dxl, dyl), dyh);
-    qmin = a * dxl * dxl + 2.f * b * dxl * y + c * y * y;
-  }
-  {
-    const float y = fminf(fmaxf(nb_c * dxh, dyl), dyh);
-    qmin = fminf(qmin, a * dxh * dxh + 2.f * b * dxh * y + c * y * y);
-  }
-  {
-    const float x = fminf(fmaxf(nb_a * dyl, dxl), dxh);
-    qmin = fminf(qmin, a * x * x + 2.f * b * x * dyl + c * dyl * dyl);
-  }
-  {
-    const float x = fminf(fmaxf(nb_a * dyh, dxl), dxh);
-    qmin = fminf(qmin, a * x * x + 2.f * b * x * dyh + c * dyh * dyh);
-  }
-  return !(qmin > thr + margin);                       // NaN-safe: keep the entry unless it is provably out of reach
-}
 
 template <int PPL>
 __global__ __launch_bounds__(256 / PPL) void render_fwd_kernel(const uint2* __restrict__ ranges,

@@ -47,6 +47,15 @@ extern "C" {
 int gm_abi_version(void);
 const char* gm_last_error(void);
 
+/* Instance emission policy (process-wide; set it before gm_forward_0 and keep it until the matching gm_backward).
+ *   1 (default): a (Gaussian, tile) instance is emitted only if the Gaussian can reach alpha >= 1/255 somewhere in the
+ *      tile (exact conservative test).  Dropped instances are skipped by every pixel of the tile in the reference too
+ *      (RAST/forward.cu:344), so out_color, radii and all gradients are unchanged; num_rendered and the internal lists shrink.
+ *   0: emit every tile of the bounding rectangle exactly as the reference does (RAST/rasterizer_impl.cu:98-109);
+ *      num_rendered, point_list and ranges are then identical to the reference's. */
+void gm_set_tile_culling(int on);
+int gm_get_tile_culling(void);
+
 /* Scratch sizes.  Replace CudaRasterizer::required<GeometryState|ImageState|BinningState>(n)
  * (RAST/rasterizer_impl.h:67-73; python side rasterize_points.py:63-86). */
 size_t gm_geom_bytes(int P);

@@ -372,6 +372,34 @@ void orc_render_fwd(int W, int H, const uint32_t* ranges, const uint32_t* point_
 }
 
 /* ---------------------------------------------------------------------------------------------
+ * For every (Gaussian, tile) instance of a binned list: does ANY pixel of the tile accept the entry, i.e. pass both
+ * skips of RAST/forward.cu:336-345 (power <= 0 and alpha >= 1/255) with the float arithmetic of orc_render_fwd?
+ * Checker for the product's emission-time tile culling: every instance with needed == 1 must be emitted.
+ * tile_of[i] = tile id of instance i (key >> 32), needed uint8 [R].
+ */
+void orc_instance_needed(int64_t R, int W, int H, const uint32_t* tile_of, const uint32_t* point_list, const float* xy,
+                         const float* conic_op, uint8_t* needed) {
+  const int gx = (W + TILE - 1) / TILE;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < R; i++) {
+    const uint32_t g = point_list[i], t = tile_of[i];
+    const int tx = (int)(t % (uint32_t)gx), ty = (int)(t / (uint32_t)gx);
+    const float* co = conic_op + 4 * (size_t)g;
+    uint8_t hit = 0;
+    for (int ly = 0; ly < TILE && !hit; ly++)
+      for (int lx = 0; lx < TILE; lx++) {
+        const int px = tx * TILE + lx, py = ty * TILE + ly;
+        if (px >= W || py >= H) continue;
+        const float dx = xy[2 * (size_t)g] - (float)px, dy = xy[2 * (size_t)g + 1] - (float)py;
+        const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+        if (power > 0.0f) continue;
+        if (fminf(0.99f, co[3] * expf(power)) >= 1.0f / 255.0f) { hit = 1; break; }
+      }
+    needed[i] = hit;
+  }
+}
+
+/* ---------------------------------------------------------------------------------------------
  * [core] RAST/backward.cu:399-557 renderCUDA (backward).  Accumulators must be zero on entry:
  * dL_dmean2D [P][3] (x,y used), dL_dconic [P][4] (slots x,y,w used), dL_dopacity [P], dL_dcolor [P][3].
  * Accumulates in double per tile-serial order (deterministic); the reference uses float atomics

@@ -117,6 +117,17 @@ def bin_instances(geo, W, H):
     return dict(R=int(R), keys=keys[:R], point_list=vals[:R], ranges=ranges)
 
 
+def instance_needed(W, H, bins, geo):
+    """uint8 [R]: 1 where some pixel of the instance's tile accepts the entry (checker for emission-time tile culling)."""
+    R = bins["R"]
+    out = np.zeros(max(R, 1), np.uint8)
+    if R:
+        tile_of = np.ascontiguousarray((bins["keys"] >> np.uint64(32)).astype(np.uint32))
+        lib().orc_instance_needed(C.c_int64(R), W, H, _ptr(tile_of), _ptr(bins["point_list"]), _ptr(geo["xy"]),
+                                  _ptr(geo["conic_op"]), _ptr(out))
+    return out[:R]
+
+
 def render_fwd(W, H, bins, geo, bg):
     out = np.zeros((3, H, W), np.float32); fT = np.zeros(H * W, np.float32); nc = np.zeros(H * W, np.uint32)
     pl = bins["point_list"] if bins["R"] > 0 else np.zeros(1, np.uint32)

@@ -31,9 +31,12 @@ def _view(buf, ptr, count, dtype):
     return buf[off:off + nbytes].view(dtype).cpu().numpy()
 
 
-def forward_state(scene, cam, bg, D=3, use_precomp_cov=False, use_precomp_color=False, mod=1.0, debug=False):
-    """Low-level forward returning colour + every intermediate the oracle also exposes."""
+def forward_state(scene, cam, bg, D=3, use_precomp_cov=False, use_precomp_color=False, mod=1.0, debug=False, tile_cull=False):
+    """Low-level forward returning colour + every intermediate the oracle also exposes.
+    tile_cull=False: emit every tile of the rectangle like the reference (lists comparable 1:1 with the oracle);
+    tile_cull=True: the product default (instances the Gaussian cannot reach are not emitted)."""
     lib = _lib.lib()
+    lib.gm_set_tile_culling(1 if tile_cull else 0)
     P = scene["means"].shape[0]
     W, H = cam["W"], cam["H"]
     sh = None if use_precomp_color else T(scene["shs"])
@@ -45,6 +48,7 @@ def forward_state(scene, cam, bg, D=3, use_precomp_cov=False, use_precomp_color=
         T(bg), T(scene["means"]), col, T(scene["opac"]), sc, rot, mod, cov, T(cam["view"]), T(cam["proj"]), cam["tanx"],
         cam["tany"], H, W, sh, D, T(cam["campos"]), False, debug)
     torch.cuda.synchronize()
+    lib.gm_set_tile_culling(1)
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     out = dict(R=nr, color=color.cpu().numpy(), radii=radii.cpu().numpy(), geom=geom, binning=binning, img=img)
     if P > 0:

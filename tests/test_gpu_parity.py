@@ -15,6 +15,14 @@ pytestmark = pytest.mark.gpu
 FWD_TOL = 1e-4
 GRAD_RTOL = 1e-3
 
+
+@pytest.fixture(autouse=True)
+def _default_emission_policy():
+    from gaussianmesh_amd import _lib
+    _lib.lib().gm_set_tile_culling(1)
+    yield
+    _lib.lib().gm_set_tile_culling(1)
+
 MODES = [(False, False), (True, False), (False, True), (True, True)]
 
 
@@ -160,6 +168,64 @@ def test_backward_medium(oracle):
     for name, ref in [("means", bw["dmean3D"]), ("shs", bw["dsh"]), ("scales", bw["dscale"]), ("rots", bw["drot"])]:
         assert _rel(g[name], ref) <= GRAD_RTOL, name
     assert _rel(g["opac"].reshape(-1), bw["dopacity"]) <= GRAD_RTOL
+
+
+@pytest.mark.parametrize("case", ["small", "medium", "huge_splats"])
+def test_tile_culling_is_exact(oracle, case):
+    """Product default (emission-time tile culling) vs the reference emission policy: the culled list is the
+    reference list minus instances no pixel of the tile accepts; images are bit-identical; gradients agree."""
+    from gpu_utils import forward_state
+    from gaussianmesh_amd import scenes
+    if case == "small":
+        sc, cam = small_scene(P=600, W=70, H=50, seed=3)
+    elif case == "medium":
+        sc = scenes.make_cloud(10000, seed=0, scale_lo=0.02, scale_hi=0.25); cam = scenes.orbit_camera(2, 9, 250, 130, radius=7.0)
+    else:                                       # rectangles of more than 64 tiles (chunked path) and needle-shaped splats
+        sc = scenes.make_cloud(300, seed=5, scale_lo=0.02, scale_hi=2.5); cam = scenes.orbit_camera(1, 5, 320, 200, radius=7.0)
+    bg = np.array([0.3, 0.6, 0.1], np.float32)
+    fw = oracle.forward_full(sc, cam, bg, D=3)
+    ex = forward_state(sc, cam, bg, D=3, tile_cull=False)
+    cu = forward_state(sc, cam, bg, D=3, tile_cull=True)
+    assert np.array_equal(ex["point_list"], fw["bins"]["point_list"])
+    assert np.array_equal(cu["radii"], ex["radii"])
+    assert cu["R"] <= ex["R"]
+    # images: same per-pixel arithmetic on the same accepted entries -> identical bits
+    assert np.array_equal(cu["color"], ex["color"])
+    assert np.array_equal(cu["final_T"], ex["final_T"])
+    # list structure: per tile, culled list is an order-preserving subsequence of the reference list ...
+    needed = oracle.instance_needed(cam["W"], cam["H"], fw["bins"], fw["geo"]).astype(bool)
+    tile_of = (fw["bins"]["keys"] >> np.uint64(32)).astype(np.uint32)
+    kept = np.zeros(ex["R"], bool)
+    for t in range(ex["ranges"].shape[0]):
+        a0, a1 = ex["ranges"][t]; b0, b1 = cu["ranges"][t]
+        ref = ex["point_list"][a0:a1]; sub = cu["point_list"][b0:b1]
+        j = 0
+        for g in sub:                            # two-pointer subsequence check (ids are unique within a tile)
+            while j < len(ref) and ref[j] != g:
+                j += 1
+            assert j < len(ref), "culled list is not a subsequence of the reference list in tile %d" % t
+            kept[a0 + j] = True
+            j += 1
+    # ... that contains every instance some pixel accepts (conservative), and drops a good share of the others
+    assert not (needed & ~kept).any()
+    assert np.array_equal(cu["tile_keys"], tile_of[kept])
+    if case != "small":
+        assert cu["R"] < 0.8 * ex["R"]
+
+
+def test_tile_culling_gradients_match_reference_policy(oracle):
+    from gaussianmesh_amd import _lib
+    D = 3
+    sc, cam = small_scene(P=500, W=70, H=50, seed=7, D=D)
+    bg = np.array([0.3, 0.2, 0.7], np.float32)
+    dpix = np.random.default_rng(1).normal(size=(3, cam["H"], cam["W"])).astype(np.float32)
+    _lib.lib().gm_set_tile_culling(0)
+    c0, r0, g0 = _grads_gpu(sc, cam, bg, dpix, D, False, False)
+    _lib.lib().gm_set_tile_culling(1)
+    c1, r1, g1 = _grads_gpu(sc, cam, bg, dpix, D, False, False)
+    assert np.array_equal(c0, c1) and np.array_equal(r0, r1)
+    for k in g0:
+        assert _rel(g1[k], g0[k]) <= 1e-5, k       # same terms, only the float-atomic summation order differs
 
 
 def test_edge_cases(oracle):
