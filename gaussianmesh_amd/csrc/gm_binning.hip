@@ -95,13 +95,10 @@ __device__ __forceinline__ void get_rect(float px, float py, int r, int gx, int 
 }
 
 // Instance emission.  Workgroup b owns sorted positions [b*512, (b+1)*512); thread t owns 2 consecutive ones and
-// gathers their bin records (candidate rectangle + emit mask, written by preprocess) and instance counts.  After the
-// block scan of the counts each WAVE emits the instances of its own Gaussians: it walks its non-empty items (ballot +
-// s_ff1), broadcasts the item with v_readlane and lets lane l handle candidate tile l of the rectangle, writing it at
-// offset + popcount(mask below l) if its mask bit is set: one store instruction covers a whole splat with consecutive
-// addresses, where the reference serialises one lane per Gaussian over its rectangle (RAST/rasterizer_impl.cu:98-109).
-// Rectangles of more than 64 tiles re-run the tile test in 64-tile chunks.  Emitted order = Gaussian order (depth, id),
-// then rectangle row-major - the reference's order restricted to the emitted tiles.
+// gathers their bin records (candidate rectangle + emit mask, written by preprocess) and instance counts; the block
+// scans the counts into output offsets; then instances are written (see (1) and (2) in the body).
+// Emitted order = Gaussian order (depth, id), then rectangle row-major - the reference's order
+// (RAST/rasterizer_impl.cu:98-109) restricted to the emitted tiles.
 __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* __restrict__ order,
                                                                 const uint4* __restrict__ bins, const uint32_t* __restrict__ tiles,
                                                                 const float4* __restrict__ splat, int tile_cull, int P, int gx,
@@ -129,9 +126,33 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
   uint32_t off = block_sums[blockIdx.x] + block_exclusive_scan(sum, wsum, total);
 #pragma unroll
   for (int i = 0; i < BN_PER_THREAD; i++) { offs[i] = off; off += cnt[i]; }
+  // (1) rectangles of <= 64 tiles (virtually all): each lane expands the emit mask of its own Gaussian.  A wave
+  //     spends max-over-lanes(popcount) iterations of ~8 instructions for 64 Gaussians; the 4-byte stores of a lane go
+  //     to its own run, neighbouring lanes' runs are adjacent, so a wave writes one compact region.
 #pragma unroll
   for (int i = 0; i < BN_PER_THREAD; i++) {
-    unsigned long long todo = __ballot(cnt[i] != 0);
+    const uint32_t w = rc[i].y & 0xFFFFu, ncand = w * (rc[i].y >> 16);
+    if (cnt[i] != 0 && ncand <= 64) {
+      const uint32_t x0 = rc[i].x & 0xFFFFu, y0 = rc[i].x >> 16;
+      const float inv_w = 1.0f / (float)w;
+      unsigned long long m = ((unsigned long long)rc[i].w << 32) | rc[i].z;
+      uint32_t pos = offs[i];
+      const uint32_t tile0 = y0 * (uint32_t)gx + x0;
+      while (m) {
+        const uint32_t k = (uint32_t)__ffsll(m) - 1u;
+        m &= m - 1;
+        const uint32_t row = (uint32_t)(((float)k + 0.5f) * inv_w);
+        keys_out[pos] = tile0 + row * (uint32_t)gx + (k - row * w);
+        vals_out[pos] = gid[i];
+        pos++;
+      }
+    }
+  }
+  // (2) rectangles of more than 64 tiles: the wave walks them one at a time, 64 candidate tiles per step
+#pragma unroll
+  for (int i = 0; i < BN_PER_THREAD; i++) {
+    const uint32_t wi = rc[i].y & 0xFFFFu;
+    unsigned long long todo = __ballot(cnt[i] != 0 && wi * (rc[i].y >> 16) > 64);
     while (todo) {
       const int j = __ffsll(todo) - 1;
       todo &= todo - 1;
@@ -139,39 +160,27 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
       const uint32_t rx = (uint32_t)__builtin_amdgcn_readlane((int)rc[i].x, j);
       const uint32_t ry = (uint32_t)__builtin_amdgcn_readlane((int)rc[i].y, j);
       const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)gid[i], j);
-      const uint32_t x0 = rx & 0xFFFFu, y0 = rx >> 16, w = ry & 0xFFFFu, ncand = w * (ry >> 16);
+      const uint32_t x0 = rx & 0xFFFFu, y0 = rx >> 16, w = ry & 0xFFFFu, h = ry >> 16, ncand = w * h;
       const float inv_w = 1.0f / (float)w;
-      if (ncand <= 64) {
-        const unsigned long long mask = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)rc[i].w, j) << 32) |
-                                        (uint32_t)__builtin_amdgcn_readlane((int)rc[i].z, j);
-        if ((mask >> lane) & 1ull) {
-          const uint32_t row = (uint32_t)(((float)lane + 0.5f) * inv_w), col = lane - row * w;
-          const uint32_t pos = o + (uint32_t)__popcll(mask & lt_mask);
+      const float4 s0 = splat[3 * (size_t)g], s1 = splat[3 * (size_t)g + 1];
+      const TileCull tc = tile_cull_setup(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, (float)(x0 * GM_TILE), (float)((x0 + w) * GM_TILE - 1),
+                                          (float)(y0 * GM_TILE), (float)((y0 + h) * GM_TILE - 1));
+      uint32_t run = o;
+      for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
+        const uint32_t k = c0 + lane;
+        const uint32_t row = (uint32_t)(((float)k + 0.5f) * inv_w), col = k - row * w;
+        bool pass = k < ncand;
+        if (pass && tile_cull) {                   // same per-row span as preprocess used for the count
+          int ta, tb;
+          pass = row_tiles(tc, s0.x, s0.y, (int)(y0 + row), (int)x0, (int)(x0 + w), ta, tb) && (int)(x0 + col) >= ta && (int)(x0 + col) <= tb;
+        }
+        const unsigned long long bal = __ballot(pass);
+        if (pass) {
+          const uint32_t pos = run + (uint32_t)__popcll(bal & lt_mask);
           keys_out[pos] = (y0 + row) * (uint32_t)gx + (x0 + col);
           vals_out[pos] = g;
         }
-      } else {
-        const float4 s0 = splat[3 * (size_t)g], s1 = splat[3 * (size_t)g + 1];
-        const uint32_t h = ry >> 16;
-        const TileCull tc = tile_cull_setup(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, (float)(x0 * GM_TILE), (float)((x0 + w) * GM_TILE - 1),
-                                            (float)(y0 * GM_TILE), (float)((y0 + h) * GM_TILE - 1));
-        uint32_t run = o;
-        for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
-          const uint32_t k = c0 + lane;
-          const uint32_t row = (uint32_t)(((float)k + 0.5f) * inv_w), col = k - row * w;
-          bool pass = k < ncand;
-          if (pass && tile_cull) {                 // same per-row span as preprocess used for the count
-            int ta, tb;
-            pass = row_tiles(tc, s0.x, s0.y, (int)(y0 + row), (int)x0, (int)(x0 + w), ta, tb) && (int)(x0 + col) >= ta && (int)(x0 + col) <= tb;
-          }
-          const unsigned long long bal = __ballot(pass);
-          if (pass) {
-            const uint32_t pos = run + (uint32_t)__popcll(bal & lt_mask);
-            keys_out[pos] = (y0 + row) * (uint32_t)gx + (x0 + col);
-            vals_out[pos] = g;
-          }
-          run += (uint32_t)__popcll(bal);
-        }
+        run += (uint32_t)__popcll(bal);
       }
     }
   }
