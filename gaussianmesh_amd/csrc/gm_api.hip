@@ -273,6 +273,12 @@ int gm_deform_shade(int N, int deg, int M, const int* tri, const float* w, const
                              reinterpret_cast<hipStream_t>(stream));
 }
 
+int gm_cov_to_scale_rot(int N, const float* cov, float* scales, float* rots, void* stream) {
+  if (N < 0 || (N > 0 && (!cov || !scales || !rots))) { set_error("gm_cov_to_scale_rot: bad args"); return GM_ERR_INVALID_ARG; }
+  if (N > 0 && (reinterpret_cast<uintptr_t>(rots) & 15)) { set_error("gm_cov_to_scale_rot: rots must be 16-byte aligned"); return GM_ERR_INVALID_ARG; }
+  return launch_cov_to_scale_rot(N, cov, scales, rots, reinterpret_cast<hipStream_t>(stream));
+}
+
 void gm_profile_enable(int on) { g_prof_on = on != 0; }
 void gm_profile_reset(void) {
   drain_profile();

@@ -189,6 +189,7 @@ int launch_sh_colors(int N, int deg, int M, const float* pos, const float* campo
 int launch_deform_shade(int N, int deg, int M, const int* tri, const float* w, const float* dV, const float* Rv, const float* Sv,
                         const float* cov, const float* pos, const float* shs, const float* campos, float* pos_out,
                         float* cov6_out, float* rgb_out, float* cov_out, float* rot_out, hipStream_t s);
+int launch_cov_to_scale_rot(int N, const float* cov, float* scales, float* rots, hipStream_t s);
 int launch_knn(int P, const float* points, float* meanDists, void* ws, size_t ws_bytes, hipStream_t s);
 size_t knn_workspace_bytes(int P);
 

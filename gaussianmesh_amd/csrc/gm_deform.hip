@@ -233,4 +233,93 @@ int launch_deform_shade(int N, int deg, int M, const int* tri, const float* w, c
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Covariance -> (scale, quaternion): replaces SceneVisualTool.render_gaussian's per-frame
+//   eigh(cov) on the device, det sign fixed on the HOST through numpy, sqrt(eigenvalues), matrix -> quaternion
+// (edittool/__init__.py:204-207 and :23-38), i.e. a device->host->device round trip of 36 B per Gaussian per frame.
+// One thread per Gaussian: cyclic Jacobi in double (3x3 symmetric, <= 8 sweeps), eigenvalues ascending like eigh,
+// eigenvector matrix multiplied by sign(det) as the reference does, quaternion (w,x,y,z) by the branch-safe
+// largest-component form (the reference's w = sqrt(1+trace)/2 divides by zero for trace <= -1), normalised.
+// Eigenvector signs are not unique, so parity is on the reconstructed covariance R diag(s^2) R^T, not on (s, q).
+__global__ __launch_bounds__(256) void cov_to_scale_rot_kernel(int N, const float* __restrict__ cov, float* __restrict__ scales,
+                                                               float* __restrict__ rots) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  double A[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  const float* c = cov + 9 * (size_t)i;
+  // symmetrise (the deformed covariance RS C RS^T is symmetric up to rounding)
+  A[0][0] = c[0]; A[1][1] = c[4]; A[2][2] = c[8];
+  A[0][1] = A[1][0] = 0.5 * ((double)c[1] + c[3]);
+  A[0][2] = A[2][0] = 0.5 * ((double)c[2] + c[6]);
+  A[1][2] = A[2][1] = 0.5 * ((double)c[5] + c[7]);
+  const double scale = fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]) + 1e-300;
+  for (int sweep = 0; sweep < 8; sweep++) {
+    const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+    if (off <= 1e-15 * scale) break;
+#pragma unroll
+    for (int pq = 0; pq < 3; pq++) {
+      const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
+      const double apq = A[p][q];
+      if (fabs(apq) <= 1e-300) continue;
+      const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+      const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+      const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+      const int r = 3 - p - q;
+      const double arp = A[r][p], arq = A[r][q];
+      A[p][p] -= t * apq; A[q][q] += t * apq; A[p][q] = A[q][p] = 0.0;
+      A[r][p] = A[p][r] = cs * arp - sn * arq;
+      A[r][q] = A[q][r] = sn * arp + cs * arq;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const double vp = V[k][p], vq = V[k][q];
+        V[k][p] = cs * vp - sn * vq; V[k][q] = sn * vp + cs * vq;
+      }
+    }
+  }
+  // ascending order of eigenvalues (columns of V follow)
+  double ev[3] = {A[0][0], A[1][1], A[2][2]};
+  int idx[3] = {0, 1, 2};
+#define CSWAP(a_, b_) if (ev[idx[a_]] > ev[idx[b_]]) { const int t_ = idx[a_]; idx[a_] = idx[b_]; idx[b_] = t_; }
+  CSWAP(0, 1) CSWAP(1, 2) CSWAP(0, 1)
+#undef CSWAP
+  double U[3][3];
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) U[k][j] = V[k][idx[j]];
+  const double det = U[0][0] * (U[1][1] * U[2][2] - U[1][2] * U[2][1]) - U[0][1] * (U[1][0] * U[2][2] - U[1][2] * U[2][0]) +
+                     U[0][2] * (U[1][0] * U[2][1] - U[1][1] * U[2][0]);
+  const double sg = det < 0 ? -1.0 : 1.0;
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) U[k][j] *= sg;
+  // rotation matrix -> quaternion, largest-component branch
+  const double tr = U[0][0] + U[1][1] + U[2][2];
+  double qw, qx, qy, qz;
+  if (tr > 0) {
+    const double s4 = 2.0 * sqrt(1.0 + tr);
+    qw = 0.25 * s4; qx = (U[2][1] - U[1][2]) / s4; qy = (U[0][2] - U[2][0]) / s4; qz = (U[1][0] - U[0][1]) / s4;
+  } else if (U[0][0] > U[1][1] && U[0][0] > U[2][2]) {
+    const double s4 = 2.0 * sqrt(1.0 + U[0][0] - U[1][1] - U[2][2]);
+    qw = (U[2][1] - U[1][2]) / s4; qx = 0.25 * s4; qy = (U[0][1] + U[1][0]) / s4; qz = (U[0][2] + U[2][0]) / s4;
+  } else if (U[1][1] > U[2][2]) {
+    const double s4 = 2.0 * sqrt(1.0 + U[1][1] - U[0][0] - U[2][2]);
+    qw = (U[0][2] - U[2][0]) / s4; qx = (U[0][1] + U[1][0]) / s4; qy = 0.25 * s4; qz = (U[1][2] + U[2][1]) / s4;
+  } else {
+    const double s4 = 2.0 * sqrt(1.0 + U[2][2] - U[0][0] - U[1][1]);
+    qw = (U[1][0] - U[0][1]) / s4; qx = (U[0][2] + U[2][0]) / s4; qy = (U[1][2] + U[2][1]) / s4; qz = 0.25 * s4;
+  }
+  const double qn = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+  reinterpret_cast<float4*>(rots)[i] = make_float4((float)(qw * qn), (float)(qx * qn), (float)(qy * qn), (float)(qz * qn));
+#pragma unroll
+  for (int j = 0; j < 3; j++) scales[3 * (size_t)i + j] = (float)sqrt(fmax(ev[idx[j]], 0.0));
+}
+
+int launch_cov_to_scale_rot(int N, const float* cov, float* scales, float* rots, hipStream_t s) {
+  if (N > 0) hipLaunchKernelGGL(cov_to_scale_rot_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, cov, scales, rots);
+  GM_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace gm

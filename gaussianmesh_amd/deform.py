@@ -84,6 +84,23 @@ def deform_shade(tri, w, dV, Rv, Sv, cov, pos, shs, campos, deg=3, want_cov_rot=
     return (pos_o, cov6, rgb, cov_o, rot_o) if want_cov_rot else (pos_o, cov6, rgb)
 
 
+def cov_to_scale_rot(cov):
+    """gm_cov_to_scale_rot: (scales [N,3], rotations [N,4]) whose covariance R diag(s^2) R^T equals cov [N,3,3]
+    (the SceneVisualTool route: edittool/__init__.py:204-207, rasterised with scales/rotations instead of cov3D_precomp)."""
+    lib = _lib.lib()
+    device = cov.device
+    if device.type != "cuda":
+        raise _lib.GmeshError("cov_to_scale_rot needs a tensor on a HIP (cuda) device; there is no CPU path")
+    cov = _f(cov)
+    N = cov.shape[0]
+    scales = torch.empty((N, 3), dtype=torch.float32, device=device)
+    rots = torch.empty((N, 4), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        _lib.check(lib.gm_cov_to_scale_rot(N, cov.data_ptr(), scales.data_ptr(), rots.data_ptr(),
+                                           torch.cuda.current_stream(device).cuda_stream))
+    return scales, rots
+
+
 class SingleObjectDeform:
     """Tensor-in counterpart of edittool.SingleObjectDeform.
 

@@ -148,6 +148,12 @@ int gm_deform_shade(int N, int deg, int M, const int* tri, const float* w, const
                     const float* cov, const float* pos, const float* shs, const float* campos, float* pos_out, float* cov6_out,
                     float* rgb_out, float* cov_out, float* rot_out, void* stream);
 
+/* Covariance -> (scale, rotation): replaces the per-frame eigh + host-side det sign + sqrt + matrix->quaternion of
+ * SceneVisualTool.render_gaussian (edittool/__init__.py:204-207, 23-38).  cov float [N,3,3] (symmetric),
+ * scales float [N,3] = sqrt of the eigenvalues in ascending order, rots float [N,4] = unit quaternion (w,x,y,z) of the
+ * eigenvector matrix made right-handed, such that R(q) diag(scales^2) R(q)^T reproduces cov. */
+int gm_cov_to_scale_rot(int N, const float* cov, float* scales, float* rots, void* stream);
+
 /* Per-stage GPU timing (HIP events recorded on `stream` around each kernel group).  Off by default.
  * gm_profile_enable(1) starts collecting, gm_profile_read synchronises the recorded events and returns
  * accumulated milliseconds and launch count for a stage name ("preprocess","depth_sort","scan",

@@ -315,3 +315,37 @@ def test_deform_and_sh_colors(oracle):
     assert np.array_equal(frgb, rgb_sep)
     fp2, fc62, frgb2 = (x.cpu().numpy() for x in deform_shade(*args, deg=3))
     assert np.array_equal(fp2, p) and np.array_equal(fc62, c6) and np.array_equal(frgb2, rgb_sep)
+
+
+def test_cov_to_scale_rot(oracle):
+    """a22: eigh + quaternion route.  Parity on the reconstructed covariance and on the eigenvalues (numpy eigh)."""
+    from gpu_utils import T, forward_state
+    from gaussianmesh_amd import scenes
+    from gaussianmesh_amd.deform import cov_to_scale_rot
+    rng = np.random.default_rng(3)
+    cl = scenes.make_cloud(4000, seed=8, scale_lo=0.01, scale_hi=0.5)
+    cov = scenes.cov3d_from_scale_rot(cl["scales"], cl["rots"])
+    cov[:10] = np.eye(3) * 0.04                                  # degenerate (all eigenvalues equal)
+    sc_rep = cl["scales"][10:20].copy(); sc_rep[:, 2] = sc_rep[:, 1]                      # repeated eigenvalue
+    cov[10:20] = scenes.cov3d_from_scale_rot(sc_rep, cl["rots"][10:20])
+    cov = cov.astype(np.float32).astype(np.float64)                 # what the kernel actually sees
+    s, q = (x.cpu().numpy().astype(np.float64) for x in cov_to_scale_rot(T(cov.astype(np.float32))))
+    w = np.linalg.eigvalsh(cov)
+    assert np.abs(s ** 2 - w).max() <= 1e-5 * np.abs(w).max()
+    assert (np.diff(s, axis=1) >= -1e-7).all()                   # ascending, like eigh
+    assert np.allclose(np.linalg.norm(q, axis=1), 1.0, atol=1e-6)
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y), 2 * (x * y + r * z), 1 - 2 * (x * x + z * z),
+                  2 * (y * z - r * x), 2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
+    rec = R @ (s[:, :, None] ** 2 * R.transpose(0, 2, 1))
+    assert np.abs(rec - cov).max() <= 2e-6 * np.abs(cov).max() + 1e-9
+    assert np.allclose(np.linalg.det(R), 1.0, atol=1e-6)
+    # rendering with (scales, rotations) from the kernel == rendering with the covariance itself
+    cam = scenes.orbit_camera(1, 6, 200, 120, radius=7.0)
+    bg = np.zeros(3, np.float32)
+    sc = dict(cl); sc["cov3D_precomp"] = scenes.strip_symmetric(cov); sc["colors_precomp"] = rng.uniform(0, 1, (4000, 3)).astype(np.float32)
+    a = forward_state(sc, cam, bg, D=3, use_precomp_cov=True, use_precomp_color=True)
+    sc2 = dict(sc); sc2["scales"] = s.astype(np.float32); sc2["rots"] = q.astype(np.float32)
+    b = forward_state(sc2, cam, bg, D=3, use_precomp_cov=False, use_precomp_color=True)
+    assert (a["radii"] != b["radii"]).mean() <= 2e-3            # ceil(3 sigma) may flip by one on a few Gaussians
+    assert np.abs(a["color"] - b["color"]).max() <= 2e-3
