@@ -120,12 +120,12 @@ __global__ __launch_bounds__(DS_THREADS) void deform_shade_kernel(int N, int deg
                                                                   float* __restrict__ cov6_out, float* __restrict__ rgb_out,
                                                                   float* __restrict__ cov_out, float* __restrict__ rot_out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* l_sh = lds;                           // [256][49]
-  float* l_cov = lds + DS_THREADS * 49;        // [256][9]
+  float4* l_sh = reinterpret_cast<float4*>(lds);   // [DS_THREADS][13] granules (12 used): SH rows, conflict-free b128 access
+  float* l_cov = lds + DS_THREADS * 52;            // [DS_THREADS][9] linear image of the covariance rows
   const size_t row0 = (size_t)blockIdx.x * DS_THREADS;
   const int nrows = min(DS_THREADS, N - (int)row0);
-  stage_rows<48, 49, DS_THREADS>(shs, row0, nrows, l_sh);
-  stage_rows<9, 9, DS_THREADS>(cov, row0, nrows, l_cov);
+  stage_rows16<12, 13, DS_THREADS>(shs, row0, nrows, l_sh);
+  stage_linear<DS_THREADS>(cov + row0 * 9, nrows * 9, l_cov);
   const int t = threadIdx.x;
   const size_t i = row0 + t;
   const bool live = t < nrows;
@@ -173,7 +173,12 @@ __global__ __launch_bounds__(DS_THREADS) void deform_shade_kernel(int N, int deg
     const float x = (Rt[0] * dx + Rt[3] * dy) + Rt[6] * dz;
     const float y = (Rt[1] * dx + Rt[4] * dy) + Rt[7] * dz;
     const float z = (Rt[2] * dx + Rt[5] * dy) + Rt[8] * dz;
-    const float* sh = l_sh + t * 49;
+    float sh[48];
+#pragma unroll
+    for (int c = 0; c < 12; c++) {
+      const float4 v = l_sh[t * 13 + c];
+      sh[4 * c] = v.x; sh[4 * c + 1] = v.y; sh[4 * c + 2] = v.z; sh[4 * c + 3] = v.w;
+    }
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
       const float r = sh_channel(deg, [&](int k) { return sh[3 * k + ch]; }, x, y, z);
@@ -219,7 +224,7 @@ int launch_deform_shade(int N, int deg, int M, const int* tri, const float* w, c
   // (load / compute / store), which keeps far more bytes in flight than a few 256-thread groups in lock-step
   const char* e = getenv("GM_DS_THREADS");
   const int th = e ? atoi(e) : 64;
-  const size_t lds_bytes = sizeof(float) * th * (49 + 9);
+  const size_t lds_bytes = sizeof(float) * th * (52 + 9);
   if (th == 256)
     hipLaunchKernelGGL(deform_shade_kernel<256>, dim3((N + 255) / 256), dim3(256), lds_bytes, s, N, deg, tri, w, dV, Rv, Sv, cov, pos,
                        shs, campos, pos_out, cov6_out, rgb_out, cov_out, rot_out);

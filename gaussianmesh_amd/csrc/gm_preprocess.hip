@@ -19,6 +19,7 @@
 #pragma clang fp contract(off)
 #include "gm_sh.h"
 #include "gm_cull.h"
+#include "gm_stage.h"
 
 namespace gm {
 
@@ -88,8 +89,17 @@ struct PreArgs {
   float4* splat; int* radii_int; int* radii_out; uint32_t* tiles; uint4* bin; int tile_cull; float* cov3D; uint8_t* clamped; uint32_t* depth_key;
 };
 
+// STAGE_SH: the workgroup's 256 SH rows (192 B each, M == 16) are copied HBM -> LDS with consecutive lanes reading
+// consecutive 16 bytes (gm_stage.h) before the per-Gaussian work; otherwise each thread walks its own row.
+template <bool STAGE_SH>
 __global__ __launch_bounds__(256) void preprocess_fwd_kernel(const PreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds_pre[];
   const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (STAGE_SH) {
+    const size_t row0 = (size_t)blockIdx.x * 256;
+    stage_rows16<12, 13, 256>(a.shs, row0, min(256, a.P - (int)row0), reinterpret_cast<float4*>(lds_pre));
+    __syncthreads();
+  }
   if (idx >= a.P) return;
   int radius_i = 0;
   uint32_t tiles = 0, dkey = 0xFFFFFFFFu;
@@ -150,7 +160,13 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(const PreArgs a) {
       dx = dx / len; dy = dy / len; dz = dz / len;
       float sh[48];
       const int ncoef = (a.D + 1) * (a.D + 1);
-      load_sh(a.shs, idx, a.M, ncoef, sh);
+      if (STAGE_SH) {
+        const float4* row = reinterpret_cast<const float4*>(lds_pre) + threadIdx.x * 13;
+#pragma unroll
+        for (int c = 0; c < 12; c++) { const float4 v = row[c]; sh[4 * c] = v.x; sh[4 * c + 1] = v.y; sh[4 * c + 2] = v.z; sh[4 * c + 3] = v.w; }
+      } else {
+        load_sh(a.shs, idx, a.M, ncoef, sh);
+      }
 #pragma unroll
       for (int ch = 0; ch < 3; ch++) {
         float r = sh_channel(a.D, [&](int i) { return sh[3 * i + ch]; }, dx, dy, dz);
@@ -207,7 +223,12 @@ int launch_preprocess(const RasterArgs& r, GeomState& g, int* radii) {
   a.fy = r.H / (2.0f * r.tan_fovy); a.fx = r.W / (2.0f * r.tan_fovx);   // rasterizer_impl.cu:359-360
   a.splat = g.splat; a.radii_int = g.radii; a.radii_out = radii; a.tiles = g.tiles_touched; a.bin = g.bin; a.tile_cull = r.tile_cull; a.cov3D = g.cov3D;
   a.clamped = g.clamped; a.depth_key = g.depth_key[0];
-  if (r.P > 0) hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((r.P + 255) / 256), dim3(256), 0, r.stream, a);
+  if (r.P > 0) {
+    if (a.shs && a.M == 16 && aligned16(a.shs))
+      hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3((r.P + 255) / 256), dim3(256), sizeof(float4) * 256 * 13, r.stream, a);
+    else
+      hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3((r.P + 255) / 256), dim3(256), 0, r.stream, a);
+  }
   GM_LAUNCH_CHECK(r.debug, r.stream);
   return 0;
 }
@@ -241,9 +262,31 @@ struct PreBwdArgs {
   float *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
 };
 
+template <bool STAGE_SH>
+__device__ __forceinline__ void preprocess_bwd_body(const PreBwdArgs& a, const int idx, float4* lrow);
+
+// STAGE_SH: SH rows come in through LDS and the 192-byte dL/dSH rows leave through the same LDS rows as coalesced
+// 16-byte stores (gm_stage.h); these two streams are 384 of the ~560 bytes this kernel moves per Gaussian.
+template <bool STAGE_SH>
 __global__ __launch_bounds__(256) void preprocess_bwd_kernel(const PreBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds_pre[];
+  float4* lrow = reinterpret_cast<float4*>(lds_pre) + threadIdx.x * 13;
+  const size_t row0 = (size_t)blockIdx.x * 256;
+  const int nrows = min(256, a.P - (int)row0);
+  if (STAGE_SH) {
+    stage_rows16<12, 13, 256>(a.shs, row0, nrows, reinterpret_cast<float4*>(lds_pre));
+    __syncthreads();
+  }
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= a.P) return;
+  if (idx < a.P) preprocess_bwd_body<STAGE_SH>(a, idx, lrow);
+  if (STAGE_SH) {
+    __syncthreads();
+    unstage_rows16<12, 13, 256>(a.dL_dsh, row0, nrows, reinterpret_cast<const float4*>(lds_pre));
+  }
+}
+
+template <bool STAGE_SH>
+__device__ __forceinline__ void preprocess_bwd_body(const PreBwdArgs& a, const int idx, float4* lrow) {
   const int ncoef = (a.D + 1) * (a.D + 1);
   float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const bool visible = a.radii[idx] > 0;
@@ -331,7 +374,12 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(const PreBwdArgs a)
       const float len = sqrtf(ox * ox + oy * oy + oz * oz);
       const float x = ox / len, y = oy / len, z = oz / len;
       float sh[48];
-      load_sh(a.shs, idx, a.M, ncoef, sh);
+      if (STAGE_SH) {
+#pragma unroll
+        for (int c = 0; c < 12; c++) { const float4 v = lrow[c]; sh[4 * c] = v.x; sh[4 * c + 1] = v.y; sh[4 * c + 2] = v.z; sh[4 * c + 3] = v.w; }
+      } else {
+        load_sh(a.shs, idx, a.M, ncoef, sh);
+      }
       const uint8_t cl = a.clamped[idx];
       float dRGB[3], wgt[16];
 #pragma unroll
@@ -374,17 +422,27 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(const PreBwdArgs a)
         }
       }
 #undef S
-      float* dsh = a.dL_dsh + (size_t)idx * a.M * 3;
+      if (STAGE_SH) {                              // M == 16: the row goes back through LDS
+        float o[48];
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        if (i < a.M) {
-          const bool on = i < ncoef;
+        for (int i = 0; i < 16; i++)
 #pragma unroll
-          for (int ch = 0; ch < 3; ch++) dsh[3 * i + ch] = on ? wgt[i] * dRGB[ch] : 0.f;
+          for (int ch = 0; ch < 3; ch++) o[3 * i + ch] = (i < ncoef) ? wgt[i] * dRGB[ch] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 12; c++) lrow[c] = make_float4(o[4 * c], o[4 * c + 1], o[4 * c + 2], o[4 * c + 3]);
+      } else {
+        float* dsh = a.dL_dsh + (size_t)idx * a.M * 3;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          if (i < a.M) {
+            const bool on = i < ncoef;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) dsh[3 * i + ch] = on ? wgt[i] * dRGB[ch] : 0.f;
+          }
         }
+        for (int i = 16; i < a.M; i++)
+          for (int ch = 0; ch < 3; ch++) dsh[3 * i + ch] = 0.f;
       }
-      for (int i = 16; i < a.M; i++)
-        for (int ch = 0; ch < 3; ch++) dsh[3 * i + ch] = 0.f;
       const float ddir[3] = {ddx[0] * dRGB[0] + ddx[1] * dRGB[1] + ddx[2] * dRGB[2],
                              ddy[0] * dRGB[0] + ddy[1] * dRGB[1] + ddy[2] * dRGB[2],
                              ddz[0] * dRGB[0] + ddz[1] * dRGB[1] + ddz[2] * dRGB[2]};
@@ -396,8 +454,13 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(const PreBwdArgs a)
       dmean[2] += (-ox * oz * ddir[0] - oy * oz * ddir[1] + (sum2 - oz * oz) * ddir[2]) * invsum32;
     }
   } else if (a.shs) {
-    float* dsh = a.dL_dsh + (size_t)idx * a.M * 3;
-    for (int i = 0; i < a.M * 3; i++) dsh[i] = 0.f;
+    if (STAGE_SH) {
+#pragma unroll
+      for (int c = 0; c < 12; c++) lrow[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      float* dsh = a.dL_dsh + (size_t)idx * a.M * 3;
+      for (int i = 0; i < a.M * 3; i++) dsh[i] = 0.f;
+    }
   }
 #pragma unroll
   for (int k = 0; k < 3; k++) a.dL_dmean3D[3 * (size_t)idx + k] = dmean[k];
@@ -462,7 +525,12 @@ int launch_preprocess_bwd(const RasterArgs& r, GeomState& g, const int* radii, f
   a.grad_acc = g.grad_acc;
   a.dL_dmean2D = dL_dmean2D; a.dL_dconic = dL_dconic; a.dL_dopacity = dL_dopacity; a.dL_dcolor = dL_dcolor;
   a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot;
-  if (r.P > 0) hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((r.P + 255) / 256), dim3(256), 0, r.stream, a);
+  if (r.P > 0) {
+    if (a.shs && a.M == 16 && aligned16(a.shs) && aligned16(a.dL_dsh))
+      hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3((r.P + 255) / 256), dim3(256), sizeof(float4) * 256 * 13, r.stream, a);
+    else
+      hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3((r.P + 255) / 256), dim3(256), 0, r.stream, a);
+  }
   GM_LAUNCH_CHECK(r.debug, r.stream);
   return 0;
 }

@@ -45,6 +45,38 @@ __device__ __forceinline__ void unstage_rows(float* __restrict__ g, size_t row0,
   }
 }
 
+// 16-byte-granule variants for rows that are a whole number of float4 (the 192-byte SH rows: G = 12 granules).
+// Row r, granule c lives at LDS granule r * LG + c with LG odd (13), so that a ds_read_b128 / ds_write_b128 of
+// "granule c of my row" by 16 consecutive lanes touches 16 different 16-byte bank columns: conflict-free, one LDS
+// instruction per granule instead of four scalar ones, and one divide per granule in the copy loop instead of four.
+template <int G, int LG, int THREADS>
+__device__ __forceinline__ void stage_rows16(const float* __restrict__ g, size_t row0, int nrows, float4* __restrict__ lds) {
+  const float4* src = reinterpret_cast<const float4*>(g) + row0 * G;
+  const int total = nrows * G;
+  for (int i = threadIdx.x; i < total; i += THREADS) {
+    const int r = i / G, c = i - r * G;
+    lds[r * LG + c] = src[i];
+  }
+}
+template <int G, int LG, int THREADS>
+__device__ __forceinline__ void unstage_rows16(float* __restrict__ g, size_t row0, int nrows, const float4* __restrict__ lds) {
+  float4* dst = reinterpret_cast<float4*>(g) + row0 * G;
+  const int total = nrows * G;
+  for (int i = threadIdx.x; i < total; i += THREADS) {
+    const int r = i / G, c = i - r * G;
+    dst[i] = lds[r * LG + c];
+  }
+}
+// plain linear copy of nfloats (multiple-of-4 part as float4) - rows with a stride coprime to the bank count
+// (9 or 3 dwords) can be read straight out of the linear image
+template <int THREADS>
+__device__ __forceinline__ void stage_linear(const float* __restrict__ src, int nfloats, float* __restrict__ lds) {
+  const int n4 = nfloats >> 2;
+  for (int i = threadIdx.x; i < n4; i += THREADS) reinterpret_cast<float4*>(lds)[i] = reinterpret_cast<const float4*>(src)[i];
+  const int t = (n4 << 2) + threadIdx.x;
+  if (t < nfloats) lds[t] = src[t];
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace gm
