@@ -189,159 +189,6 @@ __global__ __launch_bounds__(256 / PPL) void render_fwd_kernel(const uint2* __re
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Cooperative forward blend: one 256-thread workgroup per 16x16 tile, wave w owns the 16x4 pixel strip w
-// (one pixel per lane).  The tile's list is consumed in batches of 256 entries:
-//   A  thread t gathers entry t of the batch (id prefetched two batches ahead, record one batch ahead), tests it
-//      against the four strips (strip_mask below) and publishes record + four 64-bit survivor ballots in LDS;
-//   -- one s_barrier per batch (LDS is double-buffered) --
-//   B  wave w walks the survivors of ITS strip (s_ff1 over the ballots) reading the records as LDS broadcasts.
-// Compared with four independent waves each streaming the whole list (render_fwd_kernel<1>) the gather traffic
-// and the per-wave dependent-load chain are 4x shorter, which is what bounds tiles with 10k+ entries.
-// Exit is uniform: every wave publishes "all my pixels are done" and all waves read the same flags after the
-// next barrier.
-struct StripTest { bool keep[4]; };
-
-__device__ __forceinline__ StripTest strip_mask(float sx, float sy, float a, float b, float c, float op,
-                                                float x0, float ytile) {
-  StripTest r;
-  r.keep[0] = r.keep[1] = r.keep[2] = r.keep[3] = false;
-  if (!(op >= 0.0039f)) return r;
-  const float dxl = sx - (x0 + 15.f), dxh = sx - x0;
-  const float thr = 1.3862943611f * __builtin_amdgcn_logf(255.0f * op);
-  const float mx = fmaxf(fabsf(dxl), fabsf(dxh));
-  const float my = fmaxf(fabsf(sy - ytile), fabsf(sy - (ytile + 15.f)));
-  const float lim = thr + 4e-6f * (a * mx * mx + c * my * my + 2.0f * fabsf(b) * mx * my) + 1e-3f;
-  const float nb_c = -b * __builtin_amdgcn_rcpf(c), nb_a = -b * __builtin_amdgcn_rcpf(a);
-  const bool xin = dxl <= 0.f && dxh >= 0.f;
-  // vertical edges dx = dxl / dxh: shared pieces
-  const float yl = nb_c * dxl, yh = nb_c * dxh;
-  const float al = a * dxl * dxl, ah = a * dxh * dxh, bl = 2.f * b * dxl, bh = 2.f * b * dxh;
-#pragma unroll
-  for (int w = 0; w < 4; w++) {
-    const float dyl = sy - (ytile + (float)(4 * w + 3)), dyh = sy - (ytile + (float)(4 * w));
-    float q;
-    {
-      const float y = fminf(fmaxf(yl, dyl), dyh);
-      q = al + (bl + c * y) * y;
-    }
-    {
-      const float y = fminf(fmaxf(yh, dyl), dyh);
-      q = fminf(q, ah + (bh + c * y) * y);
-    }
-    {
-      const float x = fminf(fmaxf(nb_a * dyl, dxl), dxh);
-      q = fminf(q, (a * x + 2.f * b * dyl) * x + c * dyl * dyl);
-    }
-    {
-      const float x = fminf(fmaxf(nb_a * dyh, dxl), dxh);
-      q = fminf(q, (a * x + 2.f * b * dyh) * x + c * dyh * dyh);
-    }
-    const bool inside = xin && dyl <= 0.f && dyh >= 0.f;
-    r.keep[w] = inside || !(q > lim);
-  }
-  return r;
-}
-
-__global__ __launch_bounds__(256) void render_fwd_coop_kernel(const uint2* __restrict__ ranges,
-                                                              const uint32_t* __restrict__ point_list,
-                                                              const float4* __restrict__ splat, int W, int H, int gx,
-                                                              const float* __restrict__ bg, float* __restrict__ out_color,
-                                                              float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
-  __shared__ float4 la[2][256];
-  __shared__ float4 lb[2][256];
-  __shared__ float lc[2][256];
-  __shared__ unsigned long long masks[2][4][4];   // [buffer][strip][source wave]
-  __shared__ int flags[2][4];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile = blockIdx.x;
-  const int tx = tile % gx, ty = tile / gx;
-  const uint2 range = ranges[tile];
-  const int n = (int)(range.y - range.x);
-  const uint32_t* list = point_list + range.x;
-
-  const int px = tx * GM_TILE + (lane & 15), py = ty * GM_TILE + wave * 4 + (lane >> 4);
-  const float pixx = (float)px, pixy = (float)py;
-  const bool inside = px < W && py < H;
-  float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f;
-  uint32_t last = 0;
-  bool done = !inside;
-  const float x0 = (float)(tx * GM_TILE), ytile = (float)(ty * GM_TILE);
-
-  const int nb = (n + 255) >> 8;
-  // prologue: records of batch 0, ids of batch 1
-  float4 ca = make_float4(0.f, 0.f, 0.f, 0.f), cb = ca; float cc = 0.f;
-  if (tid < n) { const uint32_t id = list[tid]; ca = splat[3 * (size_t)id]; cb = splat[3 * (size_t)id + 1]; cc = splat[3 * (size_t)id + 2].x; }
-  uint32_t idn = (256 + tid < n) ? list[256 + tid] : 0u;
-  bool wave_done = false;
-
-  for (int b = 0; b < nb; b++) {
-    const int buf = b & 1;
-    WAIT_ALL_LOADS();
-    // ---- A: cull + publish batch b
-    StripTest st = strip_mask(ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, x0, ytile);
-    const bool live = (b * 256 + tid) < n;
-    la[buf][tid] = ca; lb[buf][tid] = cb; lc[buf][tid] = cc;
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-      const unsigned long long m = __ballot(live && st.keep[w]);
-      if (lane == 0) masks[buf][w][wave] = m;
-    }
-    // next batch's records (ids arrived during the previous B phase) and the ids after that
-    float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nbv = na; float nc = 0.f;
-    if ((b + 1) * 256 + tid < n) { na = splat[3 * (size_t)idn]; nbv = splat[3 * (size_t)idn + 1]; nc = splat[3 * (size_t)idn + 2].x; }
-    const uint32_t idn2 = ((b + 2) * 256 + tid < n) ? list[(b + 2) * 256 + tid] : 0u;
-    __syncthreads();
-    if (b > 0) {
-      const int f = flags[buf ^ 1][0] & flags[buf ^ 1][1] & flags[buf ^ 1][2] & flags[buf ^ 1][3];
-      if (f) break;
-    }
-    // ---- B: blend the survivors of this wave's strip
-    if (!wave_done) {
-#pragma unroll 1
-      for (int sw = 0; sw < 4; sw++) {
-        unsigned long long todo = masks[buf][wave][sw];
-        while (todo) {
-          const int j = __ffsll(todo) - 1;
-          todo &= todo - 1;
-          const int e = sw * 64 + j;
-          const float4 A = la[buf][e];
-          const float4 B = lb[buf][e];
-          const float dx = A.x - pixx, dy = A.y - pixy;
-          const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
-          const float alpha = fminf(0.99f, B.y * __builtin_amdgcn_exp2f(power * LOG2E));
-          bool valid = !done && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
-          const float testT = T * (1.0f - alpha);
-          const bool stop = valid && (testT < 0.0001f);
-          done = done || stop;
-          valid = valid && !stop;
-          if (__any(valid)) {
-            const float bl = lc[buf][e];
-            const float w = valid ? alpha * T : 0.0f;
-            Cr += B.z * w; Cg += B.w * w; Cb += bl * w;
-            T = valid ? testT : T;
-            last = valid ? (uint32_t)(b * 256 + e + 1) : last;
-          }
-        }
-      }
-      wave_done = __all(done);
-    }
-    if (lane == 0) flags[buf][wave] = wave_done ? 1 : 0;
-    ca = na; cb = nbv; cc = nc; idn = idn2;
-  }
-
-  if (inside) {
-    const size_t HW = (size_t)H * W;
-    const size_t pid = (size_t)W * py + px;
-    final_T[pid] = T;
-    n_contrib[pid] = last;
-    out_color[pid] = Cr + T * bg[0];
-    out_color[HW + pid] = Cg + T * bg[1];
-    out_color[2 * HW + pid] = Cb + T * bg[2];
-  }
-}
-
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
@@ -350,7 +197,7 @@ static int env_int(const char* name, int dflt) {
 int launch_render_fwd(const GeomState& g, const uint32_t* point_list, ImageState& img, int W, int H,
                       const float* background, float* out_color, int debug, hipStream_t s) {
   StageScope sc(ST_RENDER, s);
-  const int ppl = env_int("GM_RENDER_PPL", 1);          // 1/2/4 = pixels per lane of the independent-wave kernel (default 1); 0 = cooperative variant          // tuning knob, read per launch
+  const int ppl = env_int("GM_RENDER_PPL", 1);          // pixels per lane (1, 2 or 4 -> 4, 2 or 1 waves per tile); tuning knob, read per launch
   const int gx = (W + GM_TILE - 1) / GM_TILE, gy = (H + GM_TILE - 1) / GM_TILE;
   const int tiles = gx * gy;
   if (tiles > 0) {
@@ -361,10 +208,6 @@ int launch_render_fwd(const GeomState& g, const uint32_t* point_list, ImageState
         break;
       case 2:
         hipLaunchKernelGGL(render_fwd_kernel<2>, dim3(tiles), dim3(128), 0, s, img.ranges, point_list, g.splat, W, H, gx,
-                           background, out_color, img.final_T, img.n_contrib);
-        break;
-      case 0:
-        hipLaunchKernelGGL(render_fwd_coop_kernel, dim3(tiles), dim3(256), 0, s, img.ranges, point_list, g.splat, W, H, gx,
                            background, out_color, img.final_T, img.n_contrib);
         break;
       default:
