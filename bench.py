@@ -98,11 +98,19 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    # GM_BENCH_SHARE_DEVICE=1 + GM_BENCH_BACKEND=gloo: functional smoke test of the N>1 path on a one-GPU box
+    # (RCCL refuses two ranks on one device); never used for measurements.
+    if os.environ.get("GM_BENCH_SHARE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("GM_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     lib = _lib.lib()
 
     P, W, H, F = args.gaussians, args.width, args.height, args.cameras
@@ -137,9 +145,9 @@ def main():
         with torch.cuda.stream(streams[i % nstreams]):
             return step_on_stream(i, workspaces[i % nstreams], frame_bufs[i % nstreams])
 
-    def step_on_stream(i, workspace, frame_buf):
+    def step_on_stream(i, workspace, frame_buf, exchange=True):
         t = i % F
-        if world > 1:                            # real exchange step: mesh state of frame t from rank 0 (RCCL)
+        if world > 1 and exchange:               # real exchange step: mesh state of frame t from rank 0 (RCCL)
             if rank == 0:
                 frame_buf.copy_(g["mesh"][t])
             ms = multiview.broadcast_mesh_state(frame_buf, src=0)
@@ -191,7 +199,7 @@ def main():
         nprof = min(args.steps, 50)
         with torch.cuda.stream(streams[0]):
             for i in range(nprof):
-                step_on_stream(args.warmup + i, workspaces[0], frame_bufs[0])
+                step_on_stream(args.warmup + i, workspaces[0], frame_bufs[0], exchange=False)   # rank 0 only: no collective here
         torch.cuda.synchronize()
         lib.gm_profile_enable(0)
         import ctypes as C
@@ -263,6 +271,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()                           # rank 0 finishes its (collective-free) profiling pass first
         dist.destroy_process_group()
 
 
