@@ -1,0 +1,189 @@
+"""Render glue: the step immediately before / after the rasterizer in the reference.
+
+Mirrors gaussian_renderer/__init__.py:
+  render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, bg_gaussian=None)   (:26-143)
+  bg_render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, mesh_gaussians=None) (:146-260)
+and the edit tool's ObjectVisualTool.render_gaussian (edittool/__init__.py:400-475) as render_deformed().
+Same argument names, same returned dict keys; tensors are torch tensors on a HIP device.  `pc` is any object with the
+reference model's properties (get_xyz, get_opacity, get_scaling, get_rotation, get_features, get_covariance(),
+active_sh_degree, max_sh_degree, screenspace_points [+ vertex1..3 for the mesh-bound model]); MeshBoundGaussians below
+is a minimal torch holder of the mesh-bound parameterisation (scene/mesh_based_gaussian_model.py:122-174).
+"""
+import math
+
+import torch
+
+from .deform import sh_colors
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, NewGaussianRasterizer
+
+
+def _settings(cam, bg_color, scaling_modifier, sh_degree, debug):
+    return GaussianRasterizationSettings(
+        image_height=int(cam.image_height), image_width=int(cam.image_width),
+        tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=bg_color, scale_modifier=scaling_modifier,
+        viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=sh_degree,
+        campos=cam.camera_center, prefiltered=False, debug=debug)
+
+
+def strip_symmetric(cov):
+    """[N,3,3] -> [N,6] (xx,xy,xz,yy,yz,zz), utils/general_utils.py:64-72."""
+    return torch.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], dim=1)
+
+
+def _python_sh_colors(pc, cam, xyz, feats):
+    # pipe.convert_SHs_python: colours from SH on the python side of the op (gaussian_renderer/__init__.py:84-89);
+    # here a HIP kernel, forward only (the reference's python path is differentiable; use shs= for training)
+    return sh_colors(xyz, cam.camera_center, feats, rot=None, deg=pc.active_sh_degree)
+
+
+def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, bg_gaussian=None):
+    """gaussian_renderer/__init__.py:26-143.  Returns {"render", "viewspace_points", "visibility_filter", "radii",
+    "vertex1", "vertex2", "vertex3", "scale"}."""
+    screenspace_points = pc.screenspace_points
+    if bg_gaussian is not None:
+        screenspace_points = torch.cat([screenspace_points, torch.zeros_like(bg_gaussian.get_xyz)], dim=0)
+    rasterizer = GaussianRasterizer(_settings(viewpoint_camera, bg_color, scaling_modifier, pc.active_sh_degree, pipe.debug))
+    means3D, means2D, opacity = pc.get_xyz, screenspace_points, pc.get_opacity
+    scales = rotations = cov3D_precomp = None
+    if pipe.compute_cov3D_python:
+        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    else:
+        scales, rotations = pc.get_scaling, pc.get_rotation
+    shs = colors_precomp = None
+    if override_color is None:
+        if pipe.convert_SHs_python:
+            colors_precomp = _python_sh_colors(pc, viewpoint_camera, pc.get_xyz, pc.get_features)
+        else:
+            shs = pc.get_features
+    else:
+        colors_precomp = override_color
+    if bg_gaussian is not None:      # background cloud appended with precomputed covariance (:100-121)
+        if cov3D_precomp is None:
+            raise ValueError("render(bg_gaussian=...) concatenates covariances: set pipe.compute_cov3D_python as the reference does")
+        bg_cov = strip_symmetric(bg_gaussian.get_covariance(1.0)) if bg_gaussian.get_covariance(1.0).dim() == 3 else bg_gaussian.get_covariance(1.0)
+        means3D = torch.cat([means3D, bg_gaussian.get_xyz], dim=0)
+        opacity = torch.cat([opacity, bg_gaussian.get_opacity], dim=0)
+        cov3D_precomp = torch.cat([cov3D_precomp, bg_cov], dim=0)
+        if shs is not None:
+            shs = torch.cat([shs, bg_gaussian.get_features], dim=0)
+        else:
+            bgc = sh_colors(bg_gaussian.get_xyz, viewpoint_camera.camera_center, bg_gaussian.get_features, rot=None, deg=3)
+            colors_precomp = torch.cat([colors_precomp, bgc], dim=0)
+    rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
+                                       scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
+            "vertex1": getattr(pc, "vertex1", None), "vertex2": getattr(pc, "vertex2", None),
+            "vertex3": getattr(pc, "vertex3", None), "scale": scales}
+
+
+def bg_render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, mesh_gaussians=None):
+    """gaussian_renderer/__init__.py:146-260: background model trained with the (frozen) mesh Gaussians composited in."""
+    screenspace_points = pc.screenspace_points
+    if mesh_gaussians is not None:
+        screenspace_points = torch.cat([screenspace_points, mesh_gaussians.screenspace_points], dim=0)
+    rasterizer = GaussianRasterizer(_settings(viewpoint_camera, bg_color, scaling_modifier, pc.active_sh_degree, pipe.debug))
+    means3D, means2D, opacity = pc.get_xyz, screenspace_points, pc.get_opacity
+    scales = rotations = cov3D_precomp = None
+    if pipe.compute_cov3D_python:
+        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    else:
+        scales, rotations = pc.get_scaling, pc.get_rotation
+    shs = colors_precomp = None
+    if override_color is None:
+        if pipe.convert_SHs_python:
+            colors_precomp = _python_sh_colors(pc, viewpoint_camera, pc.get_xyz, pc.get_features)
+        else:
+            shs = pc.get_features
+    else:
+        colors_precomp = override_color
+    if mesh_gaussians is not None:   # .stop_grad() in the reference (:229-233)
+        means3D = torch.cat([means3D, mesh_gaussians.get_xyz.detach()], dim=0)
+        scales = torch.cat([scales, mesh_gaussians.get_scaling.detach()], dim=0)
+        rotations = torch.cat([rotations, mesh_gaussians.get_rotation.detach()], dim=0)
+        shs = torch.cat([shs, mesh_gaussians.get_features.detach()], dim=0)
+        opacity = torch.cat([opacity, mesh_gaussians.get_opacity.detach()], dim=0)
+    rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
+                                       scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
+
+
+def render_deformed(viewpoint_camera, objects, bg_color=None):
+    """ObjectVisualTool.render_gaussian (edittool/__init__.py:400-475): concatenate the deformed objects
+    (SingleObjectDeform instances after .deform()), colours from SH with the deformation-rotated view direction,
+    NewGaussianRasterizer with colors_precomp + cov3D_precomp on a white background."""
+    dev = objects[0].gaussian_deform_pos.device
+    bg = torch.ones(3, device=dev) if bg_color is None else bg_color
+    cat = (lambda xs: xs[0] if len(xs) == 1 else torch.cat(xs, dim=0))
+    means3D = cat([o.gaussian_deform_pos for o in objects])
+    shs = cat([o.gaussian_feature for o in objects])
+    rot = cat([o.gaussian_deform_rot for o in objects])
+    cov = cat([o.gaussian_deform_cov for o in objects])
+    opacity = cat([o.gaussian_o for o in objects])
+    colors_precomp = sh_colors(means3D, viewpoint_camera.camera_center, shs, rot=rot, deg=3)
+    rasterizer = NewGaussianRasterizer(_settings(viewpoint_camera, bg, 1, 3, False))
+    image, _ = rasterizer(means3D=means3D, means2D=torch.zeros_like(means3D), shs=None, colors_precomp=colors_precomp,
+                          opacities=opacity, scales=None, rotations=None, cov3D_precomp=strip_symmetric(cov))
+    return image
+
+
+class Camera:
+    """Holder with the attribute names of scene/cameras.py:16-50 (Camera) / edittool/camera_utils.py (GSCamera)."""
+
+    def __init__(self, cam_dict, device):
+        t = lambda a: torch.as_tensor(a, dtype=torch.float32, device=device)
+        self.image_width, self.image_height = cam_dict["W"], cam_dict["H"]
+        self.FoVx, self.FoVy = cam_dict["fovx"], cam_dict["fovy"]
+        self.world_view_transform = t(cam_dict["view"])
+        self.full_proj_transform = t(cam_dict["proj"])
+        self.camera_center = t(cam_dict["campos"])
+
+
+class MeshBoundGaussians(torch.nn.Module):
+    """Mesh-bound parameterisation of scene/mesh_based_gaussian_model.py (parameters and activations only; no
+    densification / optimiser / PLY):  get_xyz = softmax(bc).(v1,v2,v3) + 4 r (sigmoid(d) - 0.5) n   (:138-152)."""
+    alpha_distance = 4
+
+    def __init__(self, bc, distance, features_dc, features_rest, scaling, rotation, opacity, vertex1, vertex2, vertex3, normal, r,
+                 sh_degree=3):
+        super().__init__()
+        P = torch.nn.Parameter
+        self._bc, self._distance = P(bc), P(distance)
+        self._features_dc, self._features_rest = P(features_dc), P(features_rest)
+        self._scaling, self._rotation, self._opacity = P(scaling), P(rotation), P(opacity)
+        for n, v in dict(vertex1=vertex1, vertex2=vertex2, vertex3=vertex3, normal=normal, r=r).items():
+            self.register_buffer(n, v)
+        self.max_sh_degree = self.active_sh_degree = sh_degree
+        self.screenspace_points = torch.zeros_like(vertex1, requires_grad=True)
+
+    @property
+    def get_scaling(self):
+        return torch.exp(self._scaling)
+
+    @property
+    def get_rotation(self):
+        return torch.nn.functional.normalize(self._rotation)
+
+    @property
+    def get_opacity(self):
+        return torch.sigmoid(self._opacity)
+
+    @property
+    def get_features(self):
+        return torch.cat((self._features_dc, self._features_rest), dim=1)
+
+    @property
+    def get_proj_xyz(self):
+        bc = torch.softmax(self._bc, dim=1)
+        return bc[:, 0:1] * self.vertex1 + bc[:, 1:2] * self.vertex2 + bc[:, 2:3] * self.vertex3
+
+    @property
+    def get_xyz(self):
+        return self.get_proj_xyz + self.alpha_distance * self.r * (torch.sigmoid(self._distance) - 0.5) * self.normal
+
+    def get_covariance(self, scaling_modifier=1):
+        q = torch.nn.functional.normalize(self._rotation)
+        r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y), 2 * (x * y + r * z), 1 - 2 * (x * x + z * z),
+                         2 * (y * z - r * x), 2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=1).reshape(-1, 3, 3)
+        L = R * (scaling_modifier * self.get_scaling)[:, None, :]
+        return strip_symmetric(L @ L.transpose(1, 2))

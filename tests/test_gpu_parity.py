@@ -349,3 +349,52 @@ def test_cov_to_scale_rot(oracle):
     b = forward_state(sc2, cam, bg, D=3, use_precomp_cov=False, use_precomp_color=True)
     assert (a["radii"] != b["radii"]).mean() <= 2e-3            # ceil(3 sigma) may flip by one on a few Gaussians
     assert np.abs(a["color"] - b["color"]).max() <= 2e-3
+
+
+def test_render_glue_contract(oracle):
+    """8f-1: render() dict contract, mesh-bound get_xyz, gradients reaching the barycentric parameters."""
+    from types import SimpleNamespace
+    from gpu_utils import T
+    from gaussianmesh_amd import scenes
+    from gaussianmesh_amd.renderer import Camera, MeshBoundGaussians, render, render_deformed, strip_symmetric
+    from gaussianmesh_amd.deform import SingleObjectDeform
+    verts, faces = scenes.torus_mesh(24, 16)
+    N = 3000
+    rng = np.random.default_rng(0)
+    cl = scenes.bind_cloud_to_mesh(N, verts, faces, seed=2)
+    tri = faces[cl["fid"]]
+    v1, v2, v3 = (verts[tri[:, k]].astype(np.float32) for k in range(3))
+    n = np.cross(v2 - v1, v3 - v1); n /= np.linalg.norm(n, axis=1, keepdims=True)
+    r = ((np.linalg.norm(v2 - v1, axis=1) + np.linalg.norm(v3 - v2, axis=1) + np.linalg.norm(v1 - v3, axis=1)) / 3)[:, None]
+    pc = MeshBoundGaussians(T(rng.normal(size=(N, 3))), T(rng.normal(0, 0.3, size=(N, 1))), T(cl["shs"][:, :1]), T(cl["shs"][:, 1:]),
+                            T(np.log(cl["scales"] * 8)), T(cl["rots"]), T(rng.normal(size=(N, 1))), T(v1), T(v2), T(v3), T(n), T(r)).cuda()
+    cam_d = scenes.orbit_camera(1, 6, 160, 96, radius=7.0)
+    cam = Camera(cam_d, "cuda")
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
+    bg = torch.zeros(3, device="cuda")
+    out = render(cam, pc, pipe, bg)
+    assert set(out) == {"render", "viewspace_points", "visibility_filter", "radii", "vertex1", "vertex2", "vertex3", "scale"}
+    assert out["render"].shape == (3, 96, 160) and out["radii"].shape == (N,)
+    assert torch.equal(out["visibility_filter"], out["radii"] > 0)
+    # same image as the oracle on the model's activated parameters
+    sc = dict(means=pc.get_xyz.detach().cpu().numpy(), opac=pc.get_opacity.detach().cpu().numpy(), shs=pc.get_features.detach().cpu().numpy(),
+              scales=pc.get_scaling.detach().cpu().numpy(), rots=pc.get_rotation.detach().cpu().numpy())
+    fw = oracle.forward_full(sc, cam_d, np.zeros(3, np.float32), D=3)
+    assert np.array_equal(out["radii"].cpu().numpy(), fw["geo"]["radii"])
+    assert np.abs(out["render"].detach().cpu().numpy() - fw["color"]).max() <= FWD_TOL
+    out["render"].sum().backward()
+    for p in (pc._bc, pc._distance, pc._scaling, pc._rotation, pc._opacity, pc._features_dc, pc.screenspace_points):
+        assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().max() > 0
+    # python-side covariance / colour switches give the same picture
+    pipe2 = SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=True, debug=False)
+    with torch.no_grad():
+        out2 = render(cam, pc, pipe2, bg)
+    assert (out2["render"] - out["render"]).abs().max() <= 2e-4
+    # edit-tool route: identity deformation of an object == rendering its rest state with colours from SH
+    cov = scenes.cov3d_from_scale_rot(sc["scales"], sc["rots"]).astype(np.float32)
+    Vm = verts.shape[0]
+    I = np.tile(np.eye(3, dtype=np.float32), (Vm, 1, 1))
+    obj = SingleObjectDeform(T(sc["means"]), T(cov), T(sc["opac"]), T(sc["shs"]), T(tri, dtype=torch.int32), T(cl["weights"]), T(verts))
+    obj.deform(T(verts), T(I), T(I))
+    img = render_deformed(cam, [obj], bg_color=bg)
+    assert (img - out["render"].detach()).abs().max() <= 2e-4
