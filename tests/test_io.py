@@ -1,0 +1,61 @@
+"""8f-2: mesh-Gaussian PLY schema and cameras.json (host side, no GPU)."""
+import json
+
+import numpy as np
+
+
+def _model(P=37, seed=0):
+    r = np.random.default_rng(seed)
+    f = lambda *s: r.normal(size=s).astype(np.float32)
+    return dict(xyz=f(P, 3), normal=f(P, 3), bc=f(P, 3), v1=f(P, 3), v2=f(P, 3), v3=f(P, 3), distance=f(P, 1),
+                vertex_index=r.integers(0, 100, (P, 3)).astype(np.float32), radius=np.abs(f(P, 1)),
+                fid=r.integers(0, 50, (P, 1)).astype(np.float32), features_dc=f(P, 1, 3), features_rest=f(P, 15, 3),
+                opacity=f(P, 1), scaling=f(P, 3), rotation=f(P, 4))
+
+
+def test_ply_schema_and_roundtrip(tmp_path):
+    from gaussianmesh_amd import io
+    m = _model()
+    p = tmp_path / "point_cloud.ply"
+    io.save_mesh_gaussians(str(p), m)
+    head = p.read_bytes().split(b"end_header\n")[0].decode()
+    lines = head.splitlines()
+    assert lines[:3] == ["ply", "format binary_little_endian 1.0", "element vertex 37"]
+    props = [l.split()[-1] for l in lines if l.startswith("property")]
+    assert all(l.startswith("property float ") for l in lines[3:])
+    # scene/mesh_based_gaussian_model.py:290-303
+    assert props[:24] == ['x', 'y', 'z', 'nx', 'ny', 'nz', 'ca', 'cb', 'cc', 'v1x', 'v1y', 'v1z', 'v2x', 'v2y', 'v2z', 'v3x', 'v3y',
+                          'v3z', 'dis', 'v_index1', 'v_index2', 'v_index3', 'radius', 'face_id']
+    assert props[24:27] == ['f_dc_0', 'f_dc_1', 'f_dc_2'] and props[27] == 'f_rest_0' and props[71] == 'f_rest_44'
+    assert props[72:] == ['opacity', 'scale_0', 'scale_1', 'scale_2', 'rot_0', 'rot_1', 'rot_2', 'rot_3'] and len(props) == 80
+    back = io.load_mesh_gaussians(str(p))
+    for k in ("xyz", "bc", "normal", "v1", "v2", "v3", "distance", "radius", "features_dc", "features_rest", "opacity", "scaling", "rotation"):
+        assert np.array_equal(back[k], m[k]), k
+    assert back["fid"].dtype == np.int32 and np.array_equal(back["fid"], m["fid"].astype(np.int32))
+    # f_rest is stored channel-major: f_rest_0..14 are channel 0 of coefficients 1..15
+    names, d = io.read_ply(str(p))
+    assert np.array_equal(d[:, names.index("f_rest_1")], m["features_rest"][:, 1, 0])
+    assert np.array_equal(d[:, names.index("f_rest_15")], m["features_rest"][:, 0, 1])
+    # loader quirk of the edit tool: _bc <- x,y,z
+    q = io.load_mesh_gaussians(str(p), bc_from_xyz=True)
+    assert np.array_equal(q["bc"], m["xyz"]) and not np.array_equal(q["bc"], m["bc"])
+
+
+def test_cameras_json_roundtrip(tmp_path):
+    from gaussianmesh_amd import io, scenes
+    cams, entries = [], []
+    for k in range(3):
+        c = scenes.orbit_camera(k, 3, 640, 360)
+        # recover (R, T) the way scene/cameras.py stores them: view = getWorld2View2(R, T).T
+        Rt = c["view"].T.astype(np.float64)
+        R, T = Rt[:3, :3].T, Rt[:3, 3]
+        entries.append(io.camera_to_json(k, R, T, 640, 360, c["fovx"], c["fovy"], "img%d" % k))
+        cams.append(c)
+    p = tmp_path / "cameras.json"
+    p.write_text(json.dumps(entries))
+    assert set(entries[0]) == {"id", "img_name", "width", "height", "position", "rotation", "fy", "fx"}
+    assert np.allclose(entries[1]["position"], cams[1]["campos"], atol=1e-5)        # position = camera centre
+    back = io.load_cameras_json(str(p))
+    for a, b in zip(back, cams):
+        assert np.allclose(a["view"], b["view"], atol=1e-5) and np.allclose(a["proj"], b["proj"], atol=1e-4)
+        assert np.allclose(a["campos"], b["campos"], atol=1e-5) and abs(a["tanx"] - b["tanx"]) < 1e-6
