@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cameras", type=int, default=64)
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the frame loop alternates over (frame i runs on stream i %% streams): consecutive frames are "
                          "independent, so frame i+1's per-Gaussian stages overlap the low-occupancy tail of frame i's blend")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -137,15 +137,32 @@ def main():
     stats = {}
     nstreams = max(1, args.streams)
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
-    workspaces = [Rz.RasterWorkspace() for _ in range(nstreams)]
-    frame_bufs = [torch.empty((Vm, 21), dtype=torch.float32, device=dev) for _ in range(nstreams)]
+    nws = max(2, nstreams)                      # frame i+1 is begun before frame i is finished: two scratch sets even on one stream
+    workspaces = [Rz.RasterWorkspace() for _ in range(nws)]
+    frame_bufs = [torch.empty((Vm, 21), dtype=torch.float32, device=dev) for _ in range(nws)]
     torch.cuda.synchronize()
 
-    def step(i):
-        with torch.cuda.stream(streams[i % nstreams]):
-            return step_on_stream(i, workspaces[i % nstreams], frame_bufs[i % nstreams])
+    pending = {}
 
-    def step_on_stream(i, workspace, frame_buf, exchange=True):
+    def step(i):
+        """Issue frame i up to its instance count on stream i % nstreams, THEN complete frame i-1: the host never idles on
+        the count read-back of the frame it has just enqueued (gm_forward_0_async)."""
+        with torch.cuda.stream(streams[i % nstreams]):
+            pending[i] = step_on_stream(i, workspaces[i % nws], frame_bufs[i % nws], begin_only=True)
+        prev = pending.pop(i - 1, None)
+        return finish(prev) if prev is not None else None
+
+    def finish(h):
+        nr, color, radii, _, _, _ = h.finish()
+        stats["R"] = nr
+        stats["radii"] = radii
+        return color
+
+    def drain():
+        for k in sorted(pending):
+            finish(pending.pop(k))
+
+    def step_on_stream(i, workspace, frame_buf, exchange=True, begin_only=False):
         t = i % F
         if world > 1 and exchange:               # real exchange step: mesh state of frame t from rank 0 (RCCL)
             if rank == 0:
@@ -157,6 +174,9 @@ def main():
         dV = V1 - g["verts"]
         c = cam_t[multiview.view_for_step(i, F, rank, world)]
         pos, cov6, rgb = deform_shade(g["tri"], g["weights"], dV, Rv, Sv, g["cov"], g["pos"], g["shs"], c["campos"], deg=3)
+        if begin_only:
+            return Rz.rasterize_forward_begin(bg, pos, rgb, g["opac"], None, None, 1.0, cov6, c["view"], c["proj"], c["tanx"],
+                                              c["tany"], H, W, None, 3, c["campos"], False, False, workspace=workspace)
         nr, color, radii, _, _, _ = Rz.rasterize_forward(bg, pos, rgb, g["opac"], None, None, 1.0, cov6, c["view"], c["proj"],
                                                          c["tanx"], c["tany"], H, W, None, 3, c["campos"], False, False,
                                                          workspace=workspace)
@@ -171,10 +191,12 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    drain()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    drain()                                      # the last frame of the timed region is completed inside it
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0

@@ -27,6 +27,8 @@ SIGNATURES = {
     "gm_binning_bytes": (sz, [i64]),
     "gm_forward_0": (i32, [vp, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, f32, f32, i32,
                            vp, i32, vp, C.POINTER(i32)]),
+    "gm_forward_0_async": (i32, [vp, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, f32, f32, i32,
+                                 vp, i32, vp, vp]),
     "gm_forward_1": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp,
                            f32, f32, i32, vp, vp, i32, vp]),
     "gm_backward": (i32, [i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp,

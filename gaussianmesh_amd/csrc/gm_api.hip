@@ -118,6 +118,28 @@ size_t gm_binning_bytes(int64_t R) {
   a.cam_pos = cam_pos; a.scale_modifier = scale_modifier; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;        \
   a.prefiltered = prefiltered; a.debug = debug; a.tile_cull = g_tile_cull; a.stream = reinterpret_cast<hipStream_t>(stream);
 
+int gm_forward_0_async(void* geom_buffer, int P, int D, int M, const float* background, int width, int height,
+                       const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                       const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                       const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                       float tan_fovy, int prefiltered, int* radii, int debug, void* stream, int* num_rendered_host) {
+  FILL_ARGS(a)
+  if (int rc = check_raster_args(a)) return rc;
+  if (!num_rendered_host) { set_error("num_rendered_host is null"); return GM_ERR_INVALID_ARG; }
+  if (P == 0) { *num_rendered_host = 0; return GM_OK; }
+  if (!geom_buffer) { set_error("geom_buffer is null"); return GM_ERR_INVALID_ARG; }
+  GeomState g = GeomState::from(geom_buffer, (size_t)P);
+  if (int rc = launch_preprocess(a, g, radii)) return rc;
+  {
+    StageScope sc(ST_DEPTH_SORT, a.stream);
+    if (int rc = radix_sort_pairs(g.depth_key, g.order, g.hist, g.digit_total, (size_t)P, 32, true, debug, a.stream)) return rc;
+  }
+  if (int rc = launch_tile_count_scan(g, P, debug, a.stream)) return rc;
+  // stream-ordered copy of the instance count into (pinned) host memory; the caller waits on its own event
+  GM_HIP(hipMemcpyAsync(num_rendered_host, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, a.stream));
+  return GM_OK;
+}
+
 int gm_forward_0(void* geom_buffer, int P, int D, int M, const float* background, int width, int height,
                  const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
                  const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,

@@ -58,6 +58,13 @@ class RasterWorkspace:
     def __init__(self, growth=1.25):
         self.growth = growth
         self._bufs = {}
+        self._pinned = None
+
+    def pinned_counter(self):
+        """page-locked int32[1] receiving the instance count of an asynchronous forward"""
+        if self._pinned is None:
+            self._pinned = torch.zeros((1,), dtype=torch.int32).pin_memory()
+        return self._pinned
 
     def get(self, name, nbytes, device):
         b = self._bufs.get(name)
@@ -114,6 +121,76 @@ def rasterize_forward(bg, means3D, colors, opacity, scales, rotations, scale_mod
                                     _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
                                     int(bool(prefiltered)), _ptr(color), _ptr(radii), int(bool(debug)), stream))
     return num_rendered, color, radii, geom, binning, img
+
+
+class PendingForward:
+    """Handle returned by rasterize_forward_begin(): everything up to the instance count is enqueued; finish() waits for
+    the count (one 4-byte pinned-memory read-back), sizes the binning buffer and enqueues emission, tile sort and blend."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    def finish(self):
+        lib = _lib.lib()
+        self.event.synchronize()
+        num_rendered = int(self.count_host[0])
+        a = self.args
+        device = a["device"]
+        with torch.cuda.device(device), torch.cuda.stream(self.stream):
+            if self.workspace is not None:
+                binning = self.workspace.get("binning", lib.gm_binning_bytes(num_rendered), device)
+            else:
+                binning = torch.empty((lib.gm_binning_bytes(num_rendered),), dtype=torch.uint8, device=device)
+            _lib.check(lib.gm_forward_1(_ptr(self.geom), _ptr(binning), _ptr(self.img), a["P"], a["D"], a["M"], num_rendered,
+                                        _ptr(a["bg"]), a["W"], a["H"], _ptr(a["means3D"]), _ptr(a["sh"]), _ptr(a["colors"]),
+                                        _ptr(a["opacity"]), _ptr(a["scales"]), a["scale_modifier"], _ptr(a["rotations"]),
+                                        _ptr(a["cov3D_precomp"]), _ptr(a["viewmatrix"]), _ptr(a["projmatrix"]), _ptr(a["campos"]),
+                                        a["tan_fovx"], a["tan_fovy"], a["prefiltered"], _ptr(self.color), _ptr(self.radii),
+                                        a["debug"], self.stream.cuda_stream))
+        return num_rendered, self.color, self.radii, self.geom, binning, self.img
+
+
+def rasterize_forward_begin(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                            projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered=False,
+                            debug=False, workspace=None):
+    """First half of rasterize_forward without the host synchronisation (gm_forward_0_async); returns a PendingForward.
+    Typical loop: h_next = begin(frame i+1); outputs = h_cur.finish()."""
+    lib = _lib.lib()
+    device = means3D.device
+    if device.type != "cuda":
+        raise _lib.GmeshError("gaussianmesh_amd rasterizer needs tensors on a HIP (cuda) device; there is no CPU path")
+    means3D = _prep(means3D, device)
+    P = 0 if means3D is None else means3D.shape[0]
+    sh, colors, scales, rotations, cov3D_precomp = (_prep(t, device) for t in (sh, colors, scales, rotations, cov3D_precomp))
+    opacity = _prep(opacity, device)
+    bg, viewmatrix, projmatrix, campos = (_prep(t, device) for t in (bg, viewmatrix, projmatrix, campos))
+    H, W = int(image_height), int(image_width)
+    M = sh.shape[1] if sh is not None else 0
+    stream = torch.cuda.current_stream(device)
+    with torch.cuda.device(device):
+        color = torch.empty((3, H, W), dtype=torch.float32, device=device)
+        radii = torch.empty((P,), dtype=torch.int32, device=device)
+        if workspace is not None:
+            geom = workspace.get("geom", lib.gm_geom_bytes(P), device)
+            img = workspace.get("img", lib.gm_image_bytes(W, H), device)
+            count_host = workspace.pinned_counter()
+        else:
+            geom = torch.empty((lib.gm_geom_bytes(P),), dtype=torch.uint8, device=device)
+            img = torch.empty((lib.gm_image_bytes(W, H),), dtype=torch.uint8, device=device)
+            count_host = torch.zeros((1,), dtype=torch.int32).pin_memory()
+        _lib.check(lib.gm_forward_0_async(_ptr(geom), P, int(degree), M, _ptr(bg), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),
+                                          _ptr(opacity), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),
+                                          _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
+                                          int(bool(prefiltered)), _ptr(radii), int(bool(debug)), stream.cuda_stream,
+                                          count_host.data_ptr()))
+        event = torch.cuda.Event()
+        event.record(stream)
+    args = dict(device=device, P=P, D=int(degree), M=M, W=W, H=H, bg=bg, means3D=means3D, sh=sh, colors=colors, opacity=opacity,
+                scales=scales, scale_modifier=float(scale_modifier), rotations=rotations, cov3D_precomp=cov3D_precomp,
+                viewmatrix=viewmatrix, projmatrix=projmatrix, campos=campos, tan_fovx=float(tan_fovx), tan_fovy=float(tan_fovy),
+                prefiltered=int(bool(prefiltered)), debug=int(bool(debug)))
+    return PendingForward(args=args, geom=geom, img=img, color=color, radii=radii, count_host=count_host, event=event,
+                          stream=stream, workspace=workspace)
 
 
 def rasterize_backward(bg, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,

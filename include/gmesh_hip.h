@@ -73,6 +73,16 @@ int gm_forward_0(void* geom_buffer, int P, int D, int M, const float* background
                  const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
                  float tan_fovy, int prefiltered, int* radii, int debug, void* stream, int* num_rendered);
 
+/* gm_forward_0 without its host synchronisation: everything is enqueued on `stream`, including a copy of the instance
+ * count into *num_rendered_host (use page-locked host memory).  The caller records an event, keeps feeding the GPU (e.g.
+ * the next frame's gm_forward_0_async on another stream) and calls gm_forward_1 once the event has completed and
+ * *num_rendered_host is valid.  This is how a render loop hides the one host round trip of the reference design. */
+int gm_forward_0_async(void* geom_buffer, int P, int D, int M, const float* background, int width, int height,
+                       const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                       const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                       const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                       float tan_fovy, int prefiltered, int* radii, int debug, void* stream, int* num_rendered_host);
+
 /* Replaces CudaRasterizer::Rasterizer::forward_1 (RAST/rasterizer.h:53-76, rasterizer_impl.cu:416-511):
  * instance emission, (tile, depth) ordering, tile ranges, front-to-back alpha blend.
  * binning_buffer must hold gm_binning_bytes(num_rendered), image_buffer gm_image_bytes(W,H). */

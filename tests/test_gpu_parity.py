@@ -398,3 +398,35 @@ def test_render_glue_contract(oracle):
     obj.deform(T(verts), T(I), T(I))
     img = render_deformed(cam, [obj], bg_color=bg)
     assert (img - out["render"].detach()).abs().max() <= 2e-4
+
+
+def test_async_begin_finish_pipeline_matches_sync(oracle):
+    """gm_forward_0_async + deferred gm_forward_1 on alternating streams == the synchronous operator, bit for bit."""
+    from gpu_utils import T
+    from gaussianmesh_amd import rasterizer as Rz, scenes
+    sc = scenes.make_cloud(20000, seed=4, scale_lo=0.01, scale_hi=0.15)
+    S = scenes.cov3d_from_scale_rot(sc["scales"], sc["rots"])
+    cov6 = T(scenes.strip_symmetric(S)); rgb = T(np.random.default_rng(0).uniform(0, 1, (20000, 3)))
+    means, opac, bg = T(sc["means"]), T(sc["opac"]), T(np.ones(3))
+    cams = [scenes.orbit_camera(k, 8, 320, 200, radius=7.5) for k in range(6)]
+    ct = [{k: T(c[k]) for k in ("view", "proj", "campos")} for c in cams]
+    call = lambda k, **kw: (bg, means, rgb, opac, None, None, 1.0, cov6, ct[k]["view"], ct[k]["proj"], cams[k]["tanx"], cams[k]["tany"],
+                            200, 320, None, 3, ct[k]["campos"])
+    ref = []
+    for k in range(6):
+        nr, color, radii, *_ = Rz.rasterize_forward(*call(k), False, False)
+        ref.append((nr, color.clone(), radii.clone()))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    ws = [Rz.RasterWorkspace() for _ in range(3)]
+    out, pend = {}, {}
+    for k in range(6):
+        with torch.cuda.stream(streams[k % 3]):
+            pend[k] = Rz.rasterize_forward_begin(*call(k), workspace=ws[k % 3])
+        if k - 1 in pend:
+            out[k - 1] = pend.pop(k - 1).finish()
+    out[5] = pend.pop(5).finish()
+    torch.cuda.synchronize()
+    for k in range(6):
+        assert out[k][0] == ref[k][0]
+        assert torch.equal(out[k][1], ref[k][1]) and torch.equal(out[k][2], ref[k][2])
