@@ -101,10 +101,11 @@ __device__ __forceinline__ void get_rect(float px, float py, int r, int gx, int 
 // (RAST/rasterizer_impl.cu:98-109) restricted to the emitted tiles.
 __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* __restrict__ order,
                                                                 const uint4* __restrict__ bins, const uint32_t* __restrict__ tiles,
-                                                                const float4* __restrict__ splat, int tile_cull, int P, int gx,
+                                                                const float4* __restrict__ splat, const uint32_t* __restrict__ counters, int P, int gx,
                                                                 const uint32_t* __restrict__ block_sums,
                                                                 uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
   __shared__ uint32_t wsum[BN_THREADS / 64];
+  const int tile_cull = (int)counters[2];        // policy recorded by preprocess_fwd_kernel (the counts were made with it)
   const int lane = threadIdx.x & 63;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const int base = blockIdx.x * GM_SCAN_ITEMS + threadIdx.x * BN_PER_THREAD;
@@ -190,9 +191,9 @@ int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, int til
   StageScope sc(ST_DUPLICATE, s);
   const int nb = (P + GM_SCAN_ITEMS - 1) / GM_SCAN_ITEMS;
   const int gx = (W + GM_TILE - 1) / GM_TILE;
-  (void)H;
+  (void)H; (void)tile_cull;
   if (nb > 0)
-    hipLaunchKernelGGL(duplicate_kernel, dim3(nb), dim3(BN_THREADS), 0, s, g.order[0], g.bin, g.tiles_touched, g.splat, tile_cull,
+    hipLaunchKernelGGL(duplicate_kernel, dim3(nb), dim3(BN_THREADS), 0, s, g.order[0], g.bin, g.tiles_touched, g.splat, g.counters,
                        P, gx, g.block_sums, b.keys[0], b.vals[0]);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
