@@ -70,6 +70,21 @@ def algorithmic_bytes(stage, P, V, R, W, H, Vm, M=16):
     }[stage]
 
 
+def measured_traffic(stage, P, W, H):
+    """HBM bytes per launch of a stage from the committed PMC passes (profiles/hbm_traffic.json: FETCH_SIZE / WRITE_SIZE
+    cannot be collected from inside a timed run), or None when this workload was not the one profiled."""
+    import json
+    try:
+        t = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")))
+    except OSError:
+        return None
+    w = t["workload"]
+    if (w["gaussians"], w["width"], w["height"]) != (P, W, H) or stage not in t["stages"]:
+        return None
+    e = t["stages"][stage]
+    return int(1024 * (2 * e["fetch_kib"] + e["write_kib"]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -236,7 +251,8 @@ def main():
         ab = algorithmic_bytes(dom, P, V, Rn, W, H, Vm)
         ach = ab / (per[dom] * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": ab, "avg_ms": per[dom]}
+                           "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic(dom, P, W, H),
+                           "algorithmic_bytes": ab, "avg_ms": per[dom]}
         out["stage_ms"] = {k: round(v, 4) for k, v in per.items()}
         out["scene"] = {"P": P, "V": V, "R": Rn}
         tot_bytes = sum(algorithmic_bytes(s, P, V, Rn, W, H, Vm) for s in per)
