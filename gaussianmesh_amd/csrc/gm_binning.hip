@@ -15,7 +15,8 @@
 namespace gm {
 
 #define BN_THREADS 256
-#define BN_PER_THREAD (GM_SCAN_ITEMS / BN_THREADS)   // 8
+#define BN_PER_THREAD (GM_SCAN_ITEMS / BN_THREADS)   // 2
+#define DUP_STAGE 4096                               // instances a block can assemble in LDS (2 x 16 KB)
 
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* wsum /*[4] shared*/, uint32_t& total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
                                                                 const uint32_t* __restrict__ block_sums,
                                                                 uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
   __shared__ uint32_t wsum[BN_THREADS / 64];
+  __shared__ uint32_t stage_k[DUP_STAGE], stage_v[DUP_STAGE];
   const int tile_cull = (int)counters[2];        // policy recorded by preprocess_fwd_kernel (the counts were made with it)
   const int lane = threadIdx.x & 63;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -124,7 +126,14 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
     sum += cnt[i];
   }
   uint32_t total;
-  uint32_t off = block_sums[blockIdx.x] + block_exclusive_scan(sum, wsum, total);
+  const uint32_t block_base = block_sums[blockIdx.x];
+  uint32_t off = block_exclusive_scan(sum, wsum, total);
+  // The block's instances form one contiguous output range.  When it fits the LDS stage (nearly always) they are
+  // assembled there and copied out with full-line stores: per-lane runs written straight to HBM cost 2.3x the bytes
+  // (partial lines, WRITE_SIZE 114 MB for 48.7 MB of pairs).  Otherwise the runs are stored directly.
+  const bool staged = total <= DUP_STAGE;
+  uint32_t* __restrict__ kdst = staged ? stage_k : keys_out + block_base;
+  uint32_t* __restrict__ vdst = staged ? stage_v : vals_out + block_base;
 #pragma unroll
   for (int i = 0; i < BN_PER_THREAD; i++) { offs[i] = off; off += cnt[i]; }
   // (1) rectangles of <= 64 tiles (virtually all): each lane expands the emit mask of its own Gaussian.  A wave
@@ -143,8 +152,8 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
         const uint32_t k = (uint32_t)__ffsll(m) - 1u;
         m &= m - 1;
         const uint32_t row = (uint32_t)(((float)k + 0.5f) * inv_w);
-        keys_out[pos] = tile0 + row * (uint32_t)gx + (k - row * w);
-        vals_out[pos] = gid[i];
+        kdst[pos] = tile0 + row * (uint32_t)gx + (k - row * w);
+        vdst[pos] = gid[i];
         pos++;
       }
     }
@@ -178,11 +187,18 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
         const unsigned long long bal = __ballot(pass);
         if (pass) {
           const uint32_t pos = run + (uint32_t)__popcll(bal & lt_mask);
-          keys_out[pos] = (y0 + row) * (uint32_t)gx + (x0 + col);
-          vals_out[pos] = g;
+          kdst[pos] = (y0 + row) * (uint32_t)gx + (x0 + col);
+          vdst[pos] = g;
         }
         run += (uint32_t)__popcll(bal);
       }
+    }
+  }
+  if (staged) {
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < total; j += BN_THREADS) {
+      keys_out[block_base + j] = stage_k[j];
+      vals_out[block_base + j] = stage_v[j];
     }
   }
 }
