@@ -67,7 +67,7 @@ __device__ __forceinline__ Batch load_records(const float4* __restrict__ splat, 
 }
 
 
-template <int PPL>
+template <int PPL, bool QUAD = false>
 __global__ __launch_bounds__(256 / PPL) void render_fwd_kernel(const uint2* __restrict__ ranges,
                                                                const uint32_t* __restrict__ point_list,
                                                                const float4* __restrict__ splat, int W, int H, int gx,
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256 / PPL) void render_fwd_kernel(const uint2* __re
   const int n = (int)(range.y - range.x);
   const uint32_t* list = point_list + range.x;
 
-  const int px = tx * GM_TILE + (lane & 15);
+  const int px = QUAD ? tx * GM_TILE + (wave & 1) * 8 + (lane & 7) : tx * GM_TILE + (lane & 15);
   const float pixx = (float)px;
   int py[PPL];
   float pixy[PPL], T[PPL], Cr[PPL], Cg[PPL], Cb[PPL];
@@ -88,15 +88,17 @@ __global__ __launch_bounds__(256 / PPL) void render_fwd_kernel(const uint2* __re
   bool done[PPL];
 #pragma unroll
   for (int k = 0; k < PPL; k++) {
-    py[k] = ty * GM_TILE + (wave * PPL + k) * 4 + (lane >> 4);
+    py[k] = QUAD ? ty * GM_TILE + (wave >> 1) * 8 + (lane >> 3) : ty * GM_TILE + (wave * PPL + k) * 4 + (lane >> 4);
     pixy[k] = (float)py[k];
     T[k] = 1.0f; Cr[k] = Cg[k] = Cb[k] = 0.f; last[k] = 0;
     done[k] = !(px < W && py[k] < H);
   }
 
   // pixel-centre rectangle owned by this wave
-  const float rx0 = (float)(tx * GM_TILE), rx1 = rx0 + (float)(GM_TILE - 1);
-  const float ry0 = (float)(ty * GM_TILE + wave * PPL * 4), ry1 = ry0 + (float)(PPL * 4 - 1);
+  const float rx0 = QUAD ? (float)(tx * GM_TILE + (wave & 1) * 8) : (float)(tx * GM_TILE);
+  const float rx1 = rx0 + (QUAD ? 7.0f : (float)(GM_TILE - 1));
+  const float ry0 = QUAD ? (float)(ty * GM_TILE + (wave >> 1) * 8) : (float)(ty * GM_TILE + wave * PPL * 4);
+  const float ry1 = ry0 + (QUAD ? 7.0f : (float)(PPL * 4 - 1));
 
   // wave-private LDS copy of the current batch: survivors are re-read from here as LDS broadcasts (3 LDS
   // instructions, no VALU issue slots) instead of 9 v_readlane_b32 per survivor
@@ -211,6 +213,10 @@ int launch_render_fwd(const GeomState& g, const uint32_t* point_list, ImageState
                            background, out_color, img.final_T, img.n_contrib);
         break;
       default:
+        if (env_int("GM_RENDER_QUAD", 1))       // 8x8 quadrant per wave (default) or 16x4 strip
+          hipLaunchKernelGGL((render_fwd_kernel<1, true>), dim3(tiles), dim3(256), 0, s, img.ranges, point_list, g.splat, W, H, gx,
+                             background, out_color, img.final_T, img.n_contrib);
+        else
         hipLaunchKernelGGL(render_fwd_kernel<1>, dim3(tiles), dim3(256), 0, s, img.ranges, point_list, g.splat, W, H, gx,
                            background, out_color, img.final_T, img.n_contrib);
     }
@@ -279,7 +285,7 @@ __device__ __forceinline__ int reduce8_slot(int lane) {
 
 #define GM_ACC_STRIDE 12   // floats per Gaussian in grad_acc: dcolor rgb (0-2), moments of h: 1, dx, dy, dx^2, dx dy, dy^2 (3-8)
 
-template <int PPL>
+template <int PPL, bool QUAD = false>
 __global__ __launch_bounds__(256 / PPL) void render_bwd_kernel(const uint2* __restrict__ ranges,
                                                                const uint32_t* __restrict__ point_list,
                                                                const float4* __restrict__ splat, int W, int H, int gx,
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(256 / PPL) void render_bwd_kernel(const uint2* __re
   const size_t HW = (size_t)H * W;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 
-  const int px = tx * GM_TILE + (lane & 15);
+  const int px = QUAD ? tx * GM_TILE + (wave & 1) * 8 + (lane & 7) : tx * GM_TILE + (lane & 15);
   const float pixx = (float)px;
   float pixy[PPL], T[PPL], T_final[PPL], last_alpha[PPL], bg_dot[PPL];
   float dpr[PPL], dpg[PPL], dpb[PPL], lcr[PPL], lcg[PPL], lcb[PPL], arr[PPL], arg_[PPL], arb[PPL];
@@ -304,7 +310,7 @@ __global__ __launch_bounds__(256 / PPL) void render_bwd_kernel(const uint2* __re
   int max_last = 0;
 #pragma unroll
   for (int k = 0; k < PPL; k++) {
-    const int py = ty * GM_TILE + (wave * PPL + k) * 4 + (lane >> 4);
+    const int py = QUAD ? ty * GM_TILE + (wave >> 1) * 8 + (lane >> 3) : ty * GM_TILE + (wave * PPL + k) * 4 + (lane >> 4);
     pixy[k] = (float)py;
     const bool inside = px < W && py < H;
     const size_t pid = inside ? (size_t)W * py + px : 0;
@@ -326,8 +332,10 @@ __global__ __launch_bounds__(256 / PPL) void render_bwd_kernel(const uint2* __re
 
   const int my_slot = reduce8_slot(lane);
   const bool committer = (lane & 7) == 0;
-  const float rx0 = (float)(tx * GM_TILE), rx1 = rx0 + (float)(GM_TILE - 1);
-  const float ry0 = (float)(ty * GM_TILE + wave * PPL * 4), ry1 = ry0 + (float)(PPL * 4 - 1);
+  const float rx0 = QUAD ? (float)(tx * GM_TILE + (wave & 1) * 8) : (float)(tx * GM_TILE);
+  const float rx1 = rx0 + (QUAD ? 7.0f : (float)(GM_TILE - 1));
+  const float ry0 = QUAD ? (float)(ty * GM_TILE + (wave >> 1) * 8) : (float)(ty * GM_TILE + wave * PPL * 4);
+  const float ry1 = ry0 + (QUAD ? 7.0f : (float)(PPL * 4 - 1));
   __shared__ float4 l_rec[4 / PPL][64][3];       // wave-private LDS copy of the batch (see render_fwd_kernel)
   float4 (*rec)[3] = l_rec[wave];
   // batch b covers list positions start-1-b*64-j (j = lane), i.e. back to front
@@ -417,8 +425,12 @@ int launch_render_bwd(const GeomState& g, const uint32_t* point_list, ImageState
                            background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc);
         break;
       default:
-        hipLaunchKernelGGL(render_bwd_kernel<1>, dim3(tiles), dim3(256), 0, s, img.ranges, point_list, g.splat, W, H, gx,
-                           background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc);
+        if (env_int("GM_RENDER_QUAD", 1))
+          hipLaunchKernelGGL((render_bwd_kernel<1, true>), dim3(tiles), dim3(256), 0, s, img.ranges, point_list, g.splat, W, H, gx,
+                             background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc);
+        else
+          hipLaunchKernelGGL(render_bwd_kernel<1>, dim3(tiles), dim3(256), 0, s, img.ranges, point_list, g.splat, W, H, gx,
+                             background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc);
     }
   }
   GM_LAUNCH_CHECK(debug, s);
