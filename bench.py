@@ -286,6 +286,23 @@ def main():
         torch.cuda.synchronize()
         out["fwd_bwd"] = {"ms_per_iter": 1e3 * (time.perf_counter() - t1) / nit, "iters": nit,
                           "config": "%d Gaussians, %dx%d, SH3 + scale/rot inputs, loss = sum(w*image)" % (P, W, H)}
+        # the same iteration with the training loop's photometric loss (L1 + SSIM, gm_ssim_fwd/bwd) on the rendered image
+        from gaussianmesh_amd.loss import photometric_loss
+        gt = torch.rand((3, H, W), device=dev)
+
+        def it_loss():
+            for l in leaves + [m2d]:
+                l.grad = None
+            color, _ = rast(leaves[0], m2d, leaves[1], shs=leaves[2], scales=leaves[3], rotations=leaves[4])
+            photometric_loss(color, gt, 0.2).backward()
+        for _ in range(3):
+            it_loss()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(nit):
+            it_loss()
+        torch.cuda.synchronize()
+        out["fwd_bwd"]["ms_per_iter_with_l1_ssim_loss"] = 1e3 * (time.perf_counter() - t1) / nit
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # ---- CPU baseline: the oracle port (plain C + OpenMP) on the host cores, bounded sample of the same workload

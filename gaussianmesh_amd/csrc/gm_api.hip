@@ -28,7 +28,7 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
 
 // ---- per-stage profiling -------------------------------------------------------------------
 static const char* kStageNames[ST_COUNT] = {"preprocess", "depth_sort", "scan", "duplicate", "tile_sort", "ranges",
-                                            "render", "render_bwd", "preprocess_bwd", "deform", "sh_colors"};
+                                            "render", "render_bwd", "preprocess_bwd", "deform", "sh_colors", "loss", "loss_bwd"};
 struct EvPair { hipEvent_t a, b; int st; };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
@@ -299,6 +299,31 @@ int gm_cov_to_scale_rot(int N, const float* cov, float* scales, float* rots, voi
   if (N < 0 || (N > 0 && (!cov || !scales || !rots))) { set_error("gm_cov_to_scale_rot: bad args"); return GM_ERR_INVALID_ARG; }
   if (N > 0 && (reinterpret_cast<uintptr_t>(rots) & 15)) { set_error("gm_cov_to_scale_rot: rots must be 16-byte aligned"); return GM_ERR_INVALID_ARG; }
   return launch_cov_to_scale_rot(N, cov, scales, rots, reinterpret_cast<hipStream_t>(stream));
+}
+
+int64_t gm_ssim_partials(int planes, int H, int W) {
+  if (planes < 0 || H < 0 || W < 0) return 0;
+  return (int64_t)planes * ((H + 31) / 32) * ((W + 31) / 32);
+}
+
+int gm_ssim_fwd(const float* img1, const float* img2, int planes, int H, int W, float* dS_dmu1, float* dS_dE11, float* dS_dE12,
+                float* partial, void* stream) {
+  if (planes < 0 || H < 0 || W < 0) { set_error("gm_ssim_fwd: negative size"); return GM_ERR_INVALID_ARG; }
+  if (planes == 0 || H == 0 || W == 0) return GM_OK;
+  if (!img1 || !img2 || !partial) { set_error("gm_ssim_fwd: null image or partial buffer"); return GM_ERR_INVALID_ARG; }
+  const int nmaps = (dS_dmu1 != nullptr) + (dS_dE11 != nullptr) + (dS_dE12 != nullptr);
+  if (nmaps != 0 && nmaps != 3) { set_error("gm_ssim_fwd: pass all three derivative maps or none"); return GM_ERR_INVALID_ARG; }
+  if (planes > 65535) { set_error("gm_ssim_fwd: at most 65535 image planes per call"); return GM_ERR_INVALID_ARG; }
+  return launch_ssim_fwd(img1, img2, planes, H, W, dS_dmu1, dS_dE11, dS_dE12, partial, reinterpret_cast<hipStream_t>(stream));
+}
+
+int gm_ssim_bwd(const float* img1, const float* img2, const float* dS_dmu1, const float* dS_dE11, const float* dS_dE12, int planes,
+                int H, int W, const float* g_ssim, const float* g_l1, float* dL_dimg1, void* stream) {
+  if (planes < 0 || H < 0 || W < 0) { set_error("gm_ssim_bwd: negative size"); return GM_ERR_INVALID_ARG; }
+  if (planes == 0 || H == 0 || W == 0) return GM_OK;
+  if (!img1 || !img2 || !dS_dmu1 || !dS_dE11 || !dS_dE12 || !g_ssim || !dL_dimg1) { set_error("gm_ssim_bwd: null argument"); return GM_ERR_INVALID_ARG; }
+  if (planes > 65535) { set_error("gm_ssim_bwd: at most 65535 image planes per call"); return GM_ERR_INVALID_ARG; }
+  return launch_ssim_bwd(img1, img2, dS_dmu1, dS_dE11, dS_dE12, planes, H, W, g_ssim, g_l1, dL_dimg1, reinterpret_cast<hipStream_t>(stream));
 }
 
 void gm_profile_enable(int on) { g_prof_on = on != 0; }

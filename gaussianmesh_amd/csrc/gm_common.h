@@ -34,7 +34,7 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 // per-stage timing (gm_profile_*)
 enum Stage {
   ST_PREPROCESS = 0, ST_DEPTH_SORT, ST_SCAN, ST_DUPLICATE, ST_TILE_SORT, ST_RANGES, ST_RENDER,
-  ST_RENDER_BWD, ST_PREPROCESS_BWD, ST_DEFORM, ST_SH_COLORS, ST_COUNT
+  ST_RENDER_BWD, ST_PREPROCESS_BWD, ST_DEFORM, ST_SH_COLORS, ST_LOSS, ST_LOSS_BWD, ST_COUNT
 };
 struct StageScope {            // records start/stop events on `s` if profiling is enabled
   StageScope(Stage st, hipStream_t s);
@@ -190,6 +190,10 @@ int launch_deform_shade(int N, int deg, int M, const int* tri, const float* w, c
                         const float* cov, const float* pos, const float* shs, const float* campos, float* pos_out,
                         float* cov6_out, float* rgb_out, float* cov_out, float* rot_out, hipStream_t s);
 int launch_cov_to_scale_rot(int N, const float* cov, float* scales, float* rots, hipStream_t s);
+int launch_ssim_fwd(const float* img1, const float* img2, int planes, int H, int W, float* d_mu1, float* d_e11, float* d_e12,
+                    float* partial, hipStream_t s);
+int launch_ssim_bwd(const float* img1, const float* img2, const float* d_mu1, const float* d_e11, const float* d_e12, int planes,
+                    int H, int W, const float* g_ssim, const float* g_l1, float* dL_dimg1, hipStream_t s);
 int launch_knn(int P, const float* points, float* meanDists, void* ws, size_t ws_bytes, hipStream_t s);
 size_t knn_workspace_bytes(int P);
 

@@ -164,10 +164,26 @@ int gm_deform_shade(int N, int deg, int M, const int* tri, const float* w, const
  * eigenvector matrix made right-handed, such that R(q) diag(scales^2) R(q)^T reproduces cov. */
 int gm_cov_to_scale_rot(int N, const float* cov, float* scales, float* rots, void* stream);
 
+/* Photometric loss of the training loop (train_mesh_gaussian.py:92-94): replaces utils/loss_utils.py:17-18 (l1_loss) and
+ * :23-81 (ssim: 11x11 Gaussian window of sigma 1.5, zero padding 5, depthwise) and the autograd pass through them.
+ * img1 (rendered) / img2 (ground truth): float [planes,H,W] (planes = channels, or batch x channels).
+ * gm_ssim_fwd writes per 32x32-pixel workgroup {sum of the ssim map, sum of |img1-img2|} into partial
+ * (float [gm_ssim_partials(planes,H,W)][2], plane-major then tile rows): ssim(...) = sum/(planes H W), per-image means
+ * for size_average=False by summing a plane range.  dS_dmu1 / dS_dE11 / dS_dE12 (float [planes,H,W] each; all three or
+ * all NULL) receive the per-pixel partial derivatives gm_ssim_bwd needs.
+ * gm_ssim_bwd: dL_dimg1 = g_ssim[plane] * d(sum of ssim map)/d img1 + g_l1[0] * sign(img1 - img2); g_ssim (device float
+ * [planes]) and g_l1 (device float [1], may be NULL) carry the upstream gradient times 1/count, so no host
+ * synchronisation is needed between forward and backward. */
+int64_t gm_ssim_partials(int planes, int H, int W);
+int gm_ssim_fwd(const float* img1, const float* img2, int planes, int H, int W, float* dS_dmu1, float* dS_dE11, float* dS_dE12,
+                float* partial, void* stream);
+int gm_ssim_bwd(const float* img1, const float* img2, const float* dS_dmu1, const float* dS_dE11, const float* dS_dE12, int planes,
+                int H, int W, const float* g_ssim, const float* g_l1, float* dL_dimg1, void* stream);
+
 /* Per-stage GPU timing (HIP events recorded on `stream` around each kernel group).  Off by default.
  * gm_profile_enable(1) starts collecting, gm_profile_read synchronises the recorded events and returns
  * accumulated milliseconds and launch count for a stage name ("preprocess","depth_sort","scan",
- * "duplicate","tile_sort","ranges","render","render_bwd","preprocess_bwd","deform","sh_colors");
+ * "duplicate","tile_sort","ranges","render","render_bwd","preprocess_bwd","deform","sh_colors","loss","loss_bwd");
  * gm_profile_reset clears the accumulators. */
 void gm_profile_enable(int on);
 void gm_profile_reset(void);
