@@ -62,30 +62,50 @@ __global__ __launch_bounds__(LS_THREADS) void ssim_fwd_kernel(const float* __res
     sy[r][c] = in ? img2[p] : 0.f;
   }
   __syncthreads();
-  for (int i = tid; i < LS_SPAN * LS_TILE; i += LS_THREADS) {
-    const int r = i >> 5, c = i & 31;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+  // horizontal taps: one work item = 4 adjacent output columns of one row (14 staged values feed 4 x 11 taps);
+  // consecutive lanes take consecutive rows (row stride 43 words: conflict-free)
+  for (int i = tid; i < LS_SPAN * (LS_TILE / 4); i += LS_THREADS) {
+    const int r = i % LS_SPAN, c0 = (i / LS_SPAN) * 4;
+    float xv[14], yv[14], xx[14], yy[14], xy[14];
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-      const float x = sx[r][c + k], y = sy[r][c + k], w = win.w[k];
-      a0 += w * x; a1 += w * y; a2 += w * (x * x); a3 += w * (y * y); a4 += w * (x * y);
+    for (int k = 0; k < 14; k++) {
+      xv[k] = sx[r][c0 + k]; yv[k] = sy[r][c0 + k];
+      xx[k] = xv[k] * xv[k]; yy[k] = yv[k] * yv[k]; xy[k] = xv[k] * yv[k];
     }
-    hb[0][r][c] = a0; hb[1][r][c] = a1; hb[2][r][c] = a2; hb[3][r][c] = a3; hb[4][r][c] = a4;
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; k++) {
+        const float w = win.w[k];
+        a0 += w * xv[o + k]; a1 += w * yv[o + k]; a2 += w * xx[o + k]; a3 += w * yy[o + k]; a4 += w * xy[o + k];
+      }
+      hb[0][r][c0 + o] = a0; hb[1][r][c0 + o] = a1; hb[2][r][c0 + o] = a2; hb[3][r][c0 + o] = a3; hb[4][r][c0 + o] = a4;
+    }
   }
   __syncthreads();
   const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
   const int c = tid & 31;
   float s_sum = 0.f, l1_sum = 0.f;
+  // vertical taps: a thread owns 4 adjacent rows of one column (14 values per quantity feed 4 x 11 taps)
+  float vq[5][4];
 #pragma unroll
-  for (int j = 0; j < LS_TILE * LS_TILE / LS_THREADS; j++) {
-    const int r = (tid >> 5) + j * (LS_THREADS / 32);
-    float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+  for (int q = 0; q < 5; q++) {
+    float col[14];
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-      const float w = win.w[k];
-      mu1 += w * hb[0][r + k][c]; mu2 += w * hb[1][r + k][c];
-      e11 += w * hb[2][r + k][c]; e22 += w * hb[3][r + k][c]; e12 += w * hb[4][r + k][c];
+    for (int k = 0; k < 14; k++) col[k] = hb[q][(tid >> 5) * 4 + k][c];
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; k++) acc += win.w[k] * col[o + k];
+      vq[q][o] = acc;
     }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int r = (tid >> 5) * 4 + j;
+    const float mu1 = vq[0][j], mu2 = vq[1][j], e11 = vq[2][j], e22 = vq[3][j], e12 = vq[4][j];
     const int gx = ox + c, gy = oy + r;
     if (gx < W && gy < H) {
       const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
@@ -136,29 +156,41 @@ __global__ __launch_bounds__(LS_THREADS) void ssim_bwd_kernel(const float* __res
     sm[2][r][c] = in ? d_e12[p] : 0.f;
   }
   __syncthreads();
-  for (int i = tid; i < LS_SPAN * LS_TILE; i += LS_THREADS) {
-    const int r = i >> 5, c = i & 31;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int i = tid; i < 3 * LS_SPAN * (LS_TILE / 4); i += LS_THREADS) {      // see ssim_fwd_kernel
+    const int r = i % LS_SPAN, rest = i / LS_SPAN, c0 = (rest & 7) * 4, q = rest >> 3;
+    float v[14];
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-      const float w = win.w[k];
-      a0 += w * sm[0][r][c + k]; a1 += w * sm[1][r][c + k]; a2 += w * sm[2][r][c + k];
+    for (int k = 0; k < 14; k++) v[k] = sm[q][r][c0 + k];
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; k++) acc += win.w[k] * v[o + k];
+      hb[q][r][c0 + o] = acc;
     }
-    hb[0][r][c] = a0; hb[1][r][c] = a1; hb[2][r][c] = a2;
   }
   __syncthreads();
   const float gs = g_ssim[blockIdx.z];
   const float gl = g_l1 ? g_l1[0] : 0.f;
   const int c = tid & 31;
+  float vq[3][4];
 #pragma unroll
-  for (int j = 0; j < LS_TILE * LS_TILE / LS_THREADS; j++) {
-    const int r = (tid >> 5) + j * (LS_THREADS / 32);
-    float A = 0.f, B = 0.f, Cc = 0.f;
+  for (int q = 0; q < 3; q++) {
+    float col[14];
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-      const float w = win.w[k];
-      A += w * hb[0][r + k][c]; B += w * hb[1][r + k][c]; Cc += w * hb[2][r + k][c];
+    for (int k = 0; k < 14; k++) col[k] = hb[q][(tid >> 5) * 4 + k][c];
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; k++) acc += win.w[k] * col[o + k];
+      vq[q][o] = acc;
     }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int r = (tid >> 5) * 4 + j;
+    const float A = vq[0][j], B = vq[1][j], Cc = vq[2][j];
     const int gx = ox + c, gy = oy + r;
     if (gx < W && gy < H) {
       const size_t p = plane + (size_t)gy * W + gx;
