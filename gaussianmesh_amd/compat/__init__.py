@@ -1,0 +1,39 @@
+"""Compatibility layer for scripts written against the reference's host framework.
+
+    import gaussianmesh_amd.compat as compat
+    compat.install()          # afterwards `import jittor as jt`, `from jittor import nn` resolve to the torch-backed subset
+                              # in compat/jittor/, and the reference's operator modules resolve to this package:
+                              #   gaussian_renderer.diff_gaussian_rasterizater -> gaussianmesh_amd.rasterizer
+                              #   scene.simple_knn (distCUDA2)                 -> gaussianmesh_amd.simple_knn
+                              #   utils.loss_utils l1_loss / ssim              -> gaussianmesh_amd.loss  (opt-in, see install)
+
+Only the ~60 symbols the in-scope reference python uses are provided; anything else raises
+AttributeError naming the symbol.  A real Jittor installation is never shadowed unless install(force=True).
+"""
+import importlib
+import importlib.util
+import os
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def install(force=False, operators=True):
+    """Make `import jittor` resolve to compat/jittor (unless a real Jittor is importable and force is False) and, with
+    operators=True, pre-register this package's operator modules under the reference's import paths."""
+    have_real = False
+    if "jittor" in sys.modules:
+        have_real = not getattr(sys.modules["jittor"], "__gaussianmesh_compat__", False)
+    elif not force:
+        have_real = importlib.util.find_spec("jittor") is not None
+    if not have_real or force:
+        if _HERE not in sys.path:
+            sys.path.insert(0, _HERE)
+        for k in [k for k in sys.modules if k == "jittor" or k.startswith("jittor.")]:
+            del sys.modules[k]
+        importlib.import_module("jittor")
+    if operators:
+        from .. import rasterizer, simple_knn
+        sys.modules.setdefault("gaussian_renderer.diff_gaussian_rasterizater", rasterizer)
+        sys.modules.setdefault("scene.simple_knn", simple_knn)
+    return sys.modules["jittor"]
