@@ -3,6 +3,7 @@
 // Orchestration replaces CudaRasterizer::Rasterizer::{forward_0, forward_1, backward, markVisible}
 // (cuda_rasterizer/rasterizer_impl.cu:338-413, 416-511, 515-609, 141-153).
 #include "gm_common.h"
+#include <cstdlib>
 #include "../../include/gmesh_hip.h"
 #include <cstdarg>
 #include <cstdio>
@@ -13,7 +14,12 @@
 namespace gm {
 
 static thread_local char g_err[512] = "";
-static int g_tile_cull = 1;        // gm_set_tile_culling
+static int initial_emission_mode() {        // GM_EMISSION_MODE=0..3 overrides the built-in default (A/B runs of bench.py)
+  const char* v = getenv("GM_EMISSION_MODE");
+  const int m = v ? atoi(v) : 2;
+  return m < 0 ? 0 : (m > 3 ? 3 : m);
+}
+static int g_tile_cull = initial_emission_mode();        // gm_set_tile_culling
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -93,7 +99,7 @@ using namespace gm;
 extern "C" {
 
 int gm_abi_version(void) { return GM_ABI_VERSION; }
-void gm_set_tile_culling(int on) { g_tile_cull = on ? 1 : 0; }
+void gm_set_tile_culling(int mode) { g_tile_cull = mode < 0 ? 0 : (mode > 3 ? 3 : mode); }
 int gm_get_tile_culling(void) { return g_tile_cull; }
 const char* gm_last_error(void) { return g_err; }
 
@@ -178,7 +184,7 @@ int gm_forward_1(void* geom_buffer, void* binning_buffer, void* image_buffer, in
   if (num_rendered < 0) { set_error("negative num_rendered"); return GM_ERR_INVALID_ARG; }
   if (P > 0 && (!geom_buffer || (num_rendered > 0 && !binning_buffer))) { set_error("null scratch buffer"); return GM_ERR_INVALID_ARG; }
   ImageState img = ImageState::from(image_buffer, width, height);
-  const int tiles = ((width + GM_TILE - 1) / GM_TILE) * ((height + GM_TILE - 1) / GM_TILE);
+  const int tiles = TileGrid(width, height, a.tile_cull).ptiles;      // lists are per parent tile
   GeomState g = GeomState::from(geom_buffer, (size_t)(P > 0 ? P : 1));
   BinningState b = BinningState::from(binning_buffer, (size_t)num_rendered);
   int slot = 0;
@@ -192,7 +198,7 @@ int gm_forward_1(void* geom_buffer, void* binning_buffer, void* image_buffer, in
     slot = sort_final_slot(bits);
   }
   if (int rc = launch_tile_ranges(b, slot, img, num_rendered, tiles, debug, a.stream)) return rc;
-  return launch_render_fwd(g, b.vals[slot], img, width, height, background, out_color, debug, a.stream);
+  return launch_render_fwd(g, b.keys[slot], b.vals[slot], img, width, height, a.tile_cull, background, out_color, debug, a.stream);
 }
 
 int gm_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
@@ -215,12 +221,11 @@ int gm_backward(int P, int D, int M, int R, const float* background, int width, 
   GeomState g = GeomState::from(geom_buffer, (size_t)P);
   ImageState img = ImageState::from(image_buffer, width, height);
   BinningState b = BinningState::from(binning_buffer, (size_t)(R > 0 ? R : 0));
-  const int tiles = ((width + GM_TILE - 1) / GM_TILE) * ((height + GM_TILE - 1) / GM_TILE);
-  const int slot = sort_final_slot(tile_bits(tiles));
+  const int slot = sort_final_slot(tile_bits(TileGrid(width, height, a.tile_cull).ptiles));
   GM_HIP(hipMemsetAsync(g.grad_acc, 0, sizeof(float) * 12 * (size_t)P, a.stream));   // the only zero-fill of a backward
   if (R > 0) {
     if (!binning_buffer) { set_error("gm_backward: null binning buffer"); return GM_ERR_INVALID_ARG; }
-    if (int rc = launch_render_bwd(g, b.vals[slot], img, width, height, background, dL_dpix, debug, a.stream)) return rc;
+    if (int rc = launch_render_bwd(g, b.keys[slot], b.vals[slot], img, width, height, a.tile_cull, background, dL_dpix, debug, a.stream)) return rc;
   }
   return launch_preprocess_bwd(a, g, radii, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
                                dL_dscale, dL_drot);
@@ -253,8 +258,7 @@ void* gm_image_field(void* image_buffer, int W, int H, const char* name) {
 }
 void* gm_binning_field(void* binning_buffer, int64_t R, int W, int H, const char* name) {
   BinningState b = BinningState::from(binning_buffer, (size_t)(R > 0 ? R : 0));
-  const int tiles = ((W + GM_TILE - 1) / GM_TILE) * ((H + GM_TILE - 1) / GM_TILE);
-  const int slot = sort_final_slot(tile_bits(tiles));
+  const int slot = sort_final_slot(tile_bits(TileGrid(W, H, g_tile_cull).ptiles));
   if (!strcmp(name, "point_list")) return b.vals[slot];
   if (!strcmp(name, "tile_keys")) return b.keys[slot];
   return nullptr;

@@ -100,14 +100,23 @@ __device__ __forceinline__ void get_rect(float px, float py, int r, int gx, int 
 // scans the counts into output offsets; then instances are written (see (1) and (2) in the body).
 // Emitted order = Gaussian order (depth, id), then rectangle row-major - the reference's order
 // (RAST/rasterizer_impl.cu:98-109) restricted to the emitted tiles.
+// S > 0: one instance per PARENT tile (2^S x 2^S tiles) that has a reached child; key = parent id | child mask << 16
+// (child bit = (row in parent) << S | column in parent).  S == 0: key = tile id | 1 << 16.
+template <int S>
 __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* __restrict__ order,
                                                                 const uint4* __restrict__ bins, const uint32_t* __restrict__ tiles,
-                                                                const float4* __restrict__ splat, const uint32_t* __restrict__ counters, int P, int gx,
+                                                                const float4* __restrict__ splat, uint32_t* __restrict__ counters, int P,
+                                                                int gx, int pgx, int mode,
                                                                 const uint32_t* __restrict__ block_sums,
                                                                 uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
   __shared__ uint32_t wsum[BN_THREADS / 64];
   __shared__ uint32_t stage_k[DUP_STAGE], stage_v[DUP_STAGE];
-  const int tile_cull = (int)counters[2];        // policy recorded by preprocess_fwd_kernel (the counts were made with it)
+  if ((int)counters[2] != mode) {                // the counts were made under another policy (gm_set_tile_culling changed
+    if (threadIdx.x == 0) counters[3] = 1u;      // between gm_forward_0 and gm_forward_1): emit nothing rather than overrun
+    return;
+  }
+  const int tile_cull = mode != 0;
+  constexpr int M = (1 << S) - 1;
   const int lane = threadIdx.x & 63;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const int base = blockIdx.x * GM_SCAN_ITEMS + threadIdx.x * BN_PER_THREAD;
@@ -136,33 +145,58 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
   uint32_t* __restrict__ vdst = staged ? stage_v : vals_out + block_base;
 #pragma unroll
   for (int i = 0; i < BN_PER_THREAD; i++) { offs[i] = off; off += cnt[i]; }
-  // (1) rectangles of <= 64 tiles (virtually all): each lane expands the emit mask of its own Gaussian.  A wave
-  //     spends max-over-lanes(popcount) iterations of ~8 instructions for 64 Gaussians; the 4-byte stores of a lane go
-  //     to its own run, neighbouring lanes' runs are adjacent, so a wave writes one compact region.
+  // (1) small rectangles (<= 64 tiles; S > 0: also at most 60 wide): each lane expands the emit mask of its own
+  //     Gaussian.  The 4-byte stores of a lane go to its own run, neighbouring lanes' runs are adjacent.
 #pragma unroll
   for (int i = 0; i < BN_PER_THREAD; i++) {
-    const uint32_t w = rc[i].y & 0xFFFFu, ncand = w * (rc[i].y >> 16);
-    if (cnt[i] != 0 && ncand <= 64) {
+    const uint32_t w = rc[i].y & 0xFFFFu, h = rc[i].y >> 16, ncand = w * h;
+    const bool small = ncand <= 64 && (S == 0 || w <= 60);
+    if (cnt[i] != 0 && small) {
       const uint32_t x0 = rc[i].x & 0xFFFFu, y0 = rc[i].x >> 16;
-      const float inv_w = 1.0f / (float)w;
       unsigned long long m = ((unsigned long long)rc[i].w << 32) | rc[i].z;
       uint32_t pos = offs[i];
-      const uint32_t tile0 = y0 * (uint32_t)gx + x0;
-      while (m) {
-        const uint32_t k = (uint32_t)__ffsll(m) - 1u;
-        m &= m - 1;
-        const uint32_t row = (uint32_t)(((float)k + 0.5f) * inv_w);
-        kdst[pos] = tile0 + row * (uint32_t)gx + (k - row * w);
-        vdst[pos] = gid[i];
-        pos++;
+      if (S == 0) {
+        const float inv_w = 1.0f / (float)w;
+        const uint32_t tile0 = (y0 * (uint32_t)gx + x0) | (1u << GM_KEY_MASK_SHIFT);
+        while (m) {
+          const uint32_t k = (uint32_t)__ffsll(m) - 1u;
+          m &= m - 1;
+          const uint32_t row = (uint32_t)(((float)k + 0.5f) * inv_w);
+          kdst[pos] = tile0 + row * (uint32_t)gx + (k - row * w);
+          vdst[pos] = gid[i];
+          pos++;
+        }
+      } else {
+        const unsigned long long rowmask = (1ull << w) - 1ull;
+        const int a = (int)(x0 & M);
+        for (uint32_t pr = y0 >> S; pr <= (y0 + h - 1) >> S; pr++) {
+          unsigned long long rows[1 << S], u = 0ull;
+#pragma unroll
+          for (int j = 0; j <= M; j++) {                 // child rows of this parent row that lie inside the rectangle
+            const int rr = (int)((pr << S) + j) - (int)y0;
+            rows[j] = (rr >= 0 && rr < (int)h) ? ((m >> (rr * (int)w)) & rowmask) << a : 0ull;
+            u |= rows[j];
+          }
+          unsigned long long g = S == 1 ? ((u | (u >> 1)) & 0x5555555555555555ull) : ((u | (u >> 1) | (u >> 2) | (u >> 3)) & 0x1111111111111111ull);
+          while (g) {
+            const int b = __ffsll(g) - 1;
+            g &= g - 1;
+            uint32_t cm = 0;
+#pragma unroll
+            for (int j = 0; j <= M; j++) cm |= (uint32_t)((rows[j] >> b) & (unsigned long long)((1 << (1 << S)) - 1)) << (j << S);
+            kdst[pos] = (pr * (uint32_t)pgx + (x0 >> S) + (uint32_t)(b >> S)) | (cm << GM_KEY_MASK_SHIFT);
+            vdst[pos] = gid[i];
+            pos++;
+          }
+        }
       }
     }
   }
-  // (2) rectangles of more than 64 tiles: the wave walks them one at a time, 64 candidate tiles per step
+  // (2) the other rectangles: the wave walks them one at a time, 64 candidate (parent) tiles per step
 #pragma unroll
   for (int i = 0; i < BN_PER_THREAD; i++) {
-    const uint32_t wi = rc[i].y & 0xFFFFu;
-    unsigned long long todo = __ballot(cnt[i] != 0 && wi * (rc[i].y >> 16) > 64);
+    const uint32_t wi = rc[i].y & 0xFFFFu, nci = wi * (rc[i].y >> 16);
+    unsigned long long todo = __ballot(cnt[i] != 0 && !(nci <= 64 && (S == 0 || wi <= 60)));
     while (todo) {
       const int j = __ffsll(todo) - 1;
       todo &= todo - 1;
@@ -170,24 +204,41 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
       const uint32_t rx = (uint32_t)__builtin_amdgcn_readlane((int)rc[i].x, j);
       const uint32_t ry = (uint32_t)__builtin_amdgcn_readlane((int)rc[i].y, j);
       const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)gid[i], j);
-      const uint32_t x0 = rx & 0xFFFFu, y0 = rx >> 16, w = ry & 0xFFFFu, h = ry >> 16, ncand = w * h;
-      const float inv_w = 1.0f / (float)w;
+      const uint32_t x0 = rx & 0xFFFFu, y0 = rx >> 16, w = ry & 0xFFFFu, h = ry >> 16;
+      const uint32_t px0 = x0 >> S, py0 = y0 >> S, pw = ((x0 + w - 1) >> S) - px0 + 1, ph = ((y0 + h - 1) >> S) - py0 + 1;
+      const uint32_t ncand = pw * ph;
+      const float inv_w = 1.0f / (float)pw;
       const float4 s0 = splat[3 * (size_t)g], s1 = splat[3 * (size_t)g + 1];
       const TileCull tc = tile_cull_setup(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, (float)(x0 * GM_TILE), (float)((x0 + w) * GM_TILE - 1),
                                           (float)(y0 * GM_TILE), (float)((y0 + h) * GM_TILE - 1));
       uint32_t run = o;
       for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
         const uint32_t k = c0 + lane;
-        const uint32_t row = (uint32_t)(((float)k + 0.5f) * inv_w), col = k - row * w;
-        bool pass = k < ncand;
-        if (pass && tile_cull) {                   // same per-row span as preprocess used for the count
-          int ta, tb;
-          pass = row_tiles(tc, s0.x, s0.y, (int)(y0 + row), (int)x0, (int)(x0 + w), ta, tb) && (int)(x0 + col) >= ta && (int)(x0 + col) <= tb;
+        const uint32_t row = (uint32_t)(((float)k + 0.5f) * inv_w), col = k - row * pw;
+        const uint32_t pcx = px0 + col, pcy = py0 + row;
+        bool pass = false;
+        uint32_t cm = 0;
+        if (k < ncand) {
+          int lo = 0x7fffffff, hi = -1;              // hull over the child rows, as preprocess counted
+#pragma unroll
+          for (int jr = 0; jr <= M; jr++) {
+            const int ty = (int)(pcy << S) + jr;
+            if (ty < (int)y0 || ty >= (int)(y0 + h)) continue;
+            int ta = (int)x0, tb = (int)(x0 + w) - 1;
+            if (tile_cull && !row_tiles(tc, s0.x, s0.y, ty, (int)x0, (int)(x0 + w), ta, tb)) continue;
+            lo = min(lo, ta); hi = max(hi, tb);
+#pragma unroll
+            for (int jc = 0; jc <= M; jc++) {
+              const int tx = (int)(pcx << S) + jc;
+              if (tx >= ta && tx <= tb) cm |= 1u << ((jr << S) + jc);
+            }
+          }
+          pass = hi >= 0 && (int)pcx >= (lo >> S) && (int)pcx <= (hi >> S);
         }
         const unsigned long long bal = __ballot(pass);
         if (pass) {
           const uint32_t pos = run + (uint32_t)__popcll(bal & lt_mask);
-          kdst[pos] = (y0 + row) * (uint32_t)gx + (x0 + col);
+          kdst[pos] = (pcy * (uint32_t)pgx + pcx) | (cm << GM_KEY_MASK_SHIFT);
           vdst[pos] = g;
         }
         run += (uint32_t)__popcll(bal);
@@ -203,14 +254,16 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
   }
 }
 
-int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, int tile_cull, int debug, hipStream_t s) {
+int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, int mode, int debug, hipStream_t s) {
   StageScope sc(ST_DUPLICATE, s);
   const int nb = (P + GM_SCAN_ITEMS - 1) / GM_SCAN_ITEMS;
-  const int gx = (W + GM_TILE - 1) / GM_TILE;
-  (void)H; (void)tile_cull;
-  if (nb > 0)
-    hipLaunchKernelGGL(duplicate_kernel, dim3(nb), dim3(BN_THREADS), 0, s, g.order[0], g.bin, g.tiles_touched, g.splat, g.counters,
-                       P, gx, g.block_sums, b.keys[0], b.vals[0]);
+  const TileGrid tg(W, H, mode);
+  if (nb > 0) {
+#define GM_DUP(SH) hipLaunchKernelGGL(duplicate_kernel<SH>, dim3(nb), dim3(BN_THREADS), 0, s, g.order[0], g.bin, g.tiles_touched, g.splat, \
+                                      g.counters, P, tg.gx, tg.pgx, mode, g.block_sums, b.keys[0], b.vals[0])
+    if (tg.s == 0) GM_DUP(0); else if (tg.s == 1) GM_DUP(1); else GM_DUP(2);
+#undef GM_DUP
+  }
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }
@@ -218,10 +271,10 @@ int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, int til
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __restrict__ keys, int R, uint2* __restrict__ ranges) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= R) return;
-  const uint32_t cur = keys[i];
+  const uint32_t cur = keys[i] & GM_KEY_TILE_MASK;
   if (i == 0) ranges[cur].x = 0;
   else {
-    const uint32_t prev = keys[i - 1];
+    const uint32_t prev = keys[i - 1] & GM_KEY_TILE_MASK;
     if (cur != prev) { ranges[prev].y = (uint32_t)i; ranges[cur].x = (uint32_t)i; }
   }
   if (i == R - 1) ranges[cur].y = (uint32_t)R;

@@ -56,10 +56,12 @@ static inline T* carve(char*& p, size_t count) {
 #define GM_SORT_ITEMS 4096      // keys per workgroup per radix pass (256 threads x 16)
 #define GM_SCAN_ITEMS 512       // Gaussians per workgroup in the tiles_touched scan / instance emission (256 threads x 2)
 
-#define GM_SORT_SMALL_N (4u << 20)   // below this many keys the radix sort uses 1024-key tiles (more workgroups)
-// number of histogram columns (workgroups) the radix sort uses for n keys
+#define GM_SORT_SMALL_N (3u << 19)   // up to this many keys (1.5 M) the radix sort uses 1024-key tiles (more workgroups),
+#define GM_SORT_MID_N (4u << 20)     // up to this many 2048-key tiles, 4096-key tiles above
+// keys per workgroup / number of histogram columns (workgroups) the radix sort uses for n keys
+static inline size_t sort_tile_keys(size_t n) { return n <= GM_SORT_SMALL_N ? 1024 : (n <= GM_SORT_MID_N ? 2048 : GM_SORT_ITEMS); }
 static inline size_t sort_blocks(size_t n) {
-  const size_t tile = n <= GM_SORT_SMALL_N ? 1024 : GM_SORT_ITEMS;
+  const size_t tile = sort_tile_keys(n);
   return (n + tile - 1) / tile;
 }
 
@@ -149,6 +151,24 @@ static inline int tile_bits(int tiles) {      // bits needed to hold tile ids 0.
 // which ping-pong slot holds the result after sorting `bits` bits in 8-bit passes, starting in slot 0
 static inline int sort_final_slot(int bits) { return ((bits + 7) / 8) & 1; }
 
+// Emission policy (gm_set_tile_culling): 0 = the reference's lists (every tile of the rectangle, 16-px tiles);
+// 1 = exact culling, lists per 16-px tile; 2 / 3 = exact culling, lists per 32- / 64-px PARENT tile (the instance
+// stream shrinks ~2x / ~3x): an instance is one (Gaussian, parent tile) pair whose key carries, above bit 16, the
+// mask of the parent's 16-px child tiles the Gaussian reaches.  The blend kernels still run one workgroup per 16-px
+// tile; it walks its parent's list and takes the entries whose mask has its bit.
+#define GM_KEY_MASK_SHIFT 16
+#define GM_KEY_TILE_MASK 0xFFFFu
+static inline int tile_shift_of(int mode) { return mode >= 2 ? mode - 1 : 0; }
+struct TileGrid {
+  int s, gx, gy, pgx, pgy, ptiles;
+  TileGrid(int W, int H, int mode) {
+    s = tile_shift_of(mode);
+    gx = (W + GM_TILE - 1) / GM_TILE; gy = (H + GM_TILE - 1) / GM_TILE;
+    pgx = (gx + (1 << s) - 1) >> s; pgy = (gy + (1 << s) - 1) >> s;
+    ptiles = pgx * pgy;
+  }
+};
+
 // ---------------------------------------------------------------------------------------------
 // host launchers implemented in the other translation units (all stream-ordered, return GM_* codes)
 struct RasterArgs {
@@ -157,7 +177,7 @@ struct RasterArgs {
   const float *viewmatrix, *projmatrix, *cam_pos;
   float scale_modifier, tan_fovx, tan_fovy;
   int prefiltered, debug;
-  int tile_cull;                // 1: emit (Gaussian, tile) only if the Gaussian can reach alpha >= 1/255 inside the tile
+  int tile_cull;                // emission policy 0..3, see tile_shift_of()
   hipStream_t stream;
 };
 
@@ -176,9 +196,9 @@ int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], uint32_t* hist, uint3
 int launch_tile_count_scan(GeomState& g, int P, int debug, hipStream_t s);          // -> counters[0] = num_rendered
 int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, int tile_cull, int debug, hipStream_t s);
 int launch_tile_ranges(BinningState& b, int slot, ImageState& img, int R, int tiles, int debug, hipStream_t s);
-int launch_render_fwd(const GeomState& g, const uint32_t* point_list, ImageState& img, int W, int H,
+int launch_render_fwd(const GeomState& g, const uint32_t* tile_keys, const uint32_t* point_list, ImageState& img, int W, int H, int mode,
                       const float* background, float* out_color, int debug, hipStream_t s);
-int launch_render_bwd(const GeomState& g, const uint32_t* point_list, ImageState& img, int W, int H,
+int launch_render_bwd(const GeomState& g, const uint32_t* tile_keys, const uint32_t* point_list, ImageState& img, int W, int H, int mode,
                       const float* background, const float* dL_dpix, int debug, hipStream_t s);   // accumulates into g.grad_acc
 
 int launch_deform(int N, const int* tri, const float* w, const float* dV, const float* Rv, const float* Sv,

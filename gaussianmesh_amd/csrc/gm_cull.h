@@ -101,4 +101,15 @@ __device__ __forceinline__ bool row_tiles(const TileCull& t, float sx, float sy,
   return ta <= tb;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Parent tiles (2^s x 2^s tiles, s = 1 or 2).  `bits`: bit c = tile column x0 + c of one parent ROW is reached
+// (union over the row's child rows; at most 60 columns).  Returns the number of parent columns with a reached child.
+__device__ __forceinline__ unsigned long long fold_parent_bits(unsigned long long bits, int x0, int s) {
+  const unsigned long long f = bits << (x0 & ((1 << s) - 1));      // bit position = column - (x0 rounded down to a parent edge)
+  return s == 1 ? ((f | (f >> 1)) & 0x5555555555555555ull) : ((f | (f >> 1) | (f >> 2) | (f >> 3)) & 0x1111111111111111ull);
+}
+__device__ __forceinline__ uint32_t parents_in_row(unsigned long long bits, int x0, int s) {
+  return (uint32_t)__popcll(fold_parent_bits(bits, x0, s));
+}
+
 }  // namespace gm

@@ -193,14 +193,30 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(const PreArgs a) {
     } else {
       const TileCull tc = tile_cull_setup(pix, piy, conx, cony, conz, a.opac[idx], (float)(x0 * GM_TILE), (float)(x1 * GM_TILE - 1),
                                           (float)(y0 * GM_TILE), (float)(y1 * GM_TILE - 1));
+      // s > 0: instances are (Gaussian, parent tile) pairs, a parent = 2^s x 2^s tiles.  Small rectangles: the parents
+      // with at least one reached child (exact, from the child mask); others: per parent row the hull of the child
+      // rows' spans (duplicate_kernel applies the same two rules).
+      const int s = a.tile_cull >= 2 ? a.tile_cull - 1 : 0;
+      const bool small = ncand <= 64 && rw <= 60;
       uint32_t cnt = 0;
+      int cur_pr = -1, hull_lo = 0x7fffffff, hull_hi = -1;           // hull empty while hull_hi < 0
+      unsigned long long prow = 0ull;
       for (int ry = 0; ry < rh; ry++) {            // per tile row: the span of tiles the alpha >= 1/255 region reaches
+        const int pr = (y0 + ry) >> s;
+        if (s > 0 && pr != cur_pr) {
+          cnt += small ? parents_in_row(prow, x0, s) : (hull_hi >= 0 ? (uint32_t)((hull_hi >> s) - (hull_lo >> s) + 1) : 0u);
+          cur_pr = pr; prow = 0ull; hull_lo = 0x7fffffff; hull_hi = -1;
+        }
         int ta, tb;
         if (!row_tiles(tc, pix, piy, y0 + ry, x0, x1, ta, tb)) continue;
         const int len = tb - ta + 1, bit0 = ry * rw + (ta - x0);
-        cnt += (uint32_t)len;
-        if (ncand <= 64) mask |= (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << bit0;
+        const unsigned long long run = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
+        if (ncand <= 64) mask |= run << bit0;
+        if (s == 0) cnt += (uint32_t)len;
+        else if (small) prow |= run << (ta - x0);
+        else { hull_lo = min(hull_lo, ta); hull_hi = max(hull_hi, tb); }
       }
+      if (s > 0) cnt += small ? parents_in_row(prow, x0, s) : (hull_hi >= 0 ? (uint32_t)((hull_hi >> s) - (hull_lo >> s) + 1) : 0u);
       tiles = cnt;
     }
     bin = make_uint4((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)rw | ((uint32_t)rh << 16), (uint32_t)mask, (uint32_t)(mask >> 32));

@@ -37,6 +37,26 @@ __device__ __forceinline__ float bcast(float v, int j) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
 }
 
+// Workgroup -> 16-px tile, its parent tile (whose list it walks) and its bit in the instance keys' child mask.
+// Consecutive workgroup ids go to consecutive XCDs (8 of them, each with its own L2), so the 2^s x 2^s children of
+// a parent are given ids that are 8 apart: they run on the same XCD and share the parent's list and records in L2.
+struct TileMap {
+  int gx, gy, pgx, pgy, s;
+  __device__ __forceinline__ bool locate(int b, int& tx, int& ty, int& parent, uint32_t& child_bit) const {
+    const int nch = 1 << (2 * s);
+    const int xcd = b & 7, j = b >> 3;
+    const int p = (j >> (2 * s)) * 8 + xcd, c = j & (nch - 1);
+    if (p >= pgx * pgy) return false;
+    const int py = p / pgx, px = p - py * pgx;
+    const int cy = c >> s, cx = c & ((1 << s) - 1);
+    tx = (px << s) + cx; ty = (py << s) + cy;
+    parent = p;
+    child_bit = 1u << (GM_KEY_MASK_SHIFT + c);
+    return tx < gx && ty < gy;
+  }
+  int blocks() const { return ((pgx * pgy + 7) / 8) * 8 << (2 * s); }
+};
+
 struct Batch {      // lane j holds list entry j of the current 64-entry batch
   float4 a;         // x, y, conic.x, conic.y
   float4 b;         // conic.z, opacity, r, g
@@ -69,16 +89,19 @@ __device__ __forceinline__ Batch load_records(const float4* __restrict__ splat, 
 
 template <int PPL, bool QUAD = false>
 __global__ __launch_bounds__(256 / PPL) void render_fwd_kernel(const uint2* __restrict__ ranges,
+                                                               const uint32_t* __restrict__ tile_keys,
                                                                const uint32_t* __restrict__ point_list,
-                                                               const float4* __restrict__ splat, int W, int H, int gx,
+                                                               const float4* __restrict__ splat, int W, int H, TileMap tm,
                                                                const float* __restrict__ bg, float* __restrict__ out_color,
                                                                float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tile = blockIdx.x;
-  const int tx = tile % gx, ty = tile / gx;
-  const uint2 range = ranges[tile];
+  int tx, ty, parent;
+  uint32_t child_bit;
+  if (!tm.locate(blockIdx.x, tx, ty, parent, child_bit)) return;
+  const uint2 range = ranges[parent];
   const int n = (int)(range.y - range.x);
   const uint32_t* list = point_list + range.x;
+  const uint32_t* klist = tile_keys + range.x;
 
   const int px = QUAD ? tx * GM_TILE + (wave & 1) * 8 + (lane & 7) : tx * GM_TILE + (lane & 15);
   const float pixx = (float)px;
@@ -105,17 +128,22 @@ __global__ __launch_bounds__(256 / PPL) void render_fwd_kernel(const uint2* __re
   __shared__ float4 l_rec[4 / PPL][64][3];
   float4 (*rec)[3] = l_rec[wave];
 
-  Batch cur = load_records(splat, load_id(list, lane, n), lane < n);
+  // an entry of the parent's list concerns this tile iff its key has the tile's child bit; records are only
+  // fetched for those
+  bool mine = (load_id(klist, lane, n) & child_bit) != 0;
+  Batch cur = load_records(splat, load_id(list, lane, n), mine);
   uint32_t id_nxt = load_id(list, 64 + lane, n);
+  bool mine_nxt = (load_id(klist, 64 + lane, n) & child_bit) != 0;
   for (int base = 0; base < n; base += 64) {
     bool all_done = true;
 #pragma unroll
     for (int k = 0; k < PPL; k++) all_done = all_done && done[k];
     if (__all(all_done)) break;
     WAIT_ALL_LOADS();
-    const Batch nxt = load_records(splat, id_nxt, base + 64 + lane < n);    // records of the next batch
-    id_nxt = load_id(list, base + 128 + lane, n);                          // ids of the batch after that
-    const bool keep = (base + lane < n) && may_touch(cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, rx0, rx1, ry0, ry1);
+    const Batch nxt = load_records(splat, id_nxt, mine_nxt);               // records of the next batch
+    id_nxt = load_id(list, base + 128 + lane, n);                          // ids / keys of the batch after that
+    const bool mine_nn = (load_id(klist, base + 128 + lane, n) & child_bit) != 0;
+    const bool keep = mine && may_touch(cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, rx0, rx1, ry0, ry1);
     rec[lane][0] = cur.a; rec[lane][1] = cur.b; rec[lane][2] = make_float4(cur.c, 0.f, 0.f, 0.f);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -173,7 +201,7 @@ __global__ __launch_bounds__(256 / PPL) void render_fwd_kernel(const uint2* __re
         }
       }
     }
-    cur = nxt;
+    cur = nxt; mine = mine_nxt; mine_nxt = mine_nn;
   }
 
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
@@ -191,36 +219,14 @@ __global__ __launch_bounds__(256 / PPL) void render_fwd_kernel(const uint2* __re
   }
 }
 
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
-
-int launch_render_fwd(const GeomState& g, const uint32_t* point_list, ImageState& img, int W, int H,
+int launch_render_fwd(const GeomState& g, const uint32_t* tile_keys, const uint32_t* point_list, ImageState& img, int W, int H, int mode,
                       const float* background, float* out_color, int debug, hipStream_t s) {
   StageScope sc(ST_RENDER, s);
-  const int ppl = env_int("GM_RENDER_PPL", 1);          // pixels per lane (1, 2 or 4 -> 4, 2 or 1 waves per tile); tuning knob, read per launch
-  const int gx = (W + GM_TILE - 1) / GM_TILE, gy = (H + GM_TILE - 1) / GM_TILE;
-  const int tiles = gx * gy;
-  if (tiles > 0) {
-    switch (ppl) {
-      case 4:
-        hipLaunchKernelGGL(render_fwd_kernel<4>, dim3(tiles), dim3(64), 0, s, img.ranges, point_list, g.splat, W, H, gx,
-                           background, out_color, img.final_T, img.n_contrib);
-        break;
-      case 2:
-        hipLaunchKernelGGL(render_fwd_kernel<2>, dim3(tiles), dim3(128), 0, s, img.ranges, point_list, g.splat, W, H, gx,
-                           background, out_color, img.final_T, img.n_contrib);
-        break;
-      default:
-        if (env_int("GM_RENDER_QUAD", 1))       // 8x8 quadrant per wave (default) or 16x4 strip
-          hipLaunchKernelGGL((render_fwd_kernel<1, true>), dim3(tiles), dim3(256), 0, s, img.ranges, point_list, g.splat, W, H, gx,
-                             background, out_color, img.final_T, img.n_contrib);
-        else
-        hipLaunchKernelGGL(render_fwd_kernel<1>, dim3(tiles), dim3(256), 0, s, img.ranges, point_list, g.splat, W, H, gx,
-                           background, out_color, img.final_T, img.n_contrib);
-    }
-  }
+  const TileGrid tg(W, H, mode);
+  const TileMap tm{tg.gx, tg.gy, tg.pgx, tg.pgy, tg.s};
+  if (tg.ptiles > 0)
+    hipLaunchKernelGGL((render_fwd_kernel<1, true>), dim3(tm.blocks()), dim3(256), 0, s, img.ranges, tile_keys, point_list, g.splat, W, H, tm,
+                       background, out_color, img.final_T, img.n_contrib);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }
@@ -287,18 +293,21 @@ __device__ __forceinline__ int reduce8_slot(int lane) {
 
 template <int PPL, bool QUAD = false>
 __global__ __launch_bounds__(256 / PPL) void render_bwd_kernel(const uint2* __restrict__ ranges,
+                                                               const uint32_t* __restrict__ tile_keys,
                                                                const uint32_t* __restrict__ point_list,
-                                                               const float4* __restrict__ splat, int W, int H, int gx,
+                                                               const float4* __restrict__ splat, int W, int H, TileMap tm,
                                                                const float* __restrict__ bg, const float* __restrict__ final_T,
                                                                const uint32_t* __restrict__ n_contrib,
                                                                const float* __restrict__ dL_dpix, float* __restrict__ grad_acc) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tile = blockIdx.x;
-  const int tx = tile % gx, ty = tile / gx;
-  const uint2 range = ranges[tile];
+  int tx, ty, parent;
+  uint32_t child_bit;
+  if (!tm.locate(blockIdx.x, tx, ty, parent, child_bit)) return;
+  const uint2 range = ranges[parent];
   const int n = (int)(range.y - range.x);
   if (n == 0) return;
   const uint32_t* list = point_list + range.x;
+  const uint32_t* klist = tile_keys + range.x;
   const size_t HW = (size_t)H * W;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 
@@ -339,13 +348,16 @@ __global__ __launch_bounds__(256 / PPL) void render_bwd_kernel(const uint2* __re
   __shared__ float4 l_rec[4 / PPL][64][3];       // wave-private LDS copy of the batch (see render_fwd_kernel)
   float4 (*rec)[3] = l_rec[wave];
   // batch b covers list positions start-1-b*64-j (j = lane), i.e. back to front
-  Batch cur = load_records(splat, load_id(list, start - 1 - lane, n), start - 1 - lane >= 0);
+  bool mine = (load_id(klist, start - 1 - lane, n) & child_bit) != 0;
+  Batch cur = load_records(splat, load_id(list, start - 1 - lane, n), mine);
   uint32_t id_nxt = load_id(list, start - 1 - 64 - lane, n);
+  bool mine_nxt = (load_id(klist, start - 1 - 64 - lane, n) & child_bit) != 0;
   for (int base = 0; base < start; base += 64) {
     WAIT_ALL_LOADS();
-    const Batch nxt = load_records(splat, id_nxt, start - 1 - (base + 64) - lane >= 0);
+    const Batch nxt = load_records(splat, id_nxt, mine_nxt);
     id_nxt = load_id(list, start - 1 - (base + 128) - lane, n);
-    const bool keep = (base + lane < start) && may_touch(cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, rx0, rx1, ry0, ry1);
+    const bool mine_nn = (load_id(klist, start - 1 - (base + 128) - lane, n) & child_bit) != 0;
+    const bool keep = mine && may_touch(cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, rx0, rx1, ry0, ry1);
     rec[lane][0] = cur.a; rec[lane][1] = cur.b; rec[lane][2] = make_float4(cur.c, __uint_as_float(cur.id), 0.f, 0.f);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -404,35 +416,18 @@ __global__ __launch_bounds__(256 / PPL) void render_bwd_kernel(const uint2* __re
       if (committer || last_lane)
         atomicAdd(grad_acc + (size_t)gid * GM_ACC_STRIDE + (last_lane ? 8 : my_slot), last_lane ? q8 : tot);
     }
-    cur = nxt;
+    cur = nxt; mine = mine_nxt; mine_nxt = mine_nn;
   }
 }
 
-int launch_render_bwd(const GeomState& g, const uint32_t* point_list, ImageState& img, int W, int H,
+int launch_render_bwd(const GeomState& g, const uint32_t* tile_keys, const uint32_t* point_list, ImageState& img, int W, int H, int mode,
                       const float* background, const float* dL_dpix, int debug, hipStream_t s) {
   StageScope sc(ST_RENDER_BWD, s);
-  const int ppl = env_int("GM_RENDER_BWD_PPL", 1);      // tuning knob, read per launch
-  const int gx = (W + GM_TILE - 1) / GM_TILE, gy = (H + GM_TILE - 1) / GM_TILE;
-  const int tiles = gx * gy;
-  if (tiles > 0) {
-    switch (ppl) {
-      case 2:
-        hipLaunchKernelGGL(render_bwd_kernel<2>, dim3(tiles), dim3(128), 0, s, img.ranges, point_list, g.splat, W, H, gx,
-                           background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc);
-        break;
-      case 4:
-        hipLaunchKernelGGL(render_bwd_kernel<4>, dim3(tiles), dim3(64), 0, s, img.ranges, point_list, g.splat, W, H, gx,
-                           background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc);
-        break;
-      default:
-        if (env_int("GM_RENDER_QUAD", 1))
-          hipLaunchKernelGGL((render_bwd_kernel<1, true>), dim3(tiles), dim3(256), 0, s, img.ranges, point_list, g.splat, W, H, gx,
-                             background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc);
-        else
-          hipLaunchKernelGGL(render_bwd_kernel<1>, dim3(tiles), dim3(256), 0, s, img.ranges, point_list, g.splat, W, H, gx,
-                             background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc);
-    }
-  }
+  const TileGrid tg(W, H, mode);
+  const TileMap tm{tg.gx, tg.gy, tg.pgx, tg.pgy, tg.s};
+  if (tg.ptiles > 0)
+    hipLaunchKernelGGL((render_bwd_kernel<1, true>), dim3(tm.blocks()), dim3(256), 0, s, img.ranges, tile_keys, point_list, g.splat, W, H, tm,
+                       background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }

@@ -244,6 +244,7 @@ int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], uint32_t* hist, uint3
   if (n == 0) return 0;
   if (n > 0xFFFFFFF0ull) { set_error("radix_sort_pairs: n too large"); return 1; }
   if (n <= GM_SORT_SMALL_N) return radix_sort_pairs_t<4>(keys, vals, hist, digit_total, n, bits, iota_values, debug, s);
+  if (n <= GM_SORT_MID_N) return radix_sort_pairs_t<8>(keys, vals, hist, digit_total, n, bits, iota_values, debug, s);
   return radix_sort_pairs_t<16>(keys, vals, hist, digit_total, n, bits, iota_values, debug, s);
 }
 

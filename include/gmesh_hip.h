@@ -47,13 +47,20 @@ extern "C" {
 int gm_abi_version(void);
 const char* gm_last_error(void);
 
-/* Instance emission policy (process-wide; set it before gm_forward_0 and keep it until the matching gm_backward).
- *   1 (default): a (Gaussian, tile) instance is emitted only if the Gaussian can reach alpha >= 1/255 somewhere in the
- *      tile (exact conservative test).  Dropped instances are skipped by every pixel of the tile in the reference too
- *      (RAST/forward.cu:344), so out_color, radii and all gradients are unchanged; num_rendered and the internal lists shrink.
+/* Instance emission policy (process-wide; set it before gm_forward_0 and keep it until the matching gm_forward_1 /
+ * gm_backward / gm_binning_field: a forward_1 under another policy than its forward_0 emits nothing and renders the
+ * background).  out_color, radii and all gradients are the same under every policy; num_rendered and the internal
+ * lists differ.
  *   0: emit every tile of the bounding rectangle exactly as the reference does (RAST/rasterizer_impl.cu:98-109);
- *      num_rendered, point_list and ranges are then identical to the reference's. */
-void gm_set_tile_culling(int on);
+ *      num_rendered, point_list and ranges are then identical to the reference's.
+ *   1: a (Gaussian, tile) instance is emitted only if the Gaussian can reach alpha >= 1/255 somewhere in the 16x16
+ *      tile (exact conservative test).  Dropped instances are skipped by every pixel of the tile in the reference too
+ *      (RAST/forward.cu:344).
+ *   2 (default), 3: the same test, but instances are (Gaussian, PARENT tile) pairs for parents of 2x2 / 4x4 tiles; the
+ *      key of an instance carries the mask of the parent's child tiles the Gaussian reaches (bits 16+), and the 16x16
+ *      blend workgroups walk their parent's list.  The instance stream (and the sort over it) shrinks ~2x / ~3x.
+ * The environment variable GM_EMISSION_MODE (0..3) overrides the default when the library is loaded. */
+void gm_set_tile_culling(int mode);
 int gm_get_tile_culling(void);
 
 /* Scratch sizes.  Replace CudaRasterizer::required<GeometryState|ImageState|BinningState>(n)

@@ -25,6 +25,9 @@ def settings(cam, bg, D, mod=1.0, debug=False):
         prefiltered=False, debug=debug)
 
 
+DEFAULT_MODE = 2
+
+
 def _view(buf, ptr, count, dtype):
     off = ptr - buf.data_ptr()
     nbytes = count * torch.tensor([], dtype=dtype).element_size()
@@ -36,7 +39,8 @@ def forward_state(scene, cam, bg, D=3, use_precomp_cov=False, use_precomp_color=
     tile_cull=False: emit every tile of the rectangle like the reference (lists comparable 1:1 with the oracle);
     tile_cull=True: the product default (instances the Gaussian cannot reach are not emitted)."""
     lib = _lib.lib()
-    lib.gm_set_tile_culling(1 if tile_cull else 0)
+    mode = int(tile_cull)
+    lib.gm_set_tile_culling(mode)
     P = scene["means"].shape[0]
     W, H = cam["W"], cam["H"]
     sh = None if use_precomp_color else T(scene["shs"])
@@ -48,8 +52,9 @@ def forward_state(scene, cam, bg, D=3, use_precomp_cov=False, use_precomp_color=
         T(bg), T(scene["means"]), col, T(scene["opac"]), sc, rot, mod, cov, T(cam["view"]), T(cam["proj"]), cam["tanx"],
         cam["tany"], H, W, sh, D, T(cam["campos"]), False, debug)
     torch.cuda.synchronize()
-    lib.gm_set_tile_culling(1)
-    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    sh_ = max(mode - 1, 0)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    tiles = ((gx + (1 << sh_) - 1) >> sh_) * ((gy + (1 << sh_) - 1) >> sh_)       # lists are per parent tile
     out = dict(R=nr, color=color.cpu().numpy(), radii=radii.cpu().numpy(), geom=geom, binning=binning, img=img)
     if P > 0:
         gp = lambda n: lib.gm_geom_field(geom.data_ptr(), P, n.encode())
@@ -69,4 +74,7 @@ def forward_state(scene, cam, bg, D=3, use_precomp_cov=False, use_precomp_color=
     else:
         out["point_list"] = np.zeros(0, np.uint32)
         out["tile_keys"] = np.zeros(0, np.uint32)
+    out["child_mask"] = out["tile_keys"] >> 16
+    out["tile_keys"] = out["tile_keys"] & 0xFFFF
+    lib.gm_set_tile_culling(DEFAULT_MODE)
     return out

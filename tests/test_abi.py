@@ -22,7 +22,7 @@ def test_scratch_sizes_scale_linearly():
     from gaussianmesh_amd import _lib
     l = _lib.lib()
     g1, g2 = l.gm_geom_bytes(1_000_000), l.gm_geom_bytes(2_000_000)
-    assert 130e6 < g1 < 170e6 and abs(g2 - 2 * g1) < 1e5       # ~145 B per Gaussian (incl. 48 B backward accumulators)
+    assert 130e6 < g1 < 170e6 and abs(g2 - 2 * g1) < 2e6       # ~161 B per Gaussian (incl. 48 B backward accumulators); sort histograms are tiered
     b1 = l.gm_binning_bytes(8_000_000)
     assert 128e6 <= b1 < 140e6                                   # 16 B per instance + histograms
     i1 = l.gm_image_bytes(1920, 1080)

@@ -12,8 +12,9 @@ def _forward(sc, cam, bg, **kw):
     return forward_state(sc, cam, bg, D=3, **kw)
 
 
-def _check_list_invariants(st, cam):
-    """Structural invariants of the binning output, any size."""
+def _check_list_invariants(st, cam, mode=0):
+    """Structural invariants of the binning output, any size (lists are per parent tile of 16 << shift pixels)."""
+    shift = max(mode - 1, 0); ts = 16 << shift
     T = st["ranges"].shape[0]
     r = st["ranges"].astype(np.int64)
     nonempty = r[:, 1] > r[:, 0]
@@ -32,11 +33,12 @@ def _check_list_invariants(st, cam):
     tie = same & (dd == 0)
     assert (np.diff(st["point_list"].astype(np.int64))[tie] > 0).all()
     # every emitted instance lies inside its Gaussian's tile rectangle
-    gx = (cam["W"] + 15) // 16
+    gx = (((cam["W"] + 15) // 16) + (1 << shift) - 1) >> shift
     g = st["point_list"]
     x, y, rad = st["splat"][g, 0], st["splat"][g, 1], st["radii"][g]
     tx, ty = keys % gx, keys // gx
-    assert ((tx * 16 <= x + rad + 15) & (tx * 16 + 15 >= x - rad - 15) & (ty * 16 <= y + rad + 15) & (ty * 16 + 15 >= y - rad - 15)).all()
+    assert ((tx * ts <= x + rad + 15) & (tx * ts + ts - 1 >= x - rad - 15) & (ty * ts <= y + rad + 15) & (ty * ts + ts - 1 >= y - rad - 15)).all()
+    assert (st["child_mask"] < (1 << (1 << (2 * shift)))).all()
 
 
 def test_c1_plumbing_case(oracle):
@@ -80,23 +82,27 @@ def test_full_size_forward_properties(P, W, H):
     sc = scenes.make_cloud(P, seed=0)
     cam = scenes.orbit_camera(3, 64, W, H)
     z = np.zeros(3, np.float32)
-    ex = _forward(sc, cam, z, tile_cull=False)
+    ex = _forward(sc, cam, z, tile_cull=0)
     _check_list_invariants(ex, cam)
-    cu = _forward(sc, cam, z, tile_cull=True)
-    _check_list_invariants(cu, cam)
-    assert cu["R"] < ex["R"] and np.array_equal(cu["radii"], ex["radii"])
-    assert np.array_equal(cu["color"], ex["color"]) and np.array_equal(cu["final_T"], ex["final_T"])
-    again = _forward(sc, cam, z, tile_cull=True)
-    assert np.array_equal(again["color"], cu["color"]) and np.array_equal(again["point_list"], cu["point_list"])   # deterministic
-    one = _forward(sc, cam, np.ones(3, np.float32), tile_cull=True)
-    assert np.allclose(one["color"] - cu["color"], cu["final_T"].reshape(1, H, W), atol=1e-6)       # C + T*bg
-    assert cu["color"].min() >= 0 and np.isfinite(cu["color"]).all() and (cu["final_T"] <= 1).all() and (cu["final_T"] >= 0).all()
-    # n_contrib indexes into the tile's list
-    nc = cu["n_contrib"].reshape(H, W)
-    gx = (W + 15) // 16
-    lens = (cu["ranges"][:, 1] - cu["ranges"][:, 0]).astype(np.int64)
-    ty, tx = np.mgrid[0:H, 0:W]
-    assert (nc <= lens[(ty // 16) * gx + tx // 16]).all()
+    prev_R = ex["R"]
+    for mode in (1, 2, 3):
+        cu = _forward(sc, cam, z, tile_cull=mode)
+        _check_list_invariants(cu, cam, mode)
+        assert cu["R"] < prev_R and np.array_equal(cu["radii"], ex["radii"])
+        prev_R = cu["R"]
+        assert np.array_equal(cu["color"], ex["color"]) and np.array_equal(cu["final_T"], ex["final_T"])
+        again = _forward(sc, cam, z, tile_cull=mode)
+        assert np.array_equal(again["color"], cu["color"]) and np.array_equal(again["point_list"], cu["point_list"])   # deterministic
+        one = _forward(sc, cam, np.ones(3, np.float32), tile_cull=mode)
+        assert np.allclose(one["color"] - cu["color"], cu["final_T"].reshape(1, H, W), atol=1e-6)       # C + T*bg
+        assert cu["color"].min() >= 0 and np.isfinite(cu["color"]).all() and (cu["final_T"] <= 1).all() and (cu["final_T"] >= 0).all()
+        # n_contrib indexes into the parent tile's list
+        nc = cu["n_contrib"].reshape(H, W)
+        sh = mode - 1
+        pgx = (((W + 15) // 16) + (1 << sh) - 1) >> sh
+        lens = (cu["ranges"][:, 1] - cu["ranges"][:, 0]).astype(np.int64)
+        ty, tx = np.mgrid[0:H, 0:W]
+        assert (nc <= lens[(ty // (16 << sh)) * pgx + tx // (16 << sh)]).all()
 
 
 def test_c2_backward_properties():

@@ -19,9 +19,9 @@ GRAD_RTOL = 1e-3
 @pytest.fixture(autouse=True)
 def _default_emission_policy():
     from gaussianmesh_amd import _lib
-    _lib.lib().gm_set_tile_culling(1)
+    _lib.lib().gm_set_tile_culling(2)
     yield
-    _lib.lib().gm_set_tile_culling(1)
+    _lib.lib().gm_set_tile_culling(2)
 
 MODES = [(False, False), (True, False), (False, True), (True, True)]
 
@@ -76,18 +76,21 @@ def test_forward_sh_degrees(oracle, D):
     assert np.abs(st["color"] - fw["color"]).max() <= FWD_TOL
 
 
-@pytest.mark.parametrize("ppl", ["1", "2", "4"])
-def test_forward_medium_ragged(oracle, ppl, monkeypatch):
-    """C1-like case (10k Gaussians) at a size that is not a multiple of the tile, long lists (multi-batch)."""
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_forward_medium_ragged(oracle, mode):
+    """C1-like case (10k Gaussians) at a size that is not a multiple of the tile, long lists (multi-batch), under every
+    emission policy (0 = reference lists, 1 = culled 16-px lists, 2 / 3 = culled lists per 32- / 64-px parent tile)."""
     from gpu_utils import forward_state
     from gaussianmesh_amd import scenes
-    monkeypatch.setenv("GM_RENDER_PPL", ppl)          # pixels per lane of the blend kernel (1, 2 or 4 waves' worth)
     sc = scenes.make_cloud(10000, seed=0, scale_lo=0.02, scale_hi=0.25)
     cam = scenes.orbit_camera(2, 9, 250, 130, radius=7.0)
     bg = np.array([1, 1, 1], np.float32)
     fw = oracle.forward_full(sc, cam, bg, D=3)
-    st = forward_state(sc, cam, bg, D=3)
-    _check_geometry(oracle, st, fw, sc, False)
+    st = forward_state(sc, cam, bg, D=3, tile_cull=mode)
+    if mode == 0:
+        _check_geometry(oracle, st, fw, sc, False)
+    else:
+        assert np.array_equal(st["radii"], fw["geo"]["radii"])
     err = np.abs(st["color"] - fw["color"])
     # threshold decisions (alpha<1/255, T<1e-4) can flip on isolated pixels between exp implementations
     # a flip changes a pixel by at most ~alpha*T*|dc| <= 1/255 + 1e-4; allow 1e-4 of the pixels, bounded size
@@ -122,9 +125,10 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
-@pytest.mark.parametrize("bwd_ppl", ["1", "2", "4"])
-def test_backward_ppl_variants(oracle, bwd_ppl, monkeypatch):
-    monkeypatch.setenv("GM_RENDER_BWD_PPL", bwd_ppl)
+@pytest.mark.parametrize("mode", [0, 1, 3])
+def test_backward_under_every_emission_policy(oracle, mode):
+    from gaussianmesh_amd import _lib
+    _lib.lib().gm_set_tile_culling(mode)
     test_backward_medium(oracle)
 
 
@@ -170,10 +174,12 @@ def test_backward_medium(oracle):
     assert _rel(g["opac"].reshape(-1), bw["dopacity"]) <= GRAD_RTOL
 
 
+@pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("case", ["small", "medium", "huge_splats"])
-def test_tile_culling_is_exact(oracle, case):
-    """Product default (emission-time tile culling) vs the reference emission policy: the culled list is the
-    reference list minus instances no pixel of the tile accepts; images are bit-identical; gradients agree."""
+def test_tile_culling_is_exact(oracle, case, mode):
+    """Culled emission policies vs the reference policy: per 16-px tile the entries the blend kernel takes (the
+    parent tile's list filtered by the tile's bit in the child mask) are the reference list minus instances no pixel
+    of the tile accepts; images are bit-identical."""
     from gpu_utils import forward_state
     from gaussianmesh_amd import scenes
     if case == "small":
@@ -184,33 +190,46 @@ def test_tile_culling_is_exact(oracle, case):
         sc = scenes.make_cloud(300, seed=5, scale_lo=0.02, scale_hi=2.5); cam = scenes.orbit_camera(1, 5, 320, 200, radius=7.0)
     bg = np.array([0.3, 0.6, 0.1], np.float32)
     fw = oracle.forward_full(sc, cam, bg, D=3)
-    ex = forward_state(sc, cam, bg, D=3, tile_cull=False)
-    cu = forward_state(sc, cam, bg, D=3, tile_cull=True)
+    ex = forward_state(sc, cam, bg, D=3, tile_cull=0)
+    cu = forward_state(sc, cam, bg, D=3, tile_cull=mode)
     assert np.array_equal(ex["point_list"], fw["bins"]["point_list"])
     assert np.array_equal(cu["radii"], ex["radii"])
     assert cu["R"] <= ex["R"]
     # images: same per-pixel arithmetic on the same accepted entries -> identical bits
     assert np.array_equal(cu["color"], ex["color"])
     assert np.array_equal(cu["final_T"], ex["final_T"])
-    # list structure: per tile, culled list is an order-preserving subsequence of the reference list ...
+    # parent lists: keys sorted, ranges delimit them
+    sh = max(mode - 1, 0); m = (1 << sh) - 1
+    gx, gy = (cam["W"] + 15) // 16, (cam["H"] + 15) // 16
+    pgx = (gx + m) >> sh
+    assert np.all(np.diff(cu["tile_keys"].astype(np.int64)) >= 0)
+    for p in range(cu["ranges"].shape[0]):
+        b0, b1 = cu["ranges"][p]
+        assert np.all(cu["tile_keys"][b0:b1] == p)
+    assert sum(int(b1 - b0) for b0, b1 in cu["ranges"]) == cu["R"]
+    # list structure: per 16-px tile, the taken entries are an order-preserving subsequence of the reference list ...
     needed = oracle.instance_needed(cam["W"], cam["H"], fw["bins"], fw["geo"]).astype(bool)
-    tile_of = (fw["bins"]["keys"] >> np.uint64(32)).astype(np.uint32)
     kept = np.zeros(ex["R"], bool)
-    for t in range(ex["ranges"].shape[0]):
-        a0, a1 = ex["ranges"][t]; b0, b1 = cu["ranges"][t]
-        ref = ex["point_list"][a0:a1]; sub = cu["point_list"][b0:b1]
+    for t in range(gx * gy):
+        tx, ty = t % gx, t // gx
+        p = (ty >> sh) * pgx + (tx >> sh); c = ((ty & m) << sh) | (tx & m)
+        a0, a1 = ex["ranges"][t]; b0, b1 = cu["ranges"][p]
+        ref = ex["point_list"][a0:a1]
+        sub = cu["point_list"][b0:b1][((cu["child_mask"][b0:b1] >> c) & 1) == 1]
         j = 0
         for g in sub:                            # two-pointer subsequence check (ids are unique within a tile)
             while j < len(ref) and ref[j] != g:
                 j += 1
-            assert j < len(ref), "culled list is not a subsequence of the reference list in tile %d" % t
+            assert j < len(ref), "taken entries are not a subsequence of the reference list in tile %d" % t
             kept[a0 + j] = True
             j += 1
     # ... that contains every instance some pixel accepts (conservative), and drops a good share of the others
     assert not (needed & ~kept).any()
-    assert np.array_equal(cu["tile_keys"], tile_of[kept])
+    if mode == 1:
+        tile_of = (fw["bins"]["keys"] >> np.uint64(32)).astype(np.uint32)
+        assert np.array_equal(cu["tile_keys"], tile_of[kept]) and np.all(cu["child_mask"] == 1)
     if case != "small":
-        assert cu["R"] < 0.8 * ex["R"]
+        assert cu["R"] < (0.8, 0.5, 0.35)[mode - 1] * ex["R"]
 
 
 def test_tile_culling_gradients_match_reference_policy(oracle):
@@ -221,11 +240,12 @@ def test_tile_culling_gradients_match_reference_policy(oracle):
     dpix = np.random.default_rng(1).normal(size=(3, cam["H"], cam["W"])).astype(np.float32)
     _lib.lib().gm_set_tile_culling(0)
     c0, r0, g0 = _grads_gpu(sc, cam, bg, dpix, D, False, False)
-    _lib.lib().gm_set_tile_culling(1)
-    c1, r1, g1 = _grads_gpu(sc, cam, bg, dpix, D, False, False)
-    assert np.array_equal(c0, c1) and np.array_equal(r0, r1)
-    for k in g0:
-        assert _rel(g1[k], g0[k]) <= 1e-5, k       # same terms, only the float-atomic summation order differs
+    for mode in (1, 2, 3):
+        _lib.lib().gm_set_tile_culling(mode)
+        c1, r1, g1 = _grads_gpu(sc, cam, bg, dpix, D, False, False)
+        assert np.array_equal(c0, c1) and np.array_equal(r0, r1)
+        for k in g0:
+            assert _rel(g1[k], g0[k]) <= 1e-5, (mode, k)       # same terms, only the float-atomic summation order differs
 
 
 def test_edge_cases(oracle):
