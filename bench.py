@@ -105,7 +105,7 @@ def main():
     import torch.distributed as dist
     from gaussianmesh_amd import _lib, multiview, scenes
     from gaussianmesh_amd import rasterizer as Rz
-    from gaussianmesh_amd.deform import deform_shade
+    from gaussianmesh_amd.deform import deform_shade_packed, pack_mesh_state
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -185,10 +185,9 @@ def main():
             ms = multiview.broadcast_mesh_state(frame_buf, src=0)
         else:
             ms = g["mesh"][t]
-        V1, Rv, Sv = multiview.unpack_mesh_state(ms)
-        dV = V1 - g["verts"]
+        packed = pack_mesh_state(ms, g["verts"])            # [Vm,21] frame state -> per-vertex gather table (one small kernel)
         c = cam_t[multiview.view_for_step(i, F, rank, world)]
-        pos, cov6, rgb = deform_shade(g["tri"], g["weights"], dV, Rv, Sv, g["cov"], g["pos"], g["shs"], c["campos"], deg=3)
+        pos, cov6, rgb = deform_shade_packed(g["tri"], g["weights"], packed, g["cov"], g["pos"], g["shs"], c["campos"], deg=3)
         if begin_only:
             return Rz.rasterize_forward_begin(bg, pos, rgb, g["opac"], None, None, 1.0, cov6, c["view"], c["proj"], c["tanx"],
                                               c["tany"], H, W, None, 3, c["campos"], False, False, workspace=workspace)

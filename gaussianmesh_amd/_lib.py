@@ -42,6 +42,8 @@ SIGNATURES = {
     "gm_deform": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gm_sh_colors": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "gm_deform_shade": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "gm_pack_mesh_state": (i32, [i32, vp, vp, vp, vp]),
+    "gm_deform_shade_packed": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gm_cov_to_scale_rot": (i32, [i32, vp, vp, vp, vp]),
     "gm_ssim_partials": (i64, [i32, i32, i32]),
     "gm_ssim_fwd": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),

@@ -299,6 +299,24 @@ int gm_deform_shade(int N, int deg, int M, const int* tri, const float* w, const
                              reinterpret_cast<hipStream_t>(stream));
 }
 
+int gm_pack_mesh_state(int Vm, const float* state, const float* verts, float* packed, void* stream) {
+  if (Vm < 0 || (Vm > 0 && (!state || !verts || !packed))) { set_error("gm_pack_mesh_state: bad args"); return GM_ERR_INVALID_ARG; }
+  if (Vm > 0 && (reinterpret_cast<uintptr_t>(packed) & 15)) { set_error("gm_pack_mesh_state: packed must be 16-byte aligned"); return GM_ERR_INVALID_ARG; }
+  return launch_pack_mesh_state(Vm, state, verts, packed, reinterpret_cast<hipStream_t>(stream));
+}
+
+int gm_deform_shade_packed(int N, int deg, int M, const int* tri, const float* w, const float* packed, const float* cov,
+                           const float* pos, const float* shs, const float* campos, float* pos_out, float* cov6_out,
+                           float* rgb_out, float* cov_out, float* rot_out, void* stream) {
+  if (N < 0 || deg < 0 || deg > 3 || M < (deg + 1) * (deg + 1) ||
+      (N > 0 && (!tri || !w || !packed || !cov || !pos || !shs || !campos || !pos_out || !cov6_out || !rgb_out)) ||
+      ((cov_out == nullptr) != (rot_out == nullptr))) {
+    set_error("gm_deform_shade_packed: bad args"); return GM_ERR_INVALID_ARG;
+  }
+  return launch_deform_shade_packed(N, deg, M, tri, w, packed, cov, pos, shs, campos, pos_out, cov6_out, rgb_out, cov_out, rot_out,
+                                    reinterpret_cast<hipStream_t>(stream));
+}
+
 int gm_cov_to_scale_rot(int N, const float* cov, float* scales, float* rots, void* stream) {
   if (N < 0 || (N > 0 && (!cov || !scales || !rots))) { set_error("gm_cov_to_scale_rot: bad args"); return GM_ERR_INVALID_ARG; }
   if (N > 0 && (reinterpret_cast<uintptr_t>(rots) & 15)) { set_error("gm_cov_to_scale_rot: rots must be 16-byte aligned"); return GM_ERR_INVALID_ARG; }

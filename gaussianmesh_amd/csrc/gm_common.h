@@ -209,6 +209,10 @@ int launch_sh_colors(int N, int deg, int M, const float* pos, const float* campo
 int launch_deform_shade(int N, int deg, int M, const int* tri, const float* w, const float* dV, const float* Rv, const float* Sv,
                         const float* cov, const float* pos, const float* shs, const float* campos, float* pos_out,
                         float* cov6_out, float* rgb_out, float* cov_out, float* rot_out, hipStream_t s);
+int launch_pack_mesh_state(int Vm, const float* state, const float* verts, float* packed, hipStream_t s);
+int launch_deform_shade_packed(int N, int deg, int M, const int* tri, const float* w, const float* packed, const float* cov,
+                               const float* pos, const float* shs, const float* campos, float* pos_out, float* cov6_out,
+                               float* rgb_out, float* cov_out, float* rot_out, hipStream_t s);
 int launch_cov_to_scale_rot(int N, const float* cov, float* scales, float* rots, hipStream_t s);
 int launch_ssim_fwd(const float* img1, const float* img2, int planes, int H, int W, float* d_mu1, float* d_e11, float* d_e12,
                     float* partial, hipStream_t s);

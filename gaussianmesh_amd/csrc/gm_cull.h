@@ -49,6 +49,8 @@ __device__ __forceinline__ bool may_touch(float sx, float sy, float a, float b, 
 // would keep (up to the conservative epsilons) at a cost per row instead of per tile.
 // With d = centre - pixel, for fixed dy the ellipse spans dx in (-b dy -+ sqrt(a lim - det dy^2)) / a; over a band the
 // upper end is concave in dy (max at an end point or at dy = -dystar where it equals xext), the lower end convex.
+// The three functions below run with FMA contraction off in every translation unit: preprocess (instance counts) and
+// duplicate_kernel (instance emission) must make identical decisions.
 struct TileCull {
   float a, b, inv_a, lim, det, dymax, xext, dystar;
   int mode;          // 0 = nothing reachable, 1 = use row_span, 2 = keep every tile (degenerate conic / NaN)
@@ -56,6 +58,7 @@ struct TileCull {
 
 __device__ __forceinline__ TileCull tile_cull_setup(float sx, float sy, float a, float b, float c, float op,
                                                     float rx0, float rx1, float ry0, float ry1) {
+#pragma clang fp contract(off)
   TileCull t;
   t.a = a; t.b = b; t.inv_a = __builtin_amdgcn_rcpf(a);
   t.mode = 1;
@@ -74,6 +77,7 @@ __device__ __forceinline__ TileCull tile_cull_setup(float sx, float sy, float a,
 
 // pixel-x interval [A, B] reachable inside pixel rows [py0, py1]; false if the band is out of reach
 __device__ __forceinline__ bool row_span(const TileCull& t, float sx, float sy, float py0, float py1, float& A, float& B) {
+#pragma clang fp contract(off)
   float dyl = fmaxf(sy - py1, -t.dymax), dyh = fminf(sy - py0, t.dymax);
   if (!(dyl <= dyh)) return false;
   const float sl = sqrtf(fmaxf(t.a * t.lim - t.det * dyl * dyl, 0.f)), sh = sqrtf(fmaxf(t.a * t.lim - t.det * dyh * dyh, 0.f));
@@ -89,6 +93,7 @@ __device__ __forceinline__ bool row_span(const TileCull& t, float sx, float sy, 
 
 // tiles [ta, tb] (inclusive, clamped to [x0, x1)) of tile row ty that are emitted; false if none
 __device__ __forceinline__ bool row_tiles(const TileCull& t, float sx, float sy, int ty, int x0, int x1, int& ta, int& tb) {
+#pragma clang fp contract(off)
   if (t.mode == 0) return false;
   ta = x0; tb = x1 - 1;
   if (t.mode == 2) return true;

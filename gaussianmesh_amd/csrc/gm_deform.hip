@@ -111,7 +111,10 @@ int launch_sh_colors(int N, int deg, int M, const float* pos, const float* campo
 // Reads 264 B and writes 48 B per Gaussian (+72 B if the caller also wants Sigma' and rot), against
 // 72+108 (deform) + 240+12 (colour) for the two separate kernels.  SH and covariance rows go through LDS
 // (gm_stage.h), results leave through LDS as coalesced 16-byte stores.
-template <int DS_THREADS>
+// PACKED: dV points at the per-vertex table written by pack_mesh_state_kernel (6 float4 per vertex:
+// {dV,0} {R0..3} {R4..7} {R8,S0,S1,S2} {S3..6} {S7,S8,0,0}); the three vertex gathers of a Gaussian are then 18 16-byte
+// loads instead of 63 4-byte ones (Rv / Sv unused).
+template <int DS_THREADS, bool PACKED = false>
 __global__ __launch_bounds__(DS_THREADS) void deform_shade_kernel(int N, int deg, const int* __restrict__ tri, const float* __restrict__ w,
                                                                   const float* __restrict__ dV, const float* __restrict__ Rv,
                                                                   const float* __restrict__ Sv, const float* __restrict__ cov,
@@ -137,12 +140,31 @@ __global__ __launch_bounds__(DS_THREADS) void deform_shade_kernel(int N, int deg
     p0 = pos[3 * i]; p1 = pos[3 * i + 1]; p2 = pos[3 * i + 2];
   }
   float d[3], Rb[9], Sb[9];
+  if (PACKED) {
+    const float4* tab = reinterpret_cast<const float4*>(dV);
+    float va[24], vb[24], vc[24];
 #pragma unroll
-  for (int k = 0; k < 3; k++) d[k] = (w0 * dV[3 * (size_t)t0 + k] + w1 * dV[3 * (size_t)t1 + k]) + w2 * dV[3 * (size_t)t2 + k];
+    for (int q = 0; q < 6; q++) {
+      const float4 a = tab[6 * (size_t)t0 + q], b = tab[6 * (size_t)t1 + q], c = tab[6 * (size_t)t2 + q];
+      va[4 * q] = a.x; va[4 * q + 1] = a.y; va[4 * q + 2] = a.z; va[4 * q + 3] = a.w;
+      vb[4 * q] = b.x; vb[4 * q + 1] = b.y; vb[4 * q + 2] = b.z; vb[4 * q + 3] = b.w;
+      vc[4 * q] = c.x; vc[4 * q + 1] = c.y; vc[4 * q + 2] = c.z; vc[4 * q + 3] = c.w;
+    }
 #pragma unroll
-  for (int k = 0; k < 9; k++) {
-    Rb[k] = (w0 * Rv[9 * (size_t)t0 + k] + w1 * Rv[9 * (size_t)t1 + k]) + w2 * Rv[9 * (size_t)t2 + k];
-    Sb[k] = (w0 * Sv[9 * (size_t)t0 + k] + w1 * Sv[9 * (size_t)t1 + k]) + w2 * Sv[9 * (size_t)t2 + k];
+    for (int k = 0; k < 3; k++) d[k] = (w0 * va[k] + w1 * vb[k]) + w2 * vc[k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      Rb[k] = (w0 * va[4 + k] + w1 * vb[4 + k]) + w2 * vc[4 + k];
+      Sb[k] = (w0 * va[13 + k] + w1 * vb[13 + k]) + w2 * vc[13 + k];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 3; k++) d[k] = (w0 * dV[3 * (size_t)t0 + k] + w1 * dV[3 * (size_t)t1 + k]) + w2 * dV[3 * (size_t)t2 + k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      Rb[k] = (w0 * Rv[9 * (size_t)t0 + k] + w1 * Rv[9 * (size_t)t1 + k]) + w2 * Rv[9 * (size_t)t2 + k];
+      Sb[k] = (w0 * Sv[9 * (size_t)t0 + k] + w1 * Sv[9 * (size_t)t1 + k]) + w2 * Sv[9 * (size_t)t2 + k];
+    }
   }
   __syncthreads();
   {
@@ -206,6 +228,191 @@ __global__ __launch_bounds__(DS_THREADS) void deform_shade_kernel(int N, int deg
     unstage_rows<9, 9, DS_THREADS>(cov_out, row0, nrows, o_cov);
     unstage_rows<9, 9, DS_THREADS>(rot_out, row0, nrows, o_rot);
   }
+}
+
+// One-wave variant that brings the block's SH and covariance rows into LDS with the LDS-DMA path
+// (global_load_lds_dwordx4: no staging registers, no ds_write pass, and the loads are in flight while the wave gathers
+// its vertices): per wave the dependent memory rounds drop from three (rows -> ids -> vertex gathers) to two
+// (ids -> {rows DMA, vertex gathers}).  The LDS image is the linear image of the rows (a DMA instruction writes
+// wave-uniform base + lane x 16 B); the 192-byte row stride makes the per-thread b128 reads bank-conflicted, which is
+// immaterial next to the memory latency this kernel is bound by.
+__device__ __forceinline__ void dma16(const void* g, void* lds_base) {
+  __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)g, (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+template <bool PACKED>
+__global__ __launch_bounds__(64) void deform_shade_dma_kernel(int N, int deg, const int* __restrict__ tri, const float* __restrict__ w,
+                                                                  const float* __restrict__ dV, const float* __restrict__ Rv,
+                                                                  const float* __restrict__ Sv, const float* __restrict__ cov,
+                                                                  const float* __restrict__ pos, const float* __restrict__ shs,
+                                                                  const float* __restrict__ campos, float* __restrict__ pos_out,
+                                                                  float* __restrict__ cov6_out, float* __restrict__ rgb_out,
+                                                                  float* __restrict__ cov_out, float* __restrict__ rot_out) {
+  constexpr int DS_THREADS = 64;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float4* l_sh = reinterpret_cast<float4*>(lds);   // [64][12] granules: linear image of the block's SH rows (12 KiB)
+  float* l_cov = lds + DS_THREADS * 48;            // [64][9] linear image of the covariance rows (2.25 KiB)
+  const size_t row0 = (size_t)blockIdx.x * DS_THREADS;
+  const int nrows = min(DS_THREADS, N - (int)row0);
+  const int t = threadIdx.x;
+  const size_t i = row0 + t;
+  const bool live = t < nrows;
+  float O[9], Rt[9], npos[3], col[3];
+  int t0 = 0, t1 = 0, t2 = 0; float w0 = 0.f, w1 = 0.f, w2 = 0.f, p0 = 0.f, p1 = 0.f, p2 = 0.f;
+  if (live) {
+    t0 = tri[3 * i]; t1 = tri[3 * i + 1]; t2 = tri[3 * i + 2];
+    w0 = w[3 * i]; w1 = w[3 * i + 1]; w2 = w[3 * i + 2];
+    p0 = pos[3 * i]; p1 = pos[3 * i + 1]; p2 = pos[3 * i + 2];
+  }
+  // ids are in (first use below waits for them); now start the row DMA, then the vertex gathers behind it
+  __builtin_amdgcn_sched_barrier(0);
+  if (nrows == DS_THREADS) {
+    const char* gsh = reinterpret_cast<const char*>(shs + row0 * 48) + t * 16;
+#pragma unroll
+    for (int q = 0; q < 12; q++) dma16(gsh + q * 1024, reinterpret_cast<char*>(l_sh) + q * 1024);
+    const char* gcv = reinterpret_cast<const char*>(cov + row0 * 9) + t * 16;
+    dma16(gcv, reinterpret_cast<char*>(l_cov));
+    dma16(gcv + 1024, reinterpret_cast<char*>(l_cov) + 1024);
+    if (t < 16) dma16(gcv + 2048, reinterpret_cast<char*>(l_cov) + 2048);
+  } else if (live) {                               // last, partial block: plain copies of the thread's own rows
+#pragma unroll
+    for (int c = 0; c < 12; c++) l_sh[t * 12 + c] = reinterpret_cast<const float4*>(shs)[i * 12 + c];
+#pragma unroll
+    for (int c = 0; c < 9; c++) l_cov[t * 9 + c] = cov[i * 9 + c];
+  }
+  float d[3], Rb[9], Sb[9];
+  if (PACKED) {
+    const float4* tab = reinterpret_cast<const float4*>(dV);
+    float va[24], vb[24], vc[24];
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+      const float4 a = tab[6 * (size_t)t0 + q], b = tab[6 * (size_t)t1 + q], c = tab[6 * (size_t)t2 + q];
+      va[4 * q] = a.x; va[4 * q + 1] = a.y; va[4 * q + 2] = a.z; va[4 * q + 3] = a.w;
+      vb[4 * q] = b.x; vb[4 * q + 1] = b.y; vb[4 * q + 2] = b.z; vb[4 * q + 3] = b.w;
+      vc[4 * q] = c.x; vc[4 * q + 1] = c.y; vc[4 * q + 2] = c.z; vc[4 * q + 3] = c.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) d[k] = (w0 * va[k] + w1 * vb[k]) + w2 * vc[k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      Rb[k] = (w0 * va[4 + k] + w1 * vb[4 + k]) + w2 * vc[4 + k];
+      Sb[k] = (w0 * va[13 + k] + w1 * vb[13 + k]) + w2 * vc[13 + k];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 3; k++) d[k] = (w0 * dV[3 * (size_t)t0 + k] + w1 * dV[3 * (size_t)t1 + k]) + w2 * dV[3 * (size_t)t2 + k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      Rb[k] = (w0 * Rv[9 * (size_t)t0 + k] + w1 * Rv[9 * (size_t)t1 + k]) + w2 * Rv[9 * (size_t)t2 + k];
+      Sb[k] = (w0 * Sv[9 * (size_t)t0 + k] + w1 * Sv[9 * (size_t)t1 + k]) + w2 * Sv[9 * (size_t)t2 + k];
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): the DMA has landed
+  __syncthreads();
+  {
+    float RS[9], A[9], C[9];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) Rt[3 * a + b] = Rb[3 * b + a];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) RS[3 * a + b] = (Rt[3 * a] * Sb[b] + Rt[3 * a + 1] * Sb[3 + b]) + Rt[3 * a + 2] * Sb[6 + b];
+#pragma unroll
+    for (int k = 0; k < 9; k++) C[k] = l_cov[t * 9 + k];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) A[3 * a + b] = (RS[3 * a] * C[b] + RS[3 * a + 1] * C[3 + b]) + RS[3 * a + 2] * C[6 + b];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) O[3 * a + b] = (A[3 * a] * RS[3 * b] + A[3 * a + 1] * RS[3 * b + 1]) + A[3 * a + 2] * RS[3 * b + 2];
+    npos[0] = p0 + d[0]; npos[1] = p1 + d[1]; npos[2] = p2 + d[2];
+    float dx = npos[0] - campos[0], dy = npos[1] - campos[1], dz = npos[2] - campos[2];
+    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    dx = dx / len; dy = dy / len; dz = dz / len;
+    // dir_rot = rot^T dir with rot = Rt
+    const float x = (Rt[0] * dx + Rt[3] * dy) + Rt[6] * dz;
+    const float y = (Rt[1] * dx + Rt[4] * dy) + Rt[7] * dz;
+    const float z = (Rt[2] * dx + Rt[5] * dy) + Rt[8] * dz;
+    float sh[48];
+#pragma unroll
+    for (int c = 0; c < 12; c++) {
+      const float4 v = l_sh[t * 12 + c];
+      sh[4 * c] = v.x; sh[4 * c + 1] = v.y; sh[4 * c + 2] = v.z; sh[4 * c + 3] = v.w;
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+      const float r = sh_channel(deg, [&](int k) { return sh[3 * k + ch]; }, x, y, z);
+      col[ch] = fmaxf(r + 0.5f, 0.0f);
+    }
+  }
+  __syncthreads();                               // everyone is done reading the staged inputs: reuse LDS for the outputs
+  float* o_pos = lds;                            // [256][3]
+  float* o_rgb = lds + DS_THREADS * 3;           // [256][3]
+  float* o_c6 = lds + DS_THREADS * 6;            // [256][6]  (stride 7 to stay conflict-free)
+  float* o_cov = lds + DS_THREADS * 13;          // [256][9]
+  float* o_rot = lds + DS_THREADS * 22;          // [256][9]
+#pragma unroll
+  for (int k = 0; k < 3; k++) { o_pos[t * 3 + k] = npos[k]; o_rgb[t * 3 + k] = col[k]; }
+  o_c6[t * 7 + 0] = O[0]; o_c6[t * 7 + 1] = O[1]; o_c6[t * 7 + 2] = O[2]; o_c6[t * 7 + 3] = O[4]; o_c6[t * 7 + 4] = O[5]; o_c6[t * 7 + 5] = O[8];
+  if (cov_out) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) { o_cov[t * 9 + k] = O[k]; o_rot[t * 9 + k] = Rt[k]; }
+  }
+  __syncthreads();
+  unstage_rows<3, 3, DS_THREADS>(pos_out, row0, nrows, o_pos);
+  unstage_rows<3, 3, DS_THREADS>(rgb_out, row0, nrows, o_rgb);
+  unstage_rows<6, 7, DS_THREADS>(cov6_out, row0, nrows, o_c6);
+  if (cov_out) {
+    unstage_rows<9, 9, DS_THREADS>(cov_out, row0, nrows, o_cov);
+    unstage_rows<9, 9, DS_THREADS>(rot_out, row0, nrows, o_rot);
+  }
+}
+
+// mesh state of one deformation frame, as broadcast to the ranks ([Vm][21] = V1 | R | S), minus the rest pose -> the
+// gather table of deform_shade_kernel<.., true>
+__global__ __launch_bounds__(256) void pack_mesh_state_kernel(int Vm, const float* __restrict__ state, const float* __restrict__ verts,
+                                                               float4* __restrict__ packed) {
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= Vm) return;
+  const float* s = state + 21 * (size_t)v;
+  float4* o = packed + 6 * (size_t)v;
+  o[0] = make_float4(s[0] - verts[3 * (size_t)v], s[1] - verts[3 * (size_t)v + 1], s[2] - verts[3 * (size_t)v + 2], 0.f);
+  o[1] = make_float4(s[3], s[4], s[5], s[6]);
+  o[2] = make_float4(s[7], s[8], s[9], s[10]);
+  o[3] = make_float4(s[11], s[12], s[13], s[14]);
+  o[4] = make_float4(s[15], s[16], s[17], s[18]);
+  o[5] = make_float4(s[19], s[20], 0.f, 0.f);
+}
+
+int launch_pack_mesh_state(int Vm, const float* state, const float* verts, float* packed, hipStream_t s) {
+  if (Vm <= 0) return 0;
+  StageScope sc(ST_DEFORM, s);
+  hipLaunchKernelGGL(pack_mesh_state_kernel, dim3((Vm + 255) / 256), dim3(256), 0, s, Vm, state, verts, reinterpret_cast<float4*>(packed));
+  GM_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_deform_shade_packed(int N, int deg, int M, const int* tri, const float* w, const float* packed, const float* cov,
+                               const float* pos, const float* shs, const float* campos, float* pos_out, float* cov6_out,
+                               float* rgb_out, float* cov_out, float* rot_out, hipStream_t s) {
+  if (N <= 0) return 0;
+  if (M != 16 || !aligned16(shs) || !aligned16(cov) || !aligned16(pos_out) || !aligned16(cov6_out) || !aligned16(rgb_out) ||
+      !aligned16(packed) || (cov_out && (!aligned16(cov_out) || !aligned16(rot_out)))) {
+    set_error("gm_deform_shade_packed: needs M == 16 and 16-byte aligned buffers"); return 1;
+  }
+  StageScope sc(ST_DEFORM, s);
+  const size_t lds_bytes = sizeof(float) * 64 * (48 + 9);
+  if (getenv("GM_DS_NO_DMA"))
+    hipLaunchKernelGGL((deform_shade_kernel<64, true>), dim3((N + 63) / 64), dim3(64), sizeof(float) * 64 * (52 + 9), s, N, deg, tri, w, packed,
+                       nullptr, nullptr, cov, pos, shs, campos, pos_out, cov6_out, rgb_out, cov_out, rot_out);
+  else
+    hipLaunchKernelGGL((deform_shade_dma_kernel<true>), dim3((N + 63) / 64), dim3(64), lds_bytes, s, N, deg, tri, w, packed, nullptr, nullptr,
+                       cov, pos, shs, campos, pos_out, cov6_out, rgb_out, cov_out, rot_out);
+  GM_HIP(hipGetLastError());
+  return 0;
 }
 
 int launch_deform_shade(int N, int deg, int M, const int* tri, const float* w, const float* dV, const float* Rv, const float* Sv,

@@ -84,6 +84,44 @@ def deform_shade(tri, w, dV, Rv, Sv, cov, pos, shs, campos, deg=3, want_cov_rot=
     return (pos_o, cov6, rgb, cov_o, rot_o) if want_cov_rot else (pos_o, cov6, rgb)
 
 
+def pack_mesh_state(state, verts, out=None):
+    """gm_pack_mesh_state: [Vm,21] frame state (V1 | R | S) and rest pose verts [Vm,3] -> gather table [Vm,24]."""
+    lib = _lib.lib()
+    device = state.device
+    if device.type != "cuda":
+        raise _lib.GmeshError("pack_mesh_state needs tensors on a HIP (cuda) device; there is no CPU path")
+    state, verts = _f(state), _f(verts)
+    Vm = state.shape[0]
+    if state.shape[1] != 21 or verts.shape != (Vm, 3):
+        raise ValueError("pack_mesh_state: state must be [Vm,21] and verts [Vm,3]")
+    packed = out if out is not None else torch.empty((Vm, 24), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        _lib.check(lib.gm_pack_mesh_state(Vm, state.data_ptr(), verts.data_ptr(), packed.data_ptr(),
+                                          torch.cuda.current_stream(device).cuda_stream))
+    return packed
+
+
+def deform_shade_packed(tri, w, packed, cov, pos, shs, campos, deg=3, want_cov_rot=False):
+    """gm_deform_shade_packed: deform_shade with the per-vertex (dV, R, S) read from pack_mesh_state()'s table."""
+    lib = _lib.lib()
+    device = pos.device
+    if device.type != "cuda":
+        raise _lib.GmeshError("deform_shade needs tensors on a HIP (cuda) device; there is no CPU path")
+    tri = tri.detach().contiguous().to(torch.int32)
+    w, packed, cov, pos, shs, campos = (_f(t) for t in (w, packed, cov, pos, shs, campos))
+    N, M = pos.shape[0], shs.shape[1]
+    f = dict(dtype=torch.float32, device=device)
+    pos_o = torch.empty((N, 3), **f); cov6 = torch.empty((N, 6), **f); rgb = torch.empty((N, 3), **f)
+    cov_o = torch.empty((N, 3, 3), **f) if want_cov_rot else None
+    rot_o = torch.empty((N, 3, 3), **f) if want_cov_rot else None
+    with torch.cuda.device(device):
+        _lib.check(lib.gm_deform_shade_packed(N, int(deg), M, tri.data_ptr(), w.data_ptr(), packed.data_ptr(), cov.data_ptr(),
+                                              pos.data_ptr(), shs.data_ptr(), campos.data_ptr(), pos_o.data_ptr(), cov6.data_ptr(),
+                                              rgb.data_ptr(), None if cov_o is None else cov_o.data_ptr(),
+                                              None if rot_o is None else rot_o.data_ptr(), torch.cuda.current_stream(device).cuda_stream))
+    return (pos_o, cov6, rgb, cov_o, rot_o) if want_cov_rot else (pos_o, cov6, rgb)
+
+
 def cov_to_scale_rot(cov):
     """gm_cov_to_scale_rot: (scales [N,3], rotations [N,4]) whose covariance R diag(s^2) R^T equals cov [N,3,3]
     (the SceneVisualTool route: edittool/__init__.py:204-207, rasterised with scales/rotations instead of cov3D_precomp)."""

@@ -165,6 +165,16 @@ int gm_deform_shade(int N, int deg, int M, const int* tri, const float* w, const
                     const float* cov, const float* pos, const float* shs, const float* campos, float* pos_out, float* cov6_out,
                     float* rgb_out, float* cov_out, float* rot_out, void* stream);
 
+/* The same step for a render loop that receives the mesh state of a frame as ONE [Vm][21] array (V1 | R | S per vertex,
+ * what rank 0 broadcasts per deformation frame): gm_pack_mesh_state subtracts the rest pose verts [Vm,3] and writes the
+ * gather table packed (float [Vm][24], 16-byte aligned: {dV,0} {R0..3} {R4..7} {R8,S0,S1,S2} {S3..6} {S7,S8,0,0});
+ * gm_deform_shade_packed is gm_deform_shade reading that table (18 16-byte gathers per Gaussian instead of 63 4-byte
+ * ones).  Needs M == 16 and 16-byte aligned shs / cov / outputs. */
+int gm_pack_mesh_state(int Vm, const float* state, const float* verts, float* packed, void* stream);
+int gm_deform_shade_packed(int N, int deg, int M, const int* tri, const float* w, const float* packed, const float* cov,
+                           const float* pos, const float* shs, const float* campos, float* pos_out, float* cov6_out,
+                           float* rgb_out, float* cov_out, float* rot_out, void* stream);
+
 /* Covariance -> (scale, rotation): replaces the per-frame eigh + host-side det sign + sqrt + matrix->quaternion of
  * SceneVisualTool.render_gaussian (edittool/__init__.py:204-207, 23-38).  cov float [N,3,3] (symmetric),
  * scales float [N,3] = sqrt of the eigenvalues in ascending order, rots float [N,4] = unit quaternion (w,x,y,z) of the

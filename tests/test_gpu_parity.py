@@ -335,6 +335,18 @@ def test_deform_and_sh_colors(oracle):
     assert np.array_equal(frgb, rgb_sep)
     fp2, fc62, frgb2 = (x.cpu().numpy() for x in deform_shade(*args, deg=3))
     assert np.array_equal(fp2, p) and np.array_equal(fc62, c6) and np.array_equal(frgb2, rgb_sep)
+    # packed per-vertex table (what the render loop uses on the broadcast [Vm,21] frame state): same bits again
+    from gaussianmesh_amd.deform import deform_shade_packed, pack_mesh_state
+    state = np.concatenate([V1.astype(np.float32), Rv.reshape(-1, 9), Sv.reshape(-1, 9)], axis=1).astype(np.float32)
+    packed = pack_mesh_state(T(state), T(verts.astype(np.float32)))
+    pk = packed.cpu().numpy()
+    assert np.array_equal(pk[:, 0:3], (state[:, 0:3] - verts.astype(np.float32))) and np.array_equal(pk[:, 4:13], state[:, 3:12])
+    assert np.array_equal(pk[:, 13:22], state[:, 12:21]) and (pk[:, [3, 22, 23]] == 0).all()
+    pargs = (T(cl["tri"], dtype=torch.int32), T(cl["weights"]), packed, T(cov), T(cl["means"]), T(cl["shs"]), T(campos))
+    qp, qc6, qrgb, qcov, qrot = (x.cpu().numpy() for x in deform_shade_packed(*pargs, deg=3, want_cov_rot=True))
+    dV32 = T(pk[:, 0:3].copy())
+    rp, rc6, rrgb = (x.cpu().numpy() for x in deform_shade(args[0], args[1], dV32, *args[3:], deg=3))
+    assert np.array_equal(qp, rp) and np.array_equal(qc6, rc6) and np.array_equal(qrgb, rrgb) and np.array_equal(qrot, r)
 
 
 def test_cov_to_scale_rot(oracle):
