@@ -59,6 +59,9 @@ def algorithmic_bytes(stage, P, V, R, W, H, Vm, M=16):
     bits = max(1, int(np.ceil(np.log2(max(T, 2)))))
     return {
         "deform": P * (12 + 12 + 36 + 12 + 12 * M) + P * (12 + 24 + 12) + Vm * 84,     # fused deform + colour
+        # deform + colour + forward preprocess in one kernel: the 48 B/Gaussian of intermediates disappear, the
+        # preprocess outputs (splat 48 B per visible Gaussian; radius, count, bin, depth key 28 B) and opacity appear
+        "deform_pre": P * (12 + 12 + 36 + 12 + 12 * M + 4) + Vm * (84 + 96) + V * 48 + P * 28,
         "sh_colors": P * (12 + 36 + 12 * M) + P * 12,
         "preprocess": P * (12 + 24 + 4 + 12) + V * 48,
         "scan": P * 8,
@@ -94,6 +97,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cameras", type=int, default=64)
+    ap.add_argument("--unfused", action="store_true", help="deform+colour and the forward preprocess as two kernels (gm_deform_shade_packed, gm_forward_0_async)")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the frame loop alternates over (frame i runs on stream i %% streams): consecutive frames are "
                          "independent, so frame i+1's per-Gaussian stages overlap the low-occupancy tail of frame i's blend")
@@ -187,6 +191,16 @@ def main():
             ms = g["mesh"][t]
         packed = pack_mesh_state(ms, g["verts"])            # [Vm,21] frame state -> per-vertex gather table (one small kernel)
         c = cam_t[multiview.view_for_step(i, F, rank, world)]
+        if begin_only and not args.unfused:      # one enqueue: deform + colour + preprocess + depth sort + instance count
+            return Rz.forward_deformed_begin(bg, g["tri"], g["weights"], packed, g["cov"], g["pos"], g["shs"], g["opac"], c["view"],
+                                             c["proj"], c["tanx"], c["tany"], H, W, 3, c["campos"], False, workspace=workspace)
+        if not args.unfused:                     # same path, completed at once (per-stage timing pass)
+            nr, color, radii, _, _, _ = Rz.forward_deformed_begin(bg, g["tri"], g["weights"], packed, g["cov"], g["pos"], g["shs"], g["opac"],
+                                                                  c["view"], c["proj"], c["tanx"], c["tany"], H, W, 3, c["campos"], False,
+                                                                  workspace=workspace).finish()
+            stats["R"] = nr
+            stats["radii"] = radii
+            return color
         pos, cov6, rgb = deform_shade_packed(g["tri"], g["weights"], packed, g["cov"], g["pos"], g["shs"], c["campos"], deg=3)
         if begin_only:
             return Rz.rasterize_forward_begin(bg, pos, rgb, g["opac"], None, None, 1.0, cov6, c["view"], c["proj"], c["tanx"],
@@ -245,16 +259,17 @@ def main():
             ms = C.c_double(0); n = C.c_int64(0)
             lib.gm_profile_read(s.encode(), C.byref(ms), C.byref(n))
             if n.value:
-                per[s] = ms.value / n.value
+                per[s] = ms.value / nprof               # ms per frame (a stage may be several launches)
+        bytes_key = lambda st: "deform_pre" if (st == "deform" and not args.unfused) else st
         dom = max(per, key=per.get)
-        ab = algorithmic_bytes(dom, P, V, Rn, W, H, Vm)
+        ab = algorithmic_bytes(bytes_key(dom), P, V, Rn, W, H, Vm)
         ach = ab / (per[dom] * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic(dom, P, W, H),
                            "algorithmic_bytes": ab, "avg_ms": per[dom]}
         out["stage_ms"] = {k: round(v, 4) for k, v in per.items()}
         out["scene"] = {"P": P, "V": V, "R": Rn}
-        tot_bytes = sum(algorithmic_bytes(s, P, V, Rn, W, H, Vm) for s in per)
+        tot_bytes = sum(algorithmic_bytes(bytes_key(s), P, V, Rn, W, H, Vm) for s in per)
         out["frame_roofline"] = {"algorithmic_bytes": tot_bytes, "achieved": tot_bytes / (elapsed / args.steps) / 1e9,
                                  "frac": tot_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s",
                                  "single_stream_ms_per_frame": sum(per.values())}

@@ -43,6 +43,9 @@ SIGNATURES = {
     "gm_sh_colors": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "gm_deform_shade": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gm_pack_mesh_state": (i32, [i32, vp, vp, vp, vp]),
+    "gm_forward_0_deformed_async": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp,
+                                          i32, vp, vp]),
+    "gm_forward_1_geom": (i32, [vp, vp, vp, i32, i32, vp, i32, i32, vp, i32, vp]),
     "gm_deform_shade_packed": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gm_cov_to_scale_rot": (i32, [i32, vp, vp, vp, vp]),
     "gm_ssim_partials": (i64, [i32, i32, i32]),

@@ -146,6 +146,61 @@ int gm_forward_0_async(void* geom_buffer, int P, int D, int M, const float* back
   return GM_OK;
 }
 
+int gm_forward_0_deformed_async(void* geom_buffer, int P, int deg, int M, int width, int height, const int* tri, const float* w,
+                                const float* packed, const float* cov, const float* pos, const float* shs, const float* opacities,
+                                const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                                float tan_fovy, float* pos_out, float* cov6_out, float* rgb_out, int* radii, int debug,
+                                void* stream, int* num_rendered_host) {
+  if (P < 0 || width <= 0 || height <= 0) { set_error("invalid sizes P=%d W=%d H=%d", P, width, height); return GM_ERR_INVALID_ARG; }
+  if (!num_rendered_host) { set_error("num_rendered_host is null"); return GM_ERR_INVALID_ARG; }
+  if (P == 0) { *num_rendered_host = 0; return GM_OK; }
+  if (deg < 0 || deg > 3 || M != 16) { set_error("gm_forward_0_deformed: needs SH rows of M == 16 coefficients, degree 0..3"); return GM_ERR_INVALID_ARG; }
+  if (!geom_buffer || !tri || !w || !packed || !cov || !pos || !shs || !opacities || !viewmatrix || !projmatrix || !cam_pos) {
+    set_error("gm_forward_0_deformed: null required input"); return GM_ERR_INVALID_ARG;
+  }
+  const int nout = (pos_out != nullptr) + (cov6_out != nullptr) + (rgb_out != nullptr);
+  if (nout != 0 && nout != 3) { set_error("gm_forward_0_deformed: pass pos_out, cov6_out and rgb_out together or none"); return GM_ERR_INVALID_ARG; }
+  RasterArgs a{};
+  a.P = P; a.D = deg; a.M = M; a.W = width; a.H = height; a.opacities = opacities; a.viewmatrix = viewmatrix; a.projmatrix = projmatrix;
+  a.cam_pos = cam_pos; a.scale_modifier = 1.0f; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy; a.debug = debug; a.tile_cull = g_tile_cull;
+  a.stream = reinterpret_cast<hipStream_t>(stream);
+  GeomState g = GeomState::from(geom_buffer, (size_t)P);
+  if (int rc = launch_deform_shade_pre(a, g, radii, deg, tri, w, packed, cov, pos, shs, pos_out, cov6_out, rgb_out)) return rc;
+  {
+    StageScope sc(ST_DEPTH_SORT, a.stream);
+    if (int rc = radix_sort_pairs(g.depth_key, g.order, g.hist, g.digit_total, (size_t)P, 32, true, debug, a.stream)) return rc;
+  }
+  if (int rc = launch_tile_count_scan(g, P, debug, a.stream)) return rc;
+  GM_HIP(hipMemcpyAsync(num_rendered_host, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, a.stream));
+  return GM_OK;
+}
+
+int gm_forward_1_geom(void* geom_buffer, void* binning_buffer, void* image_buffer, int P, int num_rendered, const float* background,
+                      int width, int height, float* out_color, int debug, void* stream) {
+  if (P < 0 || width <= 0 || height <= 0) { set_error("invalid sizes P=%d W=%d H=%d", P, width, height); return GM_ERR_INVALID_ARG; }
+  if (!image_buffer || !out_color || !background) { set_error("null image_buffer / out_color / background"); return GM_ERR_INVALID_ARG; }
+  if (num_rendered < 0) { set_error("negative num_rendered"); return GM_ERR_INVALID_ARG; }
+  if (P > 0 && (!geom_buffer || (num_rendered > 0 && !binning_buffer))) { set_error("null scratch buffer"); return GM_ERR_INVALID_ARG; }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int mode = g_tile_cull;
+  ImageState img = ImageState::from(image_buffer, width, height);
+  const int tiles = TileGrid(width, height, mode).ptiles;
+  GeomState g = GeomState::from(geom_buffer, (size_t)(P > 0 ? P : 1));
+  BinningState b = BinningState::from(binning_buffer, (size_t)num_rendered);
+  int slot = 0;
+  if (P > 0 && num_rendered > 0) {
+    if (int rc = launch_duplicate(g, b, P, width, height, mode, debug, st)) return rc;
+    const int bits = tile_bits(tiles);
+    {
+      StageScope sc(ST_TILE_SORT, st);
+      if (int rc = radix_sort_pairs(b.keys, b.vals, b.hist, b.digit_total, (size_t)num_rendered, bits, false, debug, st)) return rc;
+    }
+    slot = sort_final_slot(bits);
+  }
+  if (int rc = launch_tile_ranges(b, slot, img, num_rendered, tiles, debug, st)) return rc;
+  return launch_render_fwd(g, b.keys[slot], b.vals[slot], img, width, height, mode, background, out_color, debug, st);
+}
+
 int gm_forward_0(void* geom_buffer, int P, int D, int M, const float* background, int width, int height,
                  const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
                  const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
@@ -183,22 +238,7 @@ int gm_forward_1(void* geom_buffer, void* binning_buffer, void* image_buffer, in
   if (!image_buffer || !out_color || !background) { set_error("null image_buffer / out_color / background"); return GM_ERR_INVALID_ARG; }
   if (num_rendered < 0) { set_error("negative num_rendered"); return GM_ERR_INVALID_ARG; }
   if (P > 0 && (!geom_buffer || (num_rendered > 0 && !binning_buffer))) { set_error("null scratch buffer"); return GM_ERR_INVALID_ARG; }
-  ImageState img = ImageState::from(image_buffer, width, height);
-  const int tiles = TileGrid(width, height, a.tile_cull).ptiles;      // lists are per parent tile
-  GeomState g = GeomState::from(geom_buffer, (size_t)(P > 0 ? P : 1));
-  BinningState b = BinningState::from(binning_buffer, (size_t)num_rendered);
-  int slot = 0;
-  if (P > 0 && num_rendered > 0) {
-    if (int rc = launch_duplicate(g, b, P, width, height, a.tile_cull, debug, a.stream)) return rc;
-    const int bits = tile_bits(tiles);
-    {
-      StageScope sc(ST_TILE_SORT, a.stream);
-      if (int rc = radix_sort_pairs(b.keys, b.vals, b.hist, b.digit_total, (size_t)num_rendered, bits, false, debug, a.stream)) return rc;
-    }
-    slot = sort_final_slot(bits);
-  }
-  if (int rc = launch_tile_ranges(b, slot, img, num_rendered, tiles, debug, a.stream)) return rc;
-  return launch_render_fwd(g, b.keys[slot], b.vals[slot], img, width, height, a.tile_cull, background, out_color, debug, a.stream);
+  return gm_forward_1_geom(geom_buffer, binning_buffer, image_buffer, P, num_rendered, background, width, height, out_color, debug, stream);
 }
 
 int gm_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,

@@ -209,6 +209,8 @@ int launch_sh_colors(int N, int deg, int M, const float* pos, const float* campo
 int launch_deform_shade(int N, int deg, int M, const int* tri, const float* w, const float* dV, const float* Rv, const float* Sv,
                         const float* cov, const float* pos, const float* shs, const float* campos, float* pos_out,
                         float* cov6_out, float* rgb_out, float* cov_out, float* rot_out, hipStream_t s);
+int launch_deform_shade_pre(const RasterArgs& r, GeomState& g, int* radii, int deg, const int* tri, const float* w, const float* packed,
+                            const float* cov, const float* pos, const float* shs, float* pos_out, float* cov6_out, float* rgb_out);
 int launch_pack_mesh_state(int Vm, const float* state, const float* verts, float* packed, hipStream_t s);
 int launch_deform_shade_packed(int N, int deg, int M, const int* tri, const float* w, const float* packed, const float* cov,
                                const float* pos, const float* shs, const float* campos, float* pos_out, float* cov6_out,

@@ -141,6 +141,10 @@ class PendingForward:
                 binning = self.workspace.get("binning", lib.gm_binning_bytes(num_rendered), device)
             else:
                 binning = torch.empty((lib.gm_binning_bytes(num_rendered),), dtype=torch.uint8, device=device)
+            if a.get("geom_only"):
+                _lib.check(lib.gm_forward_1_geom(_ptr(self.geom), _ptr(binning), _ptr(self.img), a["P"], num_rendered, _ptr(a["bg"]),
+                                                 a["W"], a["H"], _ptr(self.color), a["debug"], self.stream.cuda_stream))
+                return num_rendered, self.color, self.radii, self.geom, binning, self.img
             _lib.check(lib.gm_forward_1(_ptr(self.geom), _ptr(binning), _ptr(self.img), a["P"], a["D"], a["M"], num_rendered,
                                         _ptr(a["bg"]), a["W"], a["H"], _ptr(a["means3D"]), _ptr(a["sh"]), _ptr(a["colors"]),
                                         _ptr(a["opacity"]), _ptr(a["scales"]), a["scale_modifier"], _ptr(a["rotations"]),
@@ -191,6 +195,49 @@ def rasterize_forward_begin(bg, means3D, colors, opacity, scales, rotations, sca
                 prefiltered=int(bool(prefiltered)), debug=int(bool(debug)))
     return PendingForward(args=args, geom=geom, img=img, color=color, radii=radii, count_host=count_host, event=event,
                           stream=stream, workspace=workspace)
+
+
+def forward_deformed_begin(bg, tri, weights, packed, cov, pos, shs, opacity, viewmatrix, projmatrix, tan_fovx, tan_fovy,
+                           image_height, image_width, degree, campos, debug=False, workspace=None, want_deformed=False):
+    """Edit-loop frame, first half (gm_forward_0_deformed_async): mesh-driven deformation + rotated-direction SH colour +
+    forward preprocess + depth sort + instance count in one enqueue, no host synchronisation.  `packed` is
+    deform.pack_mesh_state() of the frame.  Returns a PendingForward; .finish() completes the frame
+    (gm_forward_1_geom) and returns (num_rendered, color, radii, geom, binning, img).  With want_deformed the handle
+    also carries .deformed = (pos' [N,3], cov6 [N,6], rgb [N,3])."""
+    lib = _lib.lib()
+    device = pos.device
+    if device.type != "cuda":
+        raise _lib.GmeshError("gaussianmesh_amd rasterizer needs tensors on a HIP (cuda) device; there is no CPU path")
+    tri = tri.detach().contiguous().to(torch.int32)
+    weights, packed, cov, pos, shs, opacity = (_prep(t, device) for t in (weights, packed, cov, pos, shs, opacity))
+    bg, viewmatrix, projmatrix, campos = (_prep(t, device) for t in (bg, viewmatrix, projmatrix, campos))
+    P, M = pos.shape[0], shs.shape[1]
+    H, W = int(image_height), int(image_width)
+    stream = torch.cuda.current_stream(device)
+    with torch.cuda.device(device):
+        f = dict(dtype=torch.float32, device=device)
+        color = torch.empty((3, H, W), **f)
+        radii = torch.empty((P,), dtype=torch.int32, device=device)
+        deformed = (torch.empty((P, 3), **f), torch.empty((P, 6), **f), torch.empty((P, 3), **f)) if want_deformed else None
+        if workspace is not None:
+            geom = workspace.get("geom", lib.gm_geom_bytes(P), device)
+            img = workspace.get("img", lib.gm_image_bytes(W, H), device)
+            count_host = workspace.pinned_counter()
+        else:
+            geom = torch.empty((lib.gm_geom_bytes(P),), dtype=torch.uint8, device=device)
+            img = torch.empty((lib.gm_image_bytes(W, H),), dtype=torch.uint8, device=device)
+            count_host = torch.zeros((1,), dtype=torch.int32).pin_memory()
+        dp = [None, None, None] if deformed is None else [t.data_ptr() for t in deformed]
+        _lib.check(lib.gm_forward_0_deformed_async(_ptr(geom), P, int(degree), M, W, H, _ptr(tri), _ptr(weights), _ptr(packed), _ptr(cov),
+                                                   _ptr(pos), _ptr(shs), _ptr(opacity), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos),
+                                                   float(tan_fovx), float(tan_fovy), dp[0], dp[1], dp[2], _ptr(radii), int(bool(debug)),
+                                                   stream.cuda_stream, count_host.data_ptr()))
+        event = torch.cuda.Event()
+        event.record(stream)
+    args = dict(device=device, P=P, W=W, H=H, bg=bg, debug=int(bool(debug)), geom_only=True,
+                keep=(tri, weights, packed, cov, pos, shs, opacity, viewmatrix, projmatrix, campos))
+    return PendingForward(args=args, geom=geom, img=img, color=color, radii=radii, count_host=count_host, event=event,
+                          stream=stream, workspace=workspace, deformed=deformed)
 
 
 def rasterize_backward(bg, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,

@@ -175,6 +175,20 @@ int gm_deform_shade_packed(int N, int deg, int M, const int* tri, const float* w
                            const float* pos, const float* shs, const float* campos, float* pos_out, float* cov6_out,
                            float* rgb_out, float* cov_out, float* rot_out, void* stream);
 
+/* Edit-loop fast path (ObjectVisualTool.render_gaussian, edittool/__init__.py:421-472, one frame): gm_deform_shade_packed
+ * and the first half of the forward in ONE pass over the cloud - the deformed position / covariance / colour of a
+ * Gaussian go straight into its projection, conic, radius and instance count without a round trip through HBM.
+ * Equivalent, bit for bit, to gm_deform_shade_packed followed by gm_forward_0_async(colors_precomp = rgb_out,
+ * cov3D_precomp = cov6_out, means3D = pos_out, scale_modifier 1).  pos_out / cov6_out / rgb_out: all three or all NULL.
+ * Complete the frame with gm_forward_1_geom (gm_forward_1 without the per-Gaussian input pointers it does not read). */
+int gm_forward_0_deformed_async(void* geom_buffer, int P, int deg, int M, int width, int height, const int* tri, const float* w,
+                                const float* packed, const float* cov, const float* pos, const float* shs, const float* opacities,
+                                const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                                float tan_fovy, float* pos_out, float* cov6_out, float* rgb_out, int* radii, int debug,
+                                void* stream, int* num_rendered_host);
+int gm_forward_1_geom(void* geom_buffer, void* binning_buffer, void* image_buffer, int P, int num_rendered, const float* background,
+                      int width, int height, float* out_color, int debug, void* stream);
+
 /* Covariance -> (scale, rotation): replaces the per-frame eigh + host-side det sign + sqrt + matrix->quaternion of
  * SceneVisualTool.render_gaussian (edittool/__init__.py:204-207, 23-38).  cov float [N,3,3] (symmetric),
  * scales float [N,3] = sqrt of the eigenvalues in ascending order, rots float [N,4] = unit quaternion (w,x,y,z) of the

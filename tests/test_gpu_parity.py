@@ -462,3 +462,44 @@ def test_async_begin_finish_pipeline_matches_sync(oracle):
     for k in range(6):
         assert out[k][0] == ref[k][0]
         assert torch.equal(out[k][1], ref[k][1]) and torch.equal(out[k][2], ref[k][2])
+
+
+@pytest.mark.parametrize("N", [5000, 64 * 40])
+def test_fused_deform_forward_equals_unfused_chain(oracle, N):
+    """gm_forward_0_deformed_async + gm_forward_1_geom (edit-loop fast path) == gm_deform_shade_packed followed by the
+    ordinary forward on its outputs, bit for bit (image, radii, instance count, deformed cloud), and the image matches
+    the oracle's deform -> colour -> forward chain within the forward tolerance."""
+    from gpu_utils import T
+    from gaussianmesh_amd import rasterizer as Rz, scenes
+    from gaussianmesh_amd.deform import deform_shade_packed, pack_mesh_state
+    verts, faces = scenes.torus_mesh(40, 30)
+    cl = scenes.bind_cloud_to_mesh(N, verts, faces, seed=11)
+    V1, Rv, Sv = scenes.twist_bend_frame(verts, t=5)
+    cov = scenes.cov3d_from_scale_rot(cl["scales"], cl["rots"]).astype(np.float32)
+    state = np.concatenate([V1.astype(np.float32), Rv.reshape(-1, 9), Sv.reshape(-1, 9)], axis=1).astype(np.float32)
+    W, H = 300, 170
+    cam = scenes.orbit_camera(1, 7, W, H, radius=6.0)
+    ct = {k: T(cam[k]) for k in ("view", "proj", "campos")}
+    bg = T(np.array([0.1, 0.5, 0.9], np.float32))
+    packed = pack_mesh_state(T(state), T(verts.astype(np.float32)))
+    g = dict(tri=T(cl["tri"], dtype=torch.int32), w=T(cl["weights"]), cov=T(cov), pos=T(cl["means"]), shs=T(cl["shs"]), opac=T(cl["opac"]))
+    pos, cov6, rgb = deform_shade_packed(g["tri"], g["w"], packed, g["cov"], g["pos"], g["shs"], ct["campos"], deg=3)
+    nr0, color0, radii0, *_ = Rz.rasterize_forward(bg, pos, rgb, g["opac"], None, None, 1.0, cov6, ct["view"], ct["proj"], cam["tanx"],
+                                                   cam["tany"], H, W, None, 3, ct["campos"], False, False)
+    for want in (False, True):
+        h = Rz.forward_deformed_begin(bg, g["tri"], g["w"], packed, g["cov"], g["pos"], g["shs"], g["opac"], ct["view"], ct["proj"],
+                                      cam["tanx"], cam["tany"], H, W, 3, ct["campos"], want_deformed=want)
+        nr1, color1, radii1, *_ = h.finish()
+        torch.cuda.synchronize()
+        assert nr1 == nr0 and torch.equal(radii1, radii0) and torch.equal(color1, color0)
+        if want:
+            assert torch.equal(h.deformed[0], pos) and torch.equal(h.deformed[1], cov6) and torch.equal(h.deformed[2], rgb)
+    # against the oracle chain
+    dV = (V1 - verts).astype(np.float32)
+    p_ref, c_ref, r_ref = oracle.deform(cl["tri"], cl["weights"], dV, Rv, Sv, cov, cl["means"])
+    rgb_ref = oracle.sh_colors_rotated(p_ref, cam["campos"], r_ref, cl["shs"], deg=3)
+    sc = dict(means=p_ref.astype(np.float32), opac=cl["opac"], colors_precomp=rgb_ref.astype(np.float32),
+              cov3D_precomp=scenes.strip_symmetric(c_ref).astype(np.float32))
+    fw = oracle.forward_full(sc, cam, bg.cpu().numpy(), D=3, use_precomp_cov=True, use_precomp_color=True)
+    err = np.abs(color0.cpu().numpy() - fw["color"])
+    assert (err > FWD_TOL).mean() <= 1e-4 and err.max() <= 5e-3
