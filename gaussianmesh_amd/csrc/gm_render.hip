@@ -134,17 +134,35 @@ __global__ __launch_bounds__(256 / PPL) void render_fwd_kernel(const uint2* __re
   Batch cur = load_records(splat, load_id(list, lane, n), mine);
   uint32_t id_nxt = load_id(list, 64 + lane, n);
   bool mine_nxt = (load_id(klist, 64 + lane, n) & child_bit) != 0;
+  const float qx0 = rx0, qy0 = ry0;
   for (int base = 0; base < n; base += 64) {
     bool all_done = true;
 #pragma unroll
     for (int k = 0; k < PPL; k++) all_done = all_done && done[k];
-    if (__all(all_done)) break;
+    const unsigned long long live = __ballot(!all_done);
+    if (live == 0ull) break;
+    // Entries are culled against the bounding box of the pixels that are still live, not the whole 8x8 quadrant: a
+    // quadrant kept alive by a few unsaturated pixels (silhouettes) would otherwise evaluate every entry that touches
+    // any of its 64 pixels - those waves were the 100 us tail of the kernel.  Lane = y * 8 + x; scalar bit arithmetic.
+    float cx0 = rx0, cx1 = rx1, cy0 = ry0, cy1 = ry1;
+    if (QUAD && PPL == 1) {
+      uint32_t cols = (uint32_t)live | (uint32_t)(live >> 32);
+      cols |= cols >> 16; cols |= cols >> 8; cols &= 0xFFu;
+      cx0 = qx0 + (float)(__ffs((int)cols) - 1);
+      cx1 = qx0 + (float)(31 - __clz((int)cols));
+      cy0 = qy0 + (float)((__ffsll(live) - 1) >> 3);
+      cy1 = qy0 + (float)((63 - __clzll((long long)live)) >> 3);
+    }
     WAIT_ALL_LOADS();
     const Batch nxt = load_records(splat, id_nxt, mine_nxt);               // records of the next batch
     id_nxt = load_id(list, base + 128 + lane, n);                          // ids / keys of the batch after that
     const bool mine_nn = (load_id(klist, base + 128 + lane, n) & child_bit) != 0;
-    const bool keep = mine && may_touch(cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, rx0, rx1, ry0, ry1);
-    rec[lane][0] = cur.a; rec[lane][1] = cur.b; rec[lane][2] = make_float4(cur.c, 0.f, 0.f, 0.f);
+    const bool keep = mine && may_touch(cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, cx0, cx1, cy0, cy1);
+    // staged record: the conic is stored pre-multiplied (lane-parallel, 3 multiplies per 64 entries) so that the
+    // per-survivor exponent is e = dx (a' dx + b' dy) + (c' dy) dy = power * log2(e): 5 instructions instead of 9
+    rec[lane][0] = make_float4(cur.a.x, cur.a.y, (-0.5f * LOG2E) * cur.a.z, (-LOG2E) * cur.a.w);
+    rec[lane][1] = make_float4((-0.5f * LOG2E) * cur.b.x, cur.b.y, cur.b.z, cur.b.w);
+    rec[lane][2] = make_float4(cur.c, 0.f, 0.f, 0.f);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     unsigned long long todo = __ballot(keep);
@@ -158,28 +176,30 @@ __global__ __launch_bounds__(256 / PPL) void render_fwd_kernel(const uint2* __re
       const int j1 = has1 ? __ffsll(todo) - 1 : j0;
       todo &= todo - 1;
       const float4 A0 = rec[j0][0], B0 = rec[j0][1], A1 = rec[j1][0], B1 = rec[j1][1];
-      const float sx0 = A0.x, sy0 = A0.y, cx0 = A0.z, cy0 = A0.w, cz0 = B0.x, op0 = B0.y;
-      const float sx1 = A1.x, sy1 = A1.y, cx1 = A1.z, cy1 = A1.w, cz1 = B1.x, op1 = B1.y;
+      const float sx0 = A0.x, sy0 = A0.y, qa0 = A0.z, qb0 = A0.w, qc0 = B0.x, op0 = B0.y;
+      const float sx1 = A1.x, sy1 = A1.y, qa1 = A1.z, qb1 = A1.w, qc1 = B1.x, op1 = B1.y;
       const float dx0 = sx0 - pixx, dx1 = sx1 - pixx;
-      float alpha0[PPL], alpha1[PPL], t0[PPL], t1[PPL];
+      float wa0[PPL], wa1[PPL], t0[PPL], t1[PPL];
       bool v0[PPL], v1[PPL], anyv = false;
 #pragma unroll
       for (int k = 0; k < PPL; k++) {
         const float dy0 = sy0 - pixy[k], dy1 = sy1 - pixy[k];
-        const float power0 = -0.5f * (cx0 * dx0 * dx0 + cz0 * dy0 * dy0) - cy0 * dx0 * dy0;
-        const float power1 = -0.5f * (cx1 * dx1 * dx1 + cz1 * dy1 * dy1) - cy1 * dx1 * dy1;
-        alpha0[k] = fminf(0.99f, op0 * __builtin_amdgcn_exp2f(power0 * LOG2E));
-        alpha1[k] = fminf(0.99f, op1 * __builtin_amdgcn_exp2f(power1 * LOG2E));
-        // entry j0
-        v0[k] = !done[k] && (power0 <= 0.0f) && (alpha0[k] >= 1.0f / 255.0f);
-        t0[k] = T[k] * (1.0f - alpha0[k]);
+        const float e0 = dx0 * (qa0 * dx0 + qb0 * dy0) + (qc0 * dy0) * dy0;      // power * log2(e); same sign as power
+        const float e1 = dx1 * (qa1 * dx1 + qb1 * dy1) + (qc1 * dy1) * dy1;
+        const float alpha0 = fminf(0.99f, op0 * __builtin_amdgcn_exp2f(e0));
+        const float alpha1 = fminf(0.99f, op1 * __builtin_amdgcn_exp2f(e1));
+        // entry j0: weight alpha T, new transmittance T - alpha T (= T (1 - alpha))
+        v0[k] = !done[k] && (e0 <= 0.0f) && (alpha0 >= 1.0f / 255.0f);
+        wa0[k] = alpha0 * T[k];
+        t0[k] = T[k] - wa0[k];
         const bool stop0 = v0[k] && (t0[k] < 0.0001f);
         done[k] = done[k] || stop0;
         v0[k] = v0[k] && !stop0;
         const float Tm = v0[k] ? t0[k] : T[k];
         // entry j1 (in list order after j0)
-        v1[k] = has1 && !done[k] && (power1 <= 0.0f) && (alpha1[k] >= 1.0f / 255.0f);
-        t1[k] = Tm * (1.0f - alpha1[k]);
+        v1[k] = has1 && !done[k] && (e1 <= 0.0f) && (alpha1 >= 1.0f / 255.0f);
+        wa1[k] = alpha1 * Tm;
+        t1[k] = Tm - wa1[k];
         const bool stop1 = v1[k] && (t1[k] < 0.0001f);
         done[k] = done[k] || stop1;
         v1[k] = v1[k] && !stop1;
@@ -191,9 +211,9 @@ __global__ __launch_bounds__(256 / PPL) void render_fwd_kernel(const uint2* __re
         const uint32_t c0 = (uint32_t)(base + j0 + 1), c1 = (uint32_t)(base + j1 + 1);
 #pragma unroll
         for (int k = 0; k < PPL; k++) {
-          const float w0 = v0[k] ? alpha0[k] * T[k] : 0.0f;
+          const float w0 = v0[k] ? wa0[k] : 0.0f;
           const float Tm = v0[k] ? t0[k] : T[k];
-          const float w1 = v1[k] ? alpha1[k] * Tm : 0.0f;
+          const float w1 = v1[k] ? wa1[k] : 0.0f;
           Cr[k] += r0 * w0; Cg[k] += g0 * w0; Cb[k] += b0 * w0;
           Cr[k] += r1 * w1; Cg[k] += g1 * w1; Cb[k] += b1 * w1;
           T[k] = v1[k] ? t1[k] : Tm;
