@@ -128,12 +128,32 @@ __global__ __launch_bounds__(256 / PPL) void render_fwd_kernel(const uint2* __re
   __shared__ float4 l_rec[4 / PPL][64][3];
   float4 (*rec)[3] = l_rec[wave];
 
-  // an entry of the parent's list concerns this tile iff its key has the tile's child bit; records are only
-  // fetched for those
-  bool mine = (load_id(klist, lane, n) & child_bit) != 0;
-  Batch cur = load_records(splat, load_id(list, lane, n), mine);
-  uint32_t id_nxt = load_id(list, 64 + lane, n);
-  bool mine_nxt = (load_id(klist, 64 + lane, n) & child_bit) != 0;
+  // Three-deep software pipeline of the dependent gather (list position -> id / key -> 48-byte splat record): ids and
+  // keys run three batches ahead, records two, so a wave that finds few entries of its own per batch (little
+  // arithmetic per iteration) does not advance at one memory round trip per batch.  Every iteration issues exactly
+  // 2 + 3 loads (positions past the end re-read the last entry, entries of other child tiles read record 0), ids
+  // first, so "all but the three youngest loads have landed" (vmcnt(3)) is exactly "this batch's records and the ids
+  // needed to issue the next gathers are here; the gathers issued last iteration may still be in flight".
+  // An entry of the parent's list concerns this tile iff its key has the tile's child bit.
+  const int nlast = n - 1;
+  auto ld_id = [&](int e) { return list[min(e, nlast)]; };
+  auto ld_mine = [&](int e) { const uint32_t kk = klist[min(e, nlast)]; return (e <= nlast) & ((kk & child_bit) != 0); };
+  auto ld_rec = [&](uint32_t id, bool m) { return load_records(splat, m ? id : 0u, true); };
+  if (n <= 0) {                                   // empty list: background only
+    const size_t HW_ = (size_t)H * W;
+    if (px < W && py[0] < H) {
+      const size_t pid = (size_t)W * py[0] + px;
+      final_T[pid] = 1.0f; n_contrib[pid] = 0u;
+      out_color[pid] = bg[0]; out_color[HW_ + pid] = bg[1]; out_color[2 * HW_ + pid] = bg[2];
+    }
+    return;
+  }
+  bool mine = ld_mine(lane);
+  Batch cur = ld_rec(ld_id(lane), mine);
+  bool mine_1 = ld_mine(64 + lane);
+  Batch nx1 = ld_rec(ld_id(64 + lane), mine_1);
+  uint32_t id_2 = ld_id(128 + lane);
+  bool mine_2 = ld_mine(128 + lane);
   const float qx0 = rx0, qy0 = ry0;
   for (int base = 0; base < n; base += 64) {
     bool all_done = true;
@@ -141,9 +161,9 @@ __global__ __launch_bounds__(256 / PPL) void render_fwd_kernel(const uint2* __re
     for (int k = 0; k < PPL; k++) all_done = all_done && done[k];
     const unsigned long long live = __ballot(!all_done);
     if (live == 0ull) break;
-    // Entries are culled against the bounding box of the pixels that are still live, not the whole 8x8 quadrant: a
-    // quadrant kept alive by a few unsaturated pixels (silhouettes) would otherwise evaluate every entry that touches
-    // any of its 64 pixels - those waves were the 100 us tail of the kernel.  Lane = y * 8 + x; scalar bit arithmetic.
+    // Entries are culled against the bounding box of the pixels that are still live, not the whole 8x8 quadrant
+    // (a quadrant kept alive by a few unsaturated pixels would otherwise evaluate every entry that touches any of
+    // its 64 pixels).  Lane = y * 8 + x; scalar bit arithmetic.
     float cx0 = rx0, cx1 = rx1, cy0 = ry0, cy1 = ry1;
     if (QUAD && PPL == 1) {
       uint32_t cols = (uint32_t)live | (uint32_t)(live >> 32);
@@ -153,10 +173,10 @@ __global__ __launch_bounds__(256 / PPL) void render_fwd_kernel(const uint2* __re
       cy0 = qy0 + (float)((__ffsll(live) - 1) >> 3);
       cy1 = qy0 + (float)((63 - __clzll((long long)live)) >> 3);
     }
-    WAIT_ALL_LOADS();
-    const Batch nxt = load_records(splat, id_nxt, mine_nxt);               // records of the next batch
-    id_nxt = load_id(list, base + 128 + lane, n);                          // ids / keys of the batch after that
-    const bool mine_nn = (load_id(klist, base + 128 + lane, n) & child_bit) != 0;
+    __builtin_amdgcn_s_waitcnt(0x0F73);                                    // vmcnt(3)
+    const uint32_t id_3 = ld_id(base + 192 + lane);                        // ids / keys three batches ahead ...
+    const bool mine_3 = ld_mine(base + 192 + lane);
+    const Batch nx2 = ld_rec(id_2, mine_2);                                // ... records two batches ahead
     const bool keep = mine && may_touch(cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, cx0, cx1, cy0, cy1);
     // staged record: the conic is stored pre-multiplied (lane-parallel, 3 multiplies per 64 entries) so that the
     // per-survivor exponent is e = dx (a' dx + b' dy) + (c' dy) dy = power * log2(e): 5 instructions instead of 9
@@ -221,7 +241,7 @@ __global__ __launch_bounds__(256 / PPL) void render_fwd_kernel(const uint2* __re
         }
       }
     }
-    cur = nxt; mine = mine_nxt; mine_nxt = mine_nn;
+    cur = nx1; nx1 = nx2; mine = mine_1; mine_1 = mine_2; id_2 = id_3; mine_2 = mine_3;
   }
 
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
@@ -367,17 +387,38 @@ __global__ __launch_bounds__(256 / PPL) void render_bwd_kernel(const uint2* __re
   const float ry1 = ry0 + (QUAD ? 7.0f : (float)(PPL * 4 - 1));
   __shared__ float4 l_rec[4 / PPL][64][3];       // wave-private LDS copy of the batch (see render_fwd_kernel)
   float4 (*rec)[3] = l_rec[wave];
-  // batch b covers list positions start-1-b*64-j (j = lane), i.e. back to front
-  bool mine = (load_id(klist, start - 1 - lane, n) & child_bit) != 0;
-  Batch cur = load_records(splat, load_id(list, start - 1 - lane, n), mine);
-  uint32_t id_nxt = load_id(list, start - 1 - 64 - lane, n);
-  bool mine_nxt = (load_id(klist, start - 1 - 64 - lane, n) & child_bit) != 0;
+  // batch b covers list positions start-1-b*64-j (j = lane), i.e. back to front; same three-deep gather pipeline and
+  // constant load count per iteration as render_fwd_kernel (positions below 0 re-read entry 0 and are not "mine")
+  auto ld_id = [&](int e) { return list[max(e, 0)]; };
+  auto ld_mine = [&](int e) { const uint32_t kk = klist[max(e, 0)]; return (e >= 0) & ((kk & child_bit) != 0); };
+  auto ld_rec = [&](uint32_t id, bool m) { return load_records(splat, m ? id : 0u, true); };
+  bool mine = ld_mine(start - 1 - lane);
+  Batch cur = ld_rec(ld_id(start - 1 - lane), mine);
+  bool mine_1 = ld_mine(start - 1 - 64 - lane);
+  Batch nx1 = ld_rec(ld_id(start - 1 - 64 - lane), mine_1);
+  uint32_t id_2 = ld_id(start - 1 - 128 - lane);
+  bool mine_2 = ld_mine(start - 1 - 128 - lane);
   for (int base = 0; base < start; base += 64) {
-    WAIT_ALL_LOADS();
-    const Batch nxt = load_records(splat, id_nxt, mine_nxt);
-    id_nxt = load_id(list, start - 1 - (base + 128) - lane, n);
-    const bool mine_nn = (load_id(klist, start - 1 - (base + 128) - lane, n) & child_bit) != 0;
-    const bool keep = mine && may_touch(cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, rx0, rx1, ry0, ry1);
+    // A pixel takes part in this batch only if its last contributor lies above the batch's lowest position: cull
+    // against the bounding box of those pixels (at the deep end of the walk only the few pixels that reached far
+    // into the list are still in play).  Lane = y * 8 + x.
+    float cx0 = rx0, cx1 = rx1, cy0 = ry0, cy1 = ry1;
+    if (QUAD && PPL == 1) {
+      const unsigned long long live = __ballot(last[0] > start - 64 - base);
+      uint32_t cols = (uint32_t)live | (uint32_t)(live >> 32);
+      cols |= cols >> 16; cols |= cols >> 8; cols &= 0xFFu;
+      if (live != 0ull) {
+        cx0 = rx0 + (float)(__ffs((int)cols) - 1);
+        cx1 = rx0 + (float)(31 - __clz((int)cols));
+        cy0 = ry0 + (float)((__ffsll(live) - 1) >> 3);
+        cy1 = ry0 + (float)((63 - __clzll((long long)live)) >> 3);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F73);                                    // vmcnt(3)
+    const uint32_t id_3 = ld_id(start - 1 - (base + 192) - lane);
+    const bool mine_3 = ld_mine(start - 1 - (base + 192) - lane);
+    const Batch nx2 = ld_rec(id_2, mine_2);
+    const bool keep = mine && may_touch(cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, cx0, cx1, cy0, cy1);
     rec[lane][0] = cur.a; rec[lane][1] = cur.b; rec[lane][2] = make_float4(cur.c, __uint_as_float(cur.id), 0.f, 0.f);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -436,7 +477,7 @@ __global__ __launch_bounds__(256 / PPL) void render_bwd_kernel(const uint2* __re
       if (committer || last_lane)
         atomicAdd(grad_acc + (size_t)gid * GM_ACC_STRIDE + (last_lane ? 8 : my_slot), last_lane ? q8 : tot);
     }
-    cur = nxt; mine = mine_nxt; mine_nxt = mine_nn;
+    cur = nx1; nx1 = nx2; mine = mine_1; mine_1 = mine_2; id_2 = id_3; mine_2 = mine_3;
   }
 }
 
