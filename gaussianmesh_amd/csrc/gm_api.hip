@@ -74,6 +74,10 @@ static void drain_profile() {
 
 static int check_raster_args(const RasterArgs& a) {
   if (a.P < 0 || a.W <= 0 || a.H <= 0) { set_error("invalid sizes P=%d W=%d H=%d", a.P, a.W, a.H); return GM_ERR_INVALID_ARG; }
+  if (TileGrid(a.W, a.H, a.tile_cull).ptiles > 65536) {
+    set_error("%dx%d has more than 65536 list tiles under emission policy %d; use gm_set_tile_culling(2) or (3)", a.W, a.H, a.tile_cull);
+    return GM_ERR_INVALID_ARG;
+  }
   if (a.P == 0) return 0;                       // empty cloud: every per-Gaussian pointer may be null
   if ((a.shs == nullptr) == (a.colors_precomp == nullptr)) {
     set_error("provide exactly one of shs / colors_precomp"); return GM_ERR_INVALID_ARG;
@@ -197,7 +201,7 @@ int gm_forward_1_geom(void* geom_buffer, void* binning_buffer, void* image_buffe
     }
     slot = sort_final_slot(bits);
   }
-  if (int rc = launch_tile_ranges(b, slot, img, num_rendered, tiles, debug, st)) return rc;
+  if (int rc = launch_tile_ranges(g, b, slot, img, num_rendered, tiles, debug, st)) return rc;
   return launch_render_fwd(g, b.keys[slot], b.vals[slot], img, width, height, mode, background, out_color, debug, st);
 }
 

@@ -268,22 +268,24 @@ int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, int mod
   return 0;
 }
 
-__global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __restrict__ keys, int R, uint2* __restrict__ ranges) {
+__global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __restrict__ keys, int R, uint32_t tiles, const uint32_t* __restrict__ counters,
+                                                          uint2* __restrict__ ranges) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= R) return;
+  if (i >= R || counters[3] != 0u) return;        // counters[3]: emission was refused (policy mismatch) -> every list stays empty
   const uint32_t cur = keys[i] & GM_KEY_TILE_MASK;
+  if (cur >= tiles) return;                      // only after a refused emission (policy changed between forward_0 and forward_1)
   if (i == 0) ranges[cur].x = 0;
   else {
     const uint32_t prev = keys[i - 1] & GM_KEY_TILE_MASK;
-    if (cur != prev) { ranges[prev].y = (uint32_t)i; ranges[cur].x = (uint32_t)i; }
+    if (cur != prev) { if (prev < tiles) ranges[prev].y = (uint32_t)i; ranges[cur].x = (uint32_t)i; }
   }
   if (i == R - 1) ranges[cur].y = (uint32_t)R;
 }
 
-int launch_tile_ranges(BinningState& b, int slot, ImageState& img, int R, int tiles, int debug, hipStream_t s) {
+int launch_tile_ranges(const GeomState& g, BinningState& b, int slot, ImageState& img, int R, int tiles, int debug, hipStream_t s) {
   StageScope sc(ST_RANGES, s);
   GM_HIP(hipMemsetAsync(img.ranges, 0, sizeof(uint2) * (size_t)tiles, s));
-  if (R > 0) hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, b.keys[slot], R, img.ranges);
+  if (R > 0) hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, b.keys[slot], R, (uint32_t)tiles, g.counters, img.ranges);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }

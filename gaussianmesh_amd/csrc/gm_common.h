@@ -195,7 +195,7 @@ int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], uint32_t* hist, uint3
 
 int launch_tile_count_scan(GeomState& g, int P, int debug, hipStream_t s);          // -> counters[0] = num_rendered
 int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, int tile_cull, int debug, hipStream_t s);
-int launch_tile_ranges(BinningState& b, int slot, ImageState& img, int R, int tiles, int debug, hipStream_t s);
+int launch_tile_ranges(const GeomState& g, BinningState& b, int slot, ImageState& img, int R, int tiles, int debug, hipStream_t s);
 int launch_render_fwd(const GeomState& g, const uint32_t* tile_keys, const uint32_t* point_list, ImageState& img, int W, int H, int mode,
                       const float* background, float* out_color, int debug, hipStream_t s);
 int launch_render_bwd(const GeomState& g, const uint32_t* tile_keys, const uint32_t* point_list, ImageState& img, int W, int H, int mode,

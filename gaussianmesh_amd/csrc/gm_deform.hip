@@ -513,7 +513,7 @@ __global__ __launch_bounds__(64) void deform_shade_pre_kernel(int N, int deg, co
     fp.tiles[i] = tiles;
     fp.bin[i] = bin;
     fp.depth_key[i] = dkey;
-    if (i == 0) fp.counters[2] = (uint32_t)fp.cam.tile_cull;
+    if (i == 0) { fp.counters[2] = (uint32_t)fp.cam.tile_cull; fp.counters[3] = 0u; }
   }
   if (!pos_out) return;                          // wave-uniform
   __syncthreads();                               // everyone is done reading the staged inputs: reuse LDS for the outputs

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(const PreArgs a) {
     __syncthreads();
   }
   if (idx >= a.P) return;
-  if (idx == 0) a.counters[2] = (uint32_t)a.tile_cull;   // emission policy of THIS forward, read back by duplicate_kernel
+  if (idx == 0) { a.counters[2] = (uint32_t)a.tile_cull; a.counters[3] = 0u; }   // emission policy of THIS forward (read back by duplicate_kernel), no refusal yet
   int radius_i = 0;
   uint32_t tiles = 0, dkey = 0xFFFFFFFFu;
   uint4 bin = make_uint4(0u, 0u, 0u, 0u);

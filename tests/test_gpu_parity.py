@@ -503,3 +503,26 @@ def test_fused_deform_forward_equals_unfused_chain(oracle, N):
     fw = oracle.forward_full(sc, cam, bg.cpu().numpy(), D=3, use_precomp_cov=True, use_precomp_color=True)
     err = np.abs(color0.cpu().numpy() - fw["color"])
     assert (err > FWD_TOL).mean() <= 1e-4 and err.max() <= 5e-3
+
+
+def test_policy_change_between_forward_halves_is_refused_safely():
+    """gm_forward_1 under another emission policy than its gm_forward_0: the counted size belongs to the old policy, so
+    emission is refused on the device, every list stays empty and the image is the background (no overrun, no hang)."""
+    from gpu_utils import T
+    from gaussianmesh_amd import rasterizer as Rz, scenes, _lib
+    sc = scenes.make_cloud(5000, seed=2, scale_lo=0.01, scale_hi=0.2)
+    cam = scenes.orbit_camera(0, 4, 200, 120, radius=7.0)
+    ct = {k: T(cam[k]) for k in ("view", "proj", "campos")}
+    bg = T(np.array([0.25, 0.5, 0.75], np.float32))
+    args = (bg, T(sc["means"]), None, T(sc["opac"]), T(sc["scales"]), T(sc["rots"]), 1.0, None, ct["view"], ct["proj"], cam["tanx"],
+            cam["tany"], 120, 200, T(sc["shs"]), 3, ct["campos"])
+    lib = _lib.lib()
+    lib.gm_set_tile_culling(2)
+    h = Rz.rasterize_forward_begin(*args)
+    lib.gm_set_tile_culling(0)
+    nr, color, radii, *_ = h.finish()
+    torch.cuda.synchronize()
+    assert nr > 0 and torch.equal(color, bg.view(3, 1, 1).expand(3, 120, 200))
+    lib.gm_set_tile_culling(2)
+    nr2, color2, *_ = Rz.rasterize_forward(*args, False, False)          # and the library is usable again afterwards
+    assert nr2 == nr and not torch.equal(color2, color)
