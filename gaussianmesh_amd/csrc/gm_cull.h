@@ -67,10 +67,12 @@ __device__ __forceinline__ TileCull tile_cull_setup(float sx, float sy, float a,
   t.lim = thr + 4e-6f * (a * mx * mx + c * my * my + 2.0f * fabsf(b) * mx * my) + 1e-3f;
   t.det = a * c - b * b;
   if (!(op >= 0.0039f) || t.lim <= 0.f) { t.mode = 0; return t; }
-  const float r = t.lim / t.det;
-  t.dymax = sqrtf(a * r) * 1.0001f + 1e-3f;
-  t.xext = sqrtf(c * r) * 1.0001f + 1e-3f;
-  t.dystar = b * sqrtf(r / c);
+  // hardware sqrt / rcp (1 ulp) instead of the correctly rounded sequences: this test only has to be conservative and
+  // identical wherever it is evaluated; the 1e-4 relative / 1e-3 absolute margins dwarf the approximation error
+  const float r = t.lim * __builtin_amdgcn_rcpf(t.det);
+  t.dymax = __builtin_amdgcn_sqrtf(a * r) * 1.0001f + 1e-3f;
+  t.xext = __builtin_amdgcn_sqrtf(c * r) * 1.0001f + 1e-3f;
+  t.dystar = b * __builtin_amdgcn_sqrtf(r * __builtin_amdgcn_rcpf(c));
   if (!(t.det > 0.f) || !(t.dymax < 1e30f) || !(t.xext < 1e30f) || !(t.dystar == t.dystar)) t.mode = 2;
   return t;
 }
@@ -80,7 +82,7 @@ __device__ __forceinline__ bool row_span(const TileCull& t, float sx, float sy, 
 #pragma clang fp contract(off)
   float dyl = fmaxf(sy - py1, -t.dymax), dyh = fminf(sy - py0, t.dymax);
   if (!(dyl <= dyh)) return false;
-  const float sl = sqrtf(fmaxf(t.a * t.lim - t.det * dyl * dyl, 0.f)), sh = sqrtf(fmaxf(t.a * t.lim - t.det * dyh * dyh, 0.f));
+  const float sl = __builtin_amdgcn_sqrtf(fmaxf(t.a * t.lim - t.det * dyl * dyl, 0.f)), sh = __builtin_amdgcn_sqrtf(fmaxf(t.a * t.lim - t.det * dyh * dyh, 0.f));
   float hi = fmaxf(-t.b * dyl + sl, -t.b * dyh + sh) * t.inv_a;
   float lo = fminf(-t.b * dyl - sl, -t.b * dyh - sh) * t.inv_a;
   if (-t.dystar >= dyl && -t.dystar <= dyh) hi = t.xext;
