@@ -245,6 +245,7 @@ def main():
         # ---- per-stage HIP-event timing over a second pass of the same steps (events perturb the pipelining a
         # little, so they are kept out of the region that defines `value`)
         # ... and on ONE stream, so a stage's events bracket only its own kernels
+        default_policy = lib.gm_get_tile_culling()
         lib.gm_profile_reset(); lib.gm_profile_enable(1)
         nprof = min(args.steps, 50)
         with torch.cuda.stream(streams[0]):
@@ -273,6 +274,30 @@ def main():
         out["frame_roofline"] = {"algorithmic_bytes": tot_bytes, "achieved": tot_bytes / (elapsed / args.steps) / 1e9,
                                  "frac": tot_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s",
                                  "single_stream_ms_per_frame": sum(per.values())}
+        # BASELINE.md section 3 normalises the frame against the bytes the REFERENCE's algorithm moves for the same frame
+        # (A_fwd with the reference's instance count, 12-byte pairs through ceil((32+bit)/8) sort passes,
+        # plus 156 B per Gaussian and 84 B per vertex for the deformation).  Reported beside the fraction above, which
+        # is against this implementation's own (much smaller) byte count.
+        lib.gm_set_tile_culling(0)
+        try:
+            t = args.warmup % F
+            c0 = cam_t[multiview.view_for_step(args.warmup, F, rank, world)]
+            pos0, cov60, rgb0 = deform_shade_packed(g["tri"], g["weights"], pack_mesh_state(g["mesh"][t], g["verts"]), g["cov"], g["pos"],
+                                                    g["shs"], c0["campos"], deg=3)
+            h0 = Rz.rasterize_forward_begin(bg, pos0, rgb0, g["opac"], None, None, 1.0, cov60, c0["view"], c0["proj"], c0["tanx"], c0["tany"],
+                                            H, W, None, 3, c0["campos"], False, False)
+            h0.event.synchronize()
+            R_ref = int(h0.count_host[0])
+        finally:
+            lib.gm_set_tile_culling(default_policy)
+        T16 = ((W + 15) // 16) * ((H + 15) // 16)
+        npass = (32 + max(1, int(np.ceil(np.log2(max(T16, 2))))) + 7) // 8
+        A_ref = (P * 44 + V * 12 * 16 + V * 48 + P * 8 + V * 20 + R_ref * 12 + R_ref * (8 + 24 * npass) + R_ref * 8 + T16 * 8 + R_ref * 40
+                 + W * H * 12 + P * 156 + Vm * 84)
+        out["frame_roofline"]["baseline_normalisation"] = {
+            "reference_instances": R_ref, "reference_sort_passes": npass, "reference_algorithm_bytes": A_ref,
+            "achieved": A_ref / (elapsed / args.steps) / 1e9, "frac": A_ref / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s",
+            "note": "BASELINE.md section 3: bytes of the reference's algorithm for this frame / measured frame time / 8 TB/s"}
 
     if rank == 0 and world == 1 and not args.no_fwd_bwd:
         # ---- forward + backward through the autograd operator (train-time input mode: SH + scale/rot)
