@@ -4,27 +4,28 @@
 //   RAST/forward.cu:261-374   renderCUDA (forward)
 //   RAST/backward.cu:399-557  renderCUDA (backward)
 //
-// CDNA4 mapping (DESIGN.md "blend"): the reference gives each 16x16 tile to a 256-thread block that
-// stages 256-entry batches in shared memory behind two block barriers and lets every pixel thread
-// re-read the batch from LDS (and the colour from global memory).  Here a tile is processed by
-// 4/PPL independent wave64s, each owning 64*PPL pixels (PPL pixels per lane, in registers):
-//   * a wave gathers 64 list entries at a time (lane j <- entry j: one 4-byte id + three 16-byte
-//     splat loads) into registers, double-buffered so the next batch's HBM/L2 latency hides under
-//     the current batch's arithmetic;
-//   * entry j is broadcast to all lanes with v_readlane_b32 into SGPRs (the entry is wave-uniform),
-//     so the inner loop has no LDS traffic, no s_barrier and no per-pixel global colour read;
-//   * while lane j holds entry j it also tests, once per batch and for all 64 entries in parallel, whether
-//     the entry can reach alpha >= 1/255 anywhere inside the wave's pixel rectangle (exact minimum of the
-//     conic's quadratic form over the rectangle, with a rounding margin).  A 64-bit ballot of the survivors
-//     drives the inner loop (s_ff1 over set bits), so entries whose rect merely covers the tile cost ~1 VALU
-//     op instead of ~20 per pixel.  The cull is conservative: a culled entry would have been skipped by every
-//     pixel of the wave (alpha < 1/255), so results and n_contrib are unchanged.
-//   * "is every pixel done" is a wave vote (__all) instead of __syncthreads_count; an entry that no
-//     pixel of the wave accepts is skipped with one __any.
+// CDNA4 mapping: the reference gives each 16x16 tile to a 256-thread block that stages
+// 256-entry batches in shared memory behind two block barriers and lets every pixel thread re-read the batch from LDS
+// (and the colour from global memory).  Here a 16x16 tile is four independent wave64s, each owning one 8x8 pixel
+// quadrant (one pixel per lane, lane = y * 8 + x):
+//   * the workgroup walks the list of its PARENT tile (gm_common.h: emission policies) and takes the entries whose key
+//     carries its child bit; a wave gathers 64 list entries at a time (lane j <- entry j: key, id, three 16-byte splat
+//     loads) through a three-deep software pipeline with a constant number of loads per iteration;
+//   * while lane j holds entry j it tests, once per batch and for all 64 entries in parallel, whether the entry can
+//     reach alpha >= 1/255 anywhere inside the bounding box of the quadrant's still-live pixels (exact minimum of the
+//     conic's quadratic form over the rectangle, with a rounding margin).  A 64-bit ballot of the survivors drives the
+//     inner loop (s_ff1 over set bits).  The cull is conservative: a culled entry would have been skipped by every
+//     live pixel (alpha < 1/255), so results and n_contrib are unchanged;
+//   * survivors are re-read as LDS broadcasts from a wave-private copy of the batch (conic pre-multiplied for the
+//     exp2 argument) and processed two at a time; no s_barrier, no per-pixel global colour read;
+//   * "is every pixel done" is a ballot instead of __syncthreads_count; an entry that no pixel of the wave accepts
+//     is skipped with one __any.
 // Discrete semantics are the reference's: skip power>0, skip alpha<1/255, stop (without applying the
 // entry) when T(1-alpha)<1e-4, n_contrib = 1-based list position of the last accepted entry.
 // FMA contraction is allowed here and exp() is v_exp_f32 on power*log2(e); see DESIGN.md for the
 // tolerance argument.
+// PPL (pixels per lane) and QUAD (8x8 quadrant instead of a 16x4 strip) are fixed at 1 / true: the other shapes were
+// measured slower and are no longer instantiated; the loops over k < PPL are kept trivial.
 #include "gm_common.h"
 #include "gm_cull.h"
 #include <cstdlib>
@@ -32,6 +33,8 @@
 namespace gm {
 
 #define LOG2E 1.4426950408889634f
+constexpr int PPL = 1;          // pixels per lane
+constexpr bool QUAD = true;     // a wave owns an 8x8 pixel quadrant of its tile
 
 __device__ __forceinline__ float bcast(float v, int j) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
@@ -87,8 +90,7 @@ __device__ __forceinline__ Batch load_records(const float4* __restrict__ splat, 
 }
 
 
-template <int PPL, bool QUAD = false>
-__global__ __launch_bounds__(256 / PPL) void render_fwd_kernel(const uint2* __restrict__ ranges,
+__global__ __launch_bounds__(256) void render_fwd_kernel(const uint2* __restrict__ ranges,
                                                                const uint32_t* __restrict__ tile_keys,
                                                                const uint32_t* __restrict__ point_list,
                                                                const float4* __restrict__ splat, int W, int H, TileMap tm,
@@ -265,7 +267,7 @@ int launch_render_fwd(const GeomState& g, const uint32_t* tile_keys, const uint3
   const TileGrid tg(W, H, mode);
   const TileMap tm{tg.gx, tg.gy, tg.pgx, tg.pgy, tg.s};
   if (tg.ptiles > 0)
-    hipLaunchKernelGGL((render_fwd_kernel<1, true>), dim3(tm.blocks()), dim3(256), 0, s, img.ranges, tile_keys, point_list, g.splat, W, H, tm,
+    hipLaunchKernelGGL(render_fwd_kernel, dim3(tm.blocks()), dim3(256), 0, s, img.ranges, tile_keys, point_list, g.splat, W, H, tm,
                        background, out_color, img.final_T, img.n_contrib);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
@@ -331,8 +333,7 @@ __device__ __forceinline__ int reduce8_slot(int lane) {
 
 #define GM_ACC_STRIDE 12   // floats per Gaussian in grad_acc: dcolor rgb (0-2), moments of h: 1, dx, dy, dx^2, dx dy, dy^2 (3-8)
 
-template <int PPL, bool QUAD = false>
-__global__ __launch_bounds__(256 / PPL) void render_bwd_kernel(const uint2* __restrict__ ranges,
+__global__ __launch_bounds__(256) void render_bwd_kernel(const uint2* __restrict__ ranges,
                                                                const uint32_t* __restrict__ tile_keys,
                                                                const uint32_t* __restrict__ point_list,
                                                                const float4* __restrict__ splat, int W, int H, TileMap tm,
@@ -487,7 +488,7 @@ int launch_render_bwd(const GeomState& g, const uint32_t* tile_keys, const uint3
   const TileGrid tg(W, H, mode);
   const TileMap tm{tg.gx, tg.gy, tg.pgx, tg.pgy, tg.s};
   if (tg.ptiles > 0)
-    hipLaunchKernelGGL((render_bwd_kernel<1, true>), dim3(tm.blocks()), dim3(256), 0, s, img.ranges, tile_keys, point_list, g.splat, W, H, tm,
+    hipLaunchKernelGGL(render_bwd_kernel, dim3(tm.blocks()), dim3(256), 0, s, img.ranges, tile_keys, point_list, g.splat, W, H, tm,
                        background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
