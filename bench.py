@@ -318,7 +318,7 @@ def main():
         for _ in range(3):
             it()
         torch.cuda.synchronize()
-        nit = 20
+        nit = 40
         t1 = time.perf_counter()
         for _ in range(nit):
             it()

@@ -183,3 +183,22 @@ class SingleObjectDeform:
                                       self.gaussian_cov, self.gaussian_pos, self.gaussian_feature, campos, deg)
         self.gaussian_deform_pos, self.gaussian_deform_cov6 = pos, cov6
         return pos, rgb, cov6
+
+    def deform_and_render(self, deform_vertex, cur_rot, cur_shear, viewpoint_camera, bg_color=None, workspace=None, begin_only=False):
+        """The edit loop's frame in two enqueues (gm_forward_0_deformed_async + gm_forward_1_geom): deformation, rotated-
+        direction SH colour and the rasterizer's preprocess run in one kernel, the deformed cloud is never written out.
+        viewpoint_camera carries the reference's camera attributes (image_height/width, FoVx/FoVy, world_view_transform,
+        full_proj_transform, camera_center).  Returns the image [3,H,W] (white background by default, as
+        ObjectVisualTool.render_gaussian), or with begin_only the PendingForward handle for pipelined loops."""
+        import math
+        from . import rasterizer as Rz
+        dev = self.gaussian_pos.device
+        state = torch.cat([_f(deform_vertex), _f(cur_rot).reshape(-1, 9), _f(cur_shear).reshape(-1, 9)], dim=1)
+        packed = pack_mesh_state(state, self.vertex)
+        bg = torch.ones(3, device=dev) if bg_color is None else bg_color
+        c = viewpoint_camera
+        h = Rz.forward_deformed_begin(bg, self.gaussian_triangles, self.coord, packed, self.gaussian_cov, self.gaussian_pos,
+                                      self.gaussian_feature, self.gaussian_o, c.world_view_transform, c.full_proj_transform,
+                                      math.tan(c.FoVx * 0.5), math.tan(c.FoVy * 0.5), c.image_height, c.image_width, 3, c.camera_center,
+                                      workspace=workspace)
+        return h if begin_only else h.finish()[1]

@@ -430,6 +430,9 @@ def test_render_glue_contract(oracle):
     obj.deform(T(verts), T(I), T(I))
     img = render_deformed(cam, [obj], bg_color=bg)
     assert (img - out["render"].detach()).abs().max() <= 2e-4
+    # ... and the fused frame (deformation + colour + preprocess in one kernel) gives the same picture as the two-step route
+    img2 = obj.deform_and_render(T(verts), T(I), T(I), cam, bg_color=bg)
+    assert (img2 - img).abs().max() <= 1e-6
 
 
 def test_async_begin_finish_pipeline_matches_sync(oracle):
