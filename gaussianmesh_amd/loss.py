@@ -1,6 +1,7 @@
 """Photometric losses of the training loop, mirroring utils/loss_utils.py of the reference.
 
   l1_loss(network_output, gt)                       loss_utils.py:17-18
+  mesh_restrict_loss(scale, v1, v2, v3, weight)     loss_utils.py:83-108 (torch elementwise; once per iteration on [N,3])
   l2_loss(network_output, gt)                       loss_utils.py:20-21
   ssim(img1, img2, window_size=11, size_average=True)   loss_utils.py:35-81
   photometric_loss(image, gt, lambda_dssim)         train_mesh_gaussian.py:92-94:
@@ -125,3 +126,22 @@ class _Photometric(torch.autograd.Function):
 def photometric_loss(image, gt, lambda_dssim=0.2):
     """(1 - lambda) * l1_loss(image, gt) + lambda * (1 - ssim(image, gt)) in one forward and one backward kernel."""
     return _Photometric.apply(image, gt, float(lambda_dssim))
+
+
+def distance(point1, point2):
+    """loss_utils.py:83-84"""
+    return torch.linalg.vector_norm(point1 - point2, dim=1)
+
+
+def circumradius(point1, point2, point3):
+    """loss_utils.py:86-101: despite the name, sqrt(|AB x AC|) (the square root of twice the triangle's area) - kept as
+    the reference computes it."""
+    areas = torch.linalg.vector_norm(torch.cross(point2 - point1, point3 - point1, dim=1), dim=1)
+    return torch.sqrt(areas)
+
+
+def mesh_restrict_loss(scale, point1, point2, point3, weight=10):
+    """loss_utils.py:103-108: sum over Gaussians of max(0, max_axis(scale) - weight * circumradius(face)); keeps a bound
+    Gaussian from growing past its triangle (train_mesh_gaussian.py:93)."""
+    max_s = scale.max(dim=1).values
+    return torch.clamp(max_s - weight * circumradius(point1, point2, point3), min=0).sum()

@@ -178,6 +178,22 @@ def test_reference_ssim_on_the_subset_agrees_with_loss_oracle(jt, ref_env):
     assert np.allclose(lu.gaussian(11, 1.5).numpy(), lo.window_1d(), rtol=3e-7, atol=0)     # float32 sum order may differ by an ulp
 
 
+def test_mesh_restrict_loss_matches_the_reference_function(jt, ref_env):
+    from gaussianmesh_amd import loss
+    lu = _load_ref("ref_loss_utils2", "utils/loss_utils.py")
+    rng = np.random.default_rng(5)
+    sc = np.exp(rng.standard_normal((50, 3))).astype(np.float32) * 0.3
+    p1, p2, p3 = (rng.standard_normal((50, 3)).astype(np.float32) for _ in range(3))
+    want = float(lu.mesh_restrict_loss(jt.array(sc), jt.array(p1), jt.array(p2), jt.array(p3), weight=0.4))
+    t = lambda a: torch.tensor(a, requires_grad=True)
+    ts = t(sc)
+    got = loss.mesh_restrict_loss(ts, t(p1), t(p2), t(p3), weight=0.4)
+    assert want > 0 and abs(float(got) - want) <= 1e-5 * want
+    got.backward()
+    assert ts.grad is not None and float(ts.grad.abs().sum()) > 0
+    assert torch.allclose(loss.circumradius(t(p1), t(p2), t(p3)), lu.circumradius(jt.array(p1), jt.array(p2), jt.array(p3)), rtol=1e-6)
+
+
 def test_reference_mesh_model_trains_and_densifies_on_the_subset(jt, ref_env):
     from gaussianmesh_amd import scenes
     mm = _load_ref("ref_mesh_model", "scene/mesh_based_gaussian_model.py")
