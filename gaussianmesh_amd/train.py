@@ -1,0 +1,82 @@
+"""One optimisation iteration of the mesh-Gaussian training loop, mirroring train_mesh_gaussian.py:80-148 on this
+package's operators (SURVEY.md 8f-3 "training loop harness"):
+
+    render(cam, gaussians)  ->  loss = (1 - l) L1 + l (1 - SSIM) + mesh_restrict_loss  ->  backward  ->  Adam step
+
+`Trainer` keeps the per-group learning rates of MeshBasedGaussianModel.training_setup
+(scene/mesh_based_gaussian_model.py:242-263) and the exponential position schedule
+(utils/general_utils.py:28-62 get_expon_lr_func).  Densification / pruning are host-side bookkeeping of the reference
+model class (it runs unchanged on gaussianmesh_amd.compat); this harness is the fixed-topology loop used to time and
+test the GPU path end to end.
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from .loss import mesh_restrict_loss, photometric_loss
+from .renderer import render
+
+
+def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
+    """utils/general_utils.py:28-62 (log-linear interpolation with optional delayed warm-up)."""
+    def helper(step):
+        if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+            return 0.0
+        if lr_delay_steps > 0:
+            delay_rate = lr_delay_mult + (1 - lr_delay_mult) * np.sin(0.5 * np.pi * np.clip(step / lr_delay_steps, 0, 1))
+        else:
+            delay_rate = 1.0
+        t = np.clip(step / max_steps, 0, 1)
+        return delay_rate * np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t)
+    return helper
+
+
+DEFAULT_OPT = dict(position_lr_init=0.00016, position_lr_final=0.0000016, position_lr_delay_mult=0.01, position_lr_max_steps=30000,
+                   feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001, lambda_dssim=0.2, alpha_mrloss=10.0)
+
+
+class Trainer:
+    def __init__(self, gaussians, spatial_lr_scale=1.0, **opt):
+        o = dict(DEFAULT_OPT); o.update(opt)
+        self.opt = SimpleNamespace(**o)
+        self.g = gaussians
+        s = spatial_lr_scale
+        groups = [
+            {"params": [gaussians._bc], "lr": o["position_lr_init"] * s, "name": "bc"},
+            {"params": [gaussians._distance], "lr": o["position_lr_init"] * s, "name": "distance"},
+            {"params": [gaussians._features_dc], "lr": o["feature_lr"], "name": "f_dc"},
+            {"params": [gaussians._features_rest], "lr": o["feature_lr"] / 20.0, "name": "f_rest"},
+            {"params": [gaussians._opacity], "lr": o["opacity_lr"], "name": "opacity"},
+            {"params": [gaussians._scaling], "lr": o["scaling_lr"], "name": "scaling"},
+            {"params": [gaussians._rotation], "lr": o["rotation_lr"], "name": "rotation"},
+        ]
+        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        self.bc_lr = get_expon_lr_func(o["position_lr_init"] * s, o["position_lr_final"] * s, lr_delay_mult=o["position_lr_delay_mult"],
+                                       max_steps=o["position_lr_max_steps"])
+        self.pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
+        self.iteration = 0
+
+    def update_learning_rate(self):
+        lr = self.bc_lr(self.iteration)
+        for gr in self.optimizer.param_groups:
+            if gr["name"] in ("bc", "distance"):
+                gr["lr"] = lr
+        return lr
+
+    def step(self, camera, gt_image, background):
+        """One iteration; returns (loss tensor, render package).  No host synchronisation besides the rasterizer's
+        instance-count read-back."""
+        self.iteration += 1
+        self.update_learning_rate()
+        g = self.g
+        if g.screenspace_points.grad is not None:
+            g.screenspace_points.grad = None
+        pkg = render(camera, g, self.pipe, background)
+        loss = photometric_loss(pkg["render"], gt_image, self.opt.lambda_dssim)
+        if self.opt.alpha_mrloss:
+            loss = loss + mesh_restrict_loss(pkg["scale"], pkg["vertex1"], pkg["vertex2"], pkg["vertex3"], weight=self.opt.alpha_mrloss)
+        loss.backward()
+        self.optimizer.step()
+        self.optimizer.zero_grad(set_to_none=True)
+        return loss.detach(), pkg
