@@ -342,6 +342,29 @@ def main():
             it_loss()
         torch.cuda.synchronize()
         out["fwd_bwd"]["ms_per_iter_with_l1_ssim_loss"] = 1e3 * (time.perf_counter() - t1) / nit
+        # a whole optimisation iteration of the mesh-Gaussian training loop on the same cloud (train_mesh_gaussian.py:80-148:
+        # mesh-bound positions and activations, render, L1 + SSIM + mesh-restrict loss, backward, Adam on all 7 groups)
+        from gaussianmesh_amd.renderer import Camera, MeshBoundGaussians
+        from gaussianmesh_amd.train import Trainer
+        del leaves, m2d
+        tri_np = g["tri"].cpu().numpy(); vn = g["verts"].cpu().numpy()
+        v1, v2, v3 = (torch.tensor(vn[tri_np[:, k]], device=dev) for k in range(3))
+        nrm = torch.nn.functional.normalize(torch.cross(v2 - v1, v3 - v1, dim=1), dim=1)
+        rad = (((v2 - v1).norm(dim=1) + (v3 - v2).norm(dim=1) + (v1 - v3).norm(dim=1)) / 3)[:, None]
+        model = MeshBoundGaussians(torch.log(g["weights"].clamp_min(1e-6)), torch.zeros((P, 1), device=dev), g["shs"][:, :1].clone(),
+                                   g["shs"][:, 1:].clone(), torch.log(g["scales"]), g["rots"].clone(),
+                                   torch.logit(g["opac"].reshape(-1, 1).clamp(1e-4, 1 - 1e-4)), v1, v2, v3, nrm, rad).to(dev)
+        tr = Trainer(model)
+        cam0 = Camera(cams[0], dev)
+        zero_bg = torch.zeros(3, device=dev)
+        for _ in range(3):
+            tr.step(cam0, gt, zero_bg)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(nit):
+            tr.step(cam0, gt, zero_bg)
+        torch.cuda.synchronize()
+        out["fwd_bwd"]["ms_per_training_iteration"] = 1e3 * (time.perf_counter() - t1) / nit
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # ---- CPU baseline: the oracle port (plain C + OpenMP) on the host cores, bounded sample of the same workload

@@ -3,6 +3,7 @@
 // Orchestration replaces CudaRasterizer::Rasterizer::{forward_0, forward_1, backward, markVisible}
 // (cuda_rasterizer/rasterizer_impl.cu:338-413, 416-511, 515-609, 141-153).
 #include "gm_common.h"
+#include <cmath>
 #include <cstdlib>
 #include "../../include/gmesh_hip.h"
 #include <cstdarg>
@@ -390,6 +391,66 @@ int gm_ssim_bwd(const float* img1, const float* img2, const float* dS_dmu1, cons
   if (!img1 || !img2 || !dS_dmu1 || !dS_dE11 || !dS_dE12 || !g_ssim || !dL_dimg1) { set_error("gm_ssim_bwd: null argument"); return GM_ERR_INVALID_ARG; }
   if (planes > 65535) { set_error("gm_ssim_bwd: at most 65535 image planes per call"); return GM_ERR_INVALID_ARG; }
   return launch_ssim_bwd(img1, img2, dS_dmu1, dS_dE11, dS_dE12, planes, H, W, g_ssim, g_l1, dL_dimg1, reinterpret_cast<hipStream_t>(stream));
+}
+
+static int fill_act(ActArgs& a, int N, float alpha, const float* bc, const float* dist, const float* scaling, const float* rotation,
+                    const float* opacity, const float* v1, const float* v2, const float* v3, const float* normal, const float* r) {
+  if (N < 0) { set_error("gm_mesh_activate: negative N"); return GM_ERR_INVALID_ARG; }
+  if (N > 0 && (!bc || !dist || !scaling || !rotation || !opacity || !v1 || !v2 || !v3 || !normal || !r)) {
+    set_error("gm_mesh_activate: null input"); return GM_ERR_INVALID_ARG;
+  }
+  if (N > 0 && (reinterpret_cast<uintptr_t>(rotation) & 15)) { set_error("gm_mesh_activate: rotation must be 16-byte aligned"); return GM_ERR_INVALID_ARG; }
+  a.N = N; a.alpha = alpha; a.bc = bc; a.dist = dist; a.scaling = scaling; a.rotation = rotation; a.opacity = opacity;
+  a.v1 = v1; a.v2 = v2; a.v3 = v3; a.normal = normal; a.r = r;
+  return GM_OK;
+}
+
+int gm_mesh_activate_fwd(int N, float alpha, const float* bc, const float* dist, const float* scaling, const float* rotation,
+                         const float* opacity, const float* v1, const float* v2, const float* v3, const float* normal, const float* r,
+                         float* xyz, float* scales, float* rots, float* opac, void* stream) {
+  ActArgs a;
+  if (int rc = fill_act(a, N, alpha, bc, dist, scaling, rotation, opacity, v1, v2, v3, normal, r)) return rc;
+  if (N > 0 && (!xyz || !scales || !rots || !opac || (reinterpret_cast<uintptr_t>(rots) & 15))) {
+    set_error("gm_mesh_activate_fwd: null output or unaligned rots"); return GM_ERR_INVALID_ARG;
+  }
+  return launch_mesh_activate_fwd(a, xyz, scales, rots, opac, reinterpret_cast<hipStream_t>(stream));
+}
+
+int gm_mesh_activate_bwd(int N, float alpha, const float* bc, const float* dist, const float* scaling, const float* rotation,
+                         const float* opacity, const float* v1, const float* v2, const float* v3, const float* normal, const float* r,
+                         const float* d_xyz, const float* d_scales, const float* d_rots, const float* d_opac, float* d_bc, float* d_dist,
+                         float* d_scaling, float* d_rotation, float* d_opacity, void* stream) {
+  ActArgs a;
+  if (int rc = fill_act(a, N, alpha, bc, dist, scaling, rotation, opacity, v1, v2, v3, normal, r)) return rc;
+  if (N > 0 && (!d_bc || !d_dist || !d_scaling || !d_rotation || !d_opacity || (reinterpret_cast<uintptr_t>(d_rotation) & 15) ||
+                (d_rots && (reinterpret_cast<uintptr_t>(d_rots) & 15)))) {
+    set_error("gm_mesh_activate_bwd: null output or unaligned rotation gradient"); return GM_ERR_INVALID_ARG;
+  }
+  return launch_mesh_activate_bwd(a, d_xyz, d_scales, d_rots, d_opac, d_bc, d_dist, d_scaling, d_rotation, d_opacity,
+                                  reinterpret_cast<hipStream_t>(stream));
+}
+
+int gm_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                 const uint64_t* sizes, const float* lr, const float* lr_rest, const uint32_t* period, const uint32_t* split,
+                 float beta1, float beta2, float eps, int step, void* stream) {
+  if (count < 0 || count > 8 || step < 1) { set_error("gm_adam_step: 0..8 tensors per call, step >= 1"); return GM_ERR_INVALID_ARG; }
+  if (count > 0 && (!params || !grads || !exp_avg || !exp_avg_sq || !sizes || !lr)) { set_error("gm_adam_step: null table"); return GM_ERR_INVALID_ARG; }
+  AdamTable tab;
+  tab.count = 0; tab.b1 = beta1; tab.b2 = beta2; tab.eps = eps;
+  const double corr = sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
+  for (int i = 0; i < count; i++) {
+    if (sizes[i] == 0) continue;
+    if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i]) { set_error("gm_adam_step: null tensor %d", i); return GM_ERR_INVALID_ARG; }
+    if ((reinterpret_cast<uintptr_t>(params[i]) | reinterpret_cast<uintptr_t>(grads[i]) | reinterpret_cast<uintptr_t>(exp_avg[i]) |
+         reinterpret_cast<uintptr_t>(exp_avg_sq[i])) & 15) { set_error("gm_adam_step: tensor %d is not 16-byte aligned", i); return GM_ERR_INVALID_ARG; }
+    AdamTensor& t = tab.t[tab.count++];
+    t.p = params[i]; t.g = grads[i]; t.m = exp_avg[i]; t.v = exp_avg_sq[i]; t.n = sizes[i];
+    t.step_lo = (float)(lr[i] * corr);
+    t.period = period ? period[i] : 0u; t.split = split ? split[i] : 0u;
+    if (t.period & 3u) { set_error("gm_adam_step: period must be a multiple of 4"); return GM_ERR_INVALID_ARG; }
+    t.step_hi = (float)((lr_rest && t.period) ? lr_rest[i] * corr : lr[i] * corr);
+  }
+  return launch_adam(tab, reinterpret_cast<hipStream_t>(stream));
 }
 
 void gm_profile_enable(int on) { g_prof_on = on != 0; }

@@ -220,6 +220,22 @@ int launch_ssim_fwd(const float* img1, const float* img2, int planes, int H, int
                     float* partial, hipStream_t s);
 int launch_ssim_bwd(const float* img1, const float* img2, const float* d_mu1, const float* d_e11, const float* d_e12, int planes,
                     int H, int W, const float* g_ssim, const float* g_l1, float* dL_dimg1, hipStream_t s);
+struct ActArgs {                 // mesh-bound parameter -> rasterizer-input map (gm_train.hip)
+  int N;
+  float alpha;
+  const float *bc, *dist, *scaling, *rotation, *opacity, *v1, *v2, *v3, *normal, *r;
+};
+struct AdamTensor {
+  float* p; const float* g; float* m; float* v;
+  unsigned long long n;
+  float step_lo, step_hi;      // lr * sqrt(1-b2^t)/(1-b1^t) for elements with (index % period) < split / the others
+  unsigned period, split;      // period == 0: one rate (step_lo) for the whole tensor
+};
+struct AdamTable { AdamTensor t[8]; int count; float b1, b2, eps; };
+int launch_mesh_activate_fwd(const ActArgs& a, float* xyz, float* scales, float* rots, float* opac, hipStream_t s);
+int launch_mesh_activate_bwd(const ActArgs& a, const float* d_xyz, const float* d_scales, const float* d_rots, const float* d_opac,
+                             float* d_bc, float* d_dist, float* d_scaling, float* d_rotation, float* d_opacity, hipStream_t s);
+int launch_adam(const AdamTable& tab, hipStream_t s);
 int launch_knn(int P, const float* points, float* meanDists, void* ws, size_t ws_bytes, hipStream_t s);
 size_t knn_workspace_bytes(int P);
 

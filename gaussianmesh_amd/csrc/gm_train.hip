@@ -1,0 +1,140 @@
+// gm_train.hip -- the per-Gaussian host-framework work around the rasterizer in one training iteration, fused:
+//
+//   mesh_activate_fwd / _bwd : MeshBasedGaussianModel's parameter -> rasterizer-input map and its adjoint
+//       get_xyz      = softmax(bc) . (v1,v2,v3) + alpha r (sigmoid(d) - 0.5) n      scene/mesh_based_gaussian_model.py:138-152
+//       get_scaling  = exp(_scaling)            get_rotation = normalize(_rotation)                   :122-128, 33-43
+//       get_opacity  = sigmoid(_opacity)                                                              :172-174
+//     In the reference these are ~15 Jittor elementwise ops forward and ~25 in the autograd pass, each a pass over P;
+//     here one kernel each way (60 B in, 44 B out per Gaussian forward).
+//   adam_kernel : jittor.nn.Adam's update for all parameter groups of the model in ONE launch (table of tensors,
+//     per-group learning rate; the SH tensor [P,16,3] takes two rates - coefficient 0 is the reference's "f_dc" group,
+//     the rest "f_rest" - so no concatenation / split of the 192-byte SH rows is needed per iteration):
+//       m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr sqrt(1-b2^t)/(1-b1^t) m / (sqrt(v) + eps)
+//     (scene/mesh_based_gaussian_model.py:242-263 training_setup; jittor/optim.py Adam.step).
+#include "gm_common.h"
+
+namespace gm {
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__global__ __launch_bounds__(256) void mesh_activate_fwd_kernel(const ActArgs a, float* __restrict__ xyz, float* __restrict__ scales,
+                                                                 float4* __restrict__ rots, float* __restrict__ opac) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.N) return;
+  const size_t i3 = 3 * (size_t)i;
+  const float b0 = a.bc[i3], b1 = a.bc[i3 + 1], b2 = a.bc[i3 + 2];
+  const float mx = fmaxf(b0, fmaxf(b1, b2));
+  const float e0 = __expf(b0 - mx), e1 = __expf(b1 - mx), e2 = __expf(b2 - mx);
+  const float inv = 1.0f / (e0 + e1 + e2);
+  const float w0 = e0 * inv, w1 = e1 * inv, w2 = e2 * inv;
+  const float k = a.alpha * a.r[i] * (sigmoidf(a.dist[i]) - 0.5f);
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+    xyz[i3 + c] = (w0 * a.v1[i3 + c] + w1 * a.v2[i3 + c] + w2 * a.v3[i3 + c]) + k * a.normal[i3 + c];
+#pragma unroll
+  for (int c = 0; c < 3; c++) scales[i3 + c] = __expf(a.scaling[i3 + c]);
+  const float4 q = reinterpret_cast<const float4*>(a.rotation)[i];
+  const float qn = 1.0f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);   // F.normalize eps
+  rots[i] = make_float4(q.x * qn, q.y * qn, q.z * qn, q.w * qn);
+  opac[i] = sigmoidf(a.opacity[i]);
+}
+
+__global__ __launch_bounds__(256) void mesh_activate_bwd_kernel(const ActArgs a, const float* __restrict__ d_xyz,
+                                                                 const float* __restrict__ d_scales, const float4* __restrict__ d_rots,
+                                                                 const float* __restrict__ d_opac, float* __restrict__ d_bc,
+                                                                 float* __restrict__ d_dist, float* __restrict__ d_scaling,
+                                                                 float4* __restrict__ d_rotation, float* __restrict__ d_opacity) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.N) return;
+  const size_t i3 = 3 * (size_t)i;
+  const float gx = d_xyz ? d_xyz[i3] : 0.f, gy = d_xyz ? d_xyz[i3 + 1] : 0.f, gz = d_xyz ? d_xyz[i3 + 2] : 0.f;
+  {  // softmax-barycentric position and normal offset
+    const float b0 = a.bc[i3], b1 = a.bc[i3 + 1], b2 = a.bc[i3 + 2];
+    const float mx = fmaxf(b0, fmaxf(b1, b2));
+    const float e0 = __expf(b0 - mx), e1 = __expf(b1 - mx), e2 = __expf(b2 - mx);
+    const float inv = 1.0f / (e0 + e1 + e2);
+    const float w0 = e0 * inv, w1 = e1 * inv, w2 = e2 * inv;
+    const float dw0 = gx * a.v1[i3] + gy * a.v1[i3 + 1] + gz * a.v1[i3 + 2];
+    const float dw1 = gx * a.v2[i3] + gy * a.v2[i3 + 1] + gz * a.v2[i3 + 2];
+    const float dw2 = gx * a.v3[i3] + gy * a.v3[i3 + 1] + gz * a.v3[i3 + 2];
+    const float dot = w0 * dw0 + w1 * dw1 + w2 * dw2;
+    d_bc[i3] = w0 * (dw0 - dot); d_bc[i3 + 1] = w1 * (dw1 - dot); d_bc[i3 + 2] = w2 * (dw2 - dot);
+    const float sd = sigmoidf(a.dist[i]);
+    const float gn = gx * a.normal[i3] + gy * a.normal[i3 + 1] + gz * a.normal[i3 + 2];
+    d_dist[i] = gn * a.alpha * a.r[i] * sd * (1.0f - sd);
+  }
+#pragma unroll
+  for (int c = 0; c < 3; c++) d_scaling[i3 + c] = d_scales ? d_scales[i3 + c] * __expf(a.scaling[i3 + c]) : 0.f;
+  {
+    const float4 q = reinterpret_cast<const float4*>(a.rotation)[i];
+    const float nrm = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f), qn = 1.0f / nrm;
+    const float4 y = make_float4(q.x * qn, q.y * qn, q.z * qn, q.w * qn);
+    const float4 g = d_rots ? d_rots[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float yd = y.x * g.x + y.y * g.y + y.z * g.z + y.w * g.w;
+    d_rotation[i] = make_float4((g.x - y.x * yd) * qn, (g.y - y.y * yd) * qn, (g.z - y.z * yd) * qn, (g.w - y.w * yd) * qn);
+  }
+  {
+    const float o = sigmoidf(a.opacity[i]);
+    d_opacity[i] = d_opac ? d_opac[i] * o * (1.0f - o) : 0.f;
+  }
+}
+
+int launch_mesh_activate_fwd(const ActArgs& a, float* xyz, float* scales, float* rots, float* opac, hipStream_t s) {
+  if (a.N <= 0) return 0;
+  hipLaunchKernelGGL(mesh_activate_fwd_kernel, dim3((a.N + 255) / 256), dim3(256), 0, s, a, xyz, scales, reinterpret_cast<float4*>(rots), opac);
+  GM_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_mesh_activate_bwd(const ActArgs& a, const float* d_xyz, const float* d_scales, const float* d_rots, const float* d_opac,
+                             float* d_bc, float* d_dist, float* d_scaling, float* d_rotation, float* d_opacity, hipStream_t s) {
+  if (a.N <= 0) return 0;
+  hipLaunchKernelGGL(mesh_activate_bwd_kernel, dim3((a.N + 255) / 256), dim3(256), 0, s, a, d_xyz, d_scales,
+                     reinterpret_cast<const float4*>(d_rots), d_opac, d_bc, d_dist, d_scaling, reinterpret_cast<float4*>(d_rotation), d_opacity);
+  GM_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(const AdamTable tab) {
+  const AdamTensor t = tab.t[blockIdx.y];
+  const float b1 = tab.b1, b2 = tab.b2, eps = tab.eps;
+  const unsigned long long n4 = t.n >> 2;
+  for (unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (unsigned long long)gridDim.x * 256) {
+    const float4 g = reinterpret_cast<const float4*>(t.g)[q];
+    float4 p = reinterpret_cast<float4*>(t.p)[q], m = reinterpret_cast<float4*>(t.m)[q], v = reinterpret_cast<float4*>(t.v)[q];
+    float* pp = &p.x; float* mm = &m.x; float* vv = &v.x; const float* gg = &g.x;
+    const unsigned in_period = t.period ? (unsigned)(q % (t.period >> 2)) * 4u : 0u;     // period is a multiple of 4 (checked by the API)
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const float st = (t.period && in_period + c >= t.split) ? t.step_hi : t.step_lo;
+      mm[c] = b1 * mm[c] + (1.0f - b1) * gg[c];
+      vv[c] = b2 * vv[c] + (1.0f - b2) * gg[c] * gg[c];
+      pp[c] -= st * mm[c] / (sqrtf(vv[c]) + eps);
+    }
+    reinterpret_cast<float4*>(t.p)[q] = p; reinterpret_cast<float4*>(t.m)[q] = m; reinterpret_cast<float4*>(t.v)[q] = v;
+  }
+  // tail (n not a multiple of 4): first workgroup
+  if (blockIdx.x == 0 && threadIdx.x < (t.n & 3)) {
+    const unsigned long long e = (n4 << 2) + threadIdx.x;
+    const float st = (t.period && (unsigned)(e % t.period) >= t.split) ? t.step_hi : t.step_lo;
+    const float g = t.g[e];
+    const float m = b1 * t.m[e] + (1.0f - b1) * g, v = b2 * t.v[e] + (1.0f - b2) * g * g;
+    t.m[e] = m; t.v[e] = v;
+    t.p[e] -= st * m / (sqrtf(v) + eps);
+  }
+}
+
+int launch_adam(const AdamTable& tab, hipStream_t s) {
+  if (tab.count <= 0) return 0;
+  unsigned long long mx = 0;
+  for (int i = 0; i < tab.count; i++) mx = tab.t[i].n > mx ? tab.t[i].n : mx;
+  unsigned long long nb = (mx / 4 + 255) / 256;
+  if (nb < 1) nb = 1;
+  if (nb > 16384) nb = 16384;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb, (unsigned)tab.count), dim3(256), 0, s, tab);
+  GM_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace gm

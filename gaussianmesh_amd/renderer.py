@@ -43,16 +43,21 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     if bg_gaussian is not None:
         screenspace_points = torch.cat([screenspace_points, torch.zeros_like(bg_gaussian.get_xyz)], dim=0)
     rasterizer = GaussianRasterizer(_settings(viewpoint_camera, bg_color, scaling_modifier, pc.active_sh_degree, pipe.debug))
-    means3D, means2D, opacity = pc.get_xyz, screenspace_points, pc.get_opacity
-    scales = rotations = cov3D_precomp = None
-    if pipe.compute_cov3D_python:
-        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    fused = hasattr(pc, "activated") and not pipe.compute_cov3D_python and pc.get_features.is_cuda
+    if fused:                                    # one kernel for the four activations instead of ~15 elementwise ops
+        means3D, scales, rotations, opacity = pc.activated()
+        means2D, cov3D_precomp = screenspace_points, None
     else:
-        scales, rotations = pc.get_scaling, pc.get_rotation
+        means3D, means2D, opacity = pc.get_xyz, screenspace_points, pc.get_opacity
+        scales = rotations = cov3D_precomp = None
+        if pipe.compute_cov3D_python:
+            cov3D_precomp = pc.get_covariance(scaling_modifier)
+        else:
+            scales, rotations = pc.get_scaling, pc.get_rotation
     shs = colors_precomp = None
     if override_color is None:
         if pipe.convert_SHs_python:
-            colors_precomp = _python_sh_colors(pc, viewpoint_camera, pc.get_xyz, pc.get_features)
+            colors_precomp = _python_sh_colors(pc, viewpoint_camera, means3D.detach(), pc.get_features)
         else:
             shs = pc.get_features
     else:
@@ -82,16 +87,21 @@ def bg_render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, overri
     if mesh_gaussians is not None:
         screenspace_points = torch.cat([screenspace_points, mesh_gaussians.screenspace_points], dim=0)
     rasterizer = GaussianRasterizer(_settings(viewpoint_camera, bg_color, scaling_modifier, pc.active_sh_degree, pipe.debug))
-    means3D, means2D, opacity = pc.get_xyz, screenspace_points, pc.get_opacity
-    scales = rotations = cov3D_precomp = None
-    if pipe.compute_cov3D_python:
-        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    fused = hasattr(pc, "activated") and not pipe.compute_cov3D_python and pc.get_features.is_cuda
+    if fused:                                    # one kernel for the four activations instead of ~15 elementwise ops
+        means3D, scales, rotations, opacity = pc.activated()
+        means2D, cov3D_precomp = screenspace_points, None
     else:
-        scales, rotations = pc.get_scaling, pc.get_rotation
+        means3D, means2D, opacity = pc.get_xyz, screenspace_points, pc.get_opacity
+        scales = rotations = cov3D_precomp = None
+        if pipe.compute_cov3D_python:
+            cov3D_precomp = pc.get_covariance(scaling_modifier)
+        else:
+            scales, rotations = pc.get_scaling, pc.get_rotation
     shs = colors_precomp = None
     if override_color is None:
         if pipe.convert_SHs_python:
-            colors_precomp = _python_sh_colors(pc, viewpoint_camera, pc.get_xyz, pc.get_features)
+            colors_precomp = _python_sh_colors(pc, viewpoint_camera, means3D.detach(), pc.get_features)
         else:
             shs = pc.get_features
     else:
@@ -140,7 +150,10 @@ class Camera:
 
 class MeshBoundGaussians(torch.nn.Module):
     """Mesh-bound parameterisation of scene/mesh_based_gaussian_model.py (parameters and activations only; no
-    densification / optimiser / PLY):  get_xyz = softmax(bc).(v1,v2,v3) + 4 r (sigmoid(d) - 0.5) n   (:138-152)."""
+    densification / optimiser / PLY):  get_xyz = softmax(bc).(v1,v2,v3) + 4 r (sigmoid(d) - 0.5) n   (:138-152).
+    The SH coefficients are ONE parameter `_features` [N,16,3] (`_features_dc` / `_features_rest` are views of it, so
+    get_features needs no per-iteration concatenation of the 192-byte rows; the optimizer gives coefficient 0 and the
+    rest their own learning rates, train.py).  activated() evaluates all four activations in one fused HIP kernel."""
     alpha_distance = 4
 
     def __init__(self, bc, distance, features_dc, features_rest, scaling, rotation, opacity, vertex1, vertex2, vertex3, normal, r,
@@ -148,7 +161,7 @@ class MeshBoundGaussians(torch.nn.Module):
         super().__init__()
         P = torch.nn.Parameter
         self._bc, self._distance = P(bc), P(distance)
-        self._features_dc, self._features_rest = P(features_dc), P(features_rest)
+        self._features = P(torch.cat((features_dc, features_rest), dim=1).contiguous())
         self._scaling, self._rotation, self._opacity = P(scaling), P(rotation), P(opacity)
         for n, v in dict(vertex1=vertex1, vertex2=vertex2, vertex3=vertex3, normal=normal, r=r).items():
             self.register_buffer(n, v)
@@ -168,8 +181,22 @@ class MeshBoundGaussians(torch.nn.Module):
         return torch.sigmoid(self._opacity)
 
     @property
+    def _features_dc(self):
+        return self._features[:, :1]
+
+    @property
+    def _features_rest(self):
+        return self._features[:, 1:]
+
+    @property
     def get_features(self):
-        return torch.cat((self._features_dc, self._features_rest), dim=1)
+        return self._features
+
+    def activated(self):
+        """(get_xyz, get_scaling, get_rotation, get_opacity) from one fused kernel (gm_mesh_activate_fwd / _bwd)."""
+        from .model_ops import mesh_activate
+        return mesh_activate(self._bc, self._distance, self._scaling, self._rotation, self._opacity, self.vertex1, self.vertex2,
+                             self.vertex3, self.normal, self.r, float(self.alpha_distance))
 
     @property
     def get_proj_xyz(self):

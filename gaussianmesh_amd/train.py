@@ -42,16 +42,18 @@ class Trainer:
         self.opt = SimpleNamespace(**o)
         self.g = gaussians
         s = spatial_lr_scale
+        # the reference's seven groups; "f_dc" (coefficient 0) and "f_rest" are the two learning rates of the one SH tensor
         groups = [
             {"params": [gaussians._bc], "lr": o["position_lr_init"] * s, "name": "bc"},
             {"params": [gaussians._distance], "lr": o["position_lr_init"] * s, "name": "distance"},
-            {"params": [gaussians._features_dc], "lr": o["feature_lr"], "name": "f_dc"},
-            {"params": [gaussians._features_rest], "lr": o["feature_lr"] / 20.0, "name": "f_rest"},
+            {"params": [gaussians._features], "lr": o["feature_lr"], "lr_rest": o["feature_lr"] / 20.0, "period": 48, "split": 3,
+             "name": "f_dc+f_rest"},
             {"params": [gaussians._opacity], "lr": o["opacity_lr"], "name": "opacity"},
             {"params": [gaussians._scaling], "lr": o["scaling_lr"], "name": "scaling"},
             {"params": [gaussians._rotation], "lr": o["rotation_lr"], "name": "rotation"},
         ]
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        from .model_ops import FusedAdam
+        self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
         self.bc_lr = get_expon_lr_func(o["position_lr_init"] * s, o["position_lr_final"] * s, lr_delay_mult=o["position_lr_delay_mult"],
                                        max_steps=o["position_lr_max_steps"])
         self.pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)

@@ -211,6 +211,33 @@ int gm_ssim_fwd(const float* img1, const float* img2, int planes, int H, int W, 
 int gm_ssim_bwd(const float* img1, const float* img2, const float* dS_dmu1, const float* dS_dE11, const float* dS_dE12, int planes,
                 int H, int W, const float* g_ssim, const float* g_l1, float* dL_dimg1, void* stream);
 
+/* Training-loop fusions around the rasterizer ("MeshBasedGaussianModel.get_xyz ... fused into the op").
+ * gm_mesh_activate_fwd: raw parameters -> rasterizer inputs in one pass, replacing the Jittor elementwise chains of
+ *   get_xyz = softmax(bc).(v1,v2,v3) + alpha r (sigmoid(dist) - 0.5) normal   (scene/mesh_based_gaussian_model.py:138-152)
+ *   get_scaling = exp(scaling), get_rotation = normalize(rotation) (:122-128), get_opacity = sigmoid(opacity) (:172-174).
+ *   bc/scaling/v1/v2/v3/normal float [N,3]; dist/opacity/r float [N]; rotation float [N,4] (16-byte aligned).
+ *   Outputs xyz [N,3], scales [N,3], rots [N,4] (16-byte aligned), opac [N].
+ * gm_mesh_activate_bwd: the adjoint (what Jittor's autograd derives op by op); d_xyz / d_scales / d_rots / d_opac may be
+ *   NULL (= zero); writes d_bc, d_dist, d_scaling, d_rotation, d_opacity. */
+int gm_mesh_activate_fwd(int N, float alpha, const float* bc, const float* dist, const float* scaling, const float* rotation,
+                         const float* opacity, const float* v1, const float* v2, const float* v3, const float* normal, const float* r,
+                         float* xyz, float* scales, float* rots, float* opac, void* stream);
+int gm_mesh_activate_bwd(int N, float alpha, const float* bc, const float* dist, const float* scaling, const float* rotation,
+                         const float* opacity, const float* v1, const float* v2, const float* v3, const float* normal, const float* r,
+                         const float* d_xyz, const float* d_scales, const float* d_rots, const float* d_opac, float* d_bc, float* d_dist,
+                         float* d_scaling, float* d_rotation, float* d_opacity, void* stream);
+
+/* jittor.nn.Adam's update (the optimizer of training_setup, scene/mesh_based_gaussian_model.py:242-263) for up to 8
+ * parameter tensors in one launch:  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+ *   p -= lr sqrt(1-b2^step)/(1-b1^step) m / (sqrt(v) + eps).
+ * The arrays are HOST arrays of `count` entries (device pointers, element counts, learning rates).  period/split/lr_rest
+ * (may be NULL) give a tensor two rates: elements with (index % period) < split use lr, the others lr_rest - the SH
+ * tensor [P,16,3] with period 48, split 3 is the reference's "f_dc" and "f_rest" groups without splitting the rows.
+ * All tensors 16-byte aligned; gradients are read, not cleared. */
+int gm_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                 const uint64_t* sizes, const float* lr, const float* lr_rest, const uint32_t* period, const uint32_t* split,
+                 float beta1, float beta2, float eps, int step, void* stream);
+
 /* Per-stage GPU timing (HIP events recorded on `stream` around each kernel group).  Off by default.
  * gm_profile_enable(1) starts collecting, gm_profile_read synchronises the recorded events and returns
  * accumulated milliseconds and launch count for a stage name ("preprocess","depth_sort","scan",

@@ -415,7 +415,7 @@ def test_render_glue_contract(oracle):
     assert np.array_equal(out["radii"].cpu().numpy(), fw["geo"]["radii"])
     assert np.abs(out["render"].detach().cpu().numpy() - fw["color"]).max() <= FWD_TOL
     out["render"].sum().backward()
-    for p in (pc._bc, pc._distance, pc._scaling, pc._rotation, pc._opacity, pc._features_dc, pc.screenspace_points):
+    for p in (pc._bc, pc._distance, pc._scaling, pc._rotation, pc._opacity, pc._features, pc.screenspace_points):
         assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().max() > 0
     # python-side covariance / colour switches give the same picture
     pipe2 = SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=True, debug=False)
