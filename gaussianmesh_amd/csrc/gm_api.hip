@@ -407,26 +407,26 @@ static int fill_act(ActArgs& a, int N, float alpha, const float* bc, const float
 
 int gm_mesh_activate_fwd(int N, float alpha, const float* bc, const float* dist, const float* scaling, const float* rotation,
                          const float* opacity, const float* v1, const float* v2, const float* v3, const float* normal, const float* r,
-                         float* xyz, float* scales, float* rots, float* opac, void* stream) {
+                         float* xyz, float* scales, float* rots, float* opac, float mr_weight, float* mr_partial, void* stream) {
   ActArgs a;
   if (int rc = fill_act(a, N, alpha, bc, dist, scaling, rotation, opacity, v1, v2, v3, normal, r)) return rc;
   if (N > 0 && (!xyz || !scales || !rots || !opac || (reinterpret_cast<uintptr_t>(rots) & 15))) {
     set_error("gm_mesh_activate_fwd: null output or unaligned rots"); return GM_ERR_INVALID_ARG;
   }
-  return launch_mesh_activate_fwd(a, xyz, scales, rots, opac, reinterpret_cast<hipStream_t>(stream));
+  return launch_mesh_activate_fwd(a, xyz, scales, rots, opac, mr_weight, mr_partial, reinterpret_cast<hipStream_t>(stream));
 }
 
 int gm_mesh_activate_bwd(int N, float alpha, const float* bc, const float* dist, const float* scaling, const float* rotation,
                          const float* opacity, const float* v1, const float* v2, const float* v3, const float* normal, const float* r,
                          const float* d_xyz, const float* d_scales, const float* d_rots, const float* d_opac, float* d_bc, float* d_dist,
-                         float* d_scaling, float* d_rotation, float* d_opacity, void* stream) {
+                         float* d_scaling, float* d_rotation, float* d_opacity, float mr_weight, const float* d_mr, void* stream) {
   ActArgs a;
   if (int rc = fill_act(a, N, alpha, bc, dist, scaling, rotation, opacity, v1, v2, v3, normal, r)) return rc;
   if (N > 0 && (!d_bc || !d_dist || !d_scaling || !d_rotation || !d_opacity || (reinterpret_cast<uintptr_t>(d_rotation) & 15) ||
                 (d_rots && (reinterpret_cast<uintptr_t>(d_rots) & 15)))) {
     set_error("gm_mesh_activate_bwd: null output or unaligned rotation gradient"); return GM_ERR_INVALID_ARG;
   }
-  return launch_mesh_activate_bwd(a, d_xyz, d_scales, d_rots, d_opac, d_bc, d_dist, d_scaling, d_rotation, d_opacity,
+  return launch_mesh_activate_bwd(a, d_xyz, d_scales, d_rots, d_opac, d_bc, d_dist, d_scaling, d_rotation, d_opacity, mr_weight, d_mr,
                                   reinterpret_cast<hipStream_t>(stream));
 }
 

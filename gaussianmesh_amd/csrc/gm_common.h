@@ -232,9 +232,11 @@ struct AdamTensor {
   unsigned period, split;      // period == 0: one rate (step_lo) for the whole tensor
 };
 struct AdamTable { AdamTensor t[8]; int count; float b1, b2, eps; };
-int launch_mesh_activate_fwd(const ActArgs& a, float* xyz, float* scales, float* rots, float* opac, hipStream_t s);
+int launch_mesh_activate_fwd(const ActArgs& a, float* xyz, float* scales, float* rots, float* opac, float mr_weight, float* mr_partial,
+                             hipStream_t s);
 int launch_mesh_activate_bwd(const ActArgs& a, const float* d_xyz, const float* d_scales, const float* d_rots, const float* d_opac,
-                             float* d_bc, float* d_dist, float* d_scaling, float* d_rotation, float* d_opacity, hipStream_t s);
+                             float* d_bc, float* d_dist, float* d_scaling, float* d_rotation, float* d_opacity, float mr_weight,
+                             const float* d_mr, hipStream_t s);
 int launch_adam(const AdamTable& tab, hipStream_t s);
 int launch_knn(int P, const float* points, float* meanDists, void* ws, size_t ws_bytes, hipStream_t s);
 size_t knn_workspace_bytes(int P);

@@ -17,10 +17,23 @@ namespace gm {
 
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// sqrt(|AB x AC|) of the bound face: the reference's circumradius() (utils/loss_utils.py:86-101)
+__device__ __forceinline__ float face_radius(const ActArgs& a, size_t i3) {
+  const float ax = a.v2[i3] - a.v1[i3], ay = a.v2[i3 + 1] - a.v1[i3 + 1], az = a.v2[i3 + 2] - a.v1[i3 + 2];
+  const float bx = a.v3[i3] - a.v1[i3], by = a.v3[i3 + 1] - a.v1[i3 + 1], bz = a.v3[i3 + 2] - a.v1[i3 + 2];
+  const float cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
+  return sqrtf(sqrtf(cx * cx + cy * cy + cz * cz));
+}
+
+// mr_partial (may be null): per-workgroup sums of the mesh-restrict term max(0, max_c scales - mr_weight * face_radius)
+// (utils/loss_utils.py:103-108); the host side adds the partials.
 __global__ __launch_bounds__(256) void mesh_activate_fwd_kernel(const ActArgs a, float* __restrict__ xyz, float* __restrict__ scales,
-                                                                 float4* __restrict__ rots, float* __restrict__ opac) {
+                                                                 float4* __restrict__ rots, float* __restrict__ opac,
+                                                                 float mr_weight, float* __restrict__ mr_partial) {
+  __shared__ float red[4];
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.N) return;
+  float term = 0.f;
+  if (i < a.N) {
   const size_t i3 = 3 * (size_t)i;
   const float b0 = a.bc[i3], b1 = a.bc[i3 + 1], b2 = a.bc[i3 + 2];
   const float mx = fmaxf(b0, fmaxf(b1, b2));
@@ -31,19 +44,30 @@ __global__ __launch_bounds__(256) void mesh_activate_fwd_kernel(const ActArgs a,
 #pragma unroll
   for (int c = 0; c < 3; c++)
     xyz[i3 + c] = (w0 * a.v1[i3 + c] + w1 * a.v2[i3 + c] + w2 * a.v3[i3 + c]) + k * a.normal[i3 + c];
+  float smax = -3.4e38f;
 #pragma unroll
-  for (int c = 0; c < 3; c++) scales[i3 + c] = __expf(a.scaling[i3 + c]);
+  for (int c = 0; c < 3; c++) { const float sc = __expf(a.scaling[i3 + c]); scales[i3 + c] = sc; smax = fmaxf(smax, sc); }
   const float4 q = reinterpret_cast<const float4*>(a.rotation)[i];
   const float qn = 1.0f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);   // F.normalize eps
   rots[i] = make_float4(q.x * qn, q.y * qn, q.z * qn, q.w * qn);
   opac[i] = sigmoidf(a.opacity[i]);
+  if (mr_partial) term = fmaxf(smax - mr_weight * face_radius(a, i3), 0.f);
+  }
+  if (mr_partial) {                              // wave-uniform
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) term += __shfl_xor(term, d);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = term;
+    __syncthreads();
+    if (threadIdx.x == 0) mr_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
 }
 
 __global__ __launch_bounds__(256) void mesh_activate_bwd_kernel(const ActArgs a, const float* __restrict__ d_xyz,
                                                                  const float* __restrict__ d_scales, const float4* __restrict__ d_rots,
                                                                  const float* __restrict__ d_opac, float* __restrict__ d_bc,
                                                                  float* __restrict__ d_dist, float* __restrict__ d_scaling,
-                                                                 float4* __restrict__ d_rotation, float* __restrict__ d_opacity) {
+                                                                 float4* __restrict__ d_rotation, float* __restrict__ d_opacity,
+                                                                 float mr_weight, const float* __restrict__ d_mr /*[1] or null*/) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= a.N) return;
   const size_t i3 = 3 * (size_t)i;
@@ -63,8 +87,17 @@ __global__ __launch_bounds__(256) void mesh_activate_bwd_kernel(const ActArgs a,
     const float gn = gx * a.normal[i3] + gy * a.normal[i3 + 1] + gz * a.normal[i3 + 2];
     d_dist[i] = gn * a.alpha * a.r[i] * sd * (1.0f - sd);
   }
+  {
+    float sc[3], ds[3];
 #pragma unroll
-  for (int c = 0; c < 3; c++) d_scaling[i3 + c] = d_scales ? d_scales[i3 + c] * __expf(a.scaling[i3 + c]) : 0.f;
+    for (int c = 0; c < 3; c++) { sc[c] = __expf(a.scaling[i3 + c]); ds[c] = d_scales ? d_scales[i3 + c] : 0.f; }
+    if (d_mr) {                                  // d/dscales of max(0, max_c scales - w R): one-hot on the first largest axis
+      const int am = (sc[0] >= sc[1] && sc[0] >= sc[2]) ? 0 : (sc[1] >= sc[2] ? 1 : 2);
+      if (sc[am] - mr_weight * face_radius(a, i3) > 0.f) ds[am] += d_mr[0];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) d_scaling[i3 + c] = ds[c] * sc[c];
+  }
   {
     const float4 q = reinterpret_cast<const float4*>(a.rotation)[i];
     const float nrm = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f), qn = 1.0f / nrm;
@@ -79,18 +112,22 @@ __global__ __launch_bounds__(256) void mesh_activate_bwd_kernel(const ActArgs a,
   }
 }
 
-int launch_mesh_activate_fwd(const ActArgs& a, float* xyz, float* scales, float* rots, float* opac, hipStream_t s) {
+int launch_mesh_activate_fwd(const ActArgs& a, float* xyz, float* scales, float* rots, float* opac, float mr_weight, float* mr_partial,
+                             hipStream_t s) {
   if (a.N <= 0) return 0;
-  hipLaunchKernelGGL(mesh_activate_fwd_kernel, dim3((a.N + 255) / 256), dim3(256), 0, s, a, xyz, scales, reinterpret_cast<float4*>(rots), opac);
+  hipLaunchKernelGGL(mesh_activate_fwd_kernel, dim3((a.N + 255) / 256), dim3(256), 0, s, a, xyz, scales, reinterpret_cast<float4*>(rots), opac,
+                     mr_weight, mr_partial);
   GM_HIP(hipGetLastError());
   return 0;
 }
 
 int launch_mesh_activate_bwd(const ActArgs& a, const float* d_xyz, const float* d_scales, const float* d_rots, const float* d_opac,
-                             float* d_bc, float* d_dist, float* d_scaling, float* d_rotation, float* d_opacity, hipStream_t s) {
+                             float* d_bc, float* d_dist, float* d_scaling, float* d_rotation, float* d_opacity, float mr_weight,
+                             const float* d_mr, hipStream_t s) {
   if (a.N <= 0) return 0;
   hipLaunchKernelGGL(mesh_activate_bwd_kernel, dim3((a.N + 255) / 256), dim3(256), 0, s, a, d_xyz, d_scales,
-                     reinterpret_cast<const float4*>(d_rots), d_opac, d_bc, d_dist, d_scaling, reinterpret_cast<float4*>(d_rotation), d_opacity);
+                     reinterpret_cast<const float4*>(d_rots), d_opac, d_bc, d_dist, d_scaling, reinterpret_cast<float4*>(d_rotation), d_opacity,
+                     mr_weight, d_mr);
   GM_HIP(hipGetLastError());
   return 0;
 }

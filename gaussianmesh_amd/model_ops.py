@@ -19,7 +19,7 @@ def _c(t):
 
 class _MeshActivate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, bc, distance, scaling, rotation, opacity, v1, v2, v3, normal, r, alpha):
+    def forward(ctx, bc, distance, scaling, rotation, opacity, v1, v2, v3, normal, r, alpha, mr_weight):
         lib = _lib.lib()
         dev = bc.device
         if dev.type != "cuda":
@@ -28,15 +28,19 @@ class _MeshActivate(torch.autograd.Function):
         N = ins[0].shape[0]
         f = dict(dtype=torch.float32, device=dev)
         xyz = torch.empty((N, 3), **f); scales = torch.empty((N, 3), **f); rots = torch.empty((N, 4), **f); opac = torch.empty((N, 1), **f)
+        want_mr = mr_weight is not None
+        part = torch.empty(((N + 255) // 256,), **f) if want_mr else None
         with torch.cuda.device(dev):
             _lib.check(lib.gm_mesh_activate_fwd(N, float(alpha), *[t.data_ptr() for t in ins], xyz.data_ptr(), scales.data_ptr(),
-                                                rots.data_ptr(), opac.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+                                                rots.data_ptr(), opac.data_ptr(), float(mr_weight or 0.0),
+                                                None if part is None else part.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
         ctx.save_for_backward(*ins)
-        ctx.alpha = float(alpha)
-        return xyz, scales, rots, opac
+        ctx.alpha, ctx.mr_weight = float(alpha), (float(mr_weight) if want_mr else None)
+        mr = part.sum() if want_mr else torch.zeros((), **f)
+        return xyz, scales, rots, opac, mr
 
     @staticmethod
-    def backward(ctx, d_xyz, d_scales, d_rots, d_opac):
+    def backward(ctx, d_xyz, d_scales, d_rots, d_opac, d_mr):
         lib = _lib.lib()
         ins = ctx.saved_tensors
         dev = ins[0].device
@@ -45,15 +49,20 @@ class _MeshActivate(torch.autograd.Function):
         d_bc = torch.empty((N, 3), **f); d_dist = torch.empty_like(ins[1]); d_scaling = torch.empty((N, 3), **f)
         d_rot = torch.empty((N, 4), **f); d_op = torch.empty_like(ins[4])
         g = [None if t is None else _c(t) for t in (d_xyz, d_scales, d_rots, d_opac)]
+        gm = _c(d_mr).reshape(1) if (ctx.mr_weight is not None and d_mr is not None) else None
         with torch.cuda.device(dev):
             _lib.check(lib.gm_mesh_activate_bwd(N, ctx.alpha, *[t.data_ptr() for t in ins], *[None if t is None else t.data_ptr() for t in g],
                                                 d_bc.data_ptr(), d_dist.data_ptr(), d_scaling.data_ptr(), d_rot.data_ptr(), d_op.data_ptr(),
+                                                float(ctx.mr_weight or 0.0), None if gm is None else gm.data_ptr(),
                                                 torch.cuda.current_stream(dev).cuda_stream))
-        return d_bc, d_dist, d_scaling, d_rot, d_op, None, None, None, None, None, None
+        return d_bc, d_dist, d_scaling, d_rot, d_op, None, None, None, None, None, None, None
 
 
-def mesh_activate(bc, distance, scaling, rotation, opacity, v1, v2, v3, normal, r, alpha=4.0):
-    return _MeshActivate.apply(bc, distance, scaling, rotation, opacity, v1, v2, v3, normal, r, alpha)
+def mesh_activate(bc, distance, scaling, rotation, opacity, v1, v2, v3, normal, r, alpha=4.0, mr_weight=None):
+    """Returns (xyz, scales, rotations, opacities) and, with mr_weight, a fifth output: mesh_restrict_loss(scales, v1, v2,
+    v3, weight=mr_weight) (utils/loss_utils.py:103-108) computed - and differentiated - inside the same two kernels."""
+    out = _MeshActivate.apply(bc, distance, scaling, rotation, opacity, v1, v2, v3, normal, r, alpha, mr_weight)
+    return out if mr_weight is not None else out[:4]
 
 
 class FusedAdam:

@@ -44,8 +44,12 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         screenspace_points = torch.cat([screenspace_points, torch.zeros_like(bg_gaussian.get_xyz)], dim=0)
     rasterizer = GaussianRasterizer(_settings(viewpoint_camera, bg_color, scaling_modifier, pc.active_sh_degree, pipe.debug))
     fused = hasattr(pc, "activated") and not pipe.compute_cov3D_python and pc.get_features.is_cuda
+    mrloss = None
     if fused:                                    # one kernel for the four activations instead of ~15 elementwise ops
-        means3D, scales, rotations, opacity = pc.activated()
+        mr_w = getattr(pipe, "mesh_restrict_weight", None)
+        act = pc.activated(mr_w)
+        means3D, scales, rotations, opacity = act[:4]
+        mrloss = act[4] if mr_w is not None else None
         means2D, cov3D_precomp = screenspace_points, None
     else:
         means3D, means2D, opacity = pc.get_xyz, screenspace_points, pc.get_opacity
@@ -76,9 +80,12 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
             colors_precomp = torch.cat([colors_precomp, bgc], dim=0)
     rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
                                        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
-    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
-            "vertex1": getattr(pc, "vertex1", None), "vertex2": getattr(pc, "vertex2", None),
-            "vertex3": getattr(pc, "vertex3", None), "scale": scales}
+    out = {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
+           "vertex1": getattr(pc, "vertex1", None), "vertex2": getattr(pc, "vertex2", None),
+           "vertex3": getattr(pc, "vertex3", None), "scale": scales}
+    if mrloss is not None:                       # extra key (pipe.mesh_restrict_weight set): the loss term of train_mesh_gaussian.py:93
+        out["mesh_restrict_loss"] = mrloss
+    return out
 
 
 def bg_render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, mesh_gaussians=None):
@@ -88,8 +95,12 @@ def bg_render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, overri
         screenspace_points = torch.cat([screenspace_points, mesh_gaussians.screenspace_points], dim=0)
     rasterizer = GaussianRasterizer(_settings(viewpoint_camera, bg_color, scaling_modifier, pc.active_sh_degree, pipe.debug))
     fused = hasattr(pc, "activated") and not pipe.compute_cov3D_python and pc.get_features.is_cuda
+    mrloss = None
     if fused:                                    # one kernel for the four activations instead of ~15 elementwise ops
-        means3D, scales, rotations, opacity = pc.activated()
+        mr_w = getattr(pipe, "mesh_restrict_weight", None)
+        act = pc.activated(mr_w)
+        means3D, scales, rotations, opacity = act[:4]
+        mrloss = act[4] if mr_w is not None else None
         means2D, cov3D_precomp = screenspace_points, None
     else:
         means3D, means2D, opacity = pc.get_xyz, screenspace_points, pc.get_opacity
@@ -192,11 +203,12 @@ class MeshBoundGaussians(torch.nn.Module):
     def get_features(self):
         return self._features
 
-    def activated(self):
-        """(get_xyz, get_scaling, get_rotation, get_opacity) from one fused kernel (gm_mesh_activate_fwd / _bwd)."""
+    def activated(self, mr_weight=None):
+        """(get_xyz, get_scaling, get_rotation, get_opacity[, mesh_restrict_loss]) from one fused kernel
+        (gm_mesh_activate_fwd / _bwd)."""
         from .model_ops import mesh_activate
         return mesh_activate(self._bc, self._distance, self._scaling, self._rotation, self._opacity, self.vertex1, self.vertex2,
-                             self.vertex3, self.normal, self.r, float(self.alpha_distance))
+                             self.vertex3, self.normal, self.r, float(self.alpha_distance), mr_weight)
 
     @property
     def get_proj_xyz(self):

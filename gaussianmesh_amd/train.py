@@ -56,7 +56,8 @@ class Trainer:
         self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
         self.bc_lr = get_expon_lr_func(o["position_lr_init"] * s, o["position_lr_final"] * s, lr_delay_mult=o["position_lr_delay_mult"],
                                        max_steps=o["position_lr_max_steps"])
-        self.pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
+        self.pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False,
+                                    mesh_restrict_weight=(o["alpha_mrloss"] or None))
         self.iteration = 0
 
     def update_learning_rate(self):
@@ -77,7 +78,9 @@ class Trainer:
         pkg = render(camera, g, self.pipe, background)
         loss = photometric_loss(pkg["render"], gt_image, self.opt.lambda_dssim)
         if self.opt.alpha_mrloss:
-            loss = loss + mesh_restrict_loss(pkg["scale"], pkg["vertex1"], pkg["vertex2"], pkg["vertex3"], weight=self.opt.alpha_mrloss)
+            mr = pkg.get("mesh_restrict_loss")
+            loss = loss + (mr if mr is not None else
+                           mesh_restrict_loss(pkg["scale"], pkg["vertex1"], pkg["vertex2"], pkg["vertex3"], weight=self.opt.alpha_mrloss))
         loss.backward()
         self.optimizer.step()
         self.optimizer.zero_grad(set_to_none=True)

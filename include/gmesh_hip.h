@@ -217,15 +217,19 @@ int gm_ssim_bwd(const float* img1, const float* img2, const float* dS_dmu1, cons
  *   get_scaling = exp(scaling), get_rotation = normalize(rotation) (:122-128), get_opacity = sigmoid(opacity) (:172-174).
  *   bc/scaling/v1/v2/v3/normal float [N,3]; dist/opacity/r float [N]; rotation float [N,4] (16-byte aligned).
  *   Outputs xyz [N,3], scales [N,3], rots [N,4] (16-byte aligned), opac [N].
+ *   mr_partial (may be NULL; float [ceil(N/256)]): per-workgroup sums of the mesh-restrict loss term
+ *   max(0, max_axis(scales) - mr_weight * sqrt(|AB x AC|)) (utils/loss_utils.py:86-108, train_mesh_gaussian.py:93); their
+ *   sum is mesh_restrict_loss(scales, v1, v2, v3, mr_weight).
  * gm_mesh_activate_bwd: the adjoint (what Jittor's autograd derives op by op); d_xyz / d_scales / d_rots / d_opac may be
- *   NULL (= zero); writes d_bc, d_dist, d_scaling, d_rotation, d_opacity. */
+ *   NULL (= zero); d_mr (device float [1], may be NULL) is the upstream gradient of that loss term; writes d_bc, d_dist,
+ *   d_scaling, d_rotation, d_opacity. */
 int gm_mesh_activate_fwd(int N, float alpha, const float* bc, const float* dist, const float* scaling, const float* rotation,
                          const float* opacity, const float* v1, const float* v2, const float* v3, const float* normal, const float* r,
-                         float* xyz, float* scales, float* rots, float* opac, void* stream);
+                         float* xyz, float* scales, float* rots, float* opac, float mr_weight, float* mr_partial, void* stream);
 int gm_mesh_activate_bwd(int N, float alpha, const float* bc, const float* dist, const float* scaling, const float* rotation,
                          const float* opacity, const float* v1, const float* v2, const float* v3, const float* normal, const float* r,
                          const float* d_xyz, const float* d_scales, const float* d_rots, const float* d_opac, float* d_bc, float* d_dist,
-                         float* d_scaling, float* d_rotation, float* d_opacity, void* stream);
+                         float* d_scaling, float* d_rotation, float* d_opacity, float mr_weight, const float* d_mr, void* stream);
 
 /* jittor.nn.Adam's update (the optimizer of training_setup, scene/mesh_based_gaussian_model.py:242-263) for up to 8
  * parameter tensors in one launch:  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;

@@ -43,6 +43,24 @@ def test_mesh_activate_forward_and_backward(N):
     assert float(g2[2].abs().max()) == 0.0 and float(g2[0].abs().max()) > 0
 
 
+def test_mesh_restrict_term_fused_into_the_activation():
+    """5th output of mesh_activate == loss.mesh_restrict_loss on the activated scales (value and gradient)."""
+    from gaussianmesh_amd.model_ops import mesh_activate
+    from gaussianmesh_amd.loss import mesh_restrict_loss
+    d = _inputs(5000, 7)
+    with torch.no_grad():
+        d["scaling"] += 2.0                                            # make a good share of the terms positive
+    args = (d["bc"], d["dist"], d["scaling"], d["rot"], d["opac"], d["v1"], d["v2"], d["v3"], d["n"], d["r"], 4.0)
+    xyz, sc, rt, op, mr = mesh_activate(*args, mr_weight=0.7)
+    ref = mesh_restrict_loss(torch.exp(d["scaling"].double()), d["v1"].double(), d["v2"].double(), d["v3"].double(), weight=0.7)
+    assert float(ref) > 0 and abs(float(mr) - float(ref)) <= 1e-5 * float(ref)
+    w = torch.randn_like(sc)
+    g, = torch.autograd.grad(2.5 * mr + (sc * w).sum(), [d["scaling"]])
+    gr, = torch.autograd.grad(2.5 * ref + (torch.exp(d["scaling"].double()) * w.double()).sum(), [d["scaling"]])
+    assert float((g.double() - gr).abs().max()) <= 1e-5 * float(gr.abs().max())
+    assert len(mesh_activate(*args)) == 4
+
+
 def test_fused_adam_matches_torch_adam_and_two_rate_tensor():
     from gaussianmesh_amd.model_ops import FusedAdam
     rng = np.random.default_rng(0)
