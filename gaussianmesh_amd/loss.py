@@ -57,7 +57,7 @@ def _bwd(a, b, maps, g_ssim_planes, g_l1):
     planes, _ = _planes(a)
     H, W = a.shape[-2], a.shape[-1]
     grad = torch.empty_like(a)
-    g_ssim_planes = g_ssim_planes.contiguous().float()
+    g_ssim_planes = g_ssim_planes.contiguous().float()          # views of one small tensor are contiguous already
     g_l1 = None if g_l1 is None else g_l1.reshape(1).contiguous().float()
     with torch.cuda.device(a.device):
         _lib.check(lib.gm_ssim_bwd(a.data_ptr(), b.data_ptr(), maps[0].data_ptr(), maps[1].data_ptr(), maps[2].data_ptr(), planes, H, W,
@@ -101,26 +101,38 @@ def ssim(img1, img2, window_size=11, size_average=True):
     return _Ssim.apply(img1, img2, bool(size_average))
 
 
+_COEF_CACHE = {}
+
+
+def _coefs(lam, n, planes, device):
+    """device constants of the fused loss: value = lam + <coef, (sum ssim, sum |a-b|)>; per-plane / L1 gradient scales"""
+    key = (float(lam), int(n), int(planes), device)
+    c = _COEF_CACHE.get(key)
+    if c is None:
+        val = torch.tensor([-lam / n, (1.0 - lam) / n], dtype=torch.float64, device=device)
+        grad = torch.tensor([-lam / n] * planes + [(1.0 - lam) / n], dtype=torch.float32, device=device)
+        c = _COEF_CACHE[key] = (val, grad)
+    return c
+
+
 class _Photometric(torch.autograd.Function):
     @staticmethod
     def forward(ctx, image, gt, lambda_dssim):
         a, b, maps, partial = _fwd(image, gt, ctx.needs_input_grad[0])
-        total = partial.double().sum(dim=(0, 1))                              # {sum ssim, sum |a-b|}
-        n = a.numel()
-        ctx.lam, ctx.n, ctx.shape = float(lambda_dssim), n, image.shape
+        lam, n = float(lambda_dssim), a.numel()
+        planes, _ = _planes(a)
+        val, grad = _coefs(lam, n, planes, a.device)
+        total = partial.view(-1, 2).sum(dim=0, dtype=torch.float64)            # {sum ssim, sum |a-b|}
+        ctx.shape, ctx.planes = image.shape, planes
         if maps is not None:
-            ctx.save_for_backward(a, b, maps)
-        l1 = total[1] / n
-        s = total[0] / n
-        return ((1.0 - ctx.lam) * l1 + ctx.lam * (1.0 - s)).float()
+            ctx.save_for_backward(a, b, maps, grad)
+        return (torch.dot(total, val) + lam).float()
 
     @staticmethod
     def backward(ctx, g):
-        a, b, maps = ctx.saved_tensors
-        planes, _ = _planes(a)
-        gp = (-ctx.lam * g.reshape(1) / ctx.n).expand(planes)
-        gl = (1.0 - ctx.lam) * g.reshape(1) / ctx.n
-        return _bwd(a, b, maps, gp, gl).view(ctx.shape), None, None
+        a, b, maps, grad = ctx.saved_tensors
+        gv = grad * g.reshape(1)                                               # [planes] ssim scales | [1] L1 scale
+        return _bwd(a, b, maps, gv[:ctx.planes], gv[ctx.planes:]).view(ctx.shape), None, None
 
 
 def photometric_loss(image, gt, lambda_dssim=0.2):
