@@ -208,10 +208,10 @@ def forward_deformed_begin(bg, tri, weights, packed, cov, pos, shs, opacity, vie
     device = pos.device
     if device.type != "cuda":
         raise _lib.GmeshError("gaussianmesh_amd rasterizer needs tensors on a HIP (cuda) device; there is no CPU path")
-    tri = tri.detach().contiguous().to(torch.int32)
-    weights, packed, cov, pos, shs, opacity = (_prep(t, device) for t in (weights, packed, cov, pos, shs, opacity))
-    bg, viewmatrix, projmatrix, campos = (_prep(t, device) for t in (bg, viewmatrix, projmatrix, campos))
     P, M = pos.shape[0], shs.shape[1]
+    tri = tri.detach().contiguous().to(torch.int32)
+    weights, packed, cov, pos, shs, opacity = (_prep(t, device) for t in (weights, packed, cov, pos, shs, opacity))   # None when empty
+    bg, viewmatrix, projmatrix, campos = (_prep(t, device) for t in (bg, viewmatrix, projmatrix, campos))
     H, W = int(image_height), int(image_width)
     stream = torch.cuda.current_stream(device)
     with torch.cuda.device(device):

@@ -529,3 +529,33 @@ def test_policy_change_between_forward_halves_is_refused_safely():
     lib.gm_set_tile_culling(2)
     nr2, color2, *_ = Rz.rasterize_forward(*args, False, False)          # and the library is usable again afterwards
     assert nr2 == nr and not torch.equal(color2, color)
+
+
+def test_fused_frame_edge_cases():
+    """Edit-loop fast path on an empty cloud, a one-Gaussian cloud and a cloud entirely behind the camera."""
+    from gpu_utils import T
+    from gaussianmesh_amd import rasterizer as Rz, scenes
+    from gaussianmesh_amd.deform import pack_mesh_state
+    verts, faces = scenes.torus_mesh(12, 8)
+    Vm = verts.shape[0]
+    state = np.concatenate([verts.astype(np.float32), np.tile(np.eye(3, dtype=np.float32).reshape(1, 9), (Vm, 2))], axis=1).astype(np.float32)
+    packed = pack_mesh_state(T(state), T(verts.astype(np.float32)))
+    cam = scenes.orbit_camera(0, 4, 96, 64, radius=6.0)
+    ct = {k: T(cam[k]) for k in ("view", "proj", "campos")}
+    bg = T(np.array([0.2, 0.4, 0.6], np.float32))
+    for N in (0, 1, 70):
+        cl = scenes.bind_cloud_to_mesh(max(N, 1), verts, faces, seed=1)
+        sl = lambda a: a[:N]
+        cov = scenes.cov3d_from_scale_rot(cl["scales"], cl["rots"]).astype(np.float32)
+        pos = cl["means"].copy()
+        if N == 70:
+            pos += 100.0 * (cam["campos"] - 0) / np.linalg.norm(cam["campos"])       # far behind the camera
+        h = Rz.forward_deformed_begin(bg, T(sl(cl["tri"]), dtype=torch.int32).reshape(-1, 3), T(sl(cl["weights"])).reshape(-1, 3), packed,
+                                      T(sl(cov)).reshape(-1, 3, 3), T(sl(pos)).reshape(-1, 3), T(sl(cl["shs"])).reshape(-1, 16, 3),
+                                      T(sl(cl["opac"])).reshape(-1, 1), ct["view"], ct["proj"], cam["tanx"], cam["tany"], 64, 96, 3, ct["campos"])
+        nr, color, radii, *_ = h.finish()
+        torch.cuda.synchronize()
+        assert radii.shape == (N,) and color.shape == (3, 64, 96) and torch.isfinite(color).all()
+        if N in (0, 70):
+            assert nr == 0 and torch.equal(color, bg.view(3, 1, 1).expand(3, 64, 96))
+            assert N == 0 or int((radii > 0).sum()) == 0
