@@ -339,10 +339,12 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const uint2* __restrict
                                                                const float4* __restrict__ splat, int W, int H, TileMap tm,
                                                                const float* __restrict__ bg, const float* __restrict__ final_T,
                                                                const uint32_t* __restrict__ n_contrib,
-                                                               const float* __restrict__ dL_dpix, float* __restrict__ grad_acc) {
+                                                               const float* __restrict__ dL_dpix, float* __restrict__ grad_acc,
+                                                               const uint32_t* __restrict__ counters, int mode) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int tx, ty, parent;
   uint32_t child_bit;
+  if ((int)counters[2] != mode || counters[3] != 0u) return;   // lists were built under another emission policy: contribute nothing
   if (!tm.locate(blockIdx.x, tx, ty, parent, child_bit)) return;
   const uint2 range = ranges[parent];
   const int n = (int)(range.y - range.x);
@@ -489,7 +491,7 @@ int launch_render_bwd(const GeomState& g, const uint32_t* tile_keys, const uint3
   const TileMap tm{tg.gx, tg.gy, tg.pgx, tg.pgy, tg.s};
   if (tg.ptiles > 0)
     hipLaunchKernelGGL(render_bwd_kernel, dim3(tm.blocks()), dim3(256), 0, s, img.ranges, tile_keys, point_list, g.splat, W, H, tm,
-                       background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc);
+                       background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc, g.counters, mode);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }
