@@ -422,7 +422,10 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const uint2* __restrict
     const bool mine_3 = ld_mine(start - 1 - (base + 192) - lane);
     const Batch nx2 = ld_rec(id_2, mine_2);
     const bool keep = mine && may_touch(cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, cx0, cx1, cy0, cy1);
-    rec[lane][0] = cur.a; rec[lane][1] = cur.b; rec[lane][2] = make_float4(cur.c, __uint_as_float(cur.id), 0.f, 0.f);
+    // conic pre-multiplied for the exp2 argument, as in render_fwd_kernel (the moments below only need dx, dy)
+    rec[lane][0] = make_float4(cur.a.x, cur.a.y, (-0.5f * LOG2E) * cur.a.z, (-LOG2E) * cur.a.w);
+    rec[lane][1] = make_float4((-0.5f * LOG2E) * cur.b.x, cur.b.y, cur.b.z, cur.b.w);
+    rec[lane][2] = make_float4(cur.c, __uint_as_float(cur.id), 0.f, 0.f);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     unsigned long long todo = __ballot(keep);
@@ -431,17 +434,17 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const uint2* __restrict
       todo &= todo - 1;
       const int pos = start - 1 - base - j;          // 0-based list position == reference `contributor`
       const float4 RA = rec[j][0], RB = rec[j][1];
-      const float sx = RA.x, sy = RA.y, cx = RA.z, cy = RA.w, cz = RB.x, op = RB.y;
+      const float sx = RA.x, sy = RA.y, qa = RA.z, qb = RA.w, qc = RB.x, op = RB.y;
       const float dx = sx - pixx;
       float G[PPL], alpha[PPL], dy[PPL];
       bool valid[PPL], anyv = false;
 #pragma unroll
       for (int k = 0; k < PPL; k++) {
         dy[k] = sy - pixy[k];
-        const float power = -0.5f * (cx * dx * dx + cz * dy[k] * dy[k]) - cy * dx * dy[k];
-        G[k] = __builtin_amdgcn_exp2f(power * LOG2E);
+        const float e = dx * (qa * dx + qb * dy[k]) + (qc * dy[k]) * dy[k];      // power * log2(e); same sign as power
+        G[k] = __builtin_amdgcn_exp2f(e);
         alpha[k] = fminf(0.99f, op * G[k]);
-        valid[k] = (pos < last[k]) && (power <= 0.0f) && (alpha[k] >= 1.0f / 255.0f);
+        valid[k] = (pos < last[k]) && (e <= 0.0f) && (alpha[k] >= 1.0f / 255.0f);
         anyv = anyv || valid[k];
       }
       if (!__any(anyv)) continue;
