@@ -48,6 +48,13 @@ for frame in (0, 5):
         proc = np.where(satq, np.minimum(np.ceil(q / 64) + 1, np.ceil(nq / 64)), np.ceil(nq / 64))
         print("  thr %g: saturated quadrants %.1f%% (of non-empty %.1f%%); batches processed %.0fk (saturated part %.0fk, unsaturated %.0fk)" % (
             thr, 100 * satq.mean(), 100 * (satq & (nq > 0)).sum() / max((nq > 0).sum(), 1), proc.sum() / 1e3, proc[satq].sum() / 1e3, proc[~satq].sum() / 1e3))
+    # unsaturated quadrants: how many of their 64 pixels stay live to the end of the list (they bound the walk)
+    livecnt = (Tp.reshape(gy * 2, 8, gx * 2, 8) >= 1e-3).sum(axis=(1, 3))
+    long_q = (~(tmax < 2e-2)) & (nq > 2000)
+    if long_q.any():
+        lc = livecnt[long_q]
+        print("  unsaturated quadrants on lists > 2000: %d; live pixels at the end: mean %.1f  p50 %d  p90 %d  max %d;  <=16 live: %.0f%%  <=32 live: %.0f%%" % (
+            long_q.sum(), lc.mean(), *np.percentile(lc, [50, 90]).astype(int), lc.max(), 100 * (lc <= 16).mean(), 100 * (lc <= 32).mean()))
     top = np.argsort(-n)[:5]
     print(" longest tiles:", [(int(t % gx), int(t // gx), int(n[t]), int(q.reshape(gy, 2, gx, 2)[t // gx, :, t % gx, :].max())) for t in top])
     print(" batches per wave: total %.0fk, max %d" % (np.ceil(nq / 64).sum() / 1e3, int(np.ceil(n.max() / 64))))
