@@ -64,6 +64,9 @@ static inline size_t sort_blocks(size_t n) {
   const size_t tile = sort_tile_keys(n);
   return (n + tile - 1) / tile;
 }
+#define GM_SORT_CHUNK 32             // histogram rows (workgroups) per scan workgroup
+// counters of the per-chunk digit totals: [chunks][256]
+static inline size_t sort_chunk_counters(size_t n) { return 256 * ((sort_blocks(n) + GM_SORT_CHUNK - 1) / GM_SORT_CHUNK); }
 
 struct GeomState {              // per-Gaussian state (P-sized)
   float4* splat;                // [P][3]: {x,y,con.x,con.y} {con.z,opacity,r,g} {b,depth,0,0}
@@ -75,8 +78,8 @@ struct GeomState {              // per-Gaussian state (P-sized)
   uint8_t* clamped;             // [P] bit ch = SH colour channel ch was clamped at 0
   uint32_t* depth_key[2];       // [P] ping-pong keys of the depth sort (float bits of view z)
   uint32_t* order[2];           // [P] ping-pong payload; order[0] = Gaussian ids sorted by (depth, id)
-  uint32_t* hist;               // [256][sort_blocks(P)] radix histograms of the depth sort
-  uint32_t* digit_total;        // [256]
+  uint32_t* hist;               // [sort_blocks(P)][256] radix histograms of the depth sort
+  uint32_t* digit_total;        // [chunks][256] per-chunk digit totals
   uint32_t* block_sums;         // [ceil(P/GM_SCAN_ITEMS)] tiles_touched partial sums (sorted order)
   uint32_t* counters;           // [16] device scalars: [0] = num_rendered
   float* grad_acc;              // [P][12] backward accumulators: dcolor rgb | dmean2D xy | dconic x,y,w | dopacity | pad
@@ -94,7 +97,7 @@ struct GeomState {              // per-Gaussian state (P-sized)
     g.order[0] = carve<uint32_t>(p, P);
     g.order[1] = carve<uint32_t>(p, P);
     g.hist = carve<uint32_t>(p, 256 * sort_blocks(P));
-    g.digit_total = carve<uint32_t>(p, 256);
+    g.digit_total = carve<uint32_t>(p, sort_chunk_counters(P));
     g.block_sums = carve<uint32_t>(p, (P + GM_SCAN_ITEMS - 1) / GM_SCAN_ITEMS + 1);
     g.counters = carve<uint32_t>(p, 16);
     g.grad_acc = carve<float>(p, 12 * P);
@@ -125,8 +128,8 @@ struct ImageState {             // per-pixel / per-tile state
 struct BinningState {           // per-instance state (R-sized)
   uint32_t* keys[2];            // [R] tile id per instance, ping-pong
   uint32_t* vals[2];            // [R] Gaussian id per instance, ping-pong
-  uint32_t* hist;               // [256][sort_blocks(R)]
-  uint32_t* digit_total;        // [256]
+  uint32_t* hist;               // [sort_blocks(R)][256]
+  uint32_t* digit_total;        // [chunks][256]
   static BinningState from(void* buf, size_t R) {
     char* p = reinterpret_cast<char*>(buf);
     BinningState b;
@@ -136,7 +139,7 @@ struct BinningState {           // per-instance state (R-sized)
     b.vals[0] = carve<uint32_t>(p, Rp);
     b.vals[1] = carve<uint32_t>(p, Rp);
     b.hist = carve<uint32_t>(p, 256 * sort_blocks(Rp));
-    b.digit_total = carve<uint32_t>(p, 256);
+    b.digit_total = carve<uint32_t>(p, sort_chunk_counters(Rp));
     b.end = p;
     return b;
   }

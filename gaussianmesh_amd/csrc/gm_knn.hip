@@ -31,7 +31,7 @@ struct KnnWs {
     k.keys[0] = carve<uint32_t>(p, P); k.keys[1] = carve<uint32_t>(p, P);
     k.idx[0] = carve<uint32_t>(p, P); k.idx[1] = carve<uint32_t>(p, P);
     k.hist = carve<uint32_t>(p, 256 * sort_blocks(P));
-    k.digit_total = carve<uint32_t>(p, 256);
+    k.digit_total = carve<uint32_t>(p, sort_chunk_counters(P));
     k.boxes = carve<float>(p, 6 * ((P + KNN_BOX - 1) / KNN_BOX));
     k.end = p;
     return k;

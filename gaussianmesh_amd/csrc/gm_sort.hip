@@ -12,13 +12,18 @@
 //
 // One pass = three kernels (no inter-workgroup dependency inside a launch, so no reliance on
 // cross-XCD L2 coherence):
-//   K1 radix_hist     : workgroup b counts the 256 digit values of its 4096 keys -> hist[digit][b]
-//   K2 radix_scan     : workgroup d exclusive-scans row d of hist in place, writes digit_total[d]
-//   K3 radix_scatter  : workgroup b re-reads its keys, ranks them stably (per-wave match-any with
-//                       64-bit ballots + per-wave digit counters in LDS), sorts the tile by digit inside
-//                       LDS, and streams it out: digit d's run goes to
-//                       exclusive_scan(digit_total)[d] + hist[d][b] + (position in run), so global stores
-//                       are contiguous runs rather than per-lane scatters.
+//   K1 radix_hist     : workgroup b counts the 256 digit values of its keys -> hist[b][digit] (one contiguous
+//                       1 KiB row per workgroup; the transposed [digit][b] layout of the first version turned every
+//                       4-byte counter into its own partial cache line: WRITE_SIZE 8 MB for a 1 MB table, and the
+//                       scatter's strided reads of it doubled that kernel's traffic)
+//   K2 radix_scan     : workgroup c turns rows [32 c, 32 c + 32) into exclusive prefixes per digit (thread =
+//                       digit, the 32 row loads are independent and coalesced) and writes the chunk totals
+//                       chunk_total[c][digit]
+//   K3 radix_scatter  : workgroup b sums the chunk totals below / over all chunks (digit totals), re-reads its keys,
+//                       ranks them stably (per-wave match-any with 64-bit ballots + per-wave digit counters in LDS),
+//                       sorts the tile by digit inside LDS, and streams it out: digit d's run goes to
+//                       exclusive_scan(digit totals)[d] + chunk offset[d] + hist[b][d] + (position in run), so
+//                       global stores are contiguous runs rather than per-lane scatters.
 // A workgroup is 256 threads = 4 waves; wave w owns the contiguous 1024-key slice w of the tile and
 // walks it in 16 rounds of 64 consecutive keys (lane l <-> key round*64+l), so loads are fully
 // coalesced and rank order == index order (stability).
@@ -58,39 +63,24 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint32_t* 
     if (valid && lane == __ffsll((unsigned long long)peers) - 1) atomicAdd(&h[d], (uint32_t)__popcll(peers));
   }
   __syncthreads();
-  hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+  hist[(size_t)blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];
 }
 
-// exclusive scan of one hist row (nblk entries) per workgroup; row total -> digit_total[row]
+// workgroup c: exclusive prefix per digit over the histogram rows of chunk c (in place), chunk totals -> chunk_total[c][.]
 __global__ __launch_bounds__(RS_THREADS) void radix_scan_kernel(uint32_t* __restrict__ hist, uint32_t nblk,
-                                                                 uint32_t* __restrict__ digit_total) {
-  __shared__ uint32_t wsum[RS_WAVES];
-  __shared__ uint32_t carry_s;
-  uint32_t* row = hist + (size_t)blockIdx.x * nblk;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) carry_s = 0;
-  __syncthreads();
-  for (uint32_t base = 0; base < nblk; base += RS_THREADS) {
-    const uint32_t i = base + threadIdx.x;
-    const uint32_t v = i < nblk ? row[i] : 0;
-    uint32_t incl = v;                                  // inclusive scan inside the wave
+                                                                 uint32_t* __restrict__ chunk_total) {
+  const uint32_t r0 = blockIdx.x * GM_SORT_CHUNK;
+  const uint32_t nr = min((uint32_t)GM_SORT_CHUNK, nblk - r0);
+  uint32_t v[GM_SORT_CHUNK];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t t = __shfl_up(incl, d);
-      if (lane >= d) incl += t;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    uint32_t woff = 0;
+  for (int r = 0; r < GM_SORT_CHUNK; r++) v[r] = (uint32_t)r < nr ? hist[(size_t)(r0 + r) * 256 + threadIdx.x] : 0u;
+  uint32_t run = 0;
 #pragma unroll
-    for (int w = 0; w < RS_WAVES; w++) woff += (w < wave) ? wsum[w] : 0;
-    const uint32_t carry = carry_s;
-    if (i < nblk) row[i] = carry + woff + incl - v;
-    __syncthreads();
-    if (threadIdx.x == RS_THREADS - 1) carry_s = carry + woff + incl;
-    __syncthreads();
+  for (int r = 0; r < GM_SORT_CHUNK; r++) {
+    if ((uint32_t)r < nr) hist[(size_t)(r0 + r) * 256 + threadIdx.x] = run;
+    run += v[r];
   }
-  if (threadIdx.x == 0) digit_total[blockIdx.x] = carry_s;
+  chunk_total[(size_t)blockIdx.x * 256 + threadIdx.x] = run;
 }
 
 template <bool IOTA, int RS_ROUNDS>
@@ -111,8 +101,14 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const uint32_
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
   for (int w = 0; w < RS_WAVES; w++) wcnt[w][threadIdx.x] = 0;
-  {  // exclusive scan of digit_total (256 values) + this block's row offset
-    const uint32_t v = digit_total[threadIdx.x];
+  {  // digit totals and the offset of this workgroup's chunk from the chunk totals, then the exclusive scan over digits
+    const uint32_t nchunks = (nblk + GM_SORT_CHUNK - 1) / GM_SORT_CHUNK, mychunk = blockIdx.x / GM_SORT_CHUNK;
+    uint32_t v = 0, below = 0;
+    for (uint32_t c = 0; c < nchunks; c++) {
+      const uint32_t t = digit_total[(size_t)c * 256 + threadIdx.x];
+      v += t;
+      below += c < mychunk ? t : 0u;
+    }
     __shared__ uint32_t wsum[RS_WAVES];
     uint32_t incl = v;
 #pragma unroll
@@ -125,7 +121,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const uint32_
     uint32_t woff = 0;
 #pragma unroll
     for (int w = 0; w < RS_WAVES; w++) woff += (w < wave) ? wsum[w] : 0;
-    gbase[threadIdx.x] = woff + incl - v + hist[(size_t)threadIdx.x * nblk + blockIdx.x];
+    gbase[threadIdx.x] = woff + incl - v + below + hist[(size_t)blockIdx.x * 256 + threadIdx.x];
   }
   __syncthreads();
 
@@ -224,7 +220,7 @@ static int radix_sort_pairs_t(uint32_t* keys[2], uint32_t* vals[2], uint32_t* hi
     const uint32_t mask = (1u << nb) - 1u;
     hipLaunchKernelGGL(radix_hist_kernel<ROUNDS>, dim3(nblk), dim3(RS_THREADS), 0, s, keys[cur], (uint32_t)n, shift, mask, hist, nblk);
     GM_LAUNCH_CHECK(debug, s);
-    hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(RS_THREADS), 0, s, hist, nblk, digit_total);
+    hipLaunchKernelGGL(radix_scan_kernel, dim3((nblk + GM_SORT_CHUNK - 1) / GM_SORT_CHUNK), dim3(RS_THREADS), 0, s, hist, nblk, digit_total);
     GM_LAUNCH_CHECK(debug, s);
     if (iota_values && shift == 0)
       hipLaunchKernelGGL((radix_scatter_kernel<true, ROUNDS>), dim3(nblk), dim3(RS_THREADS), 0, s, keys[cur], vals[cur], keys[cur ^ 1],
@@ -238,7 +234,7 @@ static int radix_sort_pairs_t(uint32_t* keys[2], uint32_t* vals[2], uint32_t* hi
   return 0;
 }
 
-// hist must hold 256 * sort_hist_blocks(n) counters
+// hist must hold 256 * sort_blocks(n) counters, digit_total sort_chunk_counters(n)
 int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], uint32_t* hist, uint32_t* digit_total, size_t n,
                      int bits, bool iota_values, int debug, hipStream_t s) {
   if (n == 0) return 0;
