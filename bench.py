@@ -365,6 +365,31 @@ def main():
             tr.step(cam0, gt, zero_bg)
         torch.cuda.synchronize()
         out["fwd_bwd"]["ms_per_training_iteration"] = 1e3 * (time.perf_counter() - t1) / nit
+        # BASELINE.json config C2: 500k Gaussians (the free-standing synthetic cloud of SURVEY.md 8d), 1080p, SH3, forward+backward
+        del model, tr
+        from gaussianmesh_amd import scenes as _sc
+        c2 = _sc.make_cloud(500_000, seed=0)
+        cam2 = _sc.orbit_camera(3, 64, W, H)
+        t2 = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)
+        rs2 = GaussianRasterizationSettings(H, W, cam2["tanx"], cam2["tany"], torch.zeros(3, device=dev), 1.0, t2(cam2["view"]), t2(cam2["proj"]),
+                                            3, t2(cam2["campos"]), False, False)
+        rast2 = GaussianRasterizer(rs2)
+        lv = [t2(c2[k]).requires_grad_(True) for k in ("means", "opac", "shs", "scales", "rots")]
+        m2 = torch.zeros_like(lv[0], requires_grad=True)
+
+        def it_c2():
+            for l in lv + [m2]:
+                l.grad = None
+            color, _ = rast2(lv[0], m2, lv[1], shs=lv[2], scales=lv[3], rotations=lv[4])
+            (color * wgt).sum().backward()
+        for _ in range(3):
+            it_c2()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(nit):
+            it_c2()
+        torch.cuda.synchronize()
+        out["fwd_bwd"]["c2_500k_ms_per_iter"] = 1e3 * (time.perf_counter() - t1) / nit
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # ---- CPU baseline: the oracle port (plain C + OpenMP) on the host cores, bounded sample of the same workload
