@@ -394,11 +394,15 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # ---- CPU baseline: the oracle port (plain C + OpenMP) on the host cores, bounded sample of the same workload
         from oracle import oracle as orc
-        nfr = 2
+        nfr_max, budget_s = 24, 10.0                # bounded sample: at least 2 frames, then until ~10 s of host work
         hp = {k: g[k].cpu().numpy() for k in ("tri", "weights", "pos", "cov", "opac", "shs", "verts")}
-        mesh0 = g["mesh"][:nfr].cpu().numpy()
+        mesh0 = g["mesh"][:nfr_max].cpu().numpy()
         tc = time.perf_counter()
-        for t in range(nfr):
+        nfr = 0
+        for t in range(min(nfr_max, mesh0.shape[0])):
+            if t >= 2 and time.perf_counter() - tc > budget_s:
+                break
+            nfr += 1
             ms = mesh0[t]
             dV = ms[:, 0:3] - hp["verts"]
             p2, c2, r2 = orc.deform(hp["tri"], hp["weights"], dV, ms[:, 3:12].reshape(-1, 3, 3), ms[:, 12:21].reshape(-1, 3, 3),
