@@ -237,9 +237,6 @@ __global__ __launch_bounds__(DS_THREADS) void deform_shade_kernel(int N, int deg
 // (ids -> {rows DMA, vertex gathers}).  The LDS image is the linear image of the rows (a DMA instruction writes
 // wave-uniform base + lane x 16 B); the 192-byte row stride makes the per-thread b128 reads bank-conflicted, which is
 // immaterial next to the memory latency this kernel is bound by.
-__device__ __forceinline__ void dma16(const void* g, void* lds_base) {
-  __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)g, (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
-}
 template <bool PACKED>
 __global__ __launch_bounds__(64) void deform_shade_dma_kernel(int N, int deg, const int* __restrict__ tri, const float* __restrict__ w,
                                                                   const float* __restrict__ dV, const float* __restrict__ Rv,

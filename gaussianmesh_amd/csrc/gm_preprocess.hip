@@ -21,6 +21,7 @@
 #include "gm_cull.h"
 #include "gm_stage.h"
 #include "gm_pre_body.h"
+#include <cstdlib>
 
 namespace gm {
 
@@ -33,13 +34,30 @@ struct PreArgs {
 
 // STAGE_SH: the workgroup's 256 SH rows (192 B each, M == 16) are copied HBM -> LDS with consecutive lanes reading
 // consecutive 16 bytes (gm_stage.h) before the per-Gaussian work; otherwise each thread walks its own row.
-template <bool STAGE_SH>
-__global__ __launch_bounds__(256) void preprocess_fwd_kernel(const PreArgs a) {
+// DMA (one-wave workgroups of 64 Gaussians): the rows arrive by LDS-DMA as a linear image (row stride 12 granules), as in
+// gm_deform.hip's deform_shade_dma_kernel: more, smaller workgroups in different phases and no staging registers.
+template <bool STAGE_SH, int TH = 256, bool DMA = false>
+__global__ __launch_bounds__(TH) void preprocess_fwd_kernel(const PreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds_pre[];
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+  constexpr int LROW = DMA ? 12 : 13;
+  const int idx = blockIdx.x * TH + threadIdx.x;
   if (STAGE_SH) {
-    const size_t row0 = (size_t)blockIdx.x * 256;
-    stage_rows16<12, 13, 256>(a.shs, row0, min(256, a.P - (int)row0), reinterpret_cast<float4*>(lds_pre));
+    const size_t row0 = (size_t)blockIdx.x * TH;
+    const int nrows = min(TH, a.P - (int)row0);
+    if (DMA) {
+      float4* l4 = reinterpret_cast<float4*>(lds_pre);
+      if (nrows == TH) {
+        const char* gsh = reinterpret_cast<const char*>(a.shs + row0 * 48) + threadIdx.x * 16;
+#pragma unroll
+        for (int q = 0; q < 12; q++) dma16(gsh + q * (TH * 16), reinterpret_cast<char*>(l4) + q * (TH * 16));
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+      } else if ((int)threadIdx.x < nrows) {
+#pragma unroll
+        for (int c = 0; c < 12; c++) l4[threadIdx.x * 12 + c] = reinterpret_cast<const float4*>(a.shs)[(row0 + threadIdx.x) * 12 + c];
+      }
+    } else {
+      stage_rows16<12, 13, TH>(a.shs, row0, nrows, reinterpret_cast<float4*>(lds_pre));
+    }
     __syncthreads();
   }
   if (idx >= a.P) return;
@@ -88,7 +106,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(const PreArgs a) {
       float sh[48];
       const int ncoef = (a.D + 1) * (a.D + 1);
       if (STAGE_SH) {
-        const float4* row = reinterpret_cast<const float4*>(lds_pre) + threadIdx.x * 13;
+        const float4* row = reinterpret_cast<const float4*>(lds_pre) + threadIdx.x * LROW;
 #pragma unroll
         for (int c = 0; c < 12; c++) { const float4 v = row[c]; sh[4 * c] = v.x; sh[4 * c + 1] = v.y; sh[4 * c + 2] = v.z; sh[4 * c + 3] = v.w; }
       } else {
@@ -130,8 +148,12 @@ int launch_preprocess(const RasterArgs& r, GeomState& g, int* radii) {
   a.splat = g.splat; a.radii_int = g.radii; a.radii_out = radii; a.tiles = g.tiles_touched; a.bin = g.bin; a.tile_cull = r.tile_cull; a.counters = g.counters; a.cov3D = g.cov3D;
   a.clamped = g.clamped; a.depth_key = g.depth_key[0];
   if (r.P > 0) {
-    if (a.shs && a.M == 16 && aligned16(a.shs))
-      hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3((r.P + 255) / 256), dim3(256), sizeof(float4) * 256 * 13, r.stream, a);
+    if (a.shs && a.M == 16 && aligned16(a.shs)) {
+      if (getenv("GM_PRE_NO_DMA"))
+        hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3((r.P + 255) / 256), dim3(256), sizeof(float4) * 256 * 13, r.stream, a);
+      else
+        hipLaunchKernelGGL((preprocess_fwd_kernel<true, 64, true>), dim3((r.P + 63) / 64), dim3(64), sizeof(float4) * 64 * 12, r.stream, a);
+    }
     else
       hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3((r.P + 255) / 256), dim3(256), 0, r.stream, a);
   }

@@ -77,6 +77,12 @@ __device__ __forceinline__ void stage_linear(const float* __restrict__ src, int 
   if (t < nfloats) lds[t] = src[t];
 }
 
+// LDS-DMA (global_load_lds_dwordx4): lane l of the wave copies 16 bytes from its own global address g to
+// lds_base + 16 l (lds_base is wave-uniform); no staging registers, completion is counted by vmcnt.
+__device__ __forceinline__ void dma16(const void* g, void* lds_base) {
+  __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)g, (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace gm
