@@ -195,21 +195,40 @@ __device__ __forceinline__ void preprocess_bwd_body(const PreBwdArgs& a, const i
 
 // STAGE_SH: SH rows come in through LDS and the 192-byte dL/dSH rows leave through the same LDS rows as coalesced
 // 16-byte stores (gm_stage.h); these two streams are 384 of the ~560 bytes this kernel moves per Gaussian.
-template <bool STAGE_SH>
-__global__ __launch_bounds__(256) void preprocess_bwd_kernel(const PreBwdArgs a) {
+template <bool STAGE_SH, int TH = 256, bool DMA = false>
+__global__ __launch_bounds__(TH) void preprocess_bwd_kernel(const PreBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds_pre[];
-  float4* lrow = reinterpret_cast<float4*>(lds_pre) + threadIdx.x * 13;
-  const size_t row0 = (size_t)blockIdx.x * 256;
-  const int nrows = min(256, a.P - (int)row0);
+  constexpr int LROW = DMA ? 12 : 13;          // DMA: the LDS image is the linear image of the rows (in and out)
+  float4* l4 = reinterpret_cast<float4*>(lds_pre);
+  float4* lrow = l4 + threadIdx.x * LROW;
+  const size_t row0 = (size_t)blockIdx.x * TH;
+  const int nrows = min(TH, a.P - (int)row0);
   if (STAGE_SH) {
-    stage_rows16<12, 13, 256>(a.shs, row0, nrows, reinterpret_cast<float4*>(lds_pre));
+    if (DMA) {
+      if (nrows == TH) {
+        const char* gsh = reinterpret_cast<const char*>(a.shs + row0 * 48) + threadIdx.x * 16;
+#pragma unroll
+        for (int q = 0; q < 12; q++) dma16(gsh + q * (TH * 16), reinterpret_cast<char*>(l4) + q * (TH * 16));
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+      } else if ((int)threadIdx.x < nrows) {
+#pragma unroll
+        for (int c = 0; c < 12; c++) lrow[c] = reinterpret_cast<const float4*>(a.shs)[(row0 + threadIdx.x) * 12 + c];
+      }
+    } else {
+      stage_rows16<12, 13, TH>(a.shs, row0, nrows, l4);
+    }
     __syncthreads();
   }
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int idx = blockIdx.x * TH + threadIdx.x;
   if (idx < a.P) preprocess_bwd_body<STAGE_SH>(a, idx, lrow);
   if (STAGE_SH) {
     __syncthreads();
-    unstage_rows16<12, 13, 256>(a.dL_dsh, row0, nrows, reinterpret_cast<const float4*>(lds_pre));
+    if (DMA) {
+      float4* dst = reinterpret_cast<float4*>(a.dL_dsh) + row0 * 12;
+      for (int i = threadIdx.x; i < nrows * 12; i += TH) dst[i] = l4[i];
+    } else {
+      unstage_rows16<12, 13, TH>(a.dL_dsh, row0, nrows, l4);
+    }
   }
 }
 
@@ -454,8 +473,12 @@ int launch_preprocess_bwd(const RasterArgs& r, GeomState& g, const int* radii, f
   a.dL_dmean2D = dL_dmean2D; a.dL_dconic = dL_dconic; a.dL_dopacity = dL_dopacity; a.dL_dcolor = dL_dcolor;
   a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot;
   if (r.P > 0) {
-    if (a.shs && a.M == 16 && aligned16(a.shs) && aligned16(a.dL_dsh))
-      hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3((r.P + 255) / 256), dim3(256), sizeof(float4) * 256 * 13, r.stream, a);
+    if (a.shs && a.M == 16 && aligned16(a.shs) && aligned16(a.dL_dsh)) {
+      if (getenv("GM_PRE_NO_DMA"))
+        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3((r.P + 255) / 256), dim3(256), sizeof(float4) * 256 * 13, r.stream, a);
+      else
+        hipLaunchKernelGGL((preprocess_bwd_kernel<true, 64, true>), dim3((r.P + 63) / 64), dim3(64), sizeof(float4) * 64 * 12, r.stream, a);
+    }
     else
       hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3((r.P + 255) / 256), dim3(256), 0, r.stream, a);
   }
