@@ -217,6 +217,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if rank == 0 and not args.unfused:
+        # the timed path (fused deform + colour + preprocess, async halves) must render what the unfused chain
+        # (gm_deform_shade_packed -> gm_forward_0/1) renders for the same frame: bit-identical image and radii
+        c = cam_t[multiview.view_for_step(0, F, rank, world)]
+        pk = pack_mesh_state(g["mesh"][0], g["verts"])
+        nr_f, col_f, rad_f, *_ = Rz.forward_deformed_begin(bg, g["tri"], g["weights"], pk, g["cov"], g["pos"], g["shs"], g["opac"], c["view"],
+                                                           c["proj"], c["tanx"], c["tany"], H, W, 3, c["campos"], False).finish()
+        pos_u, cov6_u, rgb_u = deform_shade_packed(g["tri"], g["weights"], pk, g["cov"], g["pos"], g["shs"], c["campos"], deg=3)
+        nr_u, col_u, rad_u, *_ = Rz.rasterize_forward(bg, pos_u, rgb_u, g["opac"], None, None, 1.0, cov6_u, c["view"], c["proj"], c["tanx"],
+                                                      c["tany"], H, W, None, 3, c["campos"], False, False)
+        torch.cuda.synchronize()
+        assert nr_f == nr_u and torch.equal(rad_f, rad_u) and torch.equal(col_f, col_u), "fused frame differs from the unfused chain"
+        del pos_u, cov6_u, rgb_u, col_u, col_f
     for i in range(args.warmup):
         step(i)
     drain()

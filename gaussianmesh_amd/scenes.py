@@ -15,37 +15,34 @@ import numpy as np
 
 # ----------------------------------------------------------------------------------------------
 # cameras
-def world2view2(R, t, translate=np.array([0.0, 0.0, 0.0]), scale=1.0):
-    """utils/graphics_utils.py:38-50 getWorld2View2 (float64 work, float32 result)."""
-    Rt = np.zeros((4, 4))
-    Rt[:3, :3] = R.transpose()
-    Rt[:3, 3] = t
-    Rt[3, 3] = 1.0
-    C2W = np.linalg.inv(Rt)
-    cam_center = C2W[:3, 3]
-    cam_center = (cam_center + translate) * scale
-    C2W[:3, 3] = cam_center
-    Rt = np.linalg.inv(C2W)
-    return np.float32(Rt)
+def world2view2(R, t, translate=(0.0, 0.0, 0.0), scale=1.0):
+    """World-to-view matrix [A | b; 0 1] of a camera whose world-to-view rotation block is R^T and translation is t, after its
+    centre has been moved by `translate` and scaled by `scale`.  Same result as the reference's getWorld2View2
+    (utils/graphics_utils.py:38-50, which inverts the 4x4 twice); pinned against it by tests/golden/camera.npz.
+    The rotation block is untouched by the recentring, so only the translation column is recomputed:
+    centre c solves A c + t = 0, c' = (c + translate) * scale, b = -A c'."""
+    A = np.asarray(R, np.float64).T
+    centre = np.linalg.solve(A, -np.asarray(t, np.float64))
+    centre = (centre + np.asarray(translate, np.float64)) * scale
+    M = np.eye(4)
+    M[:3, :3] = A
+    M[:3, 3] = -A @ centre
+    return M.astype(np.float32)
 
 
 def projection_matrix(znear, zfar, fovX, fovY):
-    """utils/graphics_utils.py:52-71 getProjectionMatrix (float32 like jt.zeros(4, 4))."""
-    tanHalfFovY = math.tan(fovY / 2)
-    tanHalfFovX = math.tan(fovX / 2)
-    top = tanHalfFovY * znear
-    bottom = -top
-    right = tanHalfFovX * znear
-    left = -right
+    """Perspective matrix of a symmetric frustum in the reference's convention (utils/graphics_utils.py:52-71
+    getProjectionMatrix: z maps to [0, 1], w = +z, float32 storage).  For a symmetric frustum the off-centre terms
+    (r+l)/(r-l), (t+b)/(t-b) vanish and 2n/(r-l) = 1/tan(fovX/2)."""
     P = np.zeros((4, 4), np.float32)
-    z_sign = 1.0
-    P[0, 0] = 2.0 * znear / (right - left)
-    P[1, 1] = 2.0 * znear / (top - bottom)
-    P[0, 2] = (right + left) / (right - left)
-    P[1, 2] = (top + bottom) / (top - bottom)
-    P[3, 2] = z_sign
-    P[2, 2] = z_sign * zfar / (zfar - znear)
-    P[2, 3] = -(zfar * znear) / (zfar - znear)
+    half_w = math.tan(fovX / 2) * znear
+    half_h = math.tan(fovY / 2) * znear
+    P[0, 0] = znear / half_w
+    P[1, 1] = znear / half_h
+    depth = zfar - znear
+    P[2, 2] = zfar / depth
+    P[2, 3] = -(zfar * znear) / depth
+    P[3, 2] = 1.0
     return P
 
 

@@ -9,6 +9,7 @@ package's operators (SURVEY.md 8f-3 "training loop harness"):
 model class (it runs unchanged on gaussianmesh_amd.compat); this harness is the fixed-topology loop used to time and
 test the GPU path end to end.
 """
+import math
 from types import SimpleNamespace
 
 import numpy as np
@@ -19,21 +20,28 @@ from .renderer import render
 
 
 def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
-    """utils/general_utils.py:28-62 (log-linear interpolation with optional delayed warm-up)."""
-    def helper(step):
-        if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+    """Learning-rate schedule of the position groups: geometric interpolation from lr_init (step 0) to lr_final
+    (step >= max_steps), optionally multiplied by a sine warm-up from lr_delay_mult to 1 over lr_delay_steps; 0 for
+    negative steps or when both rates are 0.  Same values as the reference's utils/general_utils.py:28-62
+    (same name and arguments so train_mesh_gaussian.py-style code can call it); pinned by tests/golden/schedule.npz."""
+    disabled = lr_init == 0.0 and lr_final == 0.0
+    log_ratio = 0.0 if disabled else math.log(lr_final / lr_init)
+
+    def rate(step):
+        if step < 0 or disabled:
             return 0.0
+        progress = min(max(step / max_steps, 0.0), 1.0)
+        value = lr_init * math.exp(log_ratio * progress)
         if lr_delay_steps > 0:
-            delay_rate = lr_delay_mult + (1 - lr_delay_mult) * np.sin(0.5 * np.pi * np.clip(step / lr_delay_steps, 0, 1))
-        else:
-            delay_rate = 1.0
-        t = np.clip(step / max_steps, 0, 1)
-        return delay_rate * np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t)
-    return helper
+            warm = min(max(step / lr_delay_steps, 0.0), 1.0)
+            value *= lr_delay_mult + (1.0 - lr_delay_mult) * math.sin(0.5 * math.pi * warm)
+        return value
+    return rate
 
 
+# arguments/__init__.py:70-93 OptimizationParams (pinned by tests/golden/schedule.npz)
 DEFAULT_OPT = dict(position_lr_init=0.00016, position_lr_final=0.0000016, position_lr_delay_mult=0.01, position_lr_max_steps=30000,
-                   feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001, lambda_dssim=0.2, alpha_mrloss=10.0)
+                   feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001, lambda_dssim=0.2, alpha_mrloss=6.0)
 
 
 class Trainer:

@@ -14,7 +14,7 @@
  *   - barycentric weights (orc_bary_weights)  vs  edittool/general_utils.py:get_barycentric_coordinate
  *   - camera matrices (python side)           vs  utils/graphics_utils.py:getWorld2View2
  * The core is additionally cross-checked by an independent dense numpy restatement
- * (oracle/np_oracle.py), by central finite differences of its own forward, and by structural
+ * (oracle/torch_dense.py: float64, gradients from autograd), by central finite differences of its own forward, and by structural
  * invariants (tests/test_oracle_*.py).
  *
  * Every function cites the reference file:line it restates (paths relative to /root/reference,
@@ -402,8 +402,8 @@ void orc_instance_needed(int64_t R, int W, int H, const uint32_t* tile_of, const
 /* ---------------------------------------------------------------------------------------------
  * [core] RAST/backward.cu:399-557 renderCUDA (backward).  Accumulators must be zero on entry:
  * dL_dmean2D [P][3] (x,y used), dL_dconic [P][4] (slots x,y,w used), dL_dopacity [P], dL_dcolor [P][3].
- * Accumulates in double per tile-serial order (deterministic); the reference uses float atomics
- * in nondeterministic order.
+ * Accumulates in double (tile-parallel, atomic adds); the reference uses float atomics in
+ * nondeterministic order.
  */
 void orc_render_bwd(int P, int W, int H, const uint32_t* ranges, const uint32_t* point_list,
                     const float* bg, const float* xy, const float* conic_op, const float* colors,
@@ -412,6 +412,9 @@ void orc_render_bwd(int P, int W, int H, const uint32_t* ranges, const uint32_t*
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   double* acc = (double*)calloc((size_t)P * 9, sizeof(double));
   const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+  /* tiles in parallel; the double accumulators are shared, so every update is an `omp atomic` (summation order is
+   * then arbitrary, which perturbs a double sum of float terms at the 1e-16 level) */
+#pragma omp parallel for schedule(dynamic, 4)
   for (int tile = 0; tile < gx * gy; tile++) {
     const int tx = tile % gx, ty = tile / gx;
     const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
@@ -446,7 +449,11 @@ void orc_render_bwd(int P, int W, int H, const uint32_t* ranges, const uint32_t*
             accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
             last_color[ch] = c;
             dL_dalpha += (c - accum_rec[ch]) * dpx[ch];
-            acc[9 * (size_t)g + ch] += dchannel_dcolor * dpx[ch];
+            {
+              const double add = dchannel_dcolor * dpx[ch];
+#pragma omp atomic
+              acc[9 * (size_t)g + ch] += add;
+            }
           }
           dL_dalpha *= T;
           last_alpha = alpha;
@@ -457,12 +464,12 @@ void orc_render_bwd(int P, int W, int H, const uint32_t* ranges, const uint32_t*
           const float gdx = G * dx, gdy = G * dy;
           const float dG_ddelx = -gdx * co[0] - gdy * co[1];
           const float dG_ddely = -gdy * co[2] - gdx * co[1];
-          acc[9 * (size_t)g + 3] += dL_dG * dG_ddelx * ddelx_dx;
-          acc[9 * (size_t)g + 4] += dL_dG * dG_ddely * ddely_dy;
-          acc[9 * (size_t)g + 5] += -0.5f * gdx * dx * dL_dG;
-          acc[9 * (size_t)g + 6] += -0.5f * gdx * dy * dL_dG;
-          acc[9 * (size_t)g + 7] += -0.5f * gdy * dy * dL_dG;
-          acc[9 * (size_t)g + 8] += G * dL_dalpha;
+          const double add6[6] = {dL_dG * dG_ddelx * ddelx_dx, dL_dG * dG_ddely * ddely_dy, -0.5f * gdx * dx * dL_dG,
+                                  -0.5f * gdx * dy * dL_dG, -0.5f * gdy * dy * dL_dG, G * dL_dalpha};
+          for (int k = 0; k < 6; k++) {
+#pragma omp atomic
+            acc[9 * (size_t)g + 3 + k] += add6[k];
+          }
         }
       }
   }
@@ -778,10 +785,12 @@ void orc_bary_weights(int N, const double* g, const double* p1, const double* p2
  *   dV [Vm][3] = V1 - V0, Rv/Sv [Vm][3][3] row-major per-vertex rotation / shear (pyACAP GetRS
  *   output reshaped, :112-113), cov [N][3][3], pos [N][3].
  * Outputs: pos' [N][3], cov' [N][3][3], rot [N][3][3] (= blended R transposed, :122).
- * R and S are blended linearly, no re-orthonormalisation.  The reference holds vertices,
- * weights, R and S as float64 (numpy/igl/pyACAP defaults) so its blend and matrix products
- * promote to float64; the oracle therefore evaluates in double and rounds the outputs to
- * float.  The HIP kernel works in fp32 and is compared with a relative tolerance.
+ * R and S are blended linearly, no re-orthonormalisation.  The reference computes this in fp32: numpy / igl /
+ * pyACAP hand over float64 arrays, but jt.array() narrows float64 to float32 (Jittor's default), so the blend and
+ * the matrix products run in fp32 in an order Jittor's reduce / bmm kernels choose.  No fp32 evaluation order can
+ * be pinned from the reference source, so the oracle evaluates the same algebra in double (the exact-arithmetic
+ * answer) and rounds the outputs to float; the HIP kernel works in fp32 and is compared with a relative tolerance
+ * of 1e-5, which any fp32 evaluation order of these 3-term sums satisfies.
  */
 void orc_deform(int N, const int* tri, const float* w, const float* dV, const float* Rv, const float* Sv,
                 const float* cov, const float* pos, float* pos_out, float* cov_out, float* rot_out) {

@@ -13,6 +13,8 @@ Functions executed (reference file:line):
   edittool/general_utils.py:73-88 get_barycentric_coordinate
   utils/graphics_utils.py:38-50  getWorld2View2
   utils/graphics_utils.py:73-77  fov2focal / focal2fov
+  utils/general_utils.py:28-62   get_expon_lr_func (position learning-rate schedule of the training loop)
+  arguments/__init__.py:70-93    OptimizationParams defaults (learning rates, lambda_dssim, alpha_mrloss, densify schedule)
 """
 import importlib.util
 import os
@@ -86,6 +88,19 @@ def main():
                     [(0.5, 640), (1.0471975511965976, 1920), (1.2, 1080)]])
     np.savez_compressed(os.path.join(OUT, "camera.npz"), R=np.array(Rs), T=np.array(Ts), translate=np.array(TRs),
                         scale=np.array(SCs), W2V=np.array(W2V), foc=foc)
+    # --- training schedule: learning-rate function and the optimisation defaults -------------------
+    gu = _load("utils/general_utils.py", "ref_utils_general_utils")
+    import argparse
+    args_mod = _load("arguments/__init__.py", "ref_arguments")
+    op = args_mod.OptimizationParams(argparse.ArgumentParser())
+    defaults = {k: (float(v) if not isinstance(v, bool) else bool(v)) for k, v in vars(op).items() if not k.startswith("_")}
+    steps = np.array([-1, 0, 1, 10, 100, 1000, 7000, 15000, 29999, 30000, 40000], np.int64)
+    cases = [(op.position_lr_init, op.position_lr_final, 0, op.position_lr_delay_mult, op.position_lr_max_steps),
+             (1e-2, 1e-4, 100, 0.1, 1000), (0.0, 0.0, 0, 1.0, 10), (3e-3, 3e-3, 50, 0.5, 500)]
+    lr = np.array([[gu.get_expon_lr_func(a, b, lr_delay_steps=d, lr_delay_mult=m, max_steps=n)(int(st)) for st in steps]
+                   for a, b, d, m, n in cases], np.float64)
+    np.savez_compressed(os.path.join(OUT, "schedule.npz"), steps=steps, cases=np.array(cases, np.float64), lr=lr,
+                        opt_names=np.array(sorted(defaults)), opt_values=np.array([float(defaults[k]) for k in sorted(defaults)]))
     print("wrote", sorted(f for f in os.listdir(OUT) if f.endswith(".npz")))
 
 

@@ -28,6 +28,11 @@ def settings(cam, bg, D, mod=1.0, debug=False):
 DEFAULT_MODE = 2
 
 
+def set_policy(mode):
+    """emission policy of the following forwards (0 = the reference's lists ... 3), see gm_common.h"""
+    _lib.lib().gm_set_tile_culling(int(mode))
+
+
 def _view(buf, ptr, count, dtype):
     off = ptr - buf.data_ptr()
     nbytes = count * torch.tensor([], dtype=dtype).element_size()

@@ -40,7 +40,7 @@ def test_training_iterations_reduce_the_loss():
     with torch.no_grad():
         targets = [render(c, teacher, pipe, bg)["render"].clone() for c in cams]
     student = _model(N, 0, perturb=True)
-    tr = Trainer(student, alpha_mrloss=10.0, feature_lr=0.02, opacity_lr=0.1)
+    tr = Trainer(student, alpha_mrloss=6.0, feature_lr=0.02, opacity_lr=0.1)
     losses = []
     for it in range(60):
         loss, pkg = tr.step(cams[it % 4], targets[it % 4], bg)
