@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s measured achievable
 
-STAGES = ["deform", "sh_colors", "preprocess", "depth_sort", "scan", "duplicate", "tile_sort", "ranges", "render"]
+STAGES = ["deform", "sh_colors", "preprocess", "depth_sort", "duplicate", "tile_sort", "ranges", "render"]
 
 
 def build_scene(P, W, H, frames, seed=0):
@@ -53,10 +53,10 @@ def build_scene(P, W, H, frames, seed=0):
                 opac=cl["opac"], shs=cl["shs"], scales=cl["scales"], rots=cl["rots"], mesh=mesh)
 
 
-def algorithmic_bytes(stage, P, V, R, W, H, Vm, M=16):
-    """SURVEY.md 8(d) per-unit figures, split per stage (precomputed colour/cov input mode)."""
-    T = ((W + 15) // 16) * ((H + 15) // 16)
-    bits = max(1, int(np.ceil(np.log2(max(T, 2)))))
+def algorithmic_bytes(stage, P, V, R, W, H, Vm, M=16, list_tiles=2040):
+    """Bytes each stage has to move for THIS implementation's algorithm, precomputed colour/cov input mode."""
+    hist = 2048 * 4                     # one histogram row per 4096 keys
+    one_pass = list_tiles <= 2048
     return {
         "deform": P * (12 + 12 + 36 + 12 + 12 * M) + P * (12 + 24 + 12) + Vm * 84,     # fused deform + colour
         # deform + colour + forward preprocess in one kernel: the 48 B/Gaussian of intermediates disappear, the
@@ -64,11 +64,11 @@ def algorithmic_bytes(stage, P, V, R, W, H, Vm, M=16):
         "deform_pre": P * (12 + 12 + 36 + 12 + 12 * M + 4) + Vm * (84 + 96) + V * 48 + P * 28,
         "sh_colors": P * (12 + 36 + 12 * M) + P * 12,
         "preprocess": P * (12 + 24 + 4 + 12) + V * 48,
-        "scan": P * 8,
-        "depth_sort": P * (4 + 16 * 4),                 # 4-byte key histogram read + 4 passes x (8 B in + 8 B out)
-        "duplicate": V * 20 + R * 8,
-        "tile_sort": R * (4 + 16 * ((bits + 7) // 8)),
-        "ranges": R * 4 + T * 8,
+        # bucket partition (key read twice, (key, id) written once) + in-LDS bucket sort ((key, id) in; id, count out; count gather)
+        "depth_sort": P * 8 + V * 8 + V * (8 + 4 + 4 + 4) + (P // 4096 + 1) * hist * 4,
+        "duplicate": V * (4 + 4) + V * 16 + R * 8,                                  # counts + ids in order, bin records, (key, id) out
+        "tile_sort": (R * (4 + 8 + 8) + (R // 4096 + 1) * hist * 4) * (1 if one_pass else 2) + list_tiles * 8,
+        "ranges": R * 4 + list_tiles * 8,
         "render": R * 40 + W * H * 12,
     }[stage]
 
@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the frame loop alternates over (frame i runs on stream i %% streams): consecutive frames are "
                          "independent, so frame i+1's per-Gaussian stages overlap the low-occupancy tail of frame i's blend")
+    ap.add_argument("--exact-count", action="store_true", help="complete every frame with the instance count read back by the host "
+                    "(gm_forward_1_geom's exact mode) instead of the sync-free mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fwd-bwd", action="store_true")
     args = ap.parse_args()
@@ -156,30 +158,45 @@ def main():
     stats = {}
     nstreams = max(1, args.streams)
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
-    nws = max(2, nstreams)                      # frame i+1 is begun before frame i is finished: two scratch sets even on one stream
-    workspaces = [Rz.RasterWorkspace() for _ in range(nws)]
+    nws = nstreams + 2                          # frame i+1 is begun before frame i is completed, and frame i's status is read one frame later
+    workspaces = [Rz.RasterWorkspace(growth=1.5) for _ in range(nws)]
     frame_bufs = [torch.empty((Vm, 21), dtype=torch.float32, device=dev) for _ in range(nws)]
     torch.cuda.synchronize()
 
     pending = {}
+    unchecked = []
+    stats["overflows"] = 0
 
     def step(i):
-        """Issue frame i up to its instance count on stream i % nstreams, THEN complete frame i-1: the host never idles on
-        the count read-back of the frame it has just enqueued (gm_forward_0_async)."""
+        """Issue frame i's first half (deform + colour + preprocess + depth order) on stream i % nstreams, THEN complete frame
+        i-1.  Default: sync-free completion - the instance count stays on the device (binning buffer at the workspace's
+        capacity, learned during warm-up), the host only reads frame i-2's status words, which landed long ago.
+        --exact-count: the host waits for frame i-1's count (one 4-byte read-back, hidden behind frame i's first half)."""
         with torch.cuda.stream(streams[i % nstreams]):
             pending[i] = step_on_stream(i, workspaces[i % nws], frame_bufs[i % nws], begin_only=True)
         prev = pending.pop(i - 1, None)
         return finish(prev) if prev is not None else None
 
-    def finish(h):
-        nr, color, radii, _, _, _ = h.finish()
+    def verify(h):
+        ok, nr = h.check()
+        if not ok:                              # instance count outgrew the binning capacity: render that frame again, exactly
+            stats["overflows"] += 1
+            nr = h.finish()[0]
         stats["R"] = nr
-        stats["radii"] = radii
-        return color
+        stats["radii"] = h.radii
+
+    def finish(h):
+        out = h.finish(sync_free=not args.exact_count)
+        unchecked.append(h)
+        while len(unchecked) > 1:
+            verify(unchecked.pop(0))
+        return out[1]
 
     def drain():
         for k in sorted(pending):
             finish(pending.pop(k))
+        while unchecked:
+            verify(unchecked.pop(0))
 
     def step_on_stream(i, workspace, frame_buf, exchange=True, begin_only=False):
         t = i % F
@@ -258,7 +275,6 @@ def main():
         # ---- per-stage HIP-event timing over a second pass of the same steps (events perturb the pipelining a
         # little, so they are kept out of the region that defines `value`)
         # ... and on ONE stream, so a stage's events bracket only its own kernels
-        default_policy = lib.gm_get_tile_culling()
         lib.gm_profile_reset(); lib.gm_profile_enable(1)
         nprof = min(args.steps, 50)
         with torch.cuda.stream(streams[0]):
@@ -287,30 +303,6 @@ def main():
         out["frame_roofline"] = {"algorithmic_bytes": tot_bytes, "achieved": tot_bytes / (elapsed / args.steps) / 1e9,
                                  "frac": tot_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s",
                                  "single_stream_ms_per_frame": sum(per.values())}
-        # BASELINE.md section 3 normalises the frame against the bytes the REFERENCE's algorithm moves for the same frame
-        # (A_fwd with the reference's instance count, 12-byte pairs through ceil((32+bit)/8) sort passes,
-        # plus 156 B per Gaussian and 84 B per vertex for the deformation).  Reported beside the fraction above, which
-        # is against this implementation's own (much smaller) byte count.
-        lib.gm_set_tile_culling(0)
-        try:
-            t = args.warmup % F
-            c0 = cam_t[multiview.view_for_step(args.warmup, F, rank, world)]
-            pos0, cov60, rgb0 = deform_shade_packed(g["tri"], g["weights"], pack_mesh_state(g["mesh"][t], g["verts"]), g["cov"], g["pos"],
-                                                    g["shs"], c0["campos"], deg=3)
-            h0 = Rz.rasterize_forward_begin(bg, pos0, rgb0, g["opac"], None, None, 1.0, cov60, c0["view"], c0["proj"], c0["tanx"], c0["tany"],
-                                            H, W, None, 3, c0["campos"], False, False)
-            h0.event.synchronize()
-            R_ref = int(h0.count_host[0])
-        finally:
-            lib.gm_set_tile_culling(default_policy)
-        T16 = ((W + 15) // 16) * ((H + 15) // 16)
-        npass = (32 + max(1, int(np.ceil(np.log2(max(T16, 2))))) + 7) // 8
-        A_ref = (P * 44 + V * 12 * 16 + V * 48 + P * 8 + V * 20 + R_ref * 12 + R_ref * (8 + 24 * npass) + R_ref * 8 + T16 * 8 + R_ref * 40
-                 + W * H * 12 + P * 156 + Vm * 84)
-        out["frame_roofline"]["baseline_normalisation"] = {
-            "reference_instances": R_ref, "reference_sort_passes": npass, "reference_algorithm_bytes": A_ref,
-            "achieved": A_ref / (elapsed / args.steps) / 1e9, "frac": A_ref / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s",
-            "note": "BASELINE.md section 3: bytes of the reference's algorithm for this frame / measured frame time / 8 TB/s"}
 
     if rank == 0 and world == 1 and not args.no_fwd_bwd:
         # ---- forward + backward through the autograd operator (train-time input mode: SH + scale/rot)

@@ -20,32 +20,33 @@ vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 SIGNATURES = {
     "gm_abi_version": (i32, []),
     "gm_last_error": (C.c_char_p, []),
-    "gm_set_tile_culling": (None, [i32]),
-    "gm_get_tile_culling": (i32, []),
     "gm_geom_bytes": (sz, [i32]),
     "gm_image_bytes": (sz, [i32, i32]),
     "gm_binning_bytes": (sz, [i64]),
     "gm_forward_0": (i32, [vp, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, f32, f32, i32,
                            vp, i32, vp, C.POINTER(i32)]),
-    "gm_forward_0_async": (i32, [vp, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, f32, f32, i32,
-                                 vp, i32, vp, vp]),
+    "gm_forward_0_async": (i32, [i32, vp, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, f32, f32, i32,
+                                 vp, i32, vp, vp, vp]),
     "gm_forward_1": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp,
                            f32, f32, i32, vp, vp, i32, vp]),
     "gm_backward": (i32, [i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp,
                           vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "gm_backward_p": (i32, [i32, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp,
+                            vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "gm_mark_visible": (i32, [i32, vp, vp, vp, vp, vp]),
     "gm_geom_field": (vp, [vp, i32, C.c_char_p]),
     "gm_image_field": (vp, [vp, i32, i32, C.c_char_p]),
-    "gm_binning_field": (vp, [vp, i64, i32, i32, C.c_char_p]),
+    "gm_binning_field": (vp, [vp, i64, i32, i32, i32, C.c_char_p]),
     "gm_knn_workspace_bytes": (sz, [i32]),
     "gm_knn": (i32, [i32, vp, vp, vp, sz, vp]),
     "gm_deform": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gm_sh_colors": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "gm_deform_shade": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gm_pack_mesh_state": (i32, [i32, vp, vp, vp, vp]),
-    "gm_forward_0_deformed_async": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp,
-                                          i32, vp, vp]),
-    "gm_forward_1_geom": (i32, [vp, vp, vp, i32, i32, vp, i32, i32, vp, i32, vp]),
+    "gm_forward_0_deformed_async": (i32, [i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp,
+                                          i32, vp, vp, vp]),
+    "gm_forward_1_geom": (i32, [i32, vp, vp, vp, i32, i32, i64, vp, i32, i32, vp, i32, vp]),
+    "gm_forward_status_async": (i32, [vp, i32, vp, vp]),
     "gm_deform_shade_packed": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gm_cov_to_scale_rot": (i32, [i32, vp, vp, vp, vp]),
     "gm_mesh_activate_fwd": (i32, [i32, f32] + [vp] * 10 + [vp] * 4 + [f32, vp] + [vp]),
@@ -90,7 +91,7 @@ def lib():
             fn = getattr(l, name)          # AttributeError if the symbol is absent -> loud failure
             fn.restype = res
             fn.argtypes = args
-        if l.gm_abi_version() != 1:
+        if l.gm_abi_version() != 2:
             raise ImportError("libgmesh_hip.so ABI version mismatch")
         _lib = l
     return _lib

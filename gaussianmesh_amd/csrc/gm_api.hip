@@ -15,12 +15,6 @@
 namespace gm {
 
 static thread_local char g_err[512] = "";
-static int initial_emission_mode() {        // GM_EMISSION_MODE=0..3 overrides the built-in default (A/B runs of bench.py)
-  const char* v = getenv("GM_EMISSION_MODE");
-  const int m = v ? atoi(v) : 2;
-  return m < 0 ? 0 : (m > 3 ? 3 : m);
-}
-static int g_tile_cull = initial_emission_mode();        // gm_set_tile_culling
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -76,7 +70,7 @@ static void drain_profile() {
 static int check_raster_args(const RasterArgs& a) {
   if (a.P < 0 || a.W <= 0 || a.H <= 0) { set_error("invalid sizes P=%d W=%d H=%d", a.P, a.W, a.H); return GM_ERR_INVALID_ARG; }
   if (TileGrid(a.W, a.H, a.tile_cull).ptiles > 65536) {
-    set_error("%dx%d has more than 65536 list tiles under emission policy %d; use gm_set_tile_culling(2) or (3)", a.W, a.H, a.tile_cull);
+    set_error("%dx%d has more than 65536 list tiles under emission policy %d; use policy 2 or 3", a.W, a.H, a.tile_cull);
     return GM_ERR_INVALID_ARG;
   }
   if (a.P == 0) return 0;                       // empty cloud: every per-Gaussian pointer may be null
@@ -104,8 +98,6 @@ using namespace gm;
 extern "C" {
 
 int gm_abi_version(void) { return GM_ABI_VERSION; }
-void gm_set_tile_culling(int mode) { g_tile_cull = mode < 0 ? 0 : (mode > 3 ? 3 : mode); }
-int gm_get_tile_culling(void) { return g_tile_cull; }
 const char* gm_last_error(void) { return g_err; }
 
 size_t gm_geom_bytes(int P) {
@@ -121,44 +113,49 @@ size_t gm_binning_bytes(int64_t R) {
   return (size_t)b.end + 256;
 }
 
-#define FILL_ARGS(a)                                                                                            \
+static int check_policy(int p) {
+  if (p < 0 || p > 3) { set_error("emission policy %d out of range 0..3", p); return GM_ERR_INVALID_ARG; }
+  return 0;
+}
+
+#define FILL_ARGS(a, POLICY)                                                                                    \
   RasterArgs a;                                                                                                 \
   a.P = P; a.D = D; a.M = M; a.W = width; a.H = height; a.background = background; a.means3D = means3D;        \
   a.shs = shs; a.colors_precomp = colors_precomp; a.opacities = opacities; a.scales = scales;                  \
   a.rotations = rotations; a.cov3D_precomp = cov3D_precomp; a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; \
   a.cam_pos = cam_pos; a.scale_modifier = scale_modifier; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;        \
-  a.prefiltered = prefiltered; a.debug = debug; a.tile_cull = g_tile_cull; a.stream = reinterpret_cast<hipStream_t>(stream);
+  a.prefiltered = prefiltered; a.debug = debug; a.tile_cull = (POLICY); a.stream = reinterpret_cast<hipStream_t>(stream);
 
-int gm_forward_0_async(void* geom_buffer, int P, int D, int M, const float* background, int width, int height,
+// first half of a forward after the per-Gaussian kernel: order the visible Gaussians, hand the instance count to the host
+static int order_and_count(GeomState& g, int P, int debug, hipStream_t st, int* num_rendered_host, void* count_event) {
+  return launch_depth_order(g, P, debug, st, num_rendered_host, reinterpret_cast<hipEvent_t>(count_event));
+}
+
+int gm_forward_0_async(int emission_policy, void* geom_buffer, int P, int D, int M, const float* background, int width, int height,
                        const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
                        const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
                        const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
-                       float tan_fovy, int prefiltered, int* radii, int debug, void* stream, int* num_rendered_host) {
-  FILL_ARGS(a)
+                       float tan_fovy, int prefiltered, int* radii, int debug, void* stream, int* num_rendered_host,
+                       void* count_event) {
+  if (int rc = check_policy(emission_policy)) return rc;
+  FILL_ARGS(a, emission_policy)
   if (int rc = check_raster_args(a)) return rc;
-  if (!num_rendered_host) { set_error("num_rendered_host is null"); return GM_ERR_INVALID_ARG; }
-  if (P == 0) { *num_rendered_host = 0; return GM_OK; }
+  if (P == 0) { if (num_rendered_host) *num_rendered_host = 0; return GM_OK; }
   if (!geom_buffer) { set_error("geom_buffer is null"); return GM_ERR_INVALID_ARG; }
   GeomState g = GeomState::from(geom_buffer, (size_t)P);
+  if (int rc = launch_arm_counters(g, a.stream)) return rc;
   if (int rc = launch_preprocess(a, g, radii)) return rc;
-  {
-    StageScope sc(ST_DEPTH_SORT, a.stream);
-    if (int rc = radix_sort_pairs(g.depth_key, g.order, g.hist, g.digit_total, (size_t)P, 32, true, debug, a.stream)) return rc;
-  }
-  if (int rc = launch_tile_count_scan(g, P, debug, a.stream)) return rc;
-  // stream-ordered copy of the instance count into (pinned) host memory; the caller waits on its own event
-  GM_HIP(hipMemcpyAsync(num_rendered_host, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, a.stream));
-  return GM_OK;
+  return order_and_count(g, P, debug, a.stream, num_rendered_host, count_event);
 }
 
-int gm_forward_0_deformed_async(void* geom_buffer, int P, int deg, int M, int width, int height, const int* tri, const float* w,
-                                const float* packed, const float* cov, const float* pos, const float* shs, const float* opacities,
-                                const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
-                                float tan_fovy, float* pos_out, float* cov6_out, float* rgb_out, int* radii, int debug,
-                                void* stream, int* num_rendered_host) {
+int gm_forward_0_deformed_async(int emission_policy, void* geom_buffer, int P, int deg, int M, int width, int height, const int* tri,
+                                const float* w, const float* packed, const float* cov, const float* pos, const float* shs,
+                                const float* opacities, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                                float tan_fovx, float tan_fovy, float* pos_out, float* cov6_out, float* rgb_out, int* radii, int debug,
+                                void* stream, int* num_rendered_host, void* count_event) {
+  if (int rc = check_policy(emission_policy)) return rc;
   if (P < 0 || width <= 0 || height <= 0) { set_error("invalid sizes P=%d W=%d H=%d", P, width, height); return GM_ERR_INVALID_ARG; }
-  if (!num_rendered_host) { set_error("num_rendered_host is null"); return GM_ERR_INVALID_ARG; }
-  if (P == 0) { *num_rendered_host = 0; return GM_OK; }
+  if (P == 0) { if (num_rendered_host) *num_rendered_host = 0; return GM_OK; }
   if (deg < 0 || deg > 3 || M != 16) { set_error("gm_forward_0_deformed: needs SH rows of M == 16 coefficients, degree 0..3"); return GM_ERR_INVALID_ARG; }
   if (!geom_buffer || !tri || !w || !packed || !cov || !pos || !shs || !opacities || !viewmatrix || !projmatrix || !cam_pos) {
     set_error("gm_forward_0_deformed: null required input"); return GM_ERR_INVALID_ARG;
@@ -167,43 +164,50 @@ int gm_forward_0_deformed_async(void* geom_buffer, int P, int deg, int M, int wi
   if (nout != 0 && nout != 3) { set_error("gm_forward_0_deformed: pass pos_out, cov6_out and rgb_out together or none"); return GM_ERR_INVALID_ARG; }
   RasterArgs a{};
   a.P = P; a.D = deg; a.M = M; a.W = width; a.H = height; a.opacities = opacities; a.viewmatrix = viewmatrix; a.projmatrix = projmatrix;
-  a.cam_pos = cam_pos; a.scale_modifier = 1.0f; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy; a.debug = debug; a.tile_cull = g_tile_cull;
+  a.cam_pos = cam_pos; a.scale_modifier = 1.0f; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy; a.debug = debug; a.tile_cull = emission_policy;
   a.stream = reinterpret_cast<hipStream_t>(stream);
+  if (TileGrid(width, height, emission_policy).ptiles > 65536) { set_error("too many list tiles for emission policy %d", emission_policy); return GM_ERR_INVALID_ARG; }
   GeomState g = GeomState::from(geom_buffer, (size_t)P);
+  if (int rc = launch_arm_counters(g, a.stream)) return rc;
   if (int rc = launch_deform_shade_pre(a, g, radii, deg, tri, w, packed, cov, pos, shs, pos_out, cov6_out, rgb_out)) return rc;
-  {
-    StageScope sc(ST_DEPTH_SORT, a.stream);
-    if (int rc = radix_sort_pairs(g.depth_key, g.order, g.hist, g.digit_total, (size_t)P, 32, true, debug, a.stream)) return rc;
-  }
-  if (int rc = launch_tile_count_scan(g, P, debug, a.stream)) return rc;
-  GM_HIP(hipMemcpyAsync(num_rendered_host, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, a.stream));
-  return GM_OK;
+  return order_and_count(g, P, debug, a.stream, num_rendered_host, count_event);
 }
 
-int gm_forward_1_geom(void* geom_buffer, void* binning_buffer, void* image_buffer, int P, int num_rendered, const float* background,
-                      int width, int height, float* out_color, int debug, void* stream) {
+int gm_forward_1_geom(int emission_policy, void* geom_buffer, void* binning_buffer, void* image_buffer, int P, int num_rendered,
+                      int64_t binning_capacity, const float* background, int width, int height, float* out_color, int debug, void* stream) {
+  if (int rc = check_policy(emission_policy)) return rc;
   if (P < 0 || width <= 0 || height <= 0) { set_error("invalid sizes P=%d W=%d H=%d", P, width, height); return GM_ERR_INVALID_ARG; }
   if (!image_buffer || !out_color || !background) { set_error("null image_buffer / out_color / background"); return GM_ERR_INVALID_ARG; }
-  if (num_rendered < 0) { set_error("negative num_rendered"); return GM_ERR_INVALID_ARG; }
-  if (P > 0 && (!geom_buffer || (num_rendered > 0 && !binning_buffer))) { set_error("null scratch buffer"); return GM_ERR_INVALID_ARG; }
+  const bool device_count = num_rendered < 0;          // sync-free: the count stays on the device, bounded by the capacity
+  const int64_t cap = device_count ? binning_capacity : (int64_t)num_rendered;
+  if (cap < 0) { set_error("negative binning capacity"); return GM_ERR_INVALID_ARG; }
+  if (P > 0 && (!geom_buffer || (cap > 0 && !binning_buffer))) { set_error("null scratch buffer"); return GM_ERR_INVALID_ARG; }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int mode = g_tile_cull;
+  const int mode = emission_policy;
   ImageState img = ImageState::from(image_buffer, width, height);
   const int tiles = TileGrid(width, height, mode).ptiles;
+  if (tiles > 65536) { set_error("too many list tiles for emission policy %d", mode); return GM_ERR_INVALID_ARG; }
   GeomState g = GeomState::from(geom_buffer, (size_t)(P > 0 ? P : 1));
-  BinningState b = BinningState::from(binning_buffer, (size_t)num_rendered);
-  int slot = 0;
-  if (P > 0 && num_rendered > 0) {
-    if (int rc = launch_duplicate(g, b, P, width, height, mode, debug, st)) return rc;
-    const int bits = tile_bits(tiles);
-    {
-      StageScope sc(ST_TILE_SORT, st);
-      if (int rc = radix_sort_pairs(b.keys, b.vals, b.hist, b.digit_total, (size_t)num_rendered, bits, false, debug, st)) return rc;
-    }
-    slot = sort_final_slot(bits);
+  BinningState b = BinningState::from(binning_buffer, (size_t)cap);
+  const int slot = sort_final_slot(tiles);
+  if (P > 0 && cap > 0) {
+    if (int rc = launch_duplicate(g, b, P, width, height, mode, (size_t)cap, debug, st)) return rc;
+    if (int rc = launch_tile_sort(g, b, img, (size_t)cap, device_count ? g.counters + GM_CNT_RENDERED : nullptr, tiles, debug, st)) return rc;
+    if (slot == 0)
+      if (int rc = launch_tile_ranges(g, b, slot, img, (int)cap, device_count ? g.counters + GM_CNT_RENDERED : nullptr, tiles, debug, st)) return rc;
+  } else {
+    GM_HIP(hipMemsetAsync(img.ranges, 0, sizeof(uint2) * (size_t)tiles, st));
   }
-  if (int rc = launch_tile_ranges(g, b, slot, img, num_rendered, tiles, debug, st)) return rc;
   return launch_render_fwd(g, b.keys[slot], b.vals[slot], img, width, height, mode, background, out_color, debug, st);
+}
+
+int gm_forward_status_async(void* geom_buffer, int P, int* status_host, void* stream) {
+  if (!status_host) { set_error("status_host is null"); return GM_ERR_INVALID_ARG; }
+  if (P <= 0) { status_host[0] = 0; status_host[1] = 0; status_host[2] = 0; status_host[3] = 0; return GM_OK; }
+  if (!geom_buffer) { set_error("geom_buffer is null"); return GM_ERR_INVALID_ARG; }
+  GeomState g = GeomState::from(geom_buffer, (size_t)P);
+  GM_HIP(hipMemcpyAsync(status_host, g.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(stream)));
+  return GM_OK;
 }
 
 int gm_forward_0(void* geom_buffer, int P, int D, int M, const float* background, int width, int height,
@@ -211,22 +215,17 @@ int gm_forward_0(void* geom_buffer, int P, int D, int M, const float* background
                  const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
                  const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
                  float tan_fovy, int prefiltered, int* radii, int debug, void* stream, int* num_rendered) {
-  FILL_ARGS(a)
-  if (int rc = check_raster_args(a)) return rc;
   if (!num_rendered) { set_error("num_rendered is null"); return GM_ERR_INVALID_ARG; }
   *num_rendered = 0;
+  if (int rc = gm_forward_0_async(GM_POLICY_DEFAULT, geom_buffer, P, D, M, background, width, height, means3D, shs, colors_precomp, opacities,
+                                  scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy,
+                                  prefiltered, radii, debug, stream, nullptr, nullptr)) return rc;
   if (P == 0) return GM_OK;
-  if (!geom_buffer) { set_error("geom_buffer is null"); return GM_ERR_INVALID_ARG; }
   GeomState g = GeomState::from(geom_buffer, (size_t)P);
-  if (int rc = launch_preprocess(a, g, radii)) return rc;
-  {  // order Gaussians by (depth bits, id): 4 radix passes over P
-    StageScope sc(ST_DEPTH_SORT, a.stream);
-    if (int rc = radix_sort_pairs(g.depth_key, g.order, g.hist, g.digit_total, (size_t)P, 32, true, debug, a.stream)) return rc;
-  }
-  if (int rc = launch_tile_count_scan(g, P, debug, a.stream)) return rc;
   uint32_t r = 0;
-  GM_HIP(hipMemcpyAsync(&r, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, a.stream));
-  GM_HIP(hipStreamSynchronize(a.stream));   // the one host sync of a forward (reference: rasterizer_impl.cu:411)
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  GM_HIP(hipMemcpyAsync(&r, g.counters + GM_CNT_RENDERED, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  GM_HIP(hipStreamSynchronize(st));         // the one host sync of a forward (reference: rasterizer_impl.cu:411)
   if (r > 0x7FFFFFFFu) { set_error("num_rendered overflows int32 (%u)", r); return GM_ERR_INVALID_ARG; }
   *num_rendered = (int)r;
   return GM_OK;
@@ -238,25 +237,26 @@ int gm_forward_1(void* geom_buffer, void* binning_buffer, void* image_buffer, in
                  const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                  const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color, int* radii,
                  int debug, void* stream) {
-  FILL_ARGS(a)
+  FILL_ARGS(a, GM_POLICY_DEFAULT)
   if (int rc = check_raster_args(a)) return rc;
-  if (!image_buffer || !out_color || !background) { set_error("null image_buffer / out_color / background"); return GM_ERR_INVALID_ARG; }
+  (void)radii;
   if (num_rendered < 0) { set_error("negative num_rendered"); return GM_ERR_INVALID_ARG; }
-  if (P > 0 && (!geom_buffer || (num_rendered > 0 && !binning_buffer))) { set_error("null scratch buffer"); return GM_ERR_INVALID_ARG; }
-  return gm_forward_1_geom(geom_buffer, binning_buffer, image_buffer, P, num_rendered, background, width, height, out_color, debug, stream);
+  return gm_forward_1_geom(GM_POLICY_DEFAULT, geom_buffer, binning_buffer, image_buffer, P, num_rendered, 0, background, width, height, out_color,
+                           debug, stream);
 }
 
-int gm_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
-                const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
-                const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
-                const float* campos, float tan_fovx, float tan_fovy, const int* radii, void* geom_buffer,
-                void* binning_buffer, void* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
-                float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
-                float* dL_dscale, float* dL_drot, int debug, void* stream) {
+int gm_backward_p(int emission_policy, int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                  const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                  const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                  const float* campos, float tan_fovx, float tan_fovy, const int* radii, void* geom_buffer,
+                  void* binning_buffer, void* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
+                  float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                  float* dL_dscale, float* dL_drot, int debug, void* stream) {
+  if (int rc = check_policy(emission_policy)) return rc;
   const float* opacities = reinterpret_cast<const float*>(1);   // not used by backward; satisfies the shared check
   const float* cam_pos = campos;
   const int prefiltered = 0;
-  FILL_ARGS(a)
+  FILL_ARGS(a, emission_policy)
   if (int rc = check_raster_args(a)) return rc;
   if (P == 0) return GM_OK;
   if (!geom_buffer || !image_buffer || !dL_dpix || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor ||
@@ -266,7 +266,7 @@ int gm_backward(int P, int D, int M, int R, const float* background, int width, 
   GeomState g = GeomState::from(geom_buffer, (size_t)P);
   ImageState img = ImageState::from(image_buffer, width, height);
   BinningState b = BinningState::from(binning_buffer, (size_t)(R > 0 ? R : 0));
-  const int slot = sort_final_slot(tile_bits(TileGrid(width, height, a.tile_cull).ptiles));
+  const int slot = sort_final_slot(TileGrid(width, height, a.tile_cull).ptiles);
   GM_HIP(hipMemsetAsync(g.grad_acc, 0, sizeof(float) * 12 * (size_t)P, a.stream));   // the only zero-fill of a backward
   if (R > 0) {
     if (!binning_buffer) { set_error("gm_backward: null binning buffer"); return GM_ERR_INVALID_ARG; }
@@ -274,6 +274,18 @@ int gm_backward(int P, int D, int M, int R, const float* background, int width, 
   }
   return launch_preprocess_bwd(a, g, radii, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
                                dL_dscale, dL_drot);
+}
+
+int gm_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                const float* campos, float tan_fovx, float tan_fovy, const int* radii, void* geom_buffer,
+                void* binning_buffer, void* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
+                float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                float* dL_dscale, float* dL_drot, int debug, void* stream) {
+  return gm_backward_p(GM_POLICY_DEFAULT, P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations,
+                       cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, image_buffer,
+                       dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, stream);
 }
 
 int gm_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
@@ -291,6 +303,7 @@ void* gm_geom_field(void* geom_buffer, int P, const char* name) {
   if (!strcmp(name, "cov3D")) return g.cov3D;
   if (!strcmp(name, "clamped")) return g.clamped;
   if (!strcmp(name, "order")) return g.order[0];
+  if (!strcmp(name, "bucket_start")) return g.bucket_start;
   if (!strcmp(name, "counters")) return g.counters;
   return nullptr;
 }
@@ -301,9 +314,9 @@ void* gm_image_field(void* image_buffer, int W, int H, const char* name) {
   if (!strcmp(name, "ranges")) return s.ranges;
   return nullptr;
 }
-void* gm_binning_field(void* binning_buffer, int64_t R, int W, int H, const char* name) {
+void* gm_binning_field(void* binning_buffer, int64_t R, int W, int H, int emission_policy, const char* name) {
   BinningState b = BinningState::from(binning_buffer, (size_t)(R > 0 ? R : 0));
-  const int slot = sort_final_slot(tile_bits(TileGrid(W, H, g_tile_cull).ptiles));
+  const int slot = sort_final_slot(TileGrid(W, H, emission_policy < 0 ? 0 : (emission_policy > 3 ? 3 : emission_policy)).ptiles);
   if (!strcmp(name, "point_list")) return b.vals[slot];
   if (!strcmp(name, "tile_keys")) return b.keys[slot];
   return nullptr;

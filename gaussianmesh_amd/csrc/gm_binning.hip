@@ -1,13 +1,13 @@
-// gm_binning.hip -- instance counting, instance emission and tile ranges.
+// gm_binning.hip -- instance emission and (for more than 2048 list tiles) tile ranges.
 //
 // Replaces (reference, RAST = gaussian_renderer/diff_gaussian_rasterizater/cuda_rasterizer):
-//   RAST/rasterizer_impl.cu:407   cub::DeviceScan::InclusiveSum over tiles_touched
 //   RAST/rasterizer_impl.cu:70-111 duplicateWithKeys
 //   RAST/rasterizer_impl.cu:116-138 identifyTileRanges (+ the cudaMemset of ranges, :485)
+// (the inclusive scan of tiles_touched, :407, is folded into the ordering: bucket_sort_kernel leaves per-bucket instance
+//  totals, gm_bucket.hip)
 //
-// Gaussians are visited in (depth, id) order (GeomState::order[0], produced by the depth sort), so the
-// emitted instance stream is already depth-ordered and only needs a stable sort by tile id afterwards.
-// Workgroup b owns sorted positions [b*2048, (b+1)*2048); thread t owns 8 consecutive positions.
+// Gaussians are visited in (depth, id) order (GeomState::order[0]), so the emitted instance stream is already
+// depth-ordered and only needs a stable sort by list tile afterwards.
 #include "gm_common.h"
 #include "gm_cull.h"
 #pragma clang fp contract(off)
@@ -39,52 +39,8 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
   return woff + incl - v;
 }
 
-__global__ __launch_bounds__(BN_THREADS) void tile_block_sums_kernel(const uint32_t* __restrict__ order,
-                                                                      const uint32_t* __restrict__ tiles, int P,
-                                                                      uint32_t* __restrict__ block_sums) {
-  __shared__ uint32_t wsum[BN_THREADS / 64];
-  const int base = blockIdx.x * GM_SCAN_ITEMS + threadIdx.x * BN_PER_THREAD;
-  uint32_t sum = 0;
-#pragma unroll
-  for (int i = 0; i < BN_PER_THREAD; i++) {
-    const int s = base + i;
-    if (s < P) sum += tiles[order[s]];
-  }
-  uint32_t total;
-  block_exclusive_scan(sum, wsum, total);
-  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
-}
-
-// single workgroup: exclusive scan of block_sums[nb] in place, grand total -> counters[0]
-__global__ __launch_bounds__(BN_THREADS) void scan_block_sums_kernel(uint32_t* __restrict__ block_sums, int nb,
-                                                                      uint32_t* __restrict__ counters) {
-  __shared__ uint32_t wsum[BN_THREADS / 64];
-  __shared__ uint32_t carry_s;
-  if (threadIdx.x == 0) carry_s = 0;
-  __syncthreads();
-  for (int base = 0; base < nb; base += BN_THREADS) {
-    const int i = base + threadIdx.x;
-    const uint32_t v = i < nb ? block_sums[i] : 0;
-    uint32_t total;
-    const uint32_t excl = block_exclusive_scan(v, wsum, total);
-    const uint32_t carry = carry_s;
-    if (i < nb) block_sums[i] = carry + excl;
-    __syncthreads();
-    if (threadIdx.x == 0) carry_s = carry + total;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) counters[0] = carry_s;
-}
-
-int launch_tile_count_scan(GeomState& g, int P, int debug, hipStream_t s) {
-  StageScope sc(ST_SCAN, s);
-  const int nb = (P + GM_SCAN_ITEMS - 1) / GM_SCAN_ITEMS;
-  if (nb > 0) {
-    hipLaunchKernelGGL(tile_block_sums_kernel, dim3(nb), dim3(BN_THREADS), 0, s, g.order[0], g.tiles_touched, P, g.block_sums);
-    GM_LAUNCH_CHECK(debug, s);
-  }
-  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(BN_THREADS), 0, s, g.block_sums, nb, g.counters);
-  GM_LAUNCH_CHECK(debug, s);
+int launch_arm_counters(GeomState& g, hipStream_t s) {
+  GM_HIP(hipMemsetAsync(g.slots, 0, sizeof(uint32_t) * (4 * GM_SLOTS + GM_CNT_COUNT), s));
   return 0;
 }
 
@@ -95,49 +51,67 @@ __device__ __forceinline__ void get_rect(float px, float py, int r, int gx, int 
   y1 = min(gy, max(0, (int)((py + r + GM_TILE - 1) / GM_TILE)));
 }
 
-// Instance emission.  Workgroup b owns sorted positions [b*512, (b+1)*512); thread t owns 2 consecutive ones and
-// gathers their bin records (candidate rectangle + emit mask, written by preprocess) and instance counts; the block
-// scans the counts into output offsets; then instances are written (see (1) and (2) in the body).
+// Instance emission.  Workgroup b owns the sorted positions of depth bucket b (gm_bucket.hip), [bucket_start[b],
+// bucket_start[b + 1]), and walks them in chunks of 512: thread t owns 2 consecutive positions of a chunk, reads their
+// instance counts (cnt_sorted, coalesced) and gathers the bin records (candidate rectangle + emit mask, written by
+// preprocess) of the Gaussians that emit anything; the chunk scans the counts into output offsets; then instances are
+// written (see (1) and (2) in the body).  The bucket's first output offset is the sum of the instance totals of the
+// buckets before it (bucket_inst, 2048 values, summed by every workgroup for itself).
 // Emitted order = Gaussian order (depth, id), then rectangle row-major - the reference's order
 // (RAST/rasterizer_impl.cu:98-109) restricted to the emitted tiles.
 // S > 0: one instance per PARENT tile (2^S x 2^S tiles) that has a reached child; key = parent id | child mask << 16
 // (child bit = (row in parent) << S | column in parent).  S == 0: key = tile id | 1 << 16.
 template <int S>
-__global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* __restrict__ order,
-                                                                const uint4* __restrict__ bins, const uint32_t* __restrict__ tiles,
-                                                                const float4* __restrict__ splat, uint32_t* __restrict__ counters, int P,
-                                                                int gx, int pgx, int mode,
-                                                                const uint32_t* __restrict__ block_sums,
-                                                                uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+__global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* __restrict__ order, const uint32_t* __restrict__ cnt_sorted,
+                                                                const uint4* __restrict__ bins, const float4* __restrict__ splat,
+                                                                uint32_t* __restrict__ counters, const uint32_t* __restrict__ bucket_start,
+                                                                const uint32_t* __restrict__ bucket_inst, int gx, int pgx, int mode,
+                                                                uint32_t capacity, uint32_t* __restrict__ keys_out,
+                                                                uint32_t* __restrict__ vals_out) {
   __shared__ uint32_t wsum[BN_THREADS / 64];
   __shared__ uint32_t stage_k[DUP_STAGE], stage_v[DUP_STAGE];
-  if ((int)counters[2] != mode) {                // the counts were made under another policy (gm_set_tile_culling changed
-    if (threadIdx.x == 0) counters[3] = 1u;      // between gm_forward_0 and gm_forward_1): emit nothing rather than overrun
+  // the counts were made under another policy (it changed between the forward halves), or the instance total exceeds the
+  // caller's binning capacity: emit nothing rather than overrun; every list stays empty (tile_ranges / bk_scan see the flag)
+  if ((int)counters[GM_CNT_POLICY] != mode || counters[GM_CNT_RENDERED] > capacity) {
+    if (threadIdx.x == 0) counters[GM_CNT_REFUSED] = 1u;
     return;
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0) counters[GM_CNT_REFUSED] = 0u;      // (a refused attempt on these buffers may have left it set)
   const int tile_cull = mode != 0;
   constexpr int M = (1 << S) - 1;
   const int lane = threadIdx.x & 63;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  const int base = blockIdx.x * GM_SCAN_ITEMS + threadIdx.x * BN_PER_THREAD;
+  const uint32_t bkt = blockIdx.x;
+  const uint32_t P0 = bucket_start[bkt], P1 = bucket_start[bkt + 1];
+  if (P0 == P1) return;
+  uint32_t ibase;
+  {
+    uint32_t part = 0;
+    for (uint32_t k = threadIdx.x; k < bkt; k += BN_THREADS) part += bucket_inst[k];
+    uint32_t tot;
+    block_exclusive_scan(part, wsum, tot);
+    ibase = tot;
+    __syncthreads();
+  }
+  for (uint32_t c0 = P0; c0 < P1; c0 += GM_SCAN_ITEMS) {
+  const uint32_t base = c0 + threadIdx.x * BN_PER_THREAD;
   uint32_t gid[BN_PER_THREAD], cnt[BN_PER_THREAD], offs[BN_PER_THREAD], sum = 0;
   uint4 rc[BN_PER_THREAD];
 #pragma unroll
   for (int i = 0; i < BN_PER_THREAD; i++) {
-    const int s = base + i;
-    gid[i] = s < P ? order[s] : 0u;
+    const uint32_t s = base + i;
+    cnt[i] = s < P1 ? cnt_sorted[s] : 0u;
+    gid[i] = (s < P1 && cnt[i]) ? order[s] : 0u;
   }
 #pragma unroll
   for (int i = 0; i < BN_PER_THREAD; i++) {
-    const int s = base + i;
-    cnt[i] = s < P ? tiles[gid[i]] : 0u;
-    rc[i] = (s < P && cnt[i]) ? bins[gid[i]] : make_uint4(0u, 0u, 0u, 0u);
+    rc[i] = cnt[i] ? bins[gid[i]] : make_uint4(0u, 0u, 0u, 0u);
     sum += cnt[i];
   }
   uint32_t total;
-  const uint32_t block_base = block_sums[blockIdx.x];
+  const uint32_t block_base = ibase;
   uint32_t off = block_exclusive_scan(sum, wsum, total);
-  // The block's instances form one contiguous output range.  When it fits the LDS stage (nearly always) they are
+  // The chunk's instances form one contiguous output range.  When it fits the LDS stage (nearly always) they are
   // assembled there and copied out with full-line stores: per-lane runs written straight to HBM cost 2.3x the bytes
   // (partial lines, WRITE_SIZE 114 MB for 48.7 MB of pairs).  Otherwise the runs are stored directly.
   const bool staged = total <= DUP_STAGE;
@@ -252,15 +226,18 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
       vals_out[block_base + j] = stage_v[j];
     }
   }
+  ibase += total;
+  __syncthreads();                                 // the stage and wsum are reused by the next chunk
+  }
 }
 
-int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, int mode, int debug, hipStream_t s) {
+int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, int mode, size_t capacity, int debug, hipStream_t s) {
   StageScope sc(ST_DUPLICATE, s);
-  const int nb = (P + GM_SCAN_ITEMS - 1) / GM_SCAN_ITEMS;
   const TileGrid tg(W, H, mode);
-  if (nb > 0) {
-#define GM_DUP(SH) hipLaunchKernelGGL(duplicate_kernel<SH>, dim3(nb), dim3(BN_THREADS), 0, s, g.order[0], g.bin, g.tiles_touched, g.splat, \
-                                      g.counters, P, tg.gx, tg.pgx, mode, g.block_sums, b.keys[0], b.vals[0])
+  const uint32_t cap = capacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)capacity;
+  if (P > 0) {
+#define GM_DUP(SH) hipLaunchKernelGGL(duplicate_kernel<SH>, dim3(1 << GM_BUCKET_BITS), dim3(BN_THREADS), 0, s, g.order[0], g.cnt_sorted, g.bin, \
+                                      g.splat, g.counters, g.bucket_start, g.bucket_inst, tg.gx, tg.pgx, mode, cap, b.keys[0], b.vals[0])
     if (tg.s == 0) GM_DUP(0); else if (tg.s == 1) GM_DUP(1); else GM_DUP(2);
 #undef GM_DUP
   }
@@ -268,12 +245,13 @@ int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, int mod
   return 0;
 }
 
-__global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __restrict__ keys, int R, uint32_t tiles, const uint32_t* __restrict__ counters,
-                                                          uint2* __restrict__ ranges) {
+__global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __restrict__ keys, int R_host, const uint32_t* __restrict__ R_dev,
+                                                          uint32_t tiles, const uint32_t* __restrict__ counters, uint2* __restrict__ ranges) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= R || counters[3] != 0u) return;        // counters[3]: emission was refused (policy mismatch) -> every list stays empty
+  const int R = R_dev ? (int)min((uint32_t)R_host, *R_dev) : R_host;
+  if (i >= R || counters[GM_CNT_REFUSED] != 0u) return;        // emission was refused -> every list stays empty
   const uint32_t cur = keys[i] & GM_KEY_TILE_MASK;
-  if (cur >= tiles) return;                      // only after a refused emission (policy changed between forward_0 and forward_1)
+  if (cur >= tiles) return;
   if (i == 0) ranges[cur].x = 0;
   else {
     const uint32_t prev = keys[i - 1] & GM_KEY_TILE_MASK;
@@ -282,10 +260,12 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __rest
   if (i == R - 1) ranges[cur].y = (uint32_t)R;
 }
 
-int launch_tile_ranges(const GeomState& g, BinningState& b, int slot, ImageState& img, int R, int tiles, int debug, hipStream_t s) {
+// only for more than 2048 list tiles (two-pass tile sort); otherwise bk_scan_kernel writes the ranges
+int launch_tile_ranges(const GeomState& g, BinningState& b, int slot, ImageState& img, int R, const uint32_t* R_dev, int tiles, int debug,
+                       hipStream_t s) {
   StageScope sc(ST_RANGES, s);
   GM_HIP(hipMemsetAsync(img.ranges, 0, sizeof(uint2) * (size_t)tiles, s));
-  if (R > 0) hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, b.keys[slot], R, (uint32_t)tiles, g.counters, img.ranges);
+  if (R > 0) hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, b.keys[slot], R, R_dev, (uint32_t)tiles, g.counters, img.ranges);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }

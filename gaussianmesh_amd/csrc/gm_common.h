@@ -68,6 +68,21 @@ static inline size_t sort_blocks(size_t n) {
 // counters of the per-chunk digit totals: [chunks][256]
 static inline size_t sort_chunk_counters(size_t n) { return 256 * ((sort_blocks(n) + GM_SORT_CHUNK - 1) / GM_SORT_CHUNK); }
 
+// ordering of a forward (gm_bucket.hip)
+#define GM_BUCKET_BITS 11            // MSD partition of the depth keys into <= 2048 buckets; also the digit of the one-pass tile sort
+#define GM_BK_TILE 4096              // keys per workgroup of a partition / tile-sort pass
+#define GM_BK_CHUNK 32               // histogram rows per scan workgroup
+static inline size_t bk_blocks(size_t n) { return (n + GM_BK_TILE - 1) / GM_BK_TILE; }
+static inline size_t bk_chunks(size_t n) { return (bk_blocks(n) + GM_BK_CHUNK - 1) / GM_BK_CHUNK; }
+// device scalars (GeomState::counters)
+#define GM_CNT_RENDERED 0            // num_rendered (instance total of this forward)
+#define GM_CNT_POLICY 2              // emission policy the counts were made under
+#define GM_CNT_REFUSED 3             // emission refused (policy mismatch / capacity overflow): every list stays empty
+#define GM_CNT_GROUP 8               // [8] digit-group totals of the scan in flight
+#define GM_CNT_DONE 16               // [9] arrival counters of the scan in flight (re-armed by its last workgroup)
+#define GM_CNT_COUNT 32
+#define GM_SLOTS 64                  // atomic slots {instance sum, max ~depth key, max depth key, -} filled by the preprocess kernel
+
 struct GeomState {              // per-Gaussian state (P-sized)
   float4* splat;                // [P][3]: {x,y,con.x,con.y} {con.z,opacity,r,g} {b,depth,0,0}
   int* radii;                   // internal radii when the caller passes none
@@ -76,16 +91,21 @@ struct GeomState {              // per-Gaussian state (P-sized)
                                 //     rectangles of <= 64 tiles, the bit mask (row-major) of the tiles actually emitted
   float* cov3D;                 // [P][6] (computed from scale/rot)
   uint8_t* clamped;             // [P] bit ch = SH colour channel ch was clamped at 0
-  uint32_t* depth_key[2];       // [P] ping-pong keys of the depth sort (float bits of view z)
-  uint32_t* order[2];           // [P] ping-pong payload; order[0] = Gaussian ids sorted by (depth, id)
-  uint32_t* hist;               // [sort_blocks(P)][256] radix histograms of the depth sort
-  uint32_t* digit_total;        // [chunks][256] per-chunk digit totals
-  uint32_t* block_sums;         // [ceil(P/GM_SCAN_ITEMS)] tiles_touched partial sums (sorted order)
-  uint32_t* counters;           // [16] device scalars: [0] = num_rendered
+  uint32_t* depth_key[2];       // [P] [0]: float bits of view z per Gaussian (0xFFFFFFFF = culled); [1]: partitioned into buckets
+  uint32_t* order[2];           // [P] [1]: ids partitioned into buckets; [0]: ids of the VISIBLE Gaussians in (depth, id) order
+  uint32_t* cnt_sorted;         // [P] tiles_touched in that order
+  uint32_t* hist;               // [bk_blocks(P)][2048] bucket histograms of the partition
+  uint32_t* chunk_total;        // [bk_chunks(P)][2048]
+  uint32_t* bucket_start;       // [2049] first sorted position of each bucket (+ total)
+  uint32_t* digit_total;        // [2048] bucket sizes
+  uint32_t* bucket_inst;        // [2048] instances emitted by each bucket
+  uint32_t* slots;              // [GM_SLOTS][4], contiguous with counters: one memset re-arms both
+  uint32_t* counters;           // [GM_CNT_COUNT] device scalars
   float* grad_acc;              // [P][12] backward accumulators: dcolor rgb | dmean2D xy | dconic x,y,w | dopacity | pad
   static GeomState from(void* buf, size_t P) {
     char* p = reinterpret_cast<char*>(buf);
     GeomState g;
+    constexpr size_t ND = size_t(1) << GM_BUCKET_BITS;
     g.splat = carve<float4>(p, 3 * P);
     g.radii = carve<int>(p, P);
     g.tiles_touched = carve<uint32_t>(p, P);
@@ -96,10 +116,14 @@ struct GeomState {              // per-Gaussian state (P-sized)
     g.depth_key[1] = carve<uint32_t>(p, P);
     g.order[0] = carve<uint32_t>(p, P);
     g.order[1] = carve<uint32_t>(p, P);
-    g.hist = carve<uint32_t>(p, 256 * sort_blocks(P));
-    g.digit_total = carve<uint32_t>(p, sort_chunk_counters(P));
-    g.block_sums = carve<uint32_t>(p, (P + GM_SCAN_ITEMS - 1) / GM_SCAN_ITEMS + 1);
-    g.counters = carve<uint32_t>(p, 16);
+    g.cnt_sorted = carve<uint32_t>(p, P);
+    g.hist = carve<uint32_t>(p, ND * bk_blocks(P));
+    g.chunk_total = carve<uint32_t>(p, ND * bk_chunks(P));
+    g.bucket_start = carve<uint32_t>(p, ND + 1);
+    g.digit_total = carve<uint32_t>(p, ND);
+    g.bucket_inst = carve<uint32_t>(p, ND);
+    g.slots = carve<uint32_t>(p, 4 * GM_SLOTS + GM_CNT_COUNT);     // 1 KiB of slots, counters right behind
+    g.counters = g.slots + 4 * GM_SLOTS;
     g.grad_acc = carve<float>(p, 12 * P);
     g.end = p;
     return g;
@@ -126,20 +150,25 @@ struct ImageState {             // per-pixel / per-tile state
 };
 
 struct BinningState {           // per-instance state (R-sized)
-  uint32_t* keys[2];            // [R] tile id per instance, ping-pong
+  uint32_t* keys[2];            // [R] list tile id | child mask << 16 per instance, ping-pong
   uint32_t* vals[2];            // [R] Gaussian id per instance, ping-pong
-  uint32_t* hist;               // [sort_blocks(R)][256]
-  uint32_t* digit_total;        // [chunks][256]
+  uint32_t* hist;               // [bk_blocks(R)][2048]
+  uint32_t* chunk_total;        // [bk_chunks(R)][2048]
+  uint32_t* digit_base;         // [2049]
+  uint32_t* digit_total;        // [2048]
   static BinningState from(void* buf, size_t R) {
     char* p = reinterpret_cast<char*>(buf);
     BinningState b;
     const size_t Rp = R ? R : 1;
+    constexpr size_t ND = size_t(1) << GM_BUCKET_BITS;
     b.keys[0] = carve<uint32_t>(p, Rp);
     b.keys[1] = carve<uint32_t>(p, Rp);
     b.vals[0] = carve<uint32_t>(p, Rp);
     b.vals[1] = carve<uint32_t>(p, Rp);
-    b.hist = carve<uint32_t>(p, 256 * sort_blocks(Rp));
-    b.digit_total = carve<uint32_t>(p, sort_chunk_counters(Rp));
+    b.hist = carve<uint32_t>(p, ND * bk_blocks(Rp));
+    b.chunk_total = carve<uint32_t>(p, ND * bk_chunks(Rp));
+    b.digit_base = carve<uint32_t>(p, ND + 1);
+    b.digit_total = carve<uint32_t>(p, ND);
     b.end = p;
     return b;
   }
@@ -151,8 +180,9 @@ static inline int tile_bits(int tiles) {      // bits needed to hold tile ids 0.
   while ((1 << b) < tiles) b++;
   return b;
 }
-// which ping-pong slot holds the result after sorting `bits` bits in 8-bit passes, starting in slot 0
-static inline int sort_final_slot(int bits) { return ((bits + 7) / 8) & 1; }
+// which ping-pong slot holds the tile-sorted instance stream (launch_tile_sort: one 11-bit pass for up to 2048 list tiles,
+// two 8-bit passes above)
+static inline int sort_final_slot(int tiles) { return tiles <= (1 << GM_BUCKET_BITS) ? 1 : 0; }
 
 // Emission policy (gm_set_tile_culling): 0 = the reference's lists (every tile of the rectangle, 16-px tiles);
 // 1 = exact culling, lists per 16-px tile; 2 / 3 = exact culling, lists per 32- / 64-px PARENT tile (the instance
@@ -196,9 +226,14 @@ int launch_preprocess_bwd(const RasterArgs& a, GeomState& g, const int* radii, f
 int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], uint32_t* hist, uint32_t* digit_total, size_t n,
                      int bits, bool iota_values, int debug, hipStream_t s);
 
-int launch_tile_count_scan(GeomState& g, int P, int debug, hipStream_t s);          // -> counters[0] = num_rendered
-int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, int tile_cull, int debug, hipStream_t s);
-int launch_tile_ranges(const GeomState& g, BinningState& b, int slot, ImageState& img, int R, int tiles, int debug, hipStream_t s);
+// (depth, id) order of the visible Gaussians + per-bucket instance totals; counters[GM_CNT_RENDERED] = num_rendered.
+// num_rendered_host (optional, pinned): receives the count by a stream-ordered copy issued as soon as it is known;
+// count_event (optional) is recorded right behind that copy.
+int launch_depth_order(GeomState& g, int P, int debug, hipStream_t s, int* num_rendered_host, hipEvent_t count_event);
+int launch_arm_counters(GeomState& g, hipStream_t s);                               // zero slots + counters (first launch of a forward)
+int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, int tile_cull, size_t capacity, int debug, hipStream_t s);
+int launch_tile_sort(GeomState& g, BinningState& b, ImageState& img, size_t n, const uint32_t* n_dev, int tiles, int debug, hipStream_t s);
+int launch_tile_ranges(const GeomState& g, BinningState& b, int slot, ImageState& img, int R, const uint32_t* R_dev, int tiles, int debug, hipStream_t s);
 int launch_render_fwd(const GeomState& g, const uint32_t* tile_keys, const uint32_t* point_list, ImageState& img, int W, int H, int mode,
                       const float* background, float* out_color, int debug, hipStream_t s);
 int launch_render_bwd(const GeomState& g, const uint32_t* tile_keys, const uint32_t* point_list, ImageState& img, int W, int H, int mode,

@@ -376,7 +376,7 @@ __global__ __launch_bounds__(64) void deform_shade_dma_kernel(int N, int deg, co
 struct FusedPre {
   PreCam cam;
   const float* opac;
-  float4* splat; int* radii_int; int* radii_out; uint32_t* tiles; uint4* bin; uint32_t* counters; uint8_t* clamped; uint32_t* depth_key;
+  float4* splat; int* radii_int; int* radii_out; uint32_t* tiles; uint4* bin; uint32_t* counters; uint32_t* slots; uint8_t* clamped; uint32_t* depth_key;
 };
 __global__ __launch_bounds__(64) void deform_shade_pre_kernel(int N, int deg, const int* __restrict__ tri, const float* __restrict__ w,
                                                               const float* __restrict__ dV, const float* __restrict__ cov,
@@ -488,9 +488,9 @@ __global__ __launch_bounds__(64) void deform_shade_pre_kernel(int N, int deg, co
     }
   }
   // ---- forward preprocess of the deformed Gaussian (colors_precomp / cov3D_precomp input mode)
+  uint32_t tiles = 0, dkey = 0xFFFFFFFFu;
   if (live) {
     int radius_i = 0;
-    uint32_t tiles = 0, dkey = 0xFFFFFFFFu;
     uint4 bin = make_uint4(0u, 0u, 0u, 0u);
     const V3 p = {npos[0], npos[1], npos[2]};
     const float c3[6] = {O[0], O[1], O[2], O[4], O[5], O[8]};
@@ -510,8 +510,9 @@ __global__ __launch_bounds__(64) void deform_shade_pre_kernel(int N, int deg, co
     fp.tiles[i] = tiles;
     fp.bin[i] = bin;
     fp.depth_key[i] = dkey;
-    if (i == 0) { fp.counters[2] = (uint32_t)fp.cam.tile_cull; fp.counters[3] = 0u; }
+    if (i == 0) fp.counters[GM_CNT_POLICY] = (uint32_t)fp.cam.tile_cull;
   }
+  slot_accumulate(fp.slots, tiles, dkey);
   if (!pos_out) return;                          // wave-uniform
   __syncthreads();                               // everyone is done reading the staged inputs: reuse LDS for the outputs
   float* o_pos = lds;                            // [256][3]
@@ -595,7 +596,7 @@ int launch_deform_shade_pre(const RasterArgs& r, GeomState& g, int* radii, int d
   fp.cam.tanx = r.tan_fovx; fp.cam.tany = r.tan_fovy;
   fp.cam.fy = r.H / (2.0f * r.tan_fovy); fp.cam.fx = r.W / (2.0f * r.tan_fovx);   // rasterizer_impl.cu:359-360
   fp.opac = r.opacities;
-  fp.splat = g.splat; fp.radii_int = g.radii; fp.radii_out = radii; fp.tiles = g.tiles_touched; fp.bin = g.bin; fp.counters = g.counters;
+  fp.splat = g.splat; fp.radii_int = g.radii; fp.radii_out = radii; fp.tiles = g.tiles_touched; fp.bin = g.bin; fp.counters = g.counters; fp.slots = g.slots;
   fp.clamped = g.clamped; fp.depth_key = g.depth_key[0];
   const size_t lds_bytes = sizeof(float) * 64 * (48 + 9);
   hipLaunchKernelGGL(deform_shade_pre_kernel, dim3((N + 63) / 64), dim3(64), lds_bytes, r.stream, N, deg, tri, w, packed, cov, pos, shs,

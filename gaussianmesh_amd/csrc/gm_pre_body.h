@@ -163,4 +163,24 @@ __device__ __forceinline__ void pre_emit(const PreCam& a, const PreGeom& g, floa
   bin = make_uint4((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)rw | ((uint32_t)rh << 16), (uint32_t)mask, (uint32_t)(mask >> 32));
 }
 
+// Per-wave partials of {instance total, max ~depth key, max depth key} of the visible Gaussians -> one of GM_SLOTS atomic
+// slots (GeomState::slots).  Every lane of the wave must call this (culled / out-of-range lanes with tiles = 0,
+// dkey = 0xFFFFFFFF).  The ordering kernels (gm_bucket.hip) reduce the slots to num_rendered and the depth range.
+__device__ __forceinline__ void slot_accumulate(uint32_t* __restrict__ slots, uint32_t tiles, uint32_t dkey) {
+  const bool vis = dkey != 0xFFFFFFFFu;
+  uint32_t s = tiles, nk = vis ? ~dkey : 0u, mk = vis ? dkey : 0u;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    s += (uint32_t)__shfl_xor((int)s, d);
+    nk = max(nk, (uint32_t)__shfl_xor((int)nk, d));
+    mk = max(mk, (uint32_t)__shfl_xor((int)mk, d));
+  }
+  if ((threadIdx.x & 63) == 0 && (mk | nk) != 0u) {
+    uint32_t* slot = slots + 4 * ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (GM_SLOTS - 1));
+    if (s) atomicAdd(slot, s);
+    atomicMax(slot + 1, nk);
+    atomicMax(slot + 2, mk);
+  }
+}
+
 }  // namespace gm

@@ -29,7 +29,7 @@ struct PreArgs {
   int P, D, M, W, H, gx, gy;
   const float *means, *scales, *rots, *opac, *shs, *cov3D_pre, *colors_pre, *view, *proj, *campos;
   float mod, tanx, tany, fx, fy;
-  float4* splat; int* radii_int; int* radii_out; uint32_t* tiles; uint4* bin; int tile_cull; uint32_t* counters; float* cov3D; uint8_t* clamped; uint32_t* depth_key;
+  float4* splat; int* radii_int; int* radii_out; uint32_t* tiles; uint4* bin; int tile_cull; uint32_t* counters; uint32_t* slots; float* cov3D; uint8_t* clamped; uint32_t* depth_key;
 };
 
 // STAGE_SH: the workgroup's 256 SH rows (192 B each, M == 16) are copied HBM -> LDS with consecutive lanes reading
@@ -60,12 +60,11 @@ __global__ __launch_bounds__(TH) void preprocess_fwd_kernel(const PreArgs a) {
     }
     __syncthreads();
   }
-  if (idx >= a.P) return;
-  if (idx == 0) { a.counters[2] = (uint32_t)a.tile_cull; a.counters[3] = 0u; }   // emission policy of THIS forward (read back by duplicate_kernel), no refusal yet
+  if (idx == 0) a.counters[GM_CNT_POLICY] = (uint32_t)a.tile_cull;   // emission policy of THIS forward (checked by duplicate_kernel / render_bwd_kernel)
   int radius_i = 0;
   uint32_t tiles = 0, dkey = 0xFFFFFFFFu;
   uint4 bin = make_uint4(0u, 0u, 0u, 0u);
-  do {
+  if (idx < a.P) do {
     const V3 p = {a.means[3 * (size_t)idx], a.means[3 * (size_t)idx + 1], a.means[3 * (size_t)idx + 2]};
     const PreCam cam = {a.W, a.H, a.gx, a.gy, a.tile_cull, a.view, a.proj, a.tanx, a.tany, a.fx, a.fy};
     {                                               // in_frustum first (auxiliary.h:153): culled Gaussians read nothing else
@@ -129,11 +128,14 @@ __global__ __launch_bounds__(TH) void preprocess_fwd_kernel(const PreArgs a) {
     pre_emit(cam, pg, opac, tiles, bin);
     dkey = __float_as_uint(pg.depth);
   } while (0);
-  a.radii_int[idx] = radius_i;
-  if (a.radii_out) a.radii_out[idx] = radius_i;
-  a.tiles[idx] = tiles;
-  a.bin[idx] = bin;
-  a.depth_key[idx] = dkey;
+  if (idx < a.P) {
+    a.radii_int[idx] = radius_i;
+    if (a.radii_out) a.radii_out[idx] = radius_i;
+    a.tiles[idx] = tiles;
+    a.bin[idx] = bin;
+    a.depth_key[idx] = dkey;
+  }
+  slot_accumulate(a.slots, tiles, dkey);
 }
 
 int launch_preprocess(const RasterArgs& r, GeomState& g, int* radii) {
@@ -145,7 +147,7 @@ int launch_preprocess(const RasterArgs& r, GeomState& g, int* radii) {
   a.cov3D_pre = r.cov3D_precomp; a.colors_pre = r.colors_precomp; a.view = r.viewmatrix; a.proj = r.projmatrix;
   a.campos = r.cam_pos; a.mod = r.scale_modifier; a.tanx = r.tan_fovx; a.tany = r.tan_fovy;
   a.fy = r.H / (2.0f * r.tan_fovy); a.fx = r.W / (2.0f * r.tan_fovx);   // rasterizer_impl.cu:359-360
-  a.splat = g.splat; a.radii_int = g.radii; a.radii_out = radii; a.tiles = g.tiles_touched; a.bin = g.bin; a.tile_cull = r.tile_cull; a.counters = g.counters; a.cov3D = g.cov3D;
+  a.splat = g.splat; a.radii_int = g.radii; a.radii_out = radii; a.tiles = g.tiles_touched; a.bin = g.bin; a.tile_cull = r.tile_cull; a.counters = g.counters; a.slots = g.slots; a.cov3D = g.cov3D;
   a.clamped = g.clamped; a.depth_key = g.depth_key[0];
   if (r.P > 0) {
     if (a.shs && a.M == 16 && aligned16(a.shs)) {

@@ -9,6 +9,7 @@ the work is done by libgmesh_hip.so through its C ABI (include/gmesh_hip.h).  Ji
 provided as an alias of forward.
 """
 import ctypes as C
+import os
 from typing import NamedTuple
 
 import torch
@@ -49,22 +50,51 @@ def _stream(device):
     return torch.cuda.current_stream(device).cuda_stream
 
 
+# Instance emission policy (include/gmesh_hip.h): an argument of every call below (`emission_policy=`); None takes this
+# module-level default (GM_EMISSION_MODE overrides the built-in 2 for A/B runs).  The C library keeps no policy state.
+_default_policy = [min(3, max(0, int(os.environ.get("GM_EMISSION_MODE", "2"))))]
+
+
+def set_default_emission_policy(mode):
+    _default_policy[0] = min(3, max(0, int(mode)))
+
+
+def get_default_emission_policy():
+    return _default_policy[0]
+
+
+def _pol(p):
+    return _default_policy[0] if p is None else int(p)
+
+
 class RasterWorkspace:
     """Caller-owned scratch (geometry / image / binning byte buffers) that is reused across forward calls and
     grows geometrically, so a render loop performs no device allocation in steady state (the reference allocates
     and zero-fills all three buffers on every call, rasterize_points.py:118-121, 192-194).  Only valid while no
-    backward pass still needs the buffers: the autograd operator uses a fresh set whenever a gradient is required."""
+    backward pass still needs the buffers: the autograd operator uses a fresh set whenever a gradient is required.
+
+    ONE forward at a time may use a workspace: *_begin() marks it in flight and PendingForward.finish() releases it;
+    beginning another frame on a workspace whose previous frame is unfinished raises (the new frame would overwrite the
+    geometry the old one still has to render from).  A pipelined loop keeps one workspace per frame in flight."""
 
     def __init__(self, growth=1.25):
         self.growth = growth
         self._bufs = {}
         self._pinned = None
+        self._status = None
+        self.in_flight = None
+        self.capacity = 0            # instances the binning buffer holds (sync-free mode)
 
     def pinned_counter(self):
         """page-locked int32[1] receiving the instance count of an asynchronous forward"""
         if self._pinned is None:
             self._pinned = torch.zeros((1,), dtype=torch.int32).pin_memory()
         return self._pinned
+
+    def pinned_status(self):
+        if self._status is None:
+            self._status = torch.zeros((4,), dtype=torch.int32).pin_memory()
+        return self._status
 
     def get(self, name, nbytes, device):
         b = self._bufs.get(name)
@@ -73,16 +103,111 @@ class RasterWorkspace:
             self._bufs[name] = b
         return b
 
+    def acquire(self, owner):
+        if self.in_flight is not None:
+            raise _lib.GmeshError("RasterWorkspace: the previous frame begun on this workspace has not been finished; use one "
+                                  "workspace per frame in flight")
+        self.in_flight = owner
 
-def rasterize_forward(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
-                      projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug,
-                      force_M=None, workspace=None):
-    """RasterizeGaussiansCUDA of the reference bridge (rasterize_points.py:88-274): returns
-    (num_rendered, color[3,H,W], radii[P], geomBuffer, binningBuffer, imgBuffer)."""
+    def release(self, owner):
+        if self.in_flight is owner:
+            self.in_flight = None
+
+
+class PendingForward:
+    """Handle returned by rasterize_forward_begin() / forward_deformed_begin(): everything up to the instance count is
+    enqueued.  finish() waits for the count (one 4-byte pinned-memory read-back, normally long complete), sizes the
+    binning buffer and enqueues emission, tile sort and blend.  finish(sync_free=True) does not wait at all: the binning
+    buffer of the workspace is used at its current capacity and the kernels read the count on the device; check()
+    later tells whether the frame fitted (False: call finish() again - it then takes the exact path)."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+        self.status_event = None
+        self.result = None
+
+    def _geom(self, binning, num_rendered, capacity):
+        lib = _lib.lib()
+        a = self.args
+        _lib.check(lib.gm_forward_1_geom(self.policy, _ptr(self.geom), _ptr(binning), _ptr(self.img), a["P"], num_rendered, capacity,
+                                         _ptr(a["bg"]), a["W"], a["H"], _ptr(self.color), a["debug"], self.stream.cuda_stream))
+
+    def finish(self, sync_free=False):
+        lib = _lib.lib()
+        a = self.args
+        device = a["device"]
+        ws = self.workspace
+        with torch.cuda.device(device), torch.cuda.stream(self.stream):
+            if sync_free and ws is not None and ws.capacity > 0 and a["P"] > 0 and self.status_event is None:
+                binning = ws.get("binning", lib.gm_binning_bytes(ws.capacity), device)
+                self._geom(binning, -1, ws.capacity)
+                st = ws.pinned_status()
+                _lib.check(lib.gm_forward_status_async(_ptr(self.geom), a["P"], st.data_ptr(), self.stream.cuda_stream))
+                self.status_event = torch.cuda.Event()
+                self.status_event.record(self.stream)
+                self.binning = binning
+                self.result = (-1, self.color, self.radii, self.geom, binning, self.img)
+                return self.result
+            self.event.synchronize()
+            num_rendered = int(self.count_host[0])
+            if ws is not None:
+                ws.capacity = max(ws.capacity, int(num_rendered * ws.growth) + 1024)
+                binning = ws.get("binning", lib.gm_binning_bytes(ws.capacity), device)
+            else:
+                binning = torch.empty((lib.gm_binning_bytes(num_rendered),), dtype=torch.uint8, device=device)
+                if len(_PINNED_POOL) < 64:
+                    _PINNED_POOL.append(self.count_host)
+            self._geom(binning, num_rendered, 0)
+            self.status_event = None
+        if ws is not None:
+            ws.release(self)
+        self.result = (num_rendered, self.color, self.radii, self.geom, binning, self.img)
+        return self.result
+
+    def check(self):
+        """After finish(sync_free=True): wait for the frame's status and return (fitted, num_rendered).  When the instance
+        count exceeded the workspace's capacity the image is the background; finish() renders the frame again, exactly."""
+        if self.status_event is None:
+            return True, (self.result[0] if self.result else 0)
+        self.status_event.synchronize()
+        st = self.workspace.pinned_status()
+        nr, refused = int(st[0]), int(st[3])
+        if refused:
+            return False, nr
+        self.workspace.release(self)
+        return True, nr
+
+
+_PINNED_POOL = []          # page-locked int32[1] counters of workspace-less forwards (allocating one per call costs ~0.1 ms)
+
+
+def _scratch(workspace, P, W, H, device):
+    lib = _lib.lib()
+    if workspace is not None:
+        return (workspace.get("geom", lib.gm_geom_bytes(P), device), workspace.get("img", lib.gm_image_bytes(W, H), device),
+                workspace.pinned_counter())
+    count = _PINNED_POOL.pop() if _PINNED_POOL else torch.zeros((1,), dtype=torch.int32).pin_memory()
+    return (torch.empty((lib.gm_geom_bytes(P),), dtype=torch.uint8, device=device),
+            torch.empty((lib.gm_image_bytes(W, H),), dtype=torch.uint8, device=device), count)
+
+
+def _count_event(stream):
+    """an event the library re-records right behind the instance-count copy (needs a live hipEvent_t handle)"""
+    ev = torch.cuda.Event()
+    ev.record(stream)
+    return ev
+
+
+def rasterize_forward_begin(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                            projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered=False,
+                            debug=False, workspace=None, emission_policy=None, force_M=None):
+    """First half of a forward without host synchronisation (gm_forward_0_async); returns a PendingForward.
+    Typical loop: h_next = begin(frame i+1, workspace=ws[(i+1) % 2]); outputs = h_cur.finish()."""
     lib = _lib.lib()
     device = means3D.device
     if device.type != "cuda":
         raise _lib.GmeshError("gaussianmesh_amd rasterizer needs tensors on a HIP (cuda) device; there is no CPU path")
+    policy = _pol(emission_policy)
     means3D = _prep(means3D, device)
     P = 0 if means3D is None else means3D.shape[0]
     sh, colors, scales, rotations, cov3D_precomp = (_prep(t, device) for t in (sh, colors, scales, rotations, cov3D_precomp))
@@ -92,115 +217,49 @@ def rasterize_forward(bg, means3D, colors, opacity, scales, rotations, scale_mod
     M = 0
     if sh is not None:
         M = sh.shape[1] if sh.dim() == 3 else sh.numel() // (3 * max(P, 1))
-    if force_M is not None and sh is not None:
-        if M != force_M:
-            raise ValueError("NewGaussianRasterizer expects shs of shape [P,%d,3]" % force_M)
-    stream = _stream(device)
-    with torch.cuda.device(device):
-        color = torch.empty((3, H, W), dtype=torch.float32, device=device)
-        radii = torch.empty((P,), dtype=torch.int32, device=device)
-        if workspace is not None:
-            geom = workspace.get("geom", lib.gm_geom_bytes(P), device)
-            img = workspace.get("img", lib.gm_image_bytes(W, H), device)
-        else:
-            geom = torch.empty((lib.gm_geom_bytes(P),), dtype=torch.uint8, device=device)
-            img = torch.empty((lib.gm_image_bytes(W, H),), dtype=torch.uint8, device=device)
-        R = C.c_int(0)
-        _lib.check(lib.gm_forward_0(_ptr(geom), P, int(degree), M, _ptr(bg), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),
-                                    _ptr(opacity), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),
-                                    _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
-                                    int(bool(prefiltered)), _ptr(radii), int(bool(debug)), stream, C.byref(R)))
-        num_rendered = R.value
-        if workspace is not None:
-            binning = workspace.get("binning", lib.gm_binning_bytes(num_rendered), device)
-        else:
-            binning = torch.empty((lib.gm_binning_bytes(num_rendered),), dtype=torch.uint8, device=device)
-        _lib.check(lib.gm_forward_1(_ptr(geom), _ptr(binning), _ptr(img), P, int(degree), M, num_rendered, _ptr(bg), W, H,
-                                    _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales),
-                                    float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
-                                    _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
-                                    int(bool(prefiltered)), _ptr(color), _ptr(radii), int(bool(debug)), stream))
-    return num_rendered, color, radii, geom, binning, img
-
-
-class PendingForward:
-    """Handle returned by rasterize_forward_begin(): everything up to the instance count is enqueued; finish() waits for
-    the count (one 4-byte pinned-memory read-back), sizes the binning buffer and enqueues emission, tile sort and blend."""
-
-    def __init__(self, **kw):
-        self.__dict__.update(kw)
-
-    def finish(self):
-        lib = _lib.lib()
-        self.event.synchronize()
-        num_rendered = int(self.count_host[0])
-        a = self.args
-        device = a["device"]
-        with torch.cuda.device(device), torch.cuda.stream(self.stream):
-            if self.workspace is not None:
-                binning = self.workspace.get("binning", lib.gm_binning_bytes(num_rendered), device)
-            else:
-                binning = torch.empty((lib.gm_binning_bytes(num_rendered),), dtype=torch.uint8, device=device)
-            if a.get("geom_only"):
-                _lib.check(lib.gm_forward_1_geom(_ptr(self.geom), _ptr(binning), _ptr(self.img), a["P"], num_rendered, _ptr(a["bg"]),
-                                                 a["W"], a["H"], _ptr(self.color), a["debug"], self.stream.cuda_stream))
-                return num_rendered, self.color, self.radii, self.geom, binning, self.img
-            _lib.check(lib.gm_forward_1(_ptr(self.geom), _ptr(binning), _ptr(self.img), a["P"], a["D"], a["M"], num_rendered,
-                                        _ptr(a["bg"]), a["W"], a["H"], _ptr(a["means3D"]), _ptr(a["sh"]), _ptr(a["colors"]),
-                                        _ptr(a["opacity"]), _ptr(a["scales"]), a["scale_modifier"], _ptr(a["rotations"]),
-                                        _ptr(a["cov3D_precomp"]), _ptr(a["viewmatrix"]), _ptr(a["projmatrix"]), _ptr(a["campos"]),
-                                        a["tan_fovx"], a["tan_fovy"], a["prefiltered"], _ptr(self.color), _ptr(self.radii),
-                                        a["debug"], self.stream.cuda_stream))
-        return num_rendered, self.color, self.radii, self.geom, binning, self.img
-
-
-def rasterize_forward_begin(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
-                            projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered=False,
-                            debug=False, workspace=None):
-    """First half of rasterize_forward without the host synchronisation (gm_forward_0_async); returns a PendingForward.
-    Typical loop: h_next = begin(frame i+1); outputs = h_cur.finish()."""
-    lib = _lib.lib()
-    device = means3D.device
-    if device.type != "cuda":
-        raise _lib.GmeshError("gaussianmesh_amd rasterizer needs tensors on a HIP (cuda) device; there is no CPU path")
-    means3D = _prep(means3D, device)
-    P = 0 if means3D is None else means3D.shape[0]
-    sh, colors, scales, rotations, cov3D_precomp = (_prep(t, device) for t in (sh, colors, scales, rotations, cov3D_precomp))
-    opacity = _prep(opacity, device)
-    bg, viewmatrix, projmatrix, campos = (_prep(t, device) for t in (bg, viewmatrix, projmatrix, campos))
-    H, W = int(image_height), int(image_width)
-    M = sh.shape[1] if sh is not None else 0
+    if force_M is not None and sh is not None and M != force_M:
+        raise ValueError("NewGaussianRasterizer expects shs of shape [P,%d,3]" % force_M)
     stream = torch.cuda.current_stream(device)
-    with torch.cuda.device(device):
-        color = torch.empty((3, H, W), dtype=torch.float32, device=device)
-        radii = torch.empty((P,), dtype=torch.int32, device=device)
+    h = PendingForward(policy=policy, workspace=workspace, stream=stream)
+    if workspace is not None:
+        workspace.acquire(h)
+    try:
+        with torch.cuda.device(device):
+            color = torch.empty((3, H, W), dtype=torch.float32, device=device)
+            radii = torch.empty((P,), dtype=torch.int32, device=device)
+            geom, img, count_host = _scratch(workspace, P, W, H, device)
+            event = _count_event(stream)
+            _lib.check(lib.gm_forward_0_async(policy, _ptr(geom), P, int(degree), M, _ptr(bg), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),
+                                              _ptr(opacity), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),
+                                              _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
+                                              int(bool(prefiltered)), _ptr(radii), int(bool(debug)), stream.cuda_stream,
+                                              count_host.data_ptr(), event.cuda_event))
+    except Exception:
         if workspace is not None:
-            geom = workspace.get("geom", lib.gm_geom_bytes(P), device)
-            img = workspace.get("img", lib.gm_image_bytes(W, H), device)
-            count_host = workspace.pinned_counter()
-        else:
-            geom = torch.empty((lib.gm_geom_bytes(P),), dtype=torch.uint8, device=device)
-            img = torch.empty((lib.gm_image_bytes(W, H),), dtype=torch.uint8, device=device)
-            count_host = torch.zeros((1,), dtype=torch.int32).pin_memory()
-        _lib.check(lib.gm_forward_0_async(_ptr(geom), P, int(degree), M, _ptr(bg), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),
-                                          _ptr(opacity), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),
-                                          _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
-                                          int(bool(prefiltered)), _ptr(radii), int(bool(debug)), stream.cuda_stream,
-                                          count_host.data_ptr()))
-        event = torch.cuda.Event()
-        event.record(stream)
-    args = dict(device=device, P=P, D=int(degree), M=M, W=W, H=H, bg=bg, means3D=means3D, sh=sh, colors=colors, opacity=opacity,
-                scales=scales, scale_modifier=float(scale_modifier), rotations=rotations, cov3D_precomp=cov3D_precomp,
-                viewmatrix=viewmatrix, projmatrix=projmatrix, campos=campos, tan_fovx=float(tan_fovx), tan_fovy=float(tan_fovy),
-                prefiltered=int(bool(prefiltered)), debug=int(bool(debug)))
-    return PendingForward(args=args, geom=geom, img=img, color=color, radii=radii, count_host=count_host, event=event,
-                          stream=stream, workspace=workspace)
+            workspace.release(h)
+        raise
+    h.args = dict(device=device, P=P, W=W, H=H, bg=bg, debug=int(bool(debug)),
+                  keep=(means3D, sh, colors, opacity, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos))
+    h.geom, h.img, h.color, h.radii, h.count_host, h.event = geom, img, color, radii, count_host, event
+    return h
+
+
+def rasterize_forward(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                      projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug,
+                      force_M=None, workspace=None, emission_policy=None):
+    """RasterizeGaussiansCUDA of the reference bridge (rasterize_points.py:88-274): returns
+    (num_rendered, color[3,H,W], radii[P], geomBuffer, binningBuffer, imgBuffer).  One host synchronisation (the
+    instance count, reference rasterizer_impl.cu:411)."""
+    return rasterize_forward_begin(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
+                                   tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug,
+                                   workspace=workspace, emission_policy=emission_policy, force_M=force_M).finish()
 
 
 def forward_deformed_begin(bg, tri, weights, packed, cov, pos, shs, opacity, viewmatrix, projmatrix, tan_fovx, tan_fovy,
-                           image_height, image_width, degree, campos, debug=False, workspace=None, want_deformed=False):
+                           image_height, image_width, degree, campos, debug=False, workspace=None, want_deformed=False,
+                           emission_policy=None):
     """Edit-loop frame, first half (gm_forward_0_deformed_async): mesh-driven deformation + rotated-direction SH colour +
-    forward preprocess + depth sort + instance count in one enqueue, no host synchronisation.  `packed` is
+    forward preprocess + depth order + instance count in one enqueue, no host synchronisation.  `packed` is
     deform.pack_mesh_state() of the frame.  Returns a PendingForward; .finish() completes the frame
     (gm_forward_1_geom) and returns (num_rendered, color, radii, geom, binning, img).  With want_deformed the handle
     also carries .deformed = (pos' [N,3], cov6 [N,6], rgb [N,3])."""
@@ -208,64 +267,71 @@ def forward_deformed_begin(bg, tri, weights, packed, cov, pos, shs, opacity, vie
     device = pos.device
     if device.type != "cuda":
         raise _lib.GmeshError("gaussianmesh_amd rasterizer needs tensors on a HIP (cuda) device; there is no CPU path")
+    policy = _pol(emission_policy)
     P, M = pos.shape[0], shs.shape[1]
     tri = tri.detach().contiguous().to(torch.int32)
     weights, packed, cov, pos, shs, opacity = (_prep(t, device) for t in (weights, packed, cov, pos, shs, opacity))   # None when empty
     bg, viewmatrix, projmatrix, campos = (_prep(t, device) for t in (bg, viewmatrix, projmatrix, campos))
     H, W = int(image_height), int(image_width)
     stream = torch.cuda.current_stream(device)
-    with torch.cuda.device(device):
-        f = dict(dtype=torch.float32, device=device)
-        color = torch.empty((3, H, W), **f)
-        radii = torch.empty((P,), dtype=torch.int32, device=device)
-        deformed = (torch.empty((P, 3), **f), torch.empty((P, 6), **f), torch.empty((P, 3), **f)) if want_deformed else None
+    h = PendingForward(policy=policy, workspace=workspace, stream=stream)
+    if workspace is not None:
+        workspace.acquire(h)
+    try:
+        with torch.cuda.device(device):
+            f = dict(dtype=torch.float32, device=device)
+            color = torch.empty((3, H, W), **f)
+            radii = torch.empty((P,), dtype=torch.int32, device=device)
+            deformed = (torch.empty((P, 3), **f), torch.empty((P, 6), **f), torch.empty((P, 3), **f)) if want_deformed else None
+            geom, img, count_host = _scratch(workspace, P, W, H, device)
+            dp = [None, None, None] if deformed is None else [t.data_ptr() for t in deformed]
+            event = _count_event(stream)
+            _lib.check(lib.gm_forward_0_deformed_async(policy, _ptr(geom), P, int(degree), M, W, H, _ptr(tri), _ptr(weights), _ptr(packed),
+                                                       _ptr(cov), _ptr(pos), _ptr(shs), _ptr(opacity), _ptr(viewmatrix), _ptr(projmatrix),
+                                                       _ptr(campos), float(tan_fovx), float(tan_fovy), dp[0], dp[1], dp[2], _ptr(radii),
+                                                       int(bool(debug)), stream.cuda_stream, count_host.data_ptr(), event.cuda_event))
+    except Exception:
         if workspace is not None:
-            geom = workspace.get("geom", lib.gm_geom_bytes(P), device)
-            img = workspace.get("img", lib.gm_image_bytes(W, H), device)
-            count_host = workspace.pinned_counter()
-        else:
-            geom = torch.empty((lib.gm_geom_bytes(P),), dtype=torch.uint8, device=device)
-            img = torch.empty((lib.gm_image_bytes(W, H),), dtype=torch.uint8, device=device)
-            count_host = torch.zeros((1,), dtype=torch.int32).pin_memory()
-        dp = [None, None, None] if deformed is None else [t.data_ptr() for t in deformed]
-        _lib.check(lib.gm_forward_0_deformed_async(_ptr(geom), P, int(degree), M, W, H, _ptr(tri), _ptr(weights), _ptr(packed), _ptr(cov),
-                                                   _ptr(pos), _ptr(shs), _ptr(opacity), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos),
-                                                   float(tan_fovx), float(tan_fovy), dp[0], dp[1], dp[2], _ptr(radii), int(bool(debug)),
-                                                   stream.cuda_stream, count_host.data_ptr()))
-        event = torch.cuda.Event()
-        event.record(stream)
-    args = dict(device=device, P=P, W=W, H=H, bg=bg, debug=int(bool(debug)), geom_only=True,
-                keep=(tri, weights, packed, cov, pos, shs, opacity, viewmatrix, projmatrix, campos))
-    return PendingForward(args=args, geom=geom, img=img, color=color, radii=radii, count_host=count_host, event=event,
-                          stream=stream, workspace=workspace, deformed=deformed)
+            workspace.release(h)
+        raise
+    h.args = dict(device=device, P=P, W=W, H=H, bg=bg, debug=int(bool(debug)),
+                  keep=(tri, weights, packed, cov, pos, shs, opacity, viewmatrix, projmatrix, campos))
+    h.geom, h.img, h.color, h.radii, h.count_host, h.event, h.deformed = geom, img, color, radii, count_host, event, deformed
+    return h
 
 
 def rasterize_backward(bg, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
-                       tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos, geom, num_rendered, binning, img, debug):
+                       tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos, geom, num_rendered, binning, img, debug,
+                       emission_policy=None):
     """RasterizeGaussiansBackwardCUDA of the reference bridge (rasterize_points.py:276-401): returns
-    (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)."""
+    (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations).
+    emission_policy: the policy the forward that filled geom / binning / img ran under."""
     lib = _lib.lib()
     device = means3D.device
-    means3D = _prep(means3D, device)
     P = means3D.shape[0]
+    f = dict(dtype=torch.float32, device=device)
+    M_in = sh.shape[1] if (sh is not None and sh.numel() > 0 and sh.dim() == 3) else 0
+    if P == 0:                                  # empty cloud: zero-size gradients, nothing to launch
+        z = lambda *shape: torch.zeros(shape, **f)
+        return z(0, 3), z(0, 3), z(0, 1), z(0, 3), z(0, 6), z(0, M_in, 3), z(0, 3), z(0, 4)
+    means3D = _prep(means3D, device)
     sh, colors, scales, rotations, cov3D_precomp = (_prep(t, device) for t in (sh, colors, scales, rotations, cov3D_precomp))
     bg, viewmatrix, projmatrix, campos = (_prep(t, device) for t in (bg, viewmatrix, projmatrix, campos))
     dpix = _prep(dL_dout_color, device)
     H, W = dpix.shape[1], dpix.shape[2]
     M = sh.shape[1] if sh is not None else 0
-    f = dict(dtype=torch.float32, device=device)
     with torch.cuda.device(device):
         dmeans2D = torch.empty((P, 3), **f); dconic = torch.empty((P, 2, 2), **f); dopac = torch.empty((P, 1), **f)
         dcolors = torch.empty((P, 3), **f); dmeans3D = torch.empty((P, 3), **f); dcov3D = torch.empty((P, 6), **f)
         dsh = torch.empty((P, M, 3), **f) if sh is not None else None
         dscales = torch.empty((P, 3), **f) if scales is not None else None
         drots = torch.empty((P, 4), **f) if scales is not None else None
-        _lib.check(lib.gm_backward(P, int(degree), M, int(num_rendered), _ptr(bg), W, H, _ptr(means3D), _ptr(sh), _ptr(colors),
-                                   _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
-                                   _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), _ptr(radii), _ptr(geom),
-                                   _ptr(binning), _ptr(img), _ptr(dpix), _ptr(dmeans2D), _ptr(dconic), _ptr(dopac),
-                                   _ptr(dcolors), _ptr(dmeans3D), _ptr(dcov3D), _ptr(dsh), _ptr(dscales), _ptr(drots),
-                                   int(bool(debug)), _stream(device)))
+        _lib.check(lib.gm_backward_p(_pol(emission_policy), P, int(degree), M, int(num_rendered), _ptr(bg), W, H, _ptr(means3D), _ptr(sh),
+                                     _ptr(colors), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
+                                     _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), _ptr(radii), _ptr(geom),
+                                     _ptr(binning), _ptr(img), _ptr(dpix), _ptr(dmeans2D), _ptr(dconic), _ptr(dopac),
+                                     _ptr(dcolors), _ptr(dmeans3D), _ptr(dcov3D), _ptr(dsh), _ptr(dscales), _ptr(drots),
+                                     int(bool(debug)), _stream(device)))
     return dmeans2D, dcolors, dopac, dmeans3D, dcov3D, dsh, dscales, drots
 
 
@@ -286,9 +352,12 @@ _WORKSPACES = {}
 
 
 def _shared_workspace(device):
-    ws = _WORKSPACES.get(device)
+    """inference scratch of the autograd operator, one per (device, stream, thread)"""
+    import threading
+    key = (device, torch.cuda.current_stream(device).cuda_stream, threading.get_ident())
+    ws = _WORKSPACES.get(key)
     if ws is None:
-        ws = _WORKSPACES[device] = RasterWorkspace()
+        ws = _WORKSPACES[key] = RasterWorkspace()
     return ws
 
 
@@ -297,13 +366,17 @@ class _RasterizeGaussians(torch.autograd.Function):
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
                 force_M):
         rs = raster_settings
+        if means3D.device.type != "cuda":
+            raise _lib.GmeshError("gaussianmesh_amd rasterizer needs tensors on a HIP (cuda) device; there is no CPU path")
         ws = None if any(ctx.needs_input_grad) else _shared_workspace(means3D.device)   # inference: reuse scratch
+        policy = get_default_emission_policy()
         num_rendered, color, radii, geom, binning, img = rasterize_forward(
             rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
             rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos,
-            rs.prefiltered, rs.debug, force_M, ws)
+            rs.prefiltered, rs.debug, force_M, ws, policy)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
+        ctx.emission_policy = policy
         ctx.opacity_shape = opacities.shape
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
         ctx.mark_non_differentiable(radii)
@@ -316,7 +389,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         g2d, gcol, gop, g3d, gcov, gsh, gsc, grot = rasterize_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
             rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos, geom, ctx.num_rendered,
-            binning, img, rs.debug)
+            binning, img, rs.debug, ctx.emission_policy)
         has = lambda t: t is not None and t.numel() > 0
         return (g3d, g2d, gsh if has(sh) else None, gcol if has(colors_precomp) else None, gop.reshape(ctx.opacity_shape),
                 gsc if has(scales) else None, grot if has(rotations) else None, gcov if has(cov3Ds_precomp) else None,

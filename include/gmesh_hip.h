@@ -43,14 +43,16 @@ extern "C" {
 #define GM_ERR_BUFFER 3        /* a caller-provided buffer is too small */
 
 /* ABI version of this header; bumped on any signature change. */
-#define GM_ABI_VERSION 1
+#define GM_ABI_VERSION 2
 int gm_abi_version(void);
 const char* gm_last_error(void);
 
-/* Instance emission policy (process-wide; set it before gm_forward_0 and keep it until the matching gm_forward_1 /
- * gm_backward / gm_binning_field: a forward_1 under another policy than its forward_0 emits nothing and renders the
- * background).  out_color, radii and all gradients are the same under every policy; num_rendered and the internal
- * lists differ.
+/* Instance emission policy: an ARGUMENT of the extended entry points (gm_forward_0_async, gm_forward_0_deformed_async,
+ * gm_forward_1_geom, gm_backward_p, gm_binning_field); the entry points with the reference's signatures (gm_forward_0,
+ * gm_forward_1, gm_backward) use GM_POLICY_DEFAULT.  The library keeps no policy state: calls on distinct buffers are
+ * independent and thread-safe.  The halves of one pass must be given the same policy; it is latched in the geometry
+ * buffer by the first half, and a second half under another policy emits nothing and renders the background.
+ * out_color, radii and all gradients are the same under every policy; num_rendered and the internal lists differ.
  *   0: emit every tile of the bounding rectangle exactly as the reference does (RAST/rasterizer_impl.cu:98-109);
  *      num_rendered, point_list and ranges are then identical to the reference's.
  *   1: a (Gaussian, tile) instance is emitted only if the Gaussian can reach alpha >= 1/255 somewhere in the 16x16
@@ -58,10 +60,9 @@ const char* gm_last_error(void);
  *      (RAST/forward.cu:344).
  *   2 (default), 3: the same test, but instances are (Gaussian, PARENT tile) pairs for parents of 2x2 / 4x4 tiles; the
  *      key of an instance carries the mask of the parent's child tiles the Gaussian reaches (bits 16+), and the 16x16
- *      blend workgroups walk their parent's list.  The instance stream (and the sort over it) shrinks ~2x / ~3x.
- * The environment variable GM_EMISSION_MODE (0..3) overrides the default when the library is loaded. */
-void gm_set_tile_culling(int mode);
-int gm_get_tile_culling(void);
+ *      blend workgroups walk their parent's list.  The instance stream (and the sort over it) shrinks ~2x / ~3x. */
+#define GM_POLICY_REFERENCE 0
+#define GM_POLICY_DEFAULT 2
 
 /* Scratch sizes.  Replace CudaRasterizer::required<GeometryState|ImageState|BinningState>(n)
  * (RAST/rasterizer_impl.h:67-73; python side rasterize_points.py:63-86). */
@@ -80,15 +81,18 @@ int gm_forward_0(void* geom_buffer, int P, int D, int M, const float* background
                  const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
                  float tan_fovy, int prefiltered, int* radii, int debug, void* stream, int* num_rendered);
 
-/* gm_forward_0 without its host synchronisation: everything is enqueued on `stream`, including a copy of the instance
- * count into *num_rendered_host (use page-locked host memory).  The caller records an event, keeps feeding the GPU (e.g.
- * the next frame's gm_forward_0_async on another stream) and calls gm_forward_1 once the event has completed and
- * *num_rendered_host is valid.  This is how a render loop hides the one host round trip of the reference design. */
-int gm_forward_0_async(void* geom_buffer, int P, int D, int M, const float* background, int width, int height,
+/* gm_forward_0 without its host synchronisation, with the emission policy as an argument: everything is enqueued on
+ * `stream`, including a copy of the instance count into *num_rendered_host (page-locked host memory; may be NULL), issued as
+ * soon as the count is known (before the depth ordering finishes).  count_event (a hipEvent_t, may be NULL) is recorded
+ * right behind that copy: the caller keeps feeding the GPU (e.g. the next frame's gm_forward_0_async on another stream)
+ * and completes the frame with gm_forward_1_geom once the event has fired.  This hides the one host round trip of the
+ * reference design; gm_forward_1_geom's sync-free mode removes it. */
+int gm_forward_0_async(int emission_policy, void* geom_buffer, int P, int D, int M, const float* background, int width, int height,
                        const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
                        const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
                        const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
-                       float tan_fovy, int prefiltered, int* radii, int debug, void* stream, int* num_rendered_host);
+                       float tan_fovy, int prefiltered, int* radii, int debug, void* stream, int* num_rendered_host,
+                       void* count_event);
 
 /* Replaces CudaRasterizer::Rasterizer::forward_1 (RAST/rasterizer.h:53-76, rasterizer_impl.cu:416-511):
  * instance emission, (tile, depth) ordering, tile ranges, front-to-back alpha blend.
@@ -114,6 +118,15 @@ int gm_backward(int P, int D, int M, int R, const float* background, int width, 
                 float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
                 float* dL_dscale, float* dL_drot, int debug, void* stream);
 
+/* gm_backward for lists built under an explicit emission policy (the one given to the forward halves). */
+int gm_backward_p(int emission_policy, int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                  const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                  const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                  const float* campos, float tan_fovx, float tan_fovy, const int* radii, void* geom_buffer,
+                  void* binning_buffer, void* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
+                  float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                  float* dL_dscale, float* dL_drot, int debug, void* stream);
+
 /* Replaces CudaRasterizer::Rasterizer::markVisible (RAST/rasterizer.h:24-29, rasterizer_impl.cu:141-153).
  * present: uint8 [P], 1 if view-space z > 0.2. */
 int gm_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
@@ -124,12 +137,13 @@ int gm_mark_visible(int P, const float* means3D, const float* viewmatrix, const 
  * Each returns a device pointer inside the given buffer, or NULL for an unknown name.
  *   geom:    "splat" float[P][12] = {x,y,conic.x,conic.y | conic.z,opacity,r,g | b,depth,0,0},
  *            "radii" int32[P] (internal copy), "tiles_touched" uint32[P], "cov3D" float[P][6],
- *            "clamped" uint8[P] (bit ch set = channel ch clamped), "order" uint32[P] (Gaussian ids by depth)
+ *            "clamped" uint8[P] (bit ch set = channel ch clamped), "order" uint32[V] (ids of the V visible Gaussians
+ *            in (depth, id) order; V = "bucket_start"[2048]), "bucket_start" uint32[2049]
  *   image:   "final_T" float[H*W], "n_contrib" uint32[H*W], "ranges" uint32[T][2]
  *   binning: "point_list" uint32[R], "tile_keys" uint32[R] (sorted tile id per instance) */
 void* gm_geom_field(void* geom_buffer, int P, const char* name);
 void* gm_image_field(void* image_buffer, int W, int H, const char* name);
-void* gm_binning_field(void* binning_buffer, int64_t R, int W, int H, const char* name);
+void* gm_binning_field(void* binning_buffer, int64_t R, int W, int H, int emission_policy, const char* name);
 
 /* Replaces SimpleKNN::knn (scene/simple_knn/cuda_headers/simple_knn.h:18, simple_knn.cu:185-221):
  * meanDists[i] = mean of the 3 smallest squared distances from point i to the other points.
@@ -180,14 +194,26 @@ int gm_deform_shade_packed(int N, int deg, int M, const int* tri, const float* w
  * Gaussian go straight into its projection, conic, radius and instance count without a round trip through HBM.
  * Equivalent, bit for bit, to gm_deform_shade_packed followed by gm_forward_0_async(colors_precomp = rgb_out,
  * cov3D_precomp = cov6_out, means3D = pos_out, scale_modifier 1).  pos_out / cov6_out / rgb_out: all three or all NULL.
- * Complete the frame with gm_forward_1_geom (gm_forward_1 without the per-Gaussian input pointers it does not read). */
-int gm_forward_0_deformed_async(void* geom_buffer, int P, int deg, int M, int width, int height, const int* tri, const float* w,
-                                const float* packed, const float* cov, const float* pos, const float* shs, const float* opacities,
-                                const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
-                                float tan_fovy, float* pos_out, float* cov6_out, float* rgb_out, int* radii, int debug,
-                                void* stream, int* num_rendered_host);
-int gm_forward_1_geom(void* geom_buffer, void* binning_buffer, void* image_buffer, int P, int num_rendered, const float* background,
-                      int width, int height, float* out_color, int debug, void* stream);
+ * Complete the frame with gm_forward_1_geom. */
+int gm_forward_0_deformed_async(int emission_policy, void* geom_buffer, int P, int deg, int M, int width, int height, const int* tri,
+                                const float* w, const float* packed, const float* cov, const float* pos, const float* shs,
+                                const float* opacities, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                                float tan_fovx, float tan_fovy, float* pos_out, float* cov6_out, float* rgb_out, int* radii, int debug,
+                                void* stream, int* num_rendered_host, void* count_event);
+
+/* Second half of a forward without the per-Gaussian input pointers gm_forward_1 does not read: instance emission, tile
+ * sort, tile ranges, blend.
+ *   num_rendered >= 0: the instance count the first half reported; binning_buffer holds gm_binning_bytes(num_rendered);
+ *                      binning_capacity is ignored.
+ *   num_rendered <  0: SYNC-FREE mode - the host never learns the count.  binning_buffer holds
+ *                      gm_binning_bytes(binning_capacity); the kernels read the count on the device.  If it exceeds the
+ *                      capacity nothing is emitted, the image is the background and the overflow is reported by
+ *                      gm_forward_status_async (grow the buffer and render the frame again).
+ * gm_forward_status_async copies {num_rendered, -, policy, refused} (4 x int32) of the forward that last used geom_buffer
+ * into status_host (page-locked), stream-ordered; refused != 0: nothing was emitted (capacity overflow or policy mismatch). */
+int gm_forward_1_geom(int emission_policy, void* geom_buffer, void* binning_buffer, void* image_buffer, int P, int num_rendered,
+                      int64_t binning_capacity, const float* background, int width, int height, float* out_color, int debug, void* stream);
+int gm_forward_status_async(void* geom_buffer, int P, int* status_host, void* stream);
 
 /* Covariance -> (scale, rotation): replaces the per-frame eigh + host-side det sign + sqrt + matrix->quaternion of
  * SceneVisualTool.render_gaussian (edittool/__init__.py:204-207, 23-38).  cov float [N,3,3] (symmetric),

@@ -30,7 +30,7 @@ DEFAULT_MODE = 2
 
 def set_policy(mode):
     """emission policy of the following forwards (0 = the reference's lists ... 3), see gm_common.h"""
-    _lib.lib().gm_set_tile_culling(int(mode))
+    R.set_default_emission_policy(int(mode))
 
 
 def _view(buf, ptr, count, dtype):
@@ -45,7 +45,6 @@ def forward_state(scene, cam, bg, D=3, use_precomp_cov=False, use_precomp_color=
     tile_cull=True: the product default (instances the Gaussian cannot reach are not emitted)."""
     lib = _lib.lib()
     mode = int(tile_cull)
-    lib.gm_set_tile_culling(mode)
     P = scene["means"].shape[0]
     W, H = cam["W"], cam["H"]
     sh = None if use_precomp_color else T(scene["shs"])
@@ -55,7 +54,7 @@ def forward_state(scene, cam, bg, D=3, use_precomp_cov=False, use_precomp_color=
     cov = T(scene["cov3D_precomp"]) if use_precomp_cov else None
     nr, color, radii, geom, binning, img = R.rasterize_forward(
         T(bg), T(scene["means"]), col, T(scene["opac"]), sc, rot, mod, cov, T(cam["view"]), T(cam["proj"]), cam["tanx"],
-        cam["tany"], H, W, sh, D, T(cam["campos"]), False, debug)
+        cam["tany"], H, W, sh, D, T(cam["campos"]), False, debug, emission_policy=mode)
     torch.cuda.synchronize()
     sh_ = max(mode - 1, 0)
     gx, gy = (W + 15) // 16, (H + 15) // 16
@@ -67,13 +66,14 @@ def forward_state(scene, cam, bg, D=3, use_precomp_cov=False, use_precomp_color=
         out["tiles"] = _view(geom, gp("tiles_touched"), P, torch.int32).astype(np.uint32)
         out["cov3D"] = _view(geom, gp("cov3D"), P * 6, torch.float32).reshape(P, 6)
         out["clamped"] = _view(geom, gp("clamped"), P, torch.uint8)
-        out["order"] = _view(geom, gp("order"), P, torch.int32).astype(np.uint32)
+        V = int(_view(geom, gp("bucket_start"), 2049, torch.int32)[2048])
+        out["order"] = _view(geom, gp("order"), P, torch.int32).astype(np.uint32)[:V]      # visible Gaussians in (depth, id) order
     ip = lambda n: lib.gm_image_field(img.data_ptr(), W, H, n.encode())
     out["final_T"] = _view(img, ip("final_T"), W * H, torch.float32)
     out["n_contrib"] = _view(img, ip("n_contrib"), W * H, torch.int32).astype(np.uint32)
     out["ranges"] = _view(img, ip("ranges"), tiles * 2, torch.int32).astype(np.uint32).reshape(tiles, 2)
     if nr > 0:
-        bp = lambda n: lib.gm_binning_field(binning.data_ptr(), nr, W, H, n.encode())
+        bp = lambda n: lib.gm_binning_field(binning.data_ptr(), nr, W, H, mode, n.encode())
         out["point_list"] = _view(binning, bp("point_list"), nr, torch.int32).astype(np.uint32)
         out["tile_keys"] = _view(binning, bp("tile_keys"), nr, torch.int32).astype(np.uint32)
     else:
@@ -81,5 +81,4 @@ def forward_state(scene, cam, bg, D=3, use_precomp_cov=False, use_precomp_color=
         out["tile_keys"] = np.zeros(0, np.uint32)
     out["child_mask"] = out["tile_keys"] >> 16
     out["tile_keys"] = out["tile_keys"] & 0xFFFF
-    lib.gm_set_tile_culling(DEFAULT_MODE)
     return out

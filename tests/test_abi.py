@@ -15,16 +15,16 @@ def test_library_exports_every_header_symbol():
     for n in names:
         assert hasattr(l, n), n
     assert set(names) == set(_lib.SIGNATURES), "python signatures out of sync with include/gmesh_hip.h"
-    assert l.gm_abi_version() == 1
+    assert l.gm_abi_version() == 2
 
 
 def test_scratch_sizes_scale_linearly():
     from gaussianmesh_amd import _lib
     l = _lib.lib()
     g1, g2 = l.gm_geom_bytes(1_000_000), l.gm_geom_bytes(2_000_000)
-    assert 130e6 < g1 < 170e6 and abs(g2 - 2 * g1) < 2e6       # ~161 B per Gaussian (incl. 48 B backward accumulators); sort histograms are tiered
+    assert 130e6 < g1 < 175e6 and abs(g2 - 2 * g1) < 2e6       # ~167 B per Gaussian (incl. 48 B backward accumulators and the bucket histograms)
     b1 = l.gm_binning_bytes(8_000_000)
-    assert 128e6 <= b1 < 140e6                                   # 16 B per instance + histograms
+    assert 128e6 <= b1 < 150e6                                   # 16 B per instance + 2 B of histogram rows
     i1 = l.gm_image_bytes(1920, 1080)
     assert 16.5e6 < i1 < 17e6                                    # 8 B per pixel + tiles
     assert l.gm_geom_bytes(0) > 0 and l.gm_binning_bytes(0) > 0
@@ -44,6 +44,9 @@ def test_argument_validation_happens_before_any_gpu_work():
     assert rc == 1 and b"SH degree" in l.gm_last_error()
     rc = l.gm_forward_0(one, -1, 0, 0, one, 64, 64, one, None, one, one, None, 1.0, None, one, one, one, one, 0.5, 0.5, 0, None, 0, None, C.byref(R))
     assert rc == 1
+    rc = l.gm_forward_0_async(7, one, 10, 3, 16, one, 64, 64, one, one, None, one, one, 1.0, one, None, one, one, one, 0.5, 0.5, 0, None, 0, None, None, None)
+    assert rc == 1 and b"emission policy" in l.gm_last_error()
+    assert l.gm_forward_1_geom(2, one, one, one, 10, -1, -5, one, 64, 64, one, 0, None) == 1          # negative capacity
     assert l.gm_knn(5, None, None, None, 0, None) == 1
     assert l.gm_sh_colors(5, 4, 16, one, one, None, one, one, None) == 1
 

@@ -18,10 +18,10 @@ GRAD_RTOL = 1e-3
 
 @pytest.fixture(autouse=True)
 def _default_emission_policy():
-    from gaussianmesh_amd import _lib
-    _lib.lib().gm_set_tile_culling(2)
+    from gaussianmesh_amd import rasterizer
+    rasterizer.set_default_emission_policy(2)
     yield
-    _lib.lib().gm_set_tile_culling(2)
+    rasterizer.set_default_emission_policy(2)
 
 MODES = [(False, False), (True, False), (False, True), (True, True)]
 
@@ -126,8 +126,8 @@ def _rel(a, b):
 
 @pytest.mark.parametrize("mode", [0, 1, 3])
 def test_backward_under_every_emission_policy(oracle, mode):
-    from gaussianmesh_amd import _lib
-    _lib.lib().gm_set_tile_culling(mode)
+    from gaussianmesh_amd import rasterizer
+    rasterizer.set_default_emission_policy(mode)
     test_backward_medium(oracle)
 
 
@@ -232,15 +232,15 @@ def test_tile_culling_is_exact(oracle, case, mode):
 
 
 def test_tile_culling_gradients_match_reference_policy(oracle):
-    from gaussianmesh_amd import _lib
+    from gaussianmesh_amd import rasterizer
     D = 3
     sc, cam = small_scene(P=500, W=70, H=50, seed=7, D=D)
     bg = np.array([0.3, 0.2, 0.7], np.float32)
     dpix = np.random.default_rng(1).normal(size=(3, cam["H"], cam["W"])).astype(np.float32)
-    _lib.lib().gm_set_tile_culling(0)
+    rasterizer.set_default_emission_policy(0)
     c0, r0, g0 = _grads_gpu(sc, cam, bg, dpix, D, False, False)
     for mode in (1, 2, 3):
-        _lib.lib().gm_set_tile_culling(mode)
+        rasterizer.set_default_emission_policy(mode)
         c1, r1, g1 = _grads_gpu(sc, cam, bg, dpix, D, False, False)
         assert np.array_equal(c0, c1) and np.array_equal(r0, r1)
         for k in g0:
@@ -507,8 +507,9 @@ def test_fused_deform_forward_equals_unfused_chain(oracle, N):
 
 
 def test_policy_change_between_forward_halves_is_refused_safely():
-    """gm_forward_1 under another emission policy than its gm_forward_0: the counted size belongs to the old policy, so
-    emission is refused on the device, every list stays empty and the image is the background (no overrun, no hang)."""
+    """gm_forward_1_geom under another emission policy than its gm_forward_0_async: the counted size belongs to the old
+    policy, so emission is refused on the device, every list stays empty and the image is the background (no overrun, no
+    hang); the status words report the refusal."""
     from gpu_utils import T
     from gaussianmesh_amd import rasterizer as Rz, scenes, _lib
     sc = scenes.make_cloud(5000, seed=2, scale_lo=0.01, scale_hi=0.2)
@@ -517,16 +518,53 @@ def test_policy_change_between_forward_halves_is_refused_safely():
     bg = T(np.array([0.25, 0.5, 0.75], np.float32))
     args = (bg, T(sc["means"]), None, T(sc["opac"]), T(sc["scales"]), T(sc["rots"]), 1.0, None, ct["view"], ct["proj"], cam["tanx"],
             cam["tany"], 120, 200, T(sc["shs"]), 3, ct["campos"])
-    lib = _lib.lib()
-    lib.gm_set_tile_culling(2)
-    h = Rz.rasterize_forward_begin(*args)
-    lib.gm_set_tile_culling(0)
-    nr, color, radii, *_ = h.finish()
+    h = Rz.rasterize_forward_begin(*args, emission_policy=2)
+    h.policy = 0                                    # the second half is issued under the reference policy
+    nr, color, radii, geom, *_ = h.finish()
+    st = torch.zeros(4, dtype=torch.int32).pin_memory()
+    _lib.check(_lib.lib().gm_forward_status_async(geom.data_ptr(), 5000, st.data_ptr(), torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     assert nr > 0 and torch.equal(color, bg.view(3, 1, 1).expand(3, 120, 200))
-    lib.gm_set_tile_culling(2)
-    nr2, color2, *_ = Rz.rasterize_forward(*args, False, False)          # and the library is usable again afterwards
+    assert int(st[0]) == nr and int(st[2]) == 2 and int(st[3]) == 1
+    nr2, color2, *_ = Rz.rasterize_forward(*args, False, False, emission_policy=2)      # and the library is usable again afterwards
     assert nr2 == nr and not torch.equal(color2, color)
+
+
+def test_sync_free_forward_matches_exact_and_reports_overflow():
+    """finish(sync_free=True): the instance count never reaches the host; the image equals the exact path's bit for bit
+    when the workspace's binning capacity suffices, and an overflow renders the background, is reported by check() and is
+    repaired by finish()."""
+    from gpu_utils import T
+    from gaussianmesh_amd import rasterizer as Rz, scenes
+    sc = scenes.make_cloud(20000, seed=6, scale_lo=0.01, scale_hi=0.15)
+    cams = [scenes.orbit_camera(k, 8, 320, 200, radius=7.5) for k in range(3)]
+    bg = T(np.array([0.1, 0.2, 0.3], np.float32))
+    def args(k):
+        ct = {n: T(cams[k][n]) for n in ("view", "proj", "campos")}
+        return (bg, T(sc["means"]), None, T(sc["opac"]), T(sc["scales"]), T(sc["rots"]), 1.0, None, ct["view"], ct["proj"], cams[k]["tanx"],
+                cams[k]["tany"], 200, 320, T(sc["shs"]), 3, ct["campos"])
+    ref = [Rz.rasterize_forward(*args(k), False, False) for k in range(3)]
+    ws = Rz.RasterWorkspace()
+    h = Rz.rasterize_forward_begin(*args(0), workspace=ws)
+    out = h.finish(sync_free=True)                 # no capacity known yet: takes the exact path and sizes the buffer
+    assert out[0] == ref[0][0] and torch.equal(out[1], ref[0][1])
+    for k in (1, 2):
+        h = Rz.rasterize_forward_begin(*args(k), workspace=ws)
+        nr, color, radii, *_ = h.finish(sync_free=True)
+        assert nr == -1
+        ok, count = h.check()
+        assert ok and count == ref[k][0] and torch.equal(color, ref[k][1]) and torch.equal(radii, ref[k][2])
+    ws.capacity = 1000                             # far too small for the next frame
+    h = Rz.rasterize_forward_begin(*args(0), workspace=ws)
+    nr, color, *_ = h.finish(sync_free=True)
+    ok, count = h.check()
+    assert not ok and count == ref[0][0] and torch.equal(color, bg.view(3, 1, 1).expand(3, 200, 320))
+    nr, color, *_ = h.finish()                     # exact path on the same frame
+    assert nr == ref[0][0] and torch.equal(color, ref[0][1])
+    with pytest.raises(Exception):                 # a workspace serves one frame at a time
+        h1 = Rz.rasterize_forward_begin(*args(1), workspace=ws)
+        Rz.rasterize_forward_begin(*args(2), workspace=ws)
+    h1.finish()
 
 
 def test_fused_frame_edge_cases():
@@ -581,3 +619,54 @@ def test_emission_policies_agree_on_random_scenes(seed):
         cu = forward_state(sc, cam, bg, D=3, tile_cull=mode)
         assert np.array_equal(cu["radii"], ref["radii"]) and np.array_equal(cu["final_T"], ref["final_T"]), mode
         assert np.array_equal(cu["color"], ref["color"]), mode
+
+
+@pytest.mark.parametrize("case", ["equal_depths", "depth_pileup", "many_tiles", "tiny"])
+def test_ordering_paths(oracle, case):
+    """gm_bucket.hip's special paths against the oracle's (tile, depth, id) stable sort, lists bit-exact:
+    equal_depths: every Gaussian at the same view depth (one bucket, no low bits: order by id, bucket larger than the LDS);
+    depth_pileup: 12k Gaussians inside a few ulps of one depth plus a sparse spread (one overfull bucket WITH low bits: the
+                  global-memory slow path of bucket_sort_kernel, several passes);
+    many_tiles:   more than 2048 list tiles (two 8-bit tile passes + tile_ranges_kernel), reference and default policy;
+    tiny:         3 Gaussians."""
+    from gpu_utils import forward_state
+    from gaussianmesh_amd import scenes
+    rng = np.random.default_rng(5)
+    W, H = 320, 200
+    if case in ("equal_depths", "depth_pileup"):
+        P = 14000
+        sc = scenes.make_cloud(P, seed=3, scale_lo=0.004, scale_hi=0.03)
+        # camera on the -z axis looking along +z: view z = world z + 6 exactly
+        cam = scenes.look_at_camera((0.0, 0.0, -6.0), (0.0, 0.0, 0.0), W, H)
+        assert cam["view"].reshape(-1)[2] == 0 and cam["view"].reshape(-1)[6] == 0
+        sc["means"][:, 2] = 0.5
+        if case == "depth_pileup":
+            sc["means"][:12000, 2] = (0.5 + rng.integers(0, 24, 12000) * 4.76837158203125e-07).astype(np.float32)
+            sc["means"][12000:, 2] = rng.uniform(-4.0, 60.0, P - 12000).astype(np.float32)
+        modes = (0, 2)
+    elif case == "many_tiles":
+        W, H = 1600, 1000                                       # 100 x 63 = 6300 16-px tiles (policy 0 / 1), 1600 parents (policy 2)
+        sc = scenes.make_cloud(3000, seed=8, scale_lo=0.01, scale_hi=0.3)
+        cam = scenes.orbit_camera(2, 9, W, H, radius=7.0)
+        modes = (0, 1, 2)
+    else:
+        sc = scenes.make_cloud(3, seed=1, scale_lo=0.05, scale_hi=0.3)
+        cam = scenes.orbit_camera(0, 4, W, H, radius=5.0)
+        modes = (0, 2)
+    bg = np.array([0.2, 0.3, 0.4], np.float32)
+    fw = oracle.forward_full(sc, cam, bg, D=3)
+    ex = None
+    for mode in modes:
+        st = forward_state(sc, cam, bg, D=3, tile_cull=mode)
+        assert np.array_equal(st["radii"], fw["geo"]["radii"])
+        vis = np.nonzero(fw["geo"]["radii"] > 0)[0]
+        dbits = fw["geo"]["depths"].view(np.uint32)[vis].astype(np.int64)
+        want = vis[np.lexsort((vis, dbits))]                   # (depth bits, id) order of the visible Gaussians
+        assert np.array_equal(st["order"], want.astype(np.uint32)), case
+        if mode == 0:
+            assert st["R"] == fw["bins"]["R"] and np.array_equal(st["point_list"], fw["bins"]["point_list"])
+            assert np.array_equal(st["ranges"], fw["bins"]["ranges"])
+            ex = st
+        else:
+            assert np.array_equal(st["color"], ex["color"]) and np.array_equal(st["final_T"], ex["final_T"])
+        assert_forward_gate(fw, st["color"], W, H, FWD_TOL, "%s policy %d" % (case, mode))
