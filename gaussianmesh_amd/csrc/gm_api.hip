@@ -198,7 +198,7 @@ int gm_forward_1_geom(int emission_policy, void* geom_buffer, void* binning_buff
   } else {
     GM_HIP(hipMemsetAsync(img.ranges, 0, sizeof(uint2) * (size_t)tiles, st));
   }
-  return launch_render_fwd(g, b.keys[slot], b.vals[slot], img, width, height, mode, background, out_color, debug, st);
+  return launch_render_fwd(g, b.pairs[slot], img, width, height, mode, background, out_color, debug, st);
 }
 
 int gm_forward_status_async(void* geom_buffer, int P, int* status_host, void* stream) {
@@ -270,7 +270,7 @@ int gm_backward_p(int emission_policy, int P, int D, int M, int R, const float* 
   GM_HIP(hipMemsetAsync(g.grad_acc, 0, sizeof(float) * 12 * (size_t)P, a.stream));   // the only zero-fill of a backward
   if (R > 0) {
     if (!binning_buffer) { set_error("gm_backward: null binning buffer"); return GM_ERR_INVALID_ARG; }
-    if (int rc = launch_render_bwd(g, b.keys[slot], b.vals[slot], img, width, height, a.tile_cull, background, dL_dpix, debug, a.stream)) return rc;
+    if (int rc = launch_render_bwd(g, b.pairs[slot], img, width, height, a.tile_cull, background, dL_dpix, debug, a.stream)) return rc;
   }
   return launch_preprocess_bwd(a, g, radii, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
                                dL_dscale, dL_drot);
@@ -302,7 +302,7 @@ void* gm_geom_field(void* geom_buffer, int P, const char* name) {
   if (!strcmp(name, "tiles_touched")) return g.tiles_touched;
   if (!strcmp(name, "cov3D")) return g.cov3D;
   if (!strcmp(name, "clamped")) return g.clamped;
-  if (!strcmp(name, "order")) return g.order[0];
+  if (!strcmp(name, "order")) return g.order;
   if (!strcmp(name, "bucket_start")) return g.bucket_start;
   if (!strcmp(name, "counters")) return g.counters;
   return nullptr;
@@ -317,8 +317,7 @@ void* gm_image_field(void* image_buffer, int W, int H, const char* name) {
 void* gm_binning_field(void* binning_buffer, int64_t R, int W, int H, int emission_policy, const char* name) {
   BinningState b = BinningState::from(binning_buffer, (size_t)(R > 0 ? R : 0));
   const int slot = sort_final_slot(TileGrid(W, H, emission_policy < 0 ? 0 : (emission_policy > 3 ? 3 : emission_policy)).ptiles);
-  if (!strcmp(name, "point_list")) return b.vals[slot];
-  if (!strcmp(name, "tile_keys")) return b.keys[slot];
+  if (!strcmp(name, "pairs")) return b.pairs[slot];
   return nullptr;
 }
 

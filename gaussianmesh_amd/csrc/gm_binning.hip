@@ -40,7 +40,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
 }
 
 int launch_arm_counters(GeomState& g, hipStream_t s) {
-  GM_HIP(hipMemsetAsync(g.slots, 0, sizeof(uint32_t) * (4 * GM_SLOTS + GM_CNT_COUNT), s));
+  GM_HIP(hipMemsetAsync(g.slots, 0, sizeof(uint32_t) * g.arm_words, s));
   return 0;
 }
 
@@ -66,10 +66,12 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
                                                                 const uint4* __restrict__ bins, const float4* __restrict__ splat,
                                                                 uint32_t* __restrict__ counters, const uint32_t* __restrict__ bucket_start,
                                                                 const uint32_t* __restrict__ bucket_inst, int gx, int pgx, int mode,
-                                                                uint32_t capacity, uint32_t* __restrict__ keys_out,
-                                                                uint32_t* __restrict__ vals_out) {
+                                                                uint32_t capacity, uint2* __restrict__ pairs_out,
+                                                                uint32_t* __restrict__ acc, uint32_t acc_words) {
   __shared__ uint32_t wsum[BN_THREADS / 64];
   __shared__ uint32_t stage_k[DUP_STAGE], stage_v[DUP_STAGE];
+  // accumulators of the tile pass that follows (bk_hist_kernel adds into them)
+  for (uint32_t i = blockIdx.x * BN_THREADS + threadIdx.x; i < acc_words; i += gridDim.x * BN_THREADS) acc[i] = 0u;
   // the counts were made under another policy (it changed between the forward halves), or the instance total exceeds the
   // caller's binning capacity: emit nothing rather than overrun; every list stays empty (tile_ranges / bk_scan see the flag)
   if ((int)counters[GM_CNT_POLICY] != mode || counters[GM_CNT_RENDERED] > capacity) {
@@ -115,8 +117,10 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
   // assembled there and copied out with full-line stores: per-lane runs written straight to HBM cost 2.3x the bytes
   // (partial lines, WRITE_SIZE 114 MB for 48.7 MB of pairs).  Otherwise the runs are stored directly.
   const bool staged = total <= DUP_STAGE;
-  uint32_t* __restrict__ kdst = staged ? stage_k : keys_out + block_base;
-  uint32_t* __restrict__ vdst = staged ? stage_v : vals_out + block_base;
+  uint32_t* __restrict__ kdst = stage_k;
+  uint32_t* __restrict__ vdst = stage_v;
+  // not staged: pairs go straight to their slots (kdst / vdst unused); EMIT covers both
+#define EMIT(POS, K, V) do { if (staged) { kdst[POS] = (K); vdst[POS] = (V); } else pairs_out[block_base + (POS)] = make_uint2((K), (V)); } while (0)
 #pragma unroll
   for (int i = 0; i < BN_PER_THREAD; i++) { offs[i] = off; off += cnt[i]; }
   // (1) small rectangles (<= 64 tiles; S > 0: also at most 60 wide): each lane expands the emit mask of its own
@@ -136,8 +140,7 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
           const uint32_t k = (uint32_t)__ffsll(m) - 1u;
           m &= m - 1;
           const uint32_t row = (uint32_t)(((float)k + 0.5f) * inv_w);
-          kdst[pos] = tile0 + row * (uint32_t)gx + (k - row * w);
-          vdst[pos] = gid[i];
+          EMIT(pos, tile0 + row * (uint32_t)gx + (k - row * w), gid[i]);
           pos++;
         }
       } else {
@@ -158,8 +161,7 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
             uint32_t cm = 0;
 #pragma unroll
             for (int j = 0; j <= M; j++) cm |= (uint32_t)((rows[j] >> b) & (unsigned long long)((1 << (1 << S)) - 1)) << (j << S);
-            kdst[pos] = (pr * (uint32_t)pgx + (x0 >> S) + (uint32_t)(b >> S)) | (cm << GM_KEY_MASK_SHIFT);
-            vdst[pos] = gid[i];
+            EMIT(pos, (pr * (uint32_t)pgx + (x0 >> S) + (uint32_t)(b >> S)) | (cm << GM_KEY_MASK_SHIFT), gid[i]);
             pos++;
           }
         }
@@ -212,8 +214,7 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
         const unsigned long long bal = __ballot(pass);
         if (pass) {
           const uint32_t pos = run + (uint32_t)__popcll(bal & lt_mask);
-          kdst[pos] = (pcy * (uint32_t)pgx + pcx) | (cm << GM_KEY_MASK_SHIFT);
-          vdst[pos] = g;
+          EMIT(pos, (pcy * (uint32_t)pgx + pcx) | (cm << GM_KEY_MASK_SHIFT), g);
         }
         run += (uint32_t)__popcll(bal);
       }
@@ -221,11 +222,9 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
   }
   if (staged) {
     __syncthreads();
-    for (uint32_t j = threadIdx.x; j < total; j += BN_THREADS) {
-      keys_out[block_base + j] = stage_k[j];
-      vals_out[block_base + j] = stage_v[j];
-    }
+    for (uint32_t j = threadIdx.x; j < total; j += BN_THREADS) pairs_out[block_base + j] = make_uint2(stage_k[j], stage_v[j]);
   }
+#undef EMIT
   ibase += total;
   __syncthreads();                                 // the stage and wsum are reused by the next chunk
   }
@@ -236,8 +235,9 @@ int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, int mod
   const TileGrid tg(W, H, mode);
   const uint32_t cap = capacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)capacity;
   if (P > 0) {
-#define GM_DUP(SH) hipLaunchKernelGGL(duplicate_kernel<SH>, dim3(1 << GM_BUCKET_BITS), dim3(BN_THREADS), 0, s, g.order[0], g.cnt_sorted, g.bin, \
-                                      g.splat, g.counters, g.bucket_start, g.bucket_inst, tg.gx, tg.pgx, mode, cap, b.keys[0], b.vals[0])
+#define GM_DUP(SH) hipLaunchKernelGGL(duplicate_kernel<SH>, dim3(1 << GM_BUCKET_BITS), dim3(BN_THREADS), 0, s, g.order, g.cnt_sorted, g.bin, \
+                                      g.splat, g.counters, g.bucket_start, g.bucket_inst, tg.gx, tg.pgx, mode, cap, b.pairs[0], b.acc, \
+                                      (uint32_t)bk_acc_words(capacity))
     if (tg.s == 0) GM_DUP(0); else if (tg.s == 1) GM_DUP(1); else GM_DUP(2);
 #undef GM_DUP
   }
@@ -245,16 +245,16 @@ int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, int mod
   return 0;
 }
 
-__global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __restrict__ keys, int R_host, const uint32_t* __restrict__ R_dev,
+__global__ __launch_bounds__(256) void tile_ranges_kernel(const uint2* __restrict__ pairs, int R_host, const uint32_t* __restrict__ R_dev,
                                                           uint32_t tiles, const uint32_t* __restrict__ counters, uint2* __restrict__ ranges) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int R = R_dev ? (int)min((uint32_t)R_host, *R_dev) : R_host;
   if (i >= R || counters[GM_CNT_REFUSED] != 0u) return;        // emission was refused -> every list stays empty
-  const uint32_t cur = keys[i] & GM_KEY_TILE_MASK;
+  const uint32_t cur = pairs[i].x & GM_KEY_TILE_MASK;
   if (cur >= tiles) return;
   if (i == 0) ranges[cur].x = 0;
   else {
-    const uint32_t prev = keys[i - 1] & GM_KEY_TILE_MASK;
+    const uint32_t prev = pairs[i - 1].x & GM_KEY_TILE_MASK;
     if (cur != prev) { if (prev < tiles) ranges[prev].y = (uint32_t)i; ranges[cur].x = (uint32_t)i; }
   }
   if (i == R - 1) ranges[cur].y = (uint32_t)R;
@@ -265,7 +265,7 @@ int launch_tile_ranges(const GeomState& g, BinningState& b, int slot, ImageState
                        hipStream_t s) {
   StageScope sc(ST_RANGES, s);
   GM_HIP(hipMemsetAsync(img.ranges, 0, sizeof(uint2) * (size_t)tiles, s));
-  if (R > 0) hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, b.keys[slot], R, R_dev, (uint32_t)tiles, g.counters, img.ranges);
+  if (R > 0) hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, b.pairs[slot], R, R_dev, (uint32_t)tiles, g.counters, img.ranges);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }

@@ -24,16 +24,22 @@
 //    bk_hist -> bk_scan -> bk_scatter; the scan's exclusive digit bases ARE the tile ranges, so identifyTileRanges and
 //    its memset disappear.  More list tiles: two 8-bit passes + tile_ranges_kernel.
 //
-// One pass = three kernels; none depends on another workgroup of the same launch except bk_scan's epilogue, where the
-// last workgroup to finish (agent-scope release -> relaxed counter -> agent-scope acquire, MI355X_MICROARCH.md
-// "valid forms") turns the per-chunk totals into bases:
-//   bk_hist     workgroup b counts the digits of its 4096 keys -> hist[b][digit] (one contiguous row)
-//   bk_scan     workgroup (c, g): rows [32 c, 32 c + 32) x digits [256 g, 256 g + 256) -> exclusive prefixes in place +
-//               chunk totals; last workgroup of digit group g: prefix over the chunks (in place), digit totals, prefix
-//               over its 256 digits; last group: adds the group bases -> digit_base[0..ND], writes the tile ranges
-//   bk_scatter  workgroup b: base[d] = digit_base[d] + chunk_base[b / 32][d] + hist[b][d]; ranks its keys stably
-//               (match-any from DB ballots + per-wave digit counters in LDS), sorts the tile by digit in LDS, streams
-//               it out as contiguous runs.
+// Streams are (key, value) pairs interleaved as uint2 (one 8-byte access per entry everywhere).
+//
+// One pass = three kernels, no workgroup ever waits for another one of the same launch:
+//   bk_hist     workgroup b counts the digits of its 4096 keys -> hist[b][digit] (one contiguous row), and adds the row to
+//               chunk_total[b / 32][digit] and its 256-digit group sums to one of 64 slots per group with atomics (<= 32
+//               resp. ~12 atomics per address; the accumulators are zeroed by the launch before: the forward's first memset
+//               for the depth partition, duplicate_kernel for the tile pass)
+//   bk_scan     workgroup (c, g): digits [256 g, 256 g + 256), rows [32 c, 32 c + 32): digit totals and the base of chunk c
+//               from the chunk totals (<= n / 131072 coalesced loads), exclusive scan over the group's digits, group base
+//               from the slots, then the rows' prefixes -> hist[row][digit] = ABSOLUTE first output position; workgroups
+//               with c == 0 also publish the digit bases (bucket starts / tile ranges)
+//   bk_scatter  workgroup b ranks its keys stably (match-any from DB ballots + per-wave digit counters in LDS), sorts the
+//               tile by digit inside LDS (the counters' memory is reused as the stage) and streams it out: digit d's run
+//               goes to hist[b][d] + (position in run), so neighbouring lanes store neighbouring pairs.  Measured: 3 M
+//               pairs stored one lane at a time (64 different lines per store instruction) run into the L2's transaction
+//               rate (25-34 us per pass); larger tiles make longer runs (tile / 2048 pairs per digit).
 #include "gm_common.h"
 
 namespace gm {
@@ -42,6 +48,9 @@ namespace gm {
 #define BK_WAVES 4
 #define BK_ROUNDS 16
 #define BK_CHUNK GM_BK_CHUNK
+#ifndef GM_TILE_PASS_WAVES
+#define GM_TILE_PASS_WAVES 8        // workgroup of the one-pass tile sort: 8 waves x 1024 keys
+#endif
 #define BS_CAP 4096                 // entries a bucket may have for the in-LDS sort (256 threads x 16)
 
 struct DigitSpec { uint32_t sub, shift, mask; };       // digit(k) = ((k - sub) >> shift) & mask
@@ -98,13 +107,23 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
   return woff + incl - v;
 }
 
+// key of entry idx: MSD input is the plain key array of the preprocess kernel, everything else is a pair stream
+template <bool MSD>
+__device__ __forceinline__ uint32_t load_key(const void* __restrict__ in, uint32_t idx) {
+  return MSD ? reinterpret_cast<const uint32_t*>(in)[idx] : reinterpret_cast<const uint2*>(in)[idx].x;
+}
+
 // ---------------------------------------------------------------------------------------------
-template <bool MSD, int DB>
-__global__ __launch_bounds__(BK_THREADS) void bk_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n_host,
+// acc: [GM_ACC_SLOTS] group slots ([group][64]) followed by chunk_total [chunks][ND]; zero on entry.
+// WAVES waves of 64 threads per workgroup, 1024 keys per wave: the depth partition (1 M keys) uses 4-wave workgroups so
+// that the launch covers the chip; the tile pass (millions of instances) 16-wave workgroups: 4x fewer histogram rows,
+// atomics and scan work per key.
+template <bool MSD, int DB, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void bk_hist_kernel(const void* __restrict__ in, uint32_t n_host,
                                                               const uint32_t* __restrict__ n_dev, DigitSpec ds,
                                                               const uint32_t* __restrict__ slots, uint32_t* __restrict__ hist,
-                                                              uint32_t* __restrict__ counters) {
-  constexpr int ND = 1 << DB;
+                                                              uint32_t* __restrict__ acc, uint32_t* __restrict__ counters) {
+  constexpr int ND = 1 << DB, THREADS = WAVES * 64, TILE = WAVES * BK_ROUNDS * 64;
   __shared__ uint32_t h[ND];
   __shared__ uint32_t s_tmp[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -116,16 +135,16 @@ __global__ __launch_bounds__(BK_THREADS) void bk_hist_kernel(const uint32_t* __r
     if (blockIdx.x == 0 && threadIdx.x == 0) counters[GM_CNT_RENDERED] = total;   // num_rendered, for the host read-back
     if (nb == 0u) return;
   }
-  const uint32_t nblk = (n + GM_BK_TILE - 1) / GM_BK_TILE;
+  const uint32_t nblk = (n + TILE - 1) / TILE;
   if (blockIdx.x >= nblk) return;
-  for (int d = threadIdx.x; d < ND; d += BK_THREADS) h[d] = 0;
+  for (int d = threadIdx.x; d < ND; d += THREADS) h[d] = 0;
   __syncthreads();
-  const uint32_t wbase = blockIdx.x * GM_BK_TILE + wave * (BK_ROUNDS * 64);
+  const uint32_t wbase = blockIdx.x * TILE + wave * (BK_ROUNDS * 64);
   uint32_t k[BK_ROUNDS];
 #pragma unroll
   for (int r = 0; r < BK_ROUNDS; r++) {
     const uint32_t idx = wbase + r * 64 + lane;
-    k[r] = idx < n ? keys[idx] : 0xFFFFFFFFu;
+    k[r] = idx < n ? load_key<MSD>(in, idx) : 0xFFFFFFFFu;
   }
 #pragma unroll
   for (int r = 0; r < BK_ROUNDS; r++) {
@@ -134,141 +153,140 @@ __global__ __launch_bounds__(BK_THREADS) void bk_hist_kernel(const uint32_t* __r
     if (valid) atomicAdd(&h[((k[r] - ds.sub) >> ds.shift) & ds.mask], 1u);
   }
   __syncthreads();
-  for (int d = threadIdx.x; d < ND; d += BK_THREADS) hist[(size_t)blockIdx.x * ND + d] = h[d];
+  uint32_t* chunk_total = acc + GM_ACC_SLOTS + (size_t)(blockIdx.x / BK_CHUNK) * ND;
+  for (int d = threadIdx.x; d < ND; d += THREADS) {   // a wave's 64 digits lie in one 256-digit group
+    const uint32_t c = h[d];
+    hist[(size_t)blockIdx.x * ND + d] = c;
+    if (c) atomicAdd(&chunk_total[d], c);
+    const uint32_t gs = wave_sum_u32(c);
+    if (lane == 0 && gs) atomicAdd(&acc[(d >> 8) * 64 + ((blockIdx.x * WAVES + wave) & 63)], gs);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
-// grid = (chunks, ND / 256).  ranges_out (optional): [nranges] uint2 {first, one past last} per digit value.
+// grid = (chunks, ND / 256).  base_out (optional): [ND + 1] exclusive digit bases; ranges_out (optional): [nranges] uint2
+// {first, one past last} per digit value, {0, 0} for an empty one.
 template <bool MSD, int DB>
-__global__ __launch_bounds__(BK_THREADS) void bk_scan_kernel(uint32_t* __restrict__ hist, uint32_t n_host, const uint32_t* __restrict__ n_dev,
-                                                              const uint32_t* __restrict__ slots, uint32_t* __restrict__ chunk_total,
-                                                              uint32_t* __restrict__ digit_base, uint32_t* __restrict__ digit_total,
-                                                              uint32_t* __restrict__ counters, uint2* __restrict__ ranges_out, uint32_t nranges) {
+__global__ __launch_bounds__(BK_THREADS) void bk_scan_kernel(uint32_t* __restrict__ hist, uint32_t tile, uint32_t n_host, const uint32_t* __restrict__ n_dev,
+                                                              const uint32_t* __restrict__ slots, const uint32_t* __restrict__ acc,
+                                                              uint32_t* __restrict__ base_out, const uint32_t* __restrict__ counters,
+                                                              uint2* __restrict__ ranges_out, uint32_t nranges) {
   constexpr int ND = 1 << DB, NG = ND / 256;
   __shared__ uint32_t wsum[4];
   __shared__ uint32_t s_tmp[4];
-  __shared__ uint32_t s_last;
+  __shared__ uint32_t gsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t n = n_host;
   if (n_dev) n = min(n, *n_dev);
   if (MSD) {
     DigitSpec ds; uint32_t total;
     if (block_msd_params(slots, s_tmp, ds, total) == 0u) n = 0;
   }
-  const uint32_t nblk = (n + GM_BK_TILE - 1) / GM_BK_TILE;
+  const uint32_t nblk = (n + tile - 1) / tile;
   const uint32_t nchunks = (nblk + BK_CHUNK - 1) / BK_CHUNK;
   const uint32_t c = blockIdx.x, g = blockIdx.y;
   const uint32_t d = g * 256 + threadIdx.x;
   if (nblk == 0) {                                  // nothing to sort: every list is empty
     if (c == 0) {
-      digit_base[d] = 0; digit_total[d] = 0;
+      if (base_out) { base_out[d] = 0; if (d == 0) base_out[ND] = 0; }
       if (ranges_out && d < nranges) ranges_out[d] = make_uint2(0u, 0u);
-      if (d == 0) digit_base[ND] = 0;
     }
     return;
   }
   if (c >= nchunks) return;
+  const uint32_t* chunk_total = acc + GM_ACC_SLOTS;
+  uint32_t tot = 0, cbase = 0;
+  for (uint32_t c0 = 0; c0 < nchunks; c0 += 8) {      // batches of independent loads
+    uint32_t t[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) t[j] = c0 + j < nchunks ? chunk_total[(size_t)(c0 + j) * ND + d] : 0u;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { tot += t[j]; cbase += (c0 + j < c) ? t[j] : 0u; }
+  }
+  uint32_t below = 0;                                 // keys in the digit groups before this one
   {
-    const uint32_t r0 = c * BK_CHUNK;
-    const uint32_t nr = min((uint32_t)BK_CHUNK, nblk - r0);
-    uint32_t v[BK_CHUNK];
+    uint32_t part = 0;
 #pragma unroll
-    for (int r = 0; r < BK_CHUNK; r++) v[r] = (uint32_t)r < nr ? hist[(size_t)(r0 + r) * ND + d] : 0u;
-    uint32_t run = 0;
-#pragma unroll
-    for (int r = 0; r < BK_CHUNK; r++) {
-      if ((uint32_t)r < nr) hist[(size_t)(r0 + r) * ND + d] = run;
-      run += v[r];
+    for (int j = 0; j < (NG * 64 + 255) / 256; j++) {
+      const uint32_t i = j * 256 + threadIdx.x;
+      if (i < NG * 64 && (i >> 6) < g) part += acc[i];
     }
-    chunk_total[(size_t)c * ND + d] = run;
+    part = wave_sum_u32(part);
+    if (lane == 0) gsum[wave] = part;
   }
-  // ---- last workgroup of this digit group: chunk totals -> chunk bases, digit totals, prefix over the group's digits
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const uint32_t old = __hip_atomic_fetch_add(&counters[GM_CNT_DONE + g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (old == nchunks - 1u) ? 1u : 0u;
-    if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  __syncthreads();
-  if (!s_last) return;
-  uint32_t run = 0;
-  for (uint32_t c2 = 0; c2 < nchunks; c2++) {
-    const uint32_t t = __hip_atomic_load(&chunk_total[(size_t)c2 * ND + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    chunk_total[(size_t)c2 * ND + d] = run;
-    run += t;
-  }
-  digit_total[d] = run;
   uint32_t gtotal;
-  const uint32_t excl = block_exclusive_scan_256(run, wsum, gtotal);
-  digit_base[d] = excl;                             // relative to the group until the epilogue below
-  if (threadIdx.x == 0) counters[GM_CNT_GROUP + g] = gtotal;
-  // ---- last digit group: add the group bases, publish the ranges, re-arm the counters
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const uint32_t old = __hip_atomic_fetch_add(&counters[GM_CNT_DONE + 8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (old == (uint32_t)NG - 1u) ? 1u : 0u;
-    if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  const uint32_t excl = block_exclusive_scan_256(tot, wsum, gtotal);    // (its barrier also publishes gsum)
+  below = gsum[0] + gsum[1] + gsum[2] + gsum[3];
+  const uint32_t base = below + excl;
+  if (c == 0) {
+    if (base_out) { base_out[d] = base; if (d == ND - 1) base_out[ND] = base + tot; }
+    if (ranges_out && d < nranges) {
+      const bool refused = !MSD && counters[GM_CNT_REFUSED] != 0u;      // emission refused: every list stays empty
+      ranges_out[d] = (refused || tot == 0u) ? make_uint2(0u, 0u) : make_uint2(base, base + tot);   // empty lists: {0, 0} as in the reference
+    }
   }
-  __syncthreads();
-  if (!s_last) return;
-  const bool refused = !MSD && counters[GM_CNT_REFUSED] != 0u;     // emission refused: every list stays empty
-  uint32_t gb = 0;
+  const uint32_t r0 = c * BK_CHUNK;
+  const uint32_t nr = min((uint32_t)BK_CHUNK, nblk - r0);
+  uint32_t v[BK_CHUNK];
 #pragma unroll
-  for (int k = 0; k < NG; k++) {
-    const uint32_t d2 = k * 256 + threadIdx.x;
-    const uint32_t base = __hip_atomic_load(&digit_base[d2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + gb;
-    const uint32_t tot = __hip_atomic_load(&digit_total[d2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    digit_base[d2] = base;
-    if (ranges_out && d2 < nranges) ranges_out[d2] = (refused || tot == 0u) ? make_uint2(0u, 0u) : make_uint2(base, base + tot);   // empty lists stay {0, 0} as in the reference (zeroed ranges)
-    gb += __hip_atomic_load(&counters[GM_CNT_GROUP + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int r = 0; r < BK_CHUNK; r++) v[r] = (uint32_t)r < nr ? hist[(size_t)(r0 + r) * ND + d] : 0u;
+  uint32_t run = base + cbase;
+#pragma unroll
+  for (int r = 0; r < BK_CHUNK; r++) {
+    if ((uint32_t)r < nr) hist[(size_t)(r0 + r) * ND + d] = run;
+    run += v[r];
   }
-  if (threadIdx.x == 0) digit_base[ND] = gb;
-  if (threadIdx.x <= 8) counters[GM_CNT_DONE + threadIdx.x] = 0u;
 }
 
 // ---------------------------------------------------------------------------------------------
-template <bool MSD, bool IOTA, int DB>
-__global__ __launch_bounds__(BK_THREADS) void bk_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                                                                 uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+// zero_acc / zero_words: accumulators of the NEXT pass (two-pass tile sort), cleared here because no earlier launch can
+template <bool MSD, int DB, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 4) void bk_scatter_kernel(const void* __restrict__ in, uint2* __restrict__ out,
                                                                  uint32_t n_host, const uint32_t* __restrict__ n_dev, DigitSpec ds,
                                                                  const uint32_t* __restrict__ slots, const uint32_t* __restrict__ hist,
-                                                                 const uint32_t* __restrict__ chunk_total,
-                                                                 const uint32_t* __restrict__ digit_base) {
-  constexpr int ND = 1 << DB, DPT = ND / 256;
-  __shared__ uint16_t wcnt[BK_WAVES][ND];    // per-wave running digit counts (<= 1024) -> per-wave exclusive offsets (< 4096)
-  __shared__ uint32_t gbase[ND];             // global base of each digit for this workgroup
-  __shared__ uint32_t dstart[ND];            // start of each digit's run inside the locally sorted tile
-  __shared__ uint32_t lkey[GM_BK_TILE];
-  __shared__ uint32_t lval[GM_BK_TILE];
-  __shared__ uint32_t wsum[4];
+                                                                 uint32_t* __restrict__ zero_acc, uint32_t zero_words) {
+  constexpr int ND = 1 << DB, THREADS = WAVES * 64, TILE = WAVES * BK_ROUNDS * 64;
+  // wcnt: per-wave running digit counts (<= 1024) -> per-wave exclusive offsets (< TILE <= 16384); once every key knows its
+  // position in the digit-sorted tile the same memory stages the tile (one 8-byte pair per key)
+  constexpr int SMEM = (WAVES * ND * 2 > TILE * 8) ? WAVES * ND * 2 : TILE * 8;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+  uint16_t (*wcnt)[ND] = reinterpret_cast<uint16_t (*)[ND]>(smem);
+  uint2* stage = reinterpret_cast<uint2*>(smem);
+  __shared__ uint32_t gbase[ND];             // first output position of each digit for this workgroup
+  __shared__ uint16_t dstart[ND];            // start of each digit's run inside the digit-sorted tile (< TILE <= 16384)
+  __shared__ uint32_t wsum[WAVES];
   __shared__ uint32_t s_tmp[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  if (zero_acc)
+    for (uint32_t i = blockIdx.x * THREADS + threadIdx.x; i < zero_words; i += gridDim.x * THREADS) zero_acc[i] = 0u;
   uint32_t n = n_host;
   if (n_dev) n = min(n, *n_dev);
   if (MSD) {
     uint32_t total;
     if (block_msd_params(slots, s_tmp, ds, total) == 0u) return;
   }
-  const uint32_t nblk = (n + GM_BK_TILE - 1) / GM_BK_TILE;
+  const uint32_t nblk = (n + TILE - 1) / TILE;
   if (blockIdx.x >= nblk) return;
-  const uint32_t chunk = blockIdx.x / BK_CHUNK;
-  for (int d = threadIdx.x; d < ND; d += BK_THREADS) {
+  for (int d = threadIdx.x; d < ND; d += THREADS) {
 #pragma unroll
-    for (int w = 0; w < BK_WAVES; w++) wcnt[w][d] = 0;
-    gbase[d] = digit_base[d] + chunk_total[(size_t)chunk * ND + d] + hist[(size_t)blockIdx.x * ND + d];
+    for (int w = 0; w < WAVES; w++) wcnt[w][d] = 0;
+    gbase[d] = hist[(size_t)blockIdx.x * ND + d];
   }
   __syncthreads();
 
-  const uint32_t wbase = blockIdx.x * GM_BK_TILE + wave * (BK_ROUNDS * 64);
-  uint32_t key[BK_ROUNDS], rank[BK_ROUNDS];
+  const uint32_t wbase = blockIdx.x * TILE + wave * (BK_ROUNDS * 64);
+  uint32_t key[BK_ROUNDS], val[BK_ROUNDS], rank[BK_ROUNDS];
 #pragma unroll
   for (int r = 0; r < BK_ROUNDS; r++) {
     const uint32_t idx = wbase + r * 64 + lane;
-    key[r] = idx < n ? keys_in[idx] : 0xFFFFFFFFu;
+    if (MSD) {
+      key[r] = idx < n ? reinterpret_cast<const uint32_t*>(in)[idx] : 0xFFFFFFFFu;
+      val[r] = idx;
+    } else {
+      const uint2 kv = idx < n ? reinterpret_cast<const uint2*>(in)[idx] : make_uint2(0xFFFFFFFFu, 0u);
+      key[r] = kv.x; val[r] = kv.y;
+    }
   }
   uint32_t vmask = 0;                          // bit r: this lane's key of round r takes part
 #pragma unroll
@@ -296,57 +314,72 @@ __global__ __launch_bounds__(BK_THREADS) void bk_scatter_kernel(const uint32_t* 
   }
   __syncthreads();
   uint32_t tile_n;
-  {  // per digit: per-wave counts -> per-wave exclusive offsets; digit counts -> start of each digit's run in the tile
+  {  // per digit: per-wave counts -> per-wave exclusive offsets; digit counts -> start of each digit's run in the sorted tile
+    constexpr int DPT = (ND + THREADS - 1) / THREADS;            // consecutive digits per thread (ND >= THREADS here or DPT == 1)
     uint32_t dc[DPT], sum = 0;
 #pragma unroll
     for (int j = 0; j < DPT; j++) {
       const int d = threadIdx.x * DPT + j;
       uint32_t run = 0;
+      if (d < ND) {
 #pragma unroll
-      for (int w = 0; w < BK_WAVES; w++) {
-        const uint32_t c = wcnt[w][d];
-        wcnt[w][d] = (uint16_t)run;
-        run += c;
+        for (int w = 0; w < WAVES; w++) {
+          const uint32_t c = wcnt[w][d];
+          wcnt[w][d] = (uint16_t)run;
+          run += c;
+        }
       }
       dc[j] = run; sum += run;
     }
-    uint32_t excl = block_exclusive_scan_256(sum, wsum, tile_n);
+    uint32_t incl = sum;                                       // workgroup-wide exclusive scan of `sum`
 #pragma unroll
-    for (int j = 0; j < DPT; j++) { dstart[threadIdx.x * DPT + j] = excl; excl += dc[j]; }
-  }
-  __syncthreads();
-  // local scatter into LDS: the tile becomes sorted by digit (stable), so the global stores below are contiguous runs
+    for (int dd = 1; dd < 64; dd <<= 1) {
+      const uint32_t t = __shfl_up(incl, dd);
+      if (lane >= dd) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
 #pragma unroll
-  for (int r = 0; r < BK_ROUNDS; r++) {
-    if ((vmask >> r) & 1u) {
-      const uint32_t idx = wbase + r * 64 + lane;
-      const uint32_t d = ((key[r] - ds.sub) >> ds.shift) & ds.mask;
-      const uint32_t lp = dstart[d] + wcnt[wave][d] + rank[r];
-      lkey[lp] = key[r];
-      lval[lp] = IOTA ? idx : vals_in[idx];
+    for (int w = 0; w < WAVES; w++) {
+      const uint32_t t = wsum[w];
+      woff += (w < wave) ? t : 0;
+      tot += t;
+    }
+    tile_n = tot;
+    uint32_t excl = woff + incl - sum;
+#pragma unroll
+    for (int j = 0; j < DPT; j++) {
+      const int d = threadIdx.x * DPT + j;
+      if (d < ND) dstart[d] = (uint16_t)excl;
+      excl += dc[j];
     }
   }
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < GM_BK_TILE / BK_THREADS; i++) {
-    const uint32_t lp = i * BK_THREADS + threadIdx.x;
-    if (lp < tile_n) {
-      const uint32_t k = lkey[lp];
-      const uint32_t d = ((k - ds.sub) >> ds.shift) & ds.mask;
-      const uint32_t dst = gbase[d] + (lp - dstart[d]);
-      keys_out[dst] = k;
-      vals_out[dst] = lval[lp];
-    }
+  for (int r = 0; r < BK_ROUNDS; r++) {        // position of each key inside the digit-sorted tile
+    const uint32_t d = ((key[r] - ds.sub) >> ds.shift) & ds.mask;
+    rank[r] += ((vmask >> r) & 1u) ? dstart[d] + wcnt[wave][d] : 0u;
+  }
+  __syncthreads();                             // wcnt is dead from here: its memory becomes the stage
+#pragma unroll
+  for (int r = 0; r < BK_ROUNDS; r++)
+    if ((vmask >> r) & 1u) stage[rank[r]] = make_uint2(key[r], val[r]);
+  __syncthreads();
+  // digit d's run goes to gbase[d] + (position in run): neighbouring lanes store neighbouring pairs
+  for (uint32_t i = threadIdx.x; i < tile_n; i += THREADS) {
+    const uint2 kv = stage[i];
+    const uint32_t d = ((kv.x - ds.sub) >> ds.shift) & ds.mask;
+    out[gbase[d] + (i - dstart[d])] = kv;
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // One workgroup per bucket of the MSD partition: (key, id) pairs [start, end) of k1 / v1 -> final order.
 // Outputs: order0[start..end) = ids in (key, id) order, cnt_sorted[start..end) = tiles_touched of those ids,
-// bucket_inst[b] = their sum.  k0 / order0 ranges [start, end) double as scratch on the slow path.
+// bucket_inst[b] = their sum.  p0[start..end) is scratch for the slow path.
 __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t* __restrict__ slots, const uint32_t* __restrict__ bucket_start,
-                                                                  uint32_t* __restrict__ k1, uint32_t* __restrict__ v1,
-                                                                  uint32_t* __restrict__ k0, uint32_t* __restrict__ order0,
+                                                                  uint2* __restrict__ p1, uint2* __restrict__ p0, uint32_t* __restrict__ order0,
                                                                   const uint32_t* __restrict__ tiles, uint32_t* __restrict__ cnt_sorted,
                                                                   uint32_t* __restrict__ bucket_inst) {
   __shared__ uint32_t wcnt[BK_WAVES][256];
@@ -376,8 +409,8 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t*
     for (int r = 0; r < BK_ROUNDS; r++) {
       const uint32_t p = (wave * rounds + r) * 64u + lane;
       const bool valid = (uint32_t)r < rounds && p < n;
-      key[r] = valid ? k1[start + p] : 0u;
-      val[r] = valid ? v1[start + p] : 0u;
+      const uint2 kv = valid ? p1[start + p] : make_uint2(0u, 0u);
+      key[r] = kv.x; val[r] = kv.y;
     }
     for (uint32_t pass = 0; pass < npass; pass++) {
       const uint32_t lo = pass * pb, pmask = (1u << min(pb, low_bits - lo)) - 1u;
@@ -456,16 +489,16 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t*
     }
   } else {
     // Slow path (more equal-depth Gaussians than the LDS holds): the workgroup sorts its own range through global memory,
-    // ping-ponging between (k1, v1) and (k0, order0) restricted to [start, end): per pass a digit histogram over the
+    // ping-ponging between p1 and p0 restricted to [start, end): per pass a digit histogram over the
     // range, then 1024-entry tiles in order, each ranked stably as above.  Exact, sequential, rare.
     __shared__ uint32_t base[256];
     __shared__ uint32_t tcount[256];
-    uint32_t* sk = k1; uint32_t* sv = v1; uint32_t* dk = k0; uint32_t* dv = order0;
+    uint2* sp = p1; uint2* dp = p0;
     for (uint32_t pass = 0; pass < npass; pass++) {
       const uint32_t lo = pass * pb, pmask = (1u << min(pb, low_bits - lo)) - 1u;
       base[threadIdx.x] = 0;
       __syncthreads();
-      for (uint32_t i = threadIdx.x; i < n; i += BK_THREADS) atomicAdd(&base[((sk[start + i] - ds.sub) >> lo) & pmask], 1u);
+      for (uint32_t i = threadIdx.x; i < n; i += BK_THREADS) atomicAdd(&base[((sp[start + i].x - ds.sub) >> lo) & pmask], 1u);
       __syncthreads();
       {
         uint32_t tot;
@@ -483,8 +516,8 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t*
         for (int r = 0; r < 4; r++) {
           const uint32_t p = t0 + (wave * 4u + r) * 64u + lane;
           const bool valid = p < n;
-          kk[r] = valid ? sk[start + p] : 0u;
-          vv[r] = valid ? sv[start + p] : 0u;
+          const uint2 kv = valid ? sp[start + p] : make_uint2(0u, 0u);
+          kk[r] = kv.x; vv[r] = kv.y;
           const uint32_t d = ((kk[r] - ds.sub) >> lo) & pmask;
           uint64_t peers = __ballot(valid);
 #pragma unroll
@@ -521,8 +554,7 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t*
           if (p < n) {
             const uint32_t d = ((kk[r] - ds.sub) >> lo) & pmask;
             const uint32_t dst = start + base[d] + wcnt[wave][d] + rk[r];
-            dk[dst] = kk[r];
-            dv[dst] = vv[r];
+            dp[dst] = make_uint2(kk[r], vv[r]);
           }
         }
         __syncthreads();
@@ -531,14 +563,12 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t*
       }
       __threadfence();                               // this workgroup's stores reach L2, its L1 forgets the old lines
       __syncthreads();
-      uint32_t* t;
-      t = sk; sk = dk; dk = t;
-      t = sv; sv = dv; dv = t;
+      uint2* t = sp; sp = dp; dp = t;
     }
     for (uint32_t i = threadIdx.x; i < n; i += BK_THREADS) {
-      const uint32_t id = sv[start + i];
+      const uint32_t id = sp[start + i].y;
       const uint32_t c = tiles[id];
-      if (sv != order0) order0[start + i] = id;
+      order0[start + i] = id;
       cnt_sorted[start + i] = c;
       inst += c;
     }
@@ -553,14 +583,14 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t*
 // ---------------------------------------------------------------------------------------------
 // host side
 int launch_depth_order(GeomState& g, int P, int debug, hipStream_t s, int* num_rendered_host, hipEvent_t count_event) {
-  constexpr int DB = GM_BUCKET_BITS;
-  const uint32_t nblk = ((uint32_t)P + GM_BK_TILE - 1) / GM_BK_TILE;
+  constexpr int DB = GM_BUCKET_BITS, WAVES = 4, TILE = WAVES * BK_ROUNDS * 64;
+  const uint32_t nblk = ((uint32_t)P + TILE - 1) / TILE;
   const uint32_t nchunks = (nblk + BK_CHUNK - 1) / BK_CHUNK;
   const DigitSpec ds{0u, 0u, 0xFFFFFFFFu};
   {
     StageScope sc(ST_DEPTH_SORT, s);
-    hipLaunchKernelGGL((bk_hist_kernel<true, DB>), dim3(nblk), dim3(BK_THREADS), 0, s, g.depth_key[0], (uint32_t)P, nullptr, ds, g.slots, g.hist,
-                       g.counters);
+    hipLaunchKernelGGL((bk_hist_kernel<true, DB, WAVES>), dim3(nblk), dim3(WAVES * 64), 0, s, g.depth_key, (uint32_t)P, nullptr, ds, g.slots, g.hist,
+                       g.acc, g.counters);
     GM_LAUNCH_CHECK(debug, s);
   }
   if (num_rendered_host) {      // the instance total is known here; the rest of the ordering overlaps the host's wait for it
@@ -568,37 +598,40 @@ int launch_depth_order(GeomState& g, int P, int debug, hipStream_t s, int* num_r
     if (count_event) GM_HIP(hipEventRecord(count_event, s));
   }
   StageScope sc(ST_DEPTH_SORT, s);
-  hipLaunchKernelGGL((bk_scan_kernel<true, DB>), dim3(nchunks, (1 << DB) / 256), dim3(BK_THREADS), 0, s, g.hist, (uint32_t)P, nullptr, g.slots,
-                     g.chunk_total, g.bucket_start, g.digit_total, g.counters, nullptr, 0u);
+  hipLaunchKernelGGL((bk_scan_kernel<true, DB>), dim3(nchunks, (1 << DB) / 256), dim3(BK_THREADS), 0, s, g.hist, (uint32_t)TILE, (uint32_t)P, nullptr,
+                     g.slots, g.acc, g.bucket_start, g.counters, nullptr, 0u);
   GM_LAUNCH_CHECK(debug, s);
-  hipLaunchKernelGGL((bk_scatter_kernel<true, true, DB>), dim3(nblk), dim3(BK_THREADS), 0, s, g.depth_key[0], nullptr, g.depth_key[1],
-                     g.order[1], (uint32_t)P, nullptr, ds, g.slots, g.hist, g.chunk_total, g.bucket_start);
+  hipLaunchKernelGGL((bk_scatter_kernel<true, DB, WAVES>), dim3(nblk), dim3(WAVES * 64), 0, s, g.depth_key, g.dpairs[1], (uint32_t)P, nullptr, ds,
+                     g.slots, g.hist, nullptr, 0u);
   GM_LAUNCH_CHECK(debug, s);
-  hipLaunchKernelGGL(bucket_sort_kernel, dim3(1 << DB), dim3(BK_THREADS), 0, s, g.slots, g.bucket_start, g.depth_key[1], g.order[1],
-                     g.depth_key[0], g.order[0], g.tiles_touched, g.cnt_sorted, g.bucket_inst);
+  hipLaunchKernelGGL(bucket_sort_kernel, dim3(1 << DB), dim3(BK_THREADS), 0, s, g.slots, g.bucket_start, g.dpairs[1], g.dpairs[0], g.order,
+                     g.tiles_touched, g.cnt_sorted, g.bucket_inst);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }
 
-// tile sort of the instance stream keys[0] / vals[0] (n instances; n_dev != nullptr: the count is read on the device and
-// n is the capacity).  tiles <= 2048: one 11-bit pass, result in slot 1, ranges written by the scan.  Otherwise two
-// 8-bit passes, result in slot 0, ranges by tile_ranges_kernel (caller).
-template <int DB>
+// One stable pass over the pair stream b.pairs[from] -> b.pairs[from ^ 1].  b.acc must be zero on entry.
+template <int DB, int WAVES>
 static int tile_pass(BinningState& b, GeomState& g, int from, uint32_t n, const uint32_t* n_dev, DigitSpec ds, uint2* ranges, uint32_t nranges,
-                     int debug, hipStream_t s) {
-  const uint32_t nblk = (n + GM_BK_TILE - 1) / GM_BK_TILE;
+                     bool zero_acc_after, int debug, hipStream_t s) {
+  constexpr uint32_t TILE = WAVES * BK_ROUNDS * 64;
+  const uint32_t nblk = (n + TILE - 1) / TILE;
   const uint32_t nchunks = (nblk + BK_CHUNK - 1) / BK_CHUNK;
-  hipLaunchKernelGGL((bk_hist_kernel<false, DB>), dim3(nblk), dim3(BK_THREADS), 0, s, b.keys[from], n, n_dev, ds, nullptr, b.hist, g.counters);
+  hipLaunchKernelGGL((bk_hist_kernel<false, DB, WAVES>), dim3(nblk), dim3(WAVES * 64), 0, s, b.pairs[from], n, n_dev, ds, nullptr, b.hist, b.acc,
+                     g.counters);
   GM_LAUNCH_CHECK(debug, s);
-  hipLaunchKernelGGL((bk_scan_kernel<false, DB>), dim3(nchunks ? nchunks : 1, (1 << DB) / 256), dim3(BK_THREADS), 0, s, b.hist, n, n_dev, nullptr,
-                     b.chunk_total, b.digit_base, b.digit_total, g.counters, ranges, nranges);
+  hipLaunchKernelGGL((bk_scan_kernel<false, DB>), dim3(nchunks ? nchunks : 1, (1 << DB) / 256), dim3(BK_THREADS), 0, s, b.hist, TILE, n, n_dev, nullptr,
+                     b.acc, nullptr, g.counters, ranges, nranges);
   GM_LAUNCH_CHECK(debug, s);
-  hipLaunchKernelGGL((bk_scatter_kernel<false, false, DB>), dim3(nblk), dim3(BK_THREADS), 0, s, b.keys[from], b.vals[from], b.keys[from ^ 1],
-                     b.vals[from ^ 1], n, n_dev, ds, nullptr, b.hist, b.chunk_total, b.digit_base);
+  hipLaunchKernelGGL((bk_scatter_kernel<false, DB, WAVES>), dim3(nblk), dim3(WAVES * 64), 0, s, b.pairs[from], b.pairs[from ^ 1], n, n_dev, ds, nullptr,
+                     b.hist, zero_acc_after ? b.acc : nullptr, (uint32_t)bk_acc_words(n));
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }
 
+// Tile sort of the instance stream b.pairs[0] (n instances; n_dev != nullptr: the count is read on the device and n is the
+// capacity).  tiles <= 2048: one 11-bit pass, result in pairs[1], ranges written by the scan.  Otherwise two 8-bit
+// passes, result in pairs[0], ranges by tile_ranges_kernel (caller).  duplicate_kernel has zeroed b.acc.
 int launch_tile_sort(GeomState& g, BinningState& b, ImageState& img, size_t n, const uint32_t* n_dev, int tiles, int debug, hipStream_t s) {
   StageScope sc(ST_TILE_SORT, s);
   if (n == 0) {
@@ -606,10 +639,16 @@ int launch_tile_sort(GeomState& g, BinningState& b, ImageState& img, size_t n, c
     return 0;
   }
   if (n > 0xFFFFF000ull) { set_error("tile sort: too many instances"); return 1; }
-  if (tiles <= (1 << GM_BUCKET_BITS))
-    return tile_pass<GM_BUCKET_BITS>(b, g, 0, (uint32_t)n, n_dev, DigitSpec{0u, 0u, (1u << GM_BUCKET_BITS) - 1u}, img.ranges, (uint32_t)tiles, debug, s);
-  if (int rc = tile_pass<8>(b, g, 0, (uint32_t)n, n_dev, DigitSpec{0u, 0u, 0xFFu}, nullptr, 0u, debug, s)) return rc;
-  return tile_pass<8>(b, g, 1, (uint32_t)n, n_dev, DigitSpec{0u, 8u, 0xFFu}, nullptr, 0u, debug, s);
+  // below ~0.5 M instances 16-wave workgroups would leave most of the chip idle: 4-wave ones
+  if (tiles <= (1 << GM_BUCKET_BITS)) {
+    if (n <= (size_t(1) << 19))
+      return tile_pass<GM_BUCKET_BITS, 4>(b, g, 0, (uint32_t)n, n_dev, DigitSpec{0u, 0u, (1u << GM_BUCKET_BITS) - 1u}, img.ranges, (uint32_t)tiles,
+                                          false, debug, s);
+    return tile_pass<GM_BUCKET_BITS, GM_TILE_PASS_WAVES>(b, g, 0, (uint32_t)n, n_dev, DigitSpec{0u, 0u, (1u << GM_BUCKET_BITS) - 1u}, img.ranges, (uint32_t)tiles,
+                                         false, debug, s);
+  }
+  if (int rc = tile_pass<8, 4>(b, g, 0, (uint32_t)n, n_dev, DigitSpec{0u, 0u, 0xFFu}, nullptr, 0u, true, debug, s)) return rc;
+  return tile_pass<8, 4>(b, g, 1, (uint32_t)n, n_dev, DigitSpec{0u, 8u, 0xFFu}, nullptr, 0u, false, debug, s);
 }
 
 }  // namespace gm

@@ -74,6 +74,8 @@ static inline size_t sort_chunk_counters(size_t n) { return 256 * ((sort_blocks(
 #define GM_BK_CHUNK 32               // histogram rows per scan workgroup
 static inline size_t bk_blocks(size_t n) { return (n + GM_BK_TILE - 1) / GM_BK_TILE; }
 static inline size_t bk_chunks(size_t n) { return (bk_blocks(n) + GM_BK_CHUNK - 1) / GM_BK_CHUNK; }
+#define GM_ACC_SLOTS 512             // accumulators of a pass: [8 digit groups][64] group-sum slots, then chunk_total [chunks][2048]
+static inline size_t bk_acc_words(size_t n) { return GM_ACC_SLOTS + (bk_chunks(n) << GM_BUCKET_BITS); }
 // device scalars (GeomState::counters)
 #define GM_CNT_RENDERED 0            // num_rendered (instance total of this forward)
 #define GM_CNT_POLICY 2              // emission policy the counts were made under
@@ -91,16 +93,16 @@ struct GeomState {              // per-Gaussian state (P-sized)
                                 //     rectangles of <= 64 tiles, the bit mask (row-major) of the tiles actually emitted
   float* cov3D;                 // [P][6] (computed from scale/rot)
   uint8_t* clamped;             // [P] bit ch = SH colour channel ch was clamped at 0
-  uint32_t* depth_key[2];       // [P] [0]: float bits of view z per Gaussian (0xFFFFFFFF = culled); [1]: partitioned into buckets
-  uint32_t* order[2];           // [P] [1]: ids partitioned into buckets; [0]: ids of the VISIBLE Gaussians in (depth, id) order
+  uint32_t* depth_key;          // [P] float bits of view z per Gaussian (0xFFFFFFFF = culled)
+  uint2* dpairs[2];             // [P] (depth key, id): [1] partitioned into buckets, [0] scratch of an overfull bucket's sort
+  uint32_t* order;              // [P] ids of the VISIBLE Gaussians in (depth, id) order
   uint32_t* cnt_sorted;         // [P] tiles_touched in that order
-  uint32_t* hist;               // [bk_blocks(P)][2048] bucket histograms of the partition
-  uint32_t* chunk_total;        // [bk_chunks(P)][2048]
+  uint32_t* hist;               // [bk_blocks(P)][2048] bucket histograms of the partition -> absolute output offsets
   uint32_t* bucket_start;       // [2049] first sorted position of each bucket (+ total)
-  uint32_t* digit_total;        // [2048] bucket sizes
   uint32_t* bucket_inst;        // [2048] instances emitted by each bucket
-  uint32_t* slots;              // [GM_SLOTS][4], contiguous with counters: one memset re-arms both
+  uint32_t* slots;              // [GM_SLOTS][4]; slots, counters and acc are contiguous: one memset re-arms all three
   uint32_t* counters;           // [GM_CNT_COUNT] device scalars
+  uint32_t* acc;                // [bk_acc_words(P)] accumulators of the partition pass
   float* grad_acc;              // [P][12] backward accumulators: dcolor rgb | dmean2D xy | dconic x,y,w | dopacity | pad
   static GeomState from(void* buf, size_t P) {
     char* p = reinterpret_cast<char*>(buf);
@@ -112,22 +114,23 @@ struct GeomState {              // per-Gaussian state (P-sized)
     g.bin = carve<uint4>(p, P);
     g.cov3D = carve<float>(p, 6 * P);
     g.clamped = carve<uint8_t>(p, P);
-    g.depth_key[0] = carve<uint32_t>(p, P);
-    g.depth_key[1] = carve<uint32_t>(p, P);
-    g.order[0] = carve<uint32_t>(p, P);
-    g.order[1] = carve<uint32_t>(p, P);
+    g.depth_key = carve<uint32_t>(p, P);
+    g.dpairs[0] = carve<uint2>(p, P);
+    g.dpairs[1] = carve<uint2>(p, P);
+    g.order = carve<uint32_t>(p, P);
     g.cnt_sorted = carve<uint32_t>(p, P);
     g.hist = carve<uint32_t>(p, ND * bk_blocks(P));
-    g.chunk_total = carve<uint32_t>(p, ND * bk_chunks(P));
     g.bucket_start = carve<uint32_t>(p, ND + 1);
-    g.digit_total = carve<uint32_t>(p, ND);
     g.bucket_inst = carve<uint32_t>(p, ND);
-    g.slots = carve<uint32_t>(p, 4 * GM_SLOTS + GM_CNT_COUNT);     // 1 KiB of slots, counters right behind
+    g.slots = carve<uint32_t>(p, 4 * GM_SLOTS + GM_CNT_COUNT + bk_acc_words(P));
     g.counters = g.slots + 4 * GM_SLOTS;
+    g.acc = g.counters + GM_CNT_COUNT;
+    g.arm_words = 4 * GM_SLOTS + GM_CNT_COUNT + bk_acc_words(P);
     g.grad_acc = carve<float>(p, 12 * P);
     g.end = p;
     return g;
   }
+  size_t arm_words;
   char* end;
 };
 
@@ -150,25 +153,18 @@ struct ImageState {             // per-pixel / per-tile state
 };
 
 struct BinningState {           // per-instance state (R-sized)
-  uint32_t* keys[2];            // [R] list tile id | child mask << 16 per instance, ping-pong
-  uint32_t* vals[2];            // [R] Gaussian id per instance, ping-pong
-  uint32_t* hist;               // [bk_blocks(R)][2048]
-  uint32_t* chunk_total;        // [bk_chunks(R)][2048]
-  uint32_t* digit_base;         // [2049]
-  uint32_t* digit_total;        // [2048]
+  uint2* pairs[2];              // [R] (list tile id | child mask << 16, Gaussian id) per instance, ping-pong
+  uint32_t* hist;               // [bk_blocks(R)][2048] -> absolute output offsets
+  uint32_t* acc;                // [bk_acc_words(R)] accumulators of a tile pass (zeroed by duplicate_kernel)
   static BinningState from(void* buf, size_t R) {
     char* p = reinterpret_cast<char*>(buf);
     BinningState b;
     const size_t Rp = R ? R : 1;
     constexpr size_t ND = size_t(1) << GM_BUCKET_BITS;
-    b.keys[0] = carve<uint32_t>(p, Rp);
-    b.keys[1] = carve<uint32_t>(p, Rp);
-    b.vals[0] = carve<uint32_t>(p, Rp);
-    b.vals[1] = carve<uint32_t>(p, Rp);
+    b.pairs[0] = carve<uint2>(p, Rp);
+    b.pairs[1] = carve<uint2>(p, Rp);
     b.hist = carve<uint32_t>(p, ND * bk_blocks(Rp));
-    b.chunk_total = carve<uint32_t>(p, ND * bk_chunks(Rp));
-    b.digit_base = carve<uint32_t>(p, ND + 1);
-    b.digit_total = carve<uint32_t>(p, ND);
+    b.acc = carve<uint32_t>(p, bk_acc_words(Rp));
     b.end = p;
     return b;
   }
@@ -234,9 +230,9 @@ int launch_arm_counters(GeomState& g, hipStream_t s);                           
 int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, int tile_cull, size_t capacity, int debug, hipStream_t s);
 int launch_tile_sort(GeomState& g, BinningState& b, ImageState& img, size_t n, const uint32_t* n_dev, int tiles, int debug, hipStream_t s);
 int launch_tile_ranges(const GeomState& g, BinningState& b, int slot, ImageState& img, int R, const uint32_t* R_dev, int tiles, int debug, hipStream_t s);
-int launch_render_fwd(const GeomState& g, const uint32_t* tile_keys, const uint32_t* point_list, ImageState& img, int W, int H, int mode,
+int launch_render_fwd(const GeomState& g, const uint2* pairs, ImageState& img, int W, int H, int mode,
                       const float* background, float* out_color, int debug, hipStream_t s);
-int launch_render_bwd(const GeomState& g, const uint32_t* tile_keys, const uint32_t* point_list, ImageState& img, int W, int H, int mode,
+int launch_render_bwd(const GeomState& g, const uint2* pairs, ImageState& img, int W, int H, int mode,
                       const float* background, const float* dL_dpix, int debug, hipStream_t s);   // accumulates into g.grad_acc
 
 int launch_deform(int N, const int* tri, const float* w, const float* dV, const float* Rv, const float* Sv,

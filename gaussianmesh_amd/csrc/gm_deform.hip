@@ -597,7 +597,7 @@ int launch_deform_shade_pre(const RasterArgs& r, GeomState& g, int* radii, int d
   fp.cam.fy = r.H / (2.0f * r.tan_fovy); fp.cam.fx = r.W / (2.0f * r.tan_fovx);   // rasterizer_impl.cu:359-360
   fp.opac = r.opacities;
   fp.splat = g.splat; fp.radii_int = g.radii; fp.radii_out = radii; fp.tiles = g.tiles_touched; fp.bin = g.bin; fp.counters = g.counters; fp.slots = g.slots;
-  fp.clamped = g.clamped; fp.depth_key = g.depth_key[0];
+  fp.clamped = g.clamped; fp.depth_key = g.depth_key;
   const size_t lds_bytes = sizeof(float) * 64 * (48 + 9);
   hipLaunchKernelGGL(deform_shade_pre_kernel, dim3((N + 63) / 64), dim3(64), lds_bytes, r.stream, N, deg, tri, w, packed, cov, pos, shs,
                      r.cam_pos, pos_out, cov6_out, rgb_out, fp);

@@ -148,7 +148,7 @@ int launch_preprocess(const RasterArgs& r, GeomState& g, int* radii) {
   a.campos = r.cam_pos; a.mod = r.scale_modifier; a.tanx = r.tan_fovx; a.tany = r.tan_fovy;
   a.fy = r.H / (2.0f * r.tan_fovy); a.fx = r.W / (2.0f * r.tan_fovx);   // rasterizer_impl.cu:359-360
   a.splat = g.splat; a.radii_int = g.radii; a.radii_out = radii; a.tiles = g.tiles_touched; a.bin = g.bin; a.tile_cull = r.tile_cull; a.counters = g.counters; a.slots = g.slots; a.cov3D = g.cov3D;
-  a.clamped = g.clamped; a.depth_key = g.depth_key[0];
+  a.clamped = g.clamped; a.depth_key = g.depth_key;
   if (r.P > 0) {
     if (a.shs && a.M == 16 && aligned16(a.shs)) {
       if (getenv("GM_PRE_NO_DMA"))

@@ -91,8 +91,7 @@ __device__ __forceinline__ Batch load_records(const float4* __restrict__ splat, 
 
 
 __global__ __launch_bounds__(256) void render_fwd_kernel(const uint2* __restrict__ ranges,
-                                                               const uint32_t* __restrict__ tile_keys,
-                                                               const uint32_t* __restrict__ point_list,
+                                                               const uint2* __restrict__ pairs,
                                                                const float4* __restrict__ splat, int W, int H, TileMap tm,
                                                                const float* __restrict__ bg, float* __restrict__ out_color,
                                                                float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
@@ -102,8 +101,7 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const uint2* __restrict
   if (!tm.locate(blockIdx.x, tx, ty, parent, child_bit)) return;
   const uint2 range = ranges[parent];
   const int n = (int)(range.y - range.x);
-  const uint32_t* list = point_list + range.x;
-  const uint32_t* klist = tile_keys + range.x;
+  const uint2* list = pairs + range.x;           // (key, Gaussian id) per list entry
 
   const int px = QUAD ? tx * GM_TILE + (wave & 1) * 8 + (lane & 7) : tx * GM_TILE + (lane & 15);
   const float pixx = (float)px;
@@ -138,8 +136,8 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const uint2* __restrict
   // needed to issue the next gathers are here; the gathers issued last iteration may still be in flight".
   // An entry of the parent's list concerns this tile iff its key has the tile's child bit.
   const int nlast = n - 1;
-  auto ld_id = [&](int e) { return list[min(e, nlast)]; };
-  auto ld_mine = [&](int e) { const uint32_t kk = klist[min(e, nlast)]; return (e <= nlast) & ((kk & child_bit) != 0); };
+  auto ld_kv = [&](int e) { return list[min(e, nlast)]; };
+  auto is_mine = [&](uint2 kv, int e) { return (e <= nlast) & ((kv.x & child_bit) != 0); };
   auto ld_rec = [&](uint32_t id, bool m) { return load_records(splat, m ? id : 0u, true); };
   if (n <= 0) {                                   // empty list: background only
     const size_t HW_ = (size_t)H * W;
@@ -150,12 +148,13 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const uint2* __restrict
     }
     return;
   }
-  bool mine = ld_mine(lane);
-  Batch cur = ld_rec(ld_id(lane), mine);
-  bool mine_1 = ld_mine(64 + lane);
-  Batch nx1 = ld_rec(ld_id(64 + lane), mine_1);
-  uint32_t id_2 = ld_id(128 + lane);
-  bool mine_2 = ld_mine(128 + lane);
+  const uint2 kv0 = ld_kv(lane), kv1 = ld_kv(64 + lane), kv2 = ld_kv(128 + lane);
+  bool mine = is_mine(kv0, lane);
+  Batch cur = ld_rec(kv0.y, mine);
+  bool mine_1 = is_mine(kv1, 64 + lane);
+  Batch nx1 = ld_rec(kv1.y, mine_1);
+  uint32_t id_2 = kv2.y;
+  bool mine_2 = is_mine(kv2, 128 + lane);
   const float qx0 = rx0, qy0 = ry0;
   for (int base = 0; base < n; base += 64) {
     bool all_done = true;
@@ -176,8 +175,9 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const uint2* __restrict
       cy1 = qy0 + (float)((63 - __clzll((long long)live)) >> 3);
     }
     __builtin_amdgcn_s_waitcnt(0x0F73);                                    // vmcnt(3)
-    const uint32_t id_3 = ld_id(base + 192 + lane);                        // ids / keys three batches ahead ...
-    const bool mine_3 = ld_mine(base + 192 + lane);
+    const uint2 kv3 = ld_kv(base + 192 + lane);                            // (key, id) pairs three batches ahead ...
+    const uint32_t id_3 = kv3.y;
+    const bool mine_3 = is_mine(kv3, base + 192 + lane);
     const Batch nx2 = ld_rec(id_2, mine_2);                                // ... records two batches ahead
     const bool keep = mine && may_touch(cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, cx0, cx1, cy0, cy1);
     // staged record: the conic is stored pre-multiplied (lane-parallel, 3 multiplies per 64 entries) so that the
@@ -261,13 +261,13 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const uint2* __restrict
   }
 }
 
-int launch_render_fwd(const GeomState& g, const uint32_t* tile_keys, const uint32_t* point_list, ImageState& img, int W, int H, int mode,
+int launch_render_fwd(const GeomState& g, const uint2* pairs, ImageState& img, int W, int H, int mode,
                       const float* background, float* out_color, int debug, hipStream_t s) {
   StageScope sc(ST_RENDER, s);
   const TileGrid tg(W, H, mode);
   const TileMap tm{tg.gx, tg.gy, tg.pgx, tg.pgy, tg.s};
   if (tg.ptiles > 0)
-    hipLaunchKernelGGL(render_fwd_kernel, dim3(tm.blocks()), dim3(256), 0, s, img.ranges, tile_keys, point_list, g.splat, W, H, tm,
+    hipLaunchKernelGGL(render_fwd_kernel, dim3(tm.blocks()), dim3(256), 0, s, img.ranges, pairs, g.splat, W, H, tm,
                        background, out_color, img.final_T, img.n_contrib);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
@@ -334,8 +334,7 @@ __device__ __forceinline__ int reduce8_slot(int lane) {
 #define GM_ACC_STRIDE 12   // floats per Gaussian in grad_acc: dcolor rgb (0-2), moments of h: 1, dx, dy, dx^2, dx dy, dy^2 (3-8)
 
 __global__ __launch_bounds__(256) void render_bwd_kernel(const uint2* __restrict__ ranges,
-                                                               const uint32_t* __restrict__ tile_keys,
-                                                               const uint32_t* __restrict__ point_list,
+                                                               const uint2* __restrict__ pairs,
                                                                const float4* __restrict__ splat, int W, int H, TileMap tm,
                                                                const float* __restrict__ bg, const float* __restrict__ final_T,
                                                                const uint32_t* __restrict__ n_contrib,
@@ -344,13 +343,12 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const uint2* __restrict
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int tx, ty, parent;
   uint32_t child_bit;
-  if ((int)counters[2] != mode || counters[3] != 0u) return;   // lists were built under another emission policy: contribute nothing
+  if ((int)counters[GM_CNT_POLICY] != mode || counters[GM_CNT_REFUSED] != 0u) return;   // lists were built under another emission policy: contribute nothing
   if (!tm.locate(blockIdx.x, tx, ty, parent, child_bit)) return;
   const uint2 range = ranges[parent];
   const int n = (int)(range.y - range.x);
   if (n == 0) return;
-  const uint32_t* list = point_list + range.x;
-  const uint32_t* klist = tile_keys + range.x;
+  const uint2* list = pairs + range.x;           // (key, Gaussian id) per list entry
   const size_t HW = (size_t)H * W;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 
@@ -392,15 +390,16 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const uint2* __restrict
   float4 (*rec)[3] = l_rec[wave];
   // batch b covers list positions start-1-b*64-j (j = lane), i.e. back to front; same three-deep gather pipeline and
   // constant load count per iteration as render_fwd_kernel (positions below 0 re-read entry 0 and are not "mine")
-  auto ld_id = [&](int e) { return list[max(e, 0)]; };
-  auto ld_mine = [&](int e) { const uint32_t kk = klist[max(e, 0)]; return (e >= 0) & ((kk & child_bit) != 0); };
+  auto ld_kv = [&](int e) { return list[max(e, 0)]; };
+  auto is_mine = [&](uint2 kv, int e) { return (e >= 0) & ((kv.x & child_bit) != 0); };
   auto ld_rec = [&](uint32_t id, bool m) { return load_records(splat, m ? id : 0u, true); };
-  bool mine = ld_mine(start - 1 - lane);
-  Batch cur = ld_rec(ld_id(start - 1 - lane), mine);
-  bool mine_1 = ld_mine(start - 1 - 64 - lane);
-  Batch nx1 = ld_rec(ld_id(start - 1 - 64 - lane), mine_1);
-  uint32_t id_2 = ld_id(start - 1 - 128 - lane);
-  bool mine_2 = ld_mine(start - 1 - 128 - lane);
+  const uint2 kv0 = ld_kv(start - 1 - lane), kv1 = ld_kv(start - 1 - 64 - lane), kv2 = ld_kv(start - 1 - 128 - lane);
+  bool mine = is_mine(kv0, start - 1 - lane);
+  Batch cur = ld_rec(kv0.y, mine);
+  bool mine_1 = is_mine(kv1, start - 1 - 64 - lane);
+  Batch nx1 = ld_rec(kv1.y, mine_1);
+  uint32_t id_2 = kv2.y;
+  bool mine_2 = is_mine(kv2, start - 1 - 128 - lane);
   for (int base = 0; base < start; base += 64) {
     // A pixel takes part in this batch only if its last contributor lies above the batch's lowest position: cull
     // against the bounding box of those pixels (at the deep end of the walk only the few pixels that reached far
@@ -418,8 +417,9 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const uint2* __restrict
       }
     }
     __builtin_amdgcn_s_waitcnt(0x0F73);                                    // vmcnt(3)
-    const uint32_t id_3 = ld_id(start - 1 - (base + 192) - lane);
-    const bool mine_3 = ld_mine(start - 1 - (base + 192) - lane);
+    const uint2 kv3 = ld_kv(start - 1 - (base + 192) - lane);
+    const uint32_t id_3 = kv3.y;
+    const bool mine_3 = is_mine(kv3, start - 1 - (base + 192) - lane);
     const Batch nx2 = ld_rec(id_2, mine_2);
     const bool keep = mine && may_touch(cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, cx0, cx1, cy0, cy1);
     // conic pre-multiplied for the exp2 argument, as in render_fwd_kernel (the moments below only need dx, dy)
@@ -487,13 +487,13 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const uint2* __restrict
   }
 }
 
-int launch_render_bwd(const GeomState& g, const uint32_t* tile_keys, const uint32_t* point_list, ImageState& img, int W, int H, int mode,
+int launch_render_bwd(const GeomState& g, const uint2* pairs, ImageState& img, int W, int H, int mode,
                       const float* background, const float* dL_dpix, int debug, hipStream_t s) {
   StageScope sc(ST_RENDER_BWD, s);
   const TileGrid tg(W, H, mode);
   const TileMap tm{tg.gx, tg.gy, tg.pgx, tg.pgy, tg.s};
   if (tg.ptiles > 0)
-    hipLaunchKernelGGL(render_bwd_kernel, dim3(tm.blocks()), dim3(256), 0, s, img.ranges, tile_keys, point_list, g.splat, W, H, tm,
+    hipLaunchKernelGGL(render_bwd_kernel, dim3(tm.blocks()), dim3(256), 0, s, img.ranges, pairs, g.splat, W, H, tm,
                        background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc, g.counters, mode);
   GM_LAUNCH_CHECK(debug, s);
   return 0;

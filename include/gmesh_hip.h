@@ -140,7 +140,8 @@ int gm_mark_visible(int P, const float* means3D, const float* viewmatrix, const 
  *            "clamped" uint8[P] (bit ch set = channel ch clamped), "order" uint32[V] (ids of the V visible Gaussians
  *            in (depth, id) order; V = "bucket_start"[2048]), "bucket_start" uint32[2049]
  *   image:   "final_T" float[H*W], "n_contrib" uint32[H*W], "ranges" uint32[T][2]
- *   binning: "point_list" uint32[R], "tile_keys" uint32[R] (sorted tile id per instance) */
+ *   binning: "pairs" uint32[R][2] = (list tile id | child mask << 16, Gaussian id) per instance, sorted by tile then
+ *            (depth, id): column 1 is the reference's point_list, column 0 its sorted tile keys */
 void* gm_geom_field(void* geom_buffer, int P, const char* name);
 void* gm_image_field(void* image_buffer, int W, int H, const char* name);
 void* gm_binning_field(void* binning_buffer, int64_t R, int W, int H, int emission_policy, const char* name);

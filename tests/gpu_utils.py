@@ -73,9 +73,10 @@ def forward_state(scene, cam, bg, D=3, use_precomp_cov=False, use_precomp_color=
     out["n_contrib"] = _view(img, ip("n_contrib"), W * H, torch.int32).astype(np.uint32)
     out["ranges"] = _view(img, ip("ranges"), tiles * 2, torch.int32).astype(np.uint32).reshape(tiles, 2)
     if nr > 0:
-        bp = lambda n: lib.gm_binning_field(binning.data_ptr(), nr, W, H, mode, n.encode())
-        out["point_list"] = _view(binning, bp("point_list"), nr, torch.int32).astype(np.uint32)
-        out["tile_keys"] = _view(binning, bp("tile_keys"), nr, torch.int32).astype(np.uint32)
+        pp = lib.gm_binning_field(binning.data_ptr(), nr, W, H, mode, b"pairs")
+        pairs = _view(binning, pp, 2 * nr, torch.int32).astype(np.uint32).reshape(nr, 2)       # (key, Gaussian id) per instance, tile-sorted
+        out["point_list"] = np.ascontiguousarray(pairs[:, 1])
+        out["tile_keys"] = np.ascontiguousarray(pairs[:, 0])
     else:
         out["point_list"] = np.zeros(0, np.uint32)
         out["tile_keys"] = np.zeros(0, np.uint32)

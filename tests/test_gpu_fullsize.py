@@ -239,7 +239,7 @@ def test_c3_bench_path_full_size_vs_oracle(oracle):
             if mode == 0:
                 from gpu_utils import _view
                 from gaussianmesh_amd import _lib
-                plist = _view(binning, _lib.lib().gm_binning_field(binning.data_ptr(), nr, W, H, 0, b"point_list"), nr, torch.int32).astype(np.uint32)
+                plist = _view(binning, _lib.lib().gm_binning_field(binning.data_ptr(), nr, W, H, 0, b"pairs"), 2 * nr, torch.int32).astype(np.uint32)[1::2]
         set_policy(2)
         assert np.array_equal(out[0][1], out[2][1]) and np.array_equal(out[0][2], out[2][2]) and out[2][0] < out[0][0]
         pos_d, cov6_d, rgb_d = out[2][3]
