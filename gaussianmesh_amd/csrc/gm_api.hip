@@ -198,6 +198,7 @@ int gm_forward_1_geom(int emission_policy, void* geom_buffer, void* binning_buff
   } else {
     GM_HIP(hipMemsetAsync(img.ranges, 0, sizeof(uint2) * (size_t)tiles, st));
   }
+  if (int rc = launch_tile_order(img, tiles, debug, st)) return rc;
   return launch_render_fwd(g, b.pairs[slot], img, width, height, mode, background, out_color, debug, st);
 }
 

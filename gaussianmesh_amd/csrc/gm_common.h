@@ -138,6 +138,7 @@ struct ImageState {             // per-pixel / per-tile state
   float* final_T;               // [H*W]
   uint32_t* n_contrib;          // [H*W]
   uint2* ranges;                // [tiles]
+  uint32_t* tile_order;         // [tiles] list tiles by descending list length (the blend kernels' dispatch order)
   static ImageState from(void* buf, int W, int H) {
     char* p = reinterpret_cast<char*>(buf);
     const size_t N = (size_t)W * H;
@@ -146,6 +147,7 @@ struct ImageState {             // per-pixel / per-tile state
     s.final_T = carve<float>(p, N);
     s.n_contrib = carve<uint32_t>(p, N);
     s.ranges = carve<uint2>(p, T);
+    s.tile_order = carve<uint32_t>(p, T);
     s.end = p;
     return s;
   }
@@ -230,6 +232,7 @@ int launch_arm_counters(GeomState& g, hipStream_t s);                           
 int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, int tile_cull, size_t capacity, int debug, hipStream_t s);
 int launch_tile_sort(GeomState& g, BinningState& b, ImageState& img, size_t n, const uint32_t* n_dev, int tiles, int debug, hipStream_t s);
 int launch_tile_ranges(const GeomState& g, BinningState& b, int slot, ImageState& img, int R, const uint32_t* R_dev, int tiles, int debug, hipStream_t s);
+int launch_tile_order(ImageState& img, int tiles, int debug, hipStream_t s);          // ranges -> tile_order
 int launch_render_fwd(const GeomState& g, const uint2* pairs, ImageState& img, int W, int H, int mode,
                       const float* background, float* out_color, int debug, hipStream_t s);
 int launch_render_bwd(const GeomState& g, const uint2* pairs, ImageState& img, int W, int H, int mode,
