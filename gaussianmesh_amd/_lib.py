@@ -49,6 +49,7 @@ SIGNATURES = {
     "gm_forward_status_async": (i32, [vp, i32, vp, vp]),
     "gm_deform_shade_packed": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gm_cov_to_scale_rot": (i32, [i32, vp, vp, vp, vp]),
+    "gm_mesh_rs": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gm_mesh_activate_fwd": (i32, [i32, f32] + [vp] * 10 + [vp] * 4 + [f32, vp] + [vp]),
     "gm_mesh_activate_bwd": (i32, [i32, f32] + [vp] * 10 + [vp] * 4 + [vp] * 5 + [f32, vp] + [vp]),
     "gm_adam_step": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, i32, vp]),

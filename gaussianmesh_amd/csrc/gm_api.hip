@@ -375,6 +375,15 @@ int gm_deform_shade_packed(int N, int deg, int M, const int* tri, const float* w
                                     reinterpret_cast<hipStream_t>(stream));
 }
 
+int gm_mesh_rs(int Vm, int nfaces, const float* V0, const float* V1, const int* faces, const int* adj_offsets, const int* adj_faces,
+               float* R, float* S, float* state, void* stream) {
+  if (Vm < 0 || nfaces < 0 || (Vm > 0 && (!V0 || !V1 || !adj_offsets || (nfaces > 0 && (!faces || !adj_faces)) || (!R && !S && !state)))) {
+    set_error("gm_mesh_rs: bad args"); return GM_ERR_INVALID_ARG;
+  }
+  if ((R == nullptr) != (S == nullptr)) { set_error("gm_mesh_rs: pass R and S together"); return GM_ERR_INVALID_ARG; }
+  return launch_mesh_rs(Vm, V0, V1, faces, adj_offsets, adj_faces, R, S, state, reinterpret_cast<hipStream_t>(stream));
+}
+
 int gm_cov_to_scale_rot(int N, const float* cov, float* scales, float* rots, void* stream) {
   if (N < 0 || (N > 0 && (!cov || !scales || !rots))) { set_error("gm_cov_to_scale_rot: bad args"); return GM_ERR_INVALID_ARG; }
   if (N > 0 && (reinterpret_cast<uintptr_t>(rots) & 15)) { set_error("gm_cov_to_scale_rot: rots must be 16-byte aligned"); return GM_ERR_INVALID_ARG; }

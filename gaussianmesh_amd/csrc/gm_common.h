@@ -253,6 +253,8 @@ int launch_deform_shade_packed(int N, int deg, int M, const int* tri, const floa
                                const float* pos, const float* shs, const float* campos, float* pos_out, float* cov6_out,
                                float* rgb_out, float* cov_out, float* rot_out, hipStream_t s);
 int launch_cov_to_scale_rot(int N, const float* cov, float* scales, float* rots, hipStream_t s);
+int launch_mesh_rs(int Vm, const float* V0, const float* V1, const int* faces, const int* adj_offsets, const int* adj_faces, float* R,
+                   float* S, float* state, hipStream_t s);
 int launch_ssim_fwd(const float* img1, const float* img2, int planes, int H, int W, float* d_mu1, float* d_e11, float* d_e12,
                     float* partial, hipStream_t s);
 int launch_ssim_bwd(const float* img1, const float* img2, const float* d_mu1, const float* d_e11, const float* d_e12, int planes,

@@ -139,6 +139,46 @@ def cov_to_scale_rot(cov):
     return scales, rots
 
 
+def vertex_face_adjacency(faces, Vm):
+    """CSR list of the faces incident to each vertex: (offsets int32 [Vm+1], face ids int32 [3F]), host side, once per mesh."""
+    import numpy as np
+    f = np.asarray(faces.detach().cpu() if hasattr(faces, "detach") else faces, dtype=np.int64).reshape(-1, 3)
+    vid = f.reshape(-1)
+    fid = np.repeat(np.arange(f.shape[0], dtype=np.int64), 3)
+    order = np.argsort(vid, kind="stable")
+    counts = np.bincount(vid, minlength=Vm)
+    offsets = np.zeros(Vm + 1, np.int64)
+    np.cumsum(counts, out=offsets[1:])
+    return offsets.astype(np.int32), fid[order].astype(np.int32)
+
+
+def mesh_rs(rest_vertices, deformed_vertices, faces, adjacency=None, want_state=False):
+    """gm_mesh_rs: per-vertex (R, S) [Vm,3,3] of a deformed proxy mesh, the pair pyACAP.GetRS hands to
+    SingleObjectDeform.deform_gaussian (edittool/__init__.py:109-113): per-face TBN deformation gradients, rest-area
+    weighted per vertex, polar decomposition; R in pyACAP's row-vector convention (the transpose of the rotation).
+    adjacency: (offsets, face ids) device int32 tensors from vertex_face_adjacency (built here when None).
+    want_state: also return the frame record [Vm,21] = V1 | R | S that pack_mesh_state consumes."""
+    lib = _lib.lib()
+    device = rest_vertices.device
+    if device.type != "cuda":
+        raise _lib.GmeshError("mesh_rs needs tensors on a HIP (cuda) device; there is no CPU path")
+    V0, V1 = _f(rest_vertices), _f(deformed_vertices)
+    Vm = V0.shape[0]
+    faces = faces.detach().contiguous().to(torch.int32)
+    if adjacency is None:
+        off, adj = vertex_face_adjacency(faces, Vm)
+        adjacency = (torch.tensor(off, device=device), torch.tensor(adj, device=device))
+    off, adj = adjacency
+    R = torch.empty((Vm, 3, 3), dtype=torch.float32, device=device)
+    S = torch.empty((Vm, 3, 3), dtype=torch.float32, device=device)
+    state = torch.empty((Vm, 21), dtype=torch.float32, device=device) if want_state else None
+    with torch.cuda.device(device):
+        _lib.check(lib.gm_mesh_rs(Vm, faces.shape[0], V0.data_ptr(), V1.data_ptr(), faces.data_ptr(), off.data_ptr(), adj.data_ptr(),
+                                  R.data_ptr(), S.data_ptr(), None if state is None else state.data_ptr(),
+                                  torch.cuda.current_stream(device).cuda_stream))
+    return (R, S, state) if want_state else (R, S)
+
+
 class SingleObjectDeform:
     """Tensor-in counterpart of edittool.SingleObjectDeform.
 

@@ -168,9 +168,10 @@ def bind_cloud_to_mesh(P, verts, faces, seed=0, M=16, alpha_distance=4.0):
 
 def twist_bend_frame(verts, t, period=64):
     """Analytic twist about +y: phi(p) = Rot_y(a*y) p, a = 0.5 sin(2 pi t / period).
-    Returns deformed verts V1 and per-vertex (R, S) from the polar decomposition of the analytic
-    Jacobian F = Rot_y(theta) + a (Rot_y'(theta) p) e_y^T  (stand-in for pyACAP GetRS, whose
-    arithmetic is not in the reference tree - SURVEY.md 8c)."""
+    Returns deformed verts V1 and per-vertex (R, S) from the polar decomposition F = Q S of the analytic Jacobian
+    F = Rot_y(theta) + a (Rot_y'(theta) p) e_y^T, with R = Q^T: the row-vector convention in which the reference's
+    deform_gaussian takes pyACAP's GetRS output (it transposes the blended R and transforms covariances by R^T S,
+    edittool/__init__.py:118-129, which is F C F^T).  gm_mesh_rs computes the same pair from the mesh itself."""
     a = 0.5 * math.sin(2 * math.pi * t / period)
     th = a * verts[:, 1]
     c, s = np.cos(th), np.sin(th)
@@ -182,6 +183,6 @@ def twist_bend_frame(verts, t, period=64):
     Fm = Rot.copy()
     Fm[:, :, 1] += a * np.einsum("nij,nj->ni", dRot, verts)
     U, sig, Vt = np.linalg.svd(Fm)
-    Rp = U @ Vt
+    Q = U @ Vt
     Sp = Vt.transpose(0, 2, 1) @ (sig[:, :, None] * Vt)
-    return V1, Rp, Sp
+    return V1, np.ascontiguousarray(Q.transpose(0, 2, 1)), Sp

@@ -216,6 +216,19 @@ int gm_forward_1_geom(int emission_policy, void* geom_buffer, void* binning_buff
                       int64_t binning_capacity, const float* background, int width, int height, float* out_color, int debug, void* stream);
 int gm_forward_status_async(void* geom_buffer, int P, int* status_host, void* stream);
 
+/* Per-vertex rotation / stretch of a deformed proxy mesh: replaces pyACAP.GetRS(rest vertices, deformed vertices, ...) at
+ * edittool/__init__.py:102, 109 (pyACAP is a binary missing from the reference tree, so the contract is the one its call
+ * site implies).  V0 / V1 float [Vm,3] rest / deformed vertices, faces int32 [nfaces,3], adj_offsets int32 [Vm+1] and
+ * adj_faces int32 [3 nfaces]: CSR list of the faces incident to each vertex (built once per mesh by the caller).
+ * Per face the deformation gradient maps the rest TBN frame (two edges + unit normal) to the deformed one; per vertex the
+ * rest-area-weighted average F of its faces' gradients is split by polar decomposition F = Q S (Q proper rotation, S
+ * symmetric).  Outputs, row-major [Vm,3,3]: R = Q^T (the row-vector convention deform_gaussian expects: it uses
+ * gaussian_deform_rot = blend(R)^T and transforms covariances by R^T S, edittool/__init__.py:118-129) and S.
+ * state (optional, float [Vm,21]) receives V1 | R | S per vertex - the frame record gm_pack_mesh_state consumes.
+ * R and S: both or neither; at least one of (R, S) / state. */
+int gm_mesh_rs(int Vm, int nfaces, const float* V0, const float* V1, const int* faces, const int* adj_offsets, const int* adj_faces,
+               float* R, float* S, float* state, void* stream);
+
 /* Covariance -> (scale, rotation): replaces the per-frame eigh + host-side det sign + sqrt + matrix->quaternion of
  * SceneVisualTool.render_gaussian (edittool/__init__.py:204-207, 23-38).  cov float [N,3,3] (symmetric),
  * scales float [N,3] = sqrt of the eigenvalues in ascending order, rots float [N,4] = unit quaternion (w,x,y,z) of the

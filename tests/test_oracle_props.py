@@ -95,3 +95,23 @@ def test_twist_frames_are_polar_decompositions():
     assert np.allclose(np.linalg.det(R), 1.0)
     V0, R0, S0 = scenes.twist_bend_frame(verts, t=0)
     assert np.allclose(V0, verts) and np.allclose(R0, np.eye(3)) and np.allclose(S0, np.eye(3))
+
+
+def test_mesh_rs_oracle_invariants():
+    """oracle/mesh_oracle.py (the checker of gm_mesh_rs): identity, rigid motion, uniform scale, affine map."""
+    from oracle import mesh_oracle
+    from gaussianmesh_amd import scenes
+    verts, faces = scenes.torus_mesh(24, 16)
+    I = np.eye(3)
+    R, S = mesh_oracle.mesh_rs(verts, verts, faces)
+    assert np.abs(R - I).max() <= 1e-12 and np.abs(S - I).max() <= 1e-12
+    c, s = np.cos(0.8), np.sin(0.8)
+    Q = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+    R, S = mesh_oracle.mesh_rs(verts, verts @ Q.T + 3.0, faces)
+    assert np.abs(R - Q.T).max() <= 1e-10 and np.abs(S - I).max() <= 1e-10
+    R, S = mesh_oracle.mesh_rs(verts, 0.6 * verts, faces)
+    assert np.abs(R - I).max() <= 1e-10 and np.abs(S - 0.6 * I).max() <= 1e-10
+    A = Q @ np.array([[1.3, 0.2, 0.0], [0.0, 0.9, 0.1], [0.1, 0.0, 1.2]])
+    R, S = mesh_oracle.mesh_rs(verts, verts @ A.T, faces)
+    assert np.abs(np.einsum("nji,njk->nik", R, S) - A).max() <= 1e-8
+    assert np.abs(np.linalg.det(R) - 1).max() <= 1e-10 and np.abs(S - S.transpose(0, 2, 1)).max() <= 1e-12
