@@ -6,6 +6,10 @@
                               #   gaussian_renderer.diff_gaussian_rasterizater -> gaussianmesh_amd.rasterizer
                               #   scene.simple_knn (distCUDA2)                 -> gaussianmesh_amd.simple_knn
                               #   utils.loss_utils l1_loss / ssim              -> gaussianmesh_amd.loss  (opt-in, see install)
+    compat.install(edit_tool=True)   # additionally, for edit.py: `from edittool import ObjectVisualTool, SceneVisualTool`
+                              # resolves to gaussianmesh_amd.edittool (the reference's package needs igl, plyfile and
+                              # the pyACAP binary), and `from render_origin import save_image` (a module missing from the
+                              # reference tree) to gaussianmesh_amd.io.save_image
 
 Only the ~60 symbols the in-scope reference python uses are provided; anything else raises
 AttributeError naming the symbol.  A real Jittor installation is never shadowed unless install(force=True).
@@ -18,9 +22,10 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def install(force=False, operators=True):
+def install(force=False, operators=True, edit_tool=False):
     """Make `import jittor` resolve to compat/jittor (unless a real Jittor is importable and force is False) and, with
-    operators=True, pre-register this package's operator modules under the reference's import paths."""
+    operators=True, pre-register this package's operator modules under the reference's import paths; edit_tool=True also
+    registers the file-based edit surface under the names edit.py imports."""
     have_real = False
     if "jittor" in sys.modules:
         have_real = not getattr(sys.modules["jittor"], "__gaussianmesh_compat__", False)
@@ -36,4 +41,11 @@ def install(force=False, operators=True):
         from .. import rasterizer, simple_knn
         sys.modules.setdefault("gaussian_renderer.diff_gaussian_rasterizater", rasterizer)
         sys.modules.setdefault("scene.simple_knn", simple_knn)
+    if edit_tool:
+        import types
+        from .. import edittool, io as gio
+        sys.modules["edittool"] = edittool
+        ro = types.ModuleType("render_origin")
+        ro.save_image = gio.save_image
+        sys.modules["render_origin"] = ro
     return sys.modules["jittor"]

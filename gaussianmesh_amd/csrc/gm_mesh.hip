@@ -8,7 +8,7 @@
 //   per vertex i the affine map of its one-ring, T_i = argmin sum_{j in N(i)} c_ij |(p'_i - p'_j) - T (p_i - p_j)|^2 with
 //   cotangent weights c_ij, i.e. T_i = (sum c e' e^T)(sum c e e^T)^-1, then the polar decomposition T_i = Q_i S_i
 //   (Q proper rotation, S symmetric).
-// Conditioning: negative cotangents are clamped to a small positive weight, and both sums get a tiny (1e-6 of the trace)
+// Conditioning: negative cotangents are clamped to a small positive weight, and both sums get a tiny (1e-9 of the trace)
 // term along the vertex normal - n n^T on the rest side, sqrt(area' / area) n' n^T on the deformed side - so that a planar
 // one-ring still yields a full-rank map (its normal direction then follows the deformed normal, scaled like a length).
 // For any affine deformation of a non-planar neighbourhood T_i is that affine map exactly: identity -> (I, I), rigid motion
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void mesh_rs_kernel(int Vm, const float* __res
   bool have = false;
   if (wsum > 0.0) {
     const double lr = sqrt(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]), ld = sqrt(nd[0] * nd[0] + nd[1] * nd[1] + nd[2] * nd[2]);
-    const double lam = 1e-6 * (M0[0][0] + M0[1][1] + M0[2][2]);
+    const double lam = 1e-9 * (M0[0][0] + M0[1][1] + M0[2][2]);
     if (lr > 1e-30 && ld > 1e-30) {
       const double sc = sqrt(ld / lr);                               // lengths scale like the square root of the area ratio
 #pragma unroll

@@ -103,6 +103,77 @@ def load_mesh_gaussians(path, max_sh_degree=3, bc_from_xyz=False):
                 features_rest=np.ascontiguousarray(f_rest), opacity=col["opacity"][:, None], scaling=scales, rotation=rots)
 
 
+PLAIN_ATTRS = ['x', 'y', 'z', 'nx', 'ny', 'nz']
+
+
+def save_plain_gaussians(path, m):
+    """The free-standing (background) Gaussian PLY of the reference: x y z nx ny nz f_dc_* f_rest_* opacity scale_* rot_*
+    (scene/gaussian_model.py save_ply; loaded by edittool/bg_gaussian.py:81-122).  m: xyz [P,3], features_dc [P,1,3],
+    features_rest [P,15,3], opacity [P,1], scaling [P,3], rotation [P,4] (all raw, pre-activation)."""
+    P = len(m["xyz"])
+    f_dc = np.asarray(m["features_dc"]).transpose(0, 2, 1).reshape(P, -1)
+    f_rest = np.asarray(m["features_rest"]).transpose(0, 2, 1).reshape(P, -1)
+    attrs = np.concatenate([m["xyz"], np.zeros((P, 3)), f_dc, f_rest, m["opacity"], m["scaling"], m["rotation"]], axis=1)
+    names = (PLAIN_ATTRS + ['f_dc_%d' % i for i in range(f_dc.shape[1])] + ['f_rest_%d' % i for i in range(f_rest.shape[1])] + ['opacity'] +
+             ['scale_%d' % i for i in range(np.asarray(m["scaling"]).shape[1])] + ['rot_%d' % i for i in range(np.asarray(m["rotation"]).shape[1])])
+    write_ply(path, {n: attrs[:, j] for j, n in enumerate(names)})
+
+
+def load_plain_gaussians(path, max_sh_degree=3):
+    """edittool/bg_gaussian.py:81-122 BGGaussianModel.load_ply."""
+    names, d = read_ply(path)
+    col = {n: d[:, j] for j, n in enumerate(names)}
+    st = lambda *ks: np.stack([col[k] for k in ks], axis=1)
+    xyz = st("x", "y", "z")
+    rest = sorted([n for n in names if n.startswith("f_rest_")], key=lambda n: int(n.split("_")[-1]))
+    assert len(rest) == 3 * (max_sh_degree + 1) ** 2 - 3
+    f_rest = st(*rest).reshape(len(xyz), 3, (max_sh_degree + 1) ** 2 - 1).transpose(0, 2, 1)
+    f_dc = st("f_dc_0", "f_dc_1", "f_dc_2").reshape(len(xyz), 3, 1).transpose(0, 2, 1)
+    scales = st(*sorted([n for n in names if n.startswith("scale_")], key=lambda n: int(n.split("_")[-1])))
+    rots = st(*sorted([n for n in names if n.startswith("rot")], key=lambda n: int(n.split("_")[-1])))
+    return dict(xyz=xyz, features_dc=np.ascontiguousarray(f_dc), features_rest=np.ascontiguousarray(f_rest), opacity=col["opacity"][:, None],
+                scaling=scales, rotation=rots)
+
+
+# ----------------------------------------------------------------------------------------------
+def read_obj(path):
+    """Triangle mesh from a Wavefront OBJ (what igl.read_triangle_mesh returns for the reference's proxy meshes,
+    edittool/__init__.py:66, 107): (vertices float64 [V,3], faces int32 [F,3]).  `v x y z` and `f a b c` records with
+    optional /vt/vn suffixes and negative (relative) indices; polygons are fan-triangulated; everything else is ignored."""
+    verts, faces = [], []
+    with open(path) as f:
+        for line in f:
+            tok = line.split()
+            if not tok:
+                continue
+            if tok[0] == "v":
+                verts.append((float(tok[1]), float(tok[2]), float(tok[3])))
+            elif tok[0] == "f":
+                idx = []
+                for t in tok[1:]:
+                    i = int(t.split("/")[0])
+                    idx.append(i - 1 if i > 0 else len(verts) + i)
+                for k in range(1, len(idx) - 1):
+                    faces.append((idx[0], idx[k], idx[k + 1]))
+    return np.asarray(verts, np.float64).reshape(-1, 3), np.asarray(faces, np.int32).reshape(-1, 3)
+
+
+def write_obj(path, vertices, faces):
+    with open(path, "w") as f:
+        for v in np.asarray(vertices, np.float64):
+            f.write("v %.17g %.17g %.17g\n" % (v[0], v[1], v[2]))
+        for t in np.asarray(faces, np.int64):
+            f.write("f %d %d %d\n" % (t[0] + 1, t[1] + 1, t[2] + 1))
+
+
+def save_image(img, path):
+    """[3,H,W] float image in [0,1] -> 8-bit PNG (the missing render_origin.save_image of edit.py:13)."""
+    from PIL import Image
+    a = np.asarray(img.detach().cpu() if hasattr(img, "detach") else img, np.float32)
+    a = (np.clip(a, 0.0, 1.0) * 255.0 + 0.5).astype(np.uint8).transpose(1, 2, 0)
+    Image.fromarray(a).save(path)
+
+
 # ----------------------------------------------------------------------------------------------
 def camera_to_json(cam_id, R, T, width, height, fovx, fovy, img_name=""):
     """utils/camera_utils.py:63-83 camera_to_JSON (R = camera-to-world rotation, T = world-to-camera translation)."""

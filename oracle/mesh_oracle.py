@@ -33,7 +33,7 @@ def mesh_rs(V0, V1, faces):
     R = np.tile(np.eye(3), (Vm, 1, 1)); S = np.tile(np.eye(3), (Vm, 1, 1))
     lr, ld = np.linalg.norm(nr, axis=1), np.linalg.norm(nd, axis=1)
     reg = (lr > 1e-30) & (ld > 1e-30)
-    lam = 1e-6 * np.trace(M0, axis1=1, axis2=2)
+    lam = 1e-9 * np.trace(M0, axis1=1, axis2=2)
     nru = nr / np.maximum(lr, 1e-300)[:, None]; ndu = nd / np.maximum(ld, 1e-300)[:, None]
     sc = np.sqrt(np.where(reg, ld / np.maximum(lr, 1e-300), 1.0))
     M0 = M0 + np.where(reg, lam, 0.0)[:, None, None] * nru[:, :, None] * nru[:, None, :]
