@@ -103,6 +103,8 @@ def main():
                          "independent, so frame i+1's per-Gaussian stages overlap the low-occupancy tail of frame i's blend")
     ap.add_argument("--exact-count", action="store_true", help="complete every frame with the instance count read back by the host "
                     "(gm_forward_1_geom's exact mode) instead of the sync-free mode")
+    ap.add_argument("--check-dir", default=None, help="every rank saves the image of its last timed step (with the step, frame and "
+                    "camera index) as <dir>/rank<r>.npz: lets a test verify that each rank rendered its own views")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fwd-bwd", action="store_true")
     args = ap.parse_args()
@@ -187,6 +189,7 @@ def main():
 
     def finish(h):
         out = h.finish(sync_free=not args.exact_count)
+        stats["last_image"] = out[1]
         unchecked.append(h)
         while len(unchecked) > 1:
             verify(unchecked.pop(0))
@@ -260,6 +263,11 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = multiview.max_over_ranks(elapsed, dev)
     fps = world * args.steps / elapsed
+    if args.check_dir:
+        last = args.warmup + args.steps - 1
+        os.makedirs(args.check_dir, exist_ok=True)
+        np.savez(os.path.join(args.check_dir, "rank%d.npz" % rank), step=last, frame=last % F, view=multiview.view_for_step(last, F, rank, world),
+                 image=stats["last_image"].cpu().numpy(), overflows=stats["overflows"])
 
     out = {
         "metric": "frames/sec (fwd), 1M Gaussians @1080p, deform+render", "value": fps, "unit": "frames/s",

@@ -38,6 +38,22 @@ def view_for_step(step, n_views, rank=None, world_size=None):
     return mine[step % len(mine)]
 
 
+def _staged(t):
+    """gloo moves host memory: device tensors are staged through the host (functional tests of the N>1 path on one GPU,
+    CPU tests); with RCCL (backend "nccl") the collective works on the device buffer itself."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def _broadcast(t, src):
+    if _staged(t):
+        h = t.detach().cpu()
+        dist.broadcast(h, src=src)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src)
+    return t
+
+
 def broadcast_cloud(tensors, src=0):
     """One-time broadcast of the shared cloud.  `tensors`: dict name -> tensor allocated with the right shape and
     dtype on every rank (contents only meaningful on `src`)."""
@@ -45,7 +61,7 @@ def broadcast_cloud(tensors, src=0):
     if ws == 1:
         return tensors
     for name in sorted(tensors):
-        dist.broadcast(tensors[name], src=src)
+        _broadcast(tensors[name], src)
     return tensors
 
 
@@ -53,7 +69,7 @@ def broadcast_mesh_state(state, src=0):
     """Per-frame broadcast of the packed mesh state [Vm, 21] = (V1 | R row-major | S row-major)."""
     rank, ws = world()
     if ws > 1:
-        dist.broadcast(state, src=src)
+        _broadcast(state, src)
     return state
 
 
@@ -66,7 +82,7 @@ def max_over_ranks(value, device):
     rank, ws = world()
     if ws == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
