@@ -88,8 +88,71 @@ def measured_traffic(stage, P, W, H):
     return int(1024 * (2 * e["fetch_kib"] + e["write_kib"]))
 
 
+def run_c5(args):
+    """BASELINE config C5 on this package's training harness: 3 M Gaussians (2 M bound to the 15 k-face torus + 1 M free
+    "background" Gaussians in a shell of radius 6-12), 3840x2160, iterations of {render, L1 + SSIM + mesh-restrict loss,
+    backward, FusedAdam on the six parameter groups, densification statistics} with cameras cycling over 32 poses and a fixed
+    random target.  One JSON line: ms per iteration, peak device memory, instance counts."""
+    import torch
+    from gaussianmesh_amd import rasterizer as Rz, scenes
+    from gaussianmesh_amd.renderer import Camera, MeshBoundGaussians
+    from gaussianmesh_amd.train import FrozenGaussians, Trainer
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    W, H = args.width if args.width != 1920 else 3840, args.height if args.height != 1080 else 2160
+    Nfg, Nbg = (2 * args.gaussians) // 3 if args.gaussians != 1_000_000 else 2_000_000, args.gaussians // 3 if args.gaussians != 1_000_000 else 1_000_000
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)
+    verts, faces = scenes.torus_mesh(100, 75)
+    cl = scenes.bind_cloud_to_mesh(Nfg, verts, faces, seed=0)
+    perm = np.argsort(cl["fid"], kind="stable")
+    tri = cl["tri"][perm]
+    v1, v2, v3 = (t(verts[tri[:, k]]) for k in range(3))
+    nrm = torch.nn.functional.normalize(torch.cross(v2 - v1, v3 - v1, dim=1), dim=1)
+    rad = (((v2 - v1).norm(dim=1) + (v3 - v2).norm(dim=1) + (v1 - v3).norm(dim=1)) / 3)[:, None]
+    shs = t(cl["shs"][perm])
+    model = MeshBoundGaussians(torch.log(t(cl["weights"][perm]).clamp_min(1e-6)), torch.zeros((Nfg, 1), device=dev), shs[:, :1].clone(),
+                               shs[:, 1:].clone(), torch.log(t(cl["scales"][perm])), t(cl["rots"][perm]),
+                               torch.logit(t(cl["opac"][perm]).reshape(-1, 1).clamp(1e-4, 1 - 1e-4)), v1, v2, v3, nrm, rad).to(dev)
+    b = scenes.make_cloud(Nbg, seed=1, extent=1.0)
+    nb = np.linalg.norm(b["means"], axis=1, keepdims=True) + 1e-6
+    bg = FrozenGaussians(t(b["means"] / nb * (6 + 6 * nb)), t(b["scales"]), torch.nn.functional.normalize(t(b["rots"])), t(b["opac"]).reshape(-1, 1),
+                         t(b["shs"]))
+    if args.policy is not None:
+        Rz.set_default_emission_policy(args.policy)
+    cams = [Camera(scenes.orbit_camera(k, 32, W, H), dev) for k in range(32)]
+    target = torch.rand((3, H, W), device=dev)
+    zero_bg = torch.zeros(3, device=dev)
+    tr = Trainer(model, densify_stats=True, sync_free=not args.exact_count, bg_gaussian=bg)
+    steps = args.steps if args.steps != 100 else 1000
+    warm = max(args.warmup, 5)
+    for i in range(warm):
+        tr.step(cams[i % 32], target, zero_bg)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss, pkg = tr.step(cams[(warm + i) % 32], target, zero_bg)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    out = {"metric": "ms/iter (fwd+bwd+optimizer), 3M Gaussians @4K training loop", "value": 1e3 * el / steps, "unit": "ms/iter", "n_gpus": 1,
+           "steps": steps, "warmup": warm, "ms_per_step": 1e3 * el / steps, "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "C5: %d mesh-bound + %d free Gaussians, %dx%d, render + L1/SSIM/mesh-restrict loss + backward + FusedAdam + "
+                                  "densification statistics, 32-camera orbit, fixed random target" % (Nfg, Nbg, W, H),
+                      "gaussians": Nfg + Nbg, "width": W, "height": H, "sh_degree": 3, "sync_free": not args.exact_count,
+                      "emission_policy": Rz.get_default_emission_policy()},
+           "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30, "iterations_redone": tr.redone,
+           "visible": int((pkg["radii"] > 0).sum().item()), "final_loss": float(loss),
+           "visited_fraction": float((tr.denom > 0).float().mean().item())}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="c3", choices=["c3", "c5"], help="c3 (default): the headline frames/s workload; c5: the "
+                    "3 M-Gaussian 4K training loop (BASELINE config C5), reported as ms per iteration")
+    ap.add_argument("--policy", type=int, default=None, help="emission policy 0..3 (default: the library's)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
@@ -108,6 +171,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fwd-bwd", action="store_true")
     args = ap.parse_args()
+    if args.config == "c5":
+        return run_c5(args)
 
     import torch
     import torch.distributed as dist

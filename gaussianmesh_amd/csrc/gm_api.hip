@@ -475,6 +475,13 @@ int gm_adam_step(int count, float* const* params, const float* const* grads, flo
   return launch_adam(tab, reinterpret_cast<hipStream_t>(stream));
 }
 
+int gm_densify_stats(int N, const int* radii, const float* viewspace_grad, float* max_radii2D, float* grad_accum, float* denom, void* stream) {
+  if (N < 0 || (N > 0 && (!radii || !viewspace_grad || !max_radii2D || !grad_accum || !denom))) {
+    set_error("gm_densify_stats: bad args"); return GM_ERR_INVALID_ARG;
+  }
+  return launch_densify_stats(N, radii, viewspace_grad, max_radii2D, grad_accum, denom, reinterpret_cast<hipStream_t>(stream));
+}
+
 void gm_profile_enable(int on) { g_prof_on = on != 0; }
 void gm_profile_reset(void) {
   drain_profile();

@@ -277,6 +277,7 @@ int launch_mesh_activate_bwd(const ActArgs& a, const float* d_xyz, const float* 
                              float* d_bc, float* d_dist, float* d_scaling, float* d_rotation, float* d_opacity, float mr_weight,
                              const float* d_mr, hipStream_t s);
 int launch_adam(const AdamTable& tab, hipStream_t s);
+int launch_densify_stats(int N, const int* radii, const float* grad2d, float* max_radii2D, float* grad_accum, float* denom, hipStream_t s);
 int launch_knn(int P, const float* points, float* meanDists, void* ws, size_t ws_bytes, hipStream_t s);
 size_t knn_workspace_bytes(int P);
 

@@ -174,4 +174,29 @@ int launch_adam(const AdamTable& tab, hipStream_t s) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Densification statistics of one training iteration (train_mesh_gaussian.py:119-126) in one pass:
+//   max_radii2D[vis] = max(max_radii2D[vis], radii[vis])                                            (:123)
+//   bc_gradient_accum[vis] += |viewspace_grad[vis, :2]| ;  denom[vis] += 1       (mesh_based_gaussian_model.py:587-589)
+// with vis = radii > 0 (render()'s visibility_filter); the reference spends three masked gather / scatter ops on each.
+__global__ __launch_bounds__(256) void densify_stats_kernel(int N, const int* __restrict__ radii, const float* __restrict__ grad2d,
+                                                            float* __restrict__ max_radii2D, float* __restrict__ grad_accum,
+                                                            float* __restrict__ denom) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const int r = radii[i];
+  if (r <= 0) return;
+  max_radii2D[i] = fmaxf(max_radii2D[i], (float)r);
+  const float gx = grad2d[3 * (size_t)i], gy = grad2d[3 * (size_t)i + 1];
+  grad_accum[i] += sqrtf(gx * gx + gy * gy);
+  denom[i] += 1.0f;
+}
+
+int launch_densify_stats(int N, const int* radii, const float* grad2d, float* max_radii2D, float* grad_accum, float* denom, hipStream_t s) {
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL(densify_stats_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, radii, grad2d, max_radii2D, grad_accum, denom);
+  GM_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace gm

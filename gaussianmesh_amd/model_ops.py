@@ -118,3 +118,20 @@ class FusedAdam:
         with torch.cuda.device(dev), torch.no_grad():
             _lib.check(lib.gm_adam_step(n, P, G, M, V, S, LR, LR2, PER, SPL, float(self.betas[0]), float(self.betas[1]), float(self.eps),
                                         int(self.n_step), torch.cuda.current_stream(dev).cuda_stream))
+
+
+def densify_stats(radii, viewspace_grad, max_radii2D, grad_accum, denom):
+    """gm_densify_stats: the per-iteration densification bookkeeping of train_mesh_gaussian.py:119-126 in one kernel, in
+    place on max_radii2D [N], grad_accum [N(,1)], denom [N(,1)] (float32); radii int32 [N], viewspace_grad [N,3]."""
+    lib = _lib.lib()
+    dev = radii.device
+    N = radii.shape[0]
+    if N == 0:
+        return
+    for t in (max_radii2D, grad_accum, denom):
+        if not t.is_contiguous() or t.dtype != torch.float32 or t.numel() != N:
+            raise ValueError("densify_stats: accumulators must be contiguous float32 of N elements")
+    g = viewspace_grad.detach().contiguous().float()
+    with torch.cuda.device(dev), torch.no_grad():
+        _lib.check(lib.gm_densify_stats(N, radii.contiguous().data_ptr(), g.data_ptr(), max_radii2D.data_ptr(), grad_accum.data_ptr(),
+                                        denom.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))

@@ -132,12 +132,23 @@ class PendingForward:
         _lib.check(lib.gm_forward_1_geom(self.policy, _ptr(self.geom), _ptr(binning), _ptr(self.img), a["P"], num_rendered, capacity,
                                          _ptr(a["bg"]), a["W"], a["H"], _ptr(self.color), a["debug"], self.stream.cuda_stream))
 
-    def finish(self, sync_free=False):
+    def finish(self, sync_free=False, capacity=0):
+        """capacity (sync_free without a workspace): instances the freshly allocated binning buffer shall hold."""
         lib = _lib.lib()
         a = self.args
         device = a["device"]
         ws = self.workspace
         with torch.cuda.device(device), torch.cuda.stream(self.stream):
+            if sync_free and ws is None and capacity > 0 and a["P"] > 0 and self.status_event is None:
+                binning = torch.empty((lib.gm_binning_bytes(capacity),), dtype=torch.uint8, device=device)
+                self._geom(binning, -1, capacity)
+                self.status_host = _PINNED_STATUS.pop() if _PINNED_STATUS else torch.zeros((4,), dtype=torch.int32).pin_memory()
+                _lib.check(lib.gm_forward_status_async(_ptr(self.geom), a["P"], self.status_host.data_ptr(), self.stream.cuda_stream))
+                self.status_event = torch.cuda.Event()
+                self.status_event.record(self.stream)
+                self.capacity = capacity
+                self.result = (-1, self.color, self.radii, self.geom, binning, self.img)
+                return self.result
             if sync_free and ws is not None and ws.capacity > 0 and a["P"] > 0 and self.status_event is None:
                 binning = ws.get("binning", lib.gm_binning_bytes(ws.capacity), device)
                 self._geom(binning, -1, ws.capacity)
@@ -170,6 +181,12 @@ class PendingForward:
         if self.status_event is None:
             return True, (self.result[0] if self.result else 0)
         self.status_event.synchronize()
+        if self.workspace is None:
+            st = self.status_host
+            nr, refused = int(st[0]), int(st[3])
+            if len(_PINNED_STATUS) < 64:
+                _PINNED_STATUS.append(st)
+            return (not refused), nr
         st = self.workspace.pinned_status()
         nr, refused = int(st[0]), int(st[3])
         if refused:
@@ -179,6 +196,7 @@ class PendingForward:
 
 
 _PINNED_POOL = []          # page-locked int32[1] counters of workspace-less forwards (allocating one per call costs ~0.1 ms)
+_PINNED_STATUS = []        # page-locked int32[4] status words of sync-free forwards without a workspace
 
 
 def _scratch(workspace, P, W, H, device):
@@ -361,6 +379,34 @@ def _shared_workspace(device):
     return ws
 
 
+# Sync-free training forward (off by default): the autograd operator never waits for the instance count.  The binning
+# buffer of an iteration is sized from the largest count seen so far (x growth); the forward's status words are checked by
+# verify_sync_free() - typically after backward() has been enqueued, so the host never idles the GPU - and an iteration
+# whose count outgrew its buffer (image = background, gradients = 0) is reported so the caller can redo it.
+_sync_free = {"on": False, "capacity": {}, "unchecked": [], "growth": 1.3}
+
+
+def set_sync_free_training(on, growth=1.3):
+    _sync_free["on"] = bool(on)
+    _sync_free["growth"] = float(growth)
+    if not on:
+        _sync_free["unchecked"].clear()
+
+
+def verify_sync_free():
+    """Wait for the status of every sync-free forward issued since the last call (the copies were enqueued right behind the
+    forwards, long before this is normally called).  Returns True when all of them fitted their binning buffers; on False the
+    capacity estimate has been raised and the caller should repeat the iteration (its image was the background)."""
+    ok = True
+    for h in _sync_free["unchecked"]:
+        fitted, nr = h.check()
+        key = h.args["device"]
+        _sync_free["capacity"][key] = max(_sync_free["capacity"].get(key, 0), int(nr * _sync_free["growth"]) + 4096)
+        ok = ok and fitted
+    _sync_free["unchecked"].clear()
+    return ok
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
@@ -368,12 +414,22 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = raster_settings
         if means3D.device.type != "cuda":
             raise _lib.GmeshError("gaussianmesh_amd rasterizer needs tensors on a HIP (cuda) device; there is no CPU path")
-        ws = None if any(ctx.needs_input_grad) else _shared_workspace(means3D.device)   # inference: reuse scratch
+        needs_grad = any(ctx.needs_input_grad)
+        ws = None if needs_grad else _shared_workspace(means3D.device)   # inference: reuse scratch
         policy = get_default_emission_policy()
-        num_rendered, color, radii, geom, binning, img = rasterize_forward(
-            rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
-            rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos,
-            rs.prefiltered, rs.debug, force_M, ws, policy)
+        cap = _sync_free["capacity"].get(means3D.device, 0) if (_sync_free["on"] and needs_grad) else 0
+        h = rasterize_forward_begin(rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                                    rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree,
+                                    rs.campos, rs.prefiltered, rs.debug, workspace=ws, emission_policy=policy, force_M=force_M)
+        if cap > 0:
+            num_rendered, color, radii, geom, binning, img = h.finish(sync_free=True, capacity=cap)
+            num_rendered = cap                        # the binning layout is that of the capacity
+            _sync_free["unchecked"].append(h)
+        else:
+            num_rendered, color, radii, geom, binning, img = h.finish()
+            if _sync_free["on"] and needs_grad:
+                key = means3D.device
+                _sync_free["capacity"][key] = max(_sync_free["capacity"].get(key, 0), int(num_rendered * _sync_free["growth"]) + 4096)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.emission_policy = policy

@@ -66,13 +66,15 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
             shs = pc.get_features
     else:
         colors_precomp = override_color
-    if bg_gaussian is not None:      # background cloud appended with precomputed covariance (:100-121)
-        if cov3D_precomp is None:
-            raise ValueError("render(bg_gaussian=...) concatenates covariances: set pipe.compute_cov3D_python as the reference does")
-        bg_cov = strip_symmetric(bg_gaussian.get_covariance(1.0)) if bg_gaussian.get_covariance(1.0).dim() == 3 else bg_gaussian.get_covariance(1.0)
+    if bg_gaussian is not None:      # background cloud appended (:100-121: the reference concatenates precomputed covariances)
         means3D = torch.cat([means3D, bg_gaussian.get_xyz], dim=0)
         opacity = torch.cat([opacity, bg_gaussian.get_opacity], dim=0)
-        cov3D_precomp = torch.cat([cov3D_precomp, bg_cov], dim=0)
+        if cov3D_precomp is not None:
+            bgc3 = bg_gaussian.get_covariance(1.0)
+            cov3D_precomp = torch.cat([cov3D_precomp, strip_symmetric(bgc3) if bgc3.dim() == 3 else bgc3], dim=0)
+        else:                        # same covariances, built inside the op from the concatenated scales / rotations
+            scales = torch.cat([scales, bg_gaussian.get_scaling], dim=0)
+            rotations = torch.cat([rotations, bg_gaussian.get_rotation], dim=0)
         if shs is not None:
             shs = torch.cat([shs, bg_gaussian.get_features], dim=0)
         else:
@@ -82,7 +84,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
                                        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
     out = {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
            "vertex1": getattr(pc, "vertex1", None), "vertex2": getattr(pc, "vertex2", None),
-           "vertex3": getattr(pc, "vertex3", None), "scale": scales}
+           "vertex3": getattr(pc, "vertex3", None), "scale": scales if bg_gaussian is None else scales[:pc.screenspace_points.shape[0]]}
     if mrloss is not None:                       # extra key (pipe.mesh_restrict_weight set): the loss term of train_mesh_gaussian.py:93
         out["mesh_restrict_loss"] = mrloss
     return out

@@ -12,7 +12,6 @@ test the GPU path end to end.
 import math
 from types import SimpleNamespace
 
-import numpy as np
 import torch
 
 from .loss import mesh_restrict_loss, photometric_loss
@@ -44,11 +43,34 @@ DEFAULT_OPT = dict(position_lr_init=0.00016, position_lr_final=0.0000016, positi
                    feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001, lambda_dssim=0.2, alpha_mrloss=6.0)
 
 
+class FrozenGaussians:
+    """A free-standing, non-trainable cloud (the bg_gaussian argument of render(), gaussian_renderer/__init__.py:100-121):
+    activated tensors held as they are."""
+
+    def __init__(self, xyz, scaling, rotation, opacity, features):
+        self.get_xyz, self.get_scaling, self.get_rotation, self.get_opacity, self.get_features = xyz, scaling, rotation, opacity, features
+
+    def get_covariance(self, scaling_modifier=1.0):
+        q = self.get_rotation
+        r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y), 2 * (x * y + r * z), 1 - 2 * (x * x + z * z),
+                         2 * (y * z - r * x), 2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=1).reshape(-1, 3, 3)
+        L = R * (scaling_modifier * self.get_scaling)[:, None, :]
+        return L @ L.transpose(1, 2)
+
+
 class Trainer:
-    def __init__(self, gaussians, spatial_lr_scale=1.0, **opt):
+    """densify_stats: keep the densification bookkeeping of train_mesh_gaussian.py:119-126 (max_radii2D, accumulated
+    view-space gradient norm, visit count) up to date every iteration (one fused kernel).
+    sync_free: the rasterizer never waits for the instance count (rasterizer.set_sync_free_training); the status of the
+    forward is checked after backward() has been enqueued and an iteration that overflowed its binning buffer is redone.
+    bg_gaussian: a FrozenGaussians cloud composited behind the trainable one."""
+
+    def __init__(self, gaussians, spatial_lr_scale=1.0, densify_stats=False, sync_free=False, bg_gaussian=None, **opt):
         o = dict(DEFAULT_OPT); o.update(opt)
         self.opt = SimpleNamespace(**o)
         self.g = gaussians
+        self.bg_gaussian = bg_gaussian
         s = spatial_lr_scale
         # the reference's seven groups; "f_dc" (coefficient 0) and "f_rest" are the two learning rates of the one SH tensor
         groups = [
@@ -67,6 +89,14 @@ class Trainer:
         self.pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False,
                                     mesh_restrict_weight=(o["alpha_mrloss"] or None))
         self.iteration = 0
+        self.sync_free = bool(sync_free)
+        self.redone = 0                          # iterations repeated because the instance count outgrew the binning buffer
+        self.densify_stats = bool(densify_stats)
+        if self.densify_stats:
+            N, dev = gaussians._bc.shape[0], gaussians._bc.device
+            self.max_radii2D = torch.zeros((N,), device=dev)
+            self.bc_gradient_accum = torch.zeros((N, 1), device=dev)
+            self.denom = torch.zeros((N, 1), device=dev)
 
     def update_learning_rate(self):
         lr = self.bc_lr(self.iteration)
@@ -75,21 +105,39 @@ class Trainer:
                 gr["lr"] = lr
         return lr
 
-    def step(self, camera, gt_image, background):
-        """One iteration; returns (loss tensor, render package).  No host synchronisation besides the rasterizer's
-        instance-count read-back."""
-        self.iteration += 1
-        self.update_learning_rate()
+    def _forward_backward(self, camera, gt_image, background):
         g = self.g
         if g.screenspace_points.grad is not None:
             g.screenspace_points.grad = None
-        pkg = render(camera, g, self.pipe, background)
+        pkg = render(camera, g, self.pipe, background, bg_gaussian=self.bg_gaussian)
         loss = photometric_loss(pkg["render"], gt_image, self.opt.lambda_dssim)
         if self.opt.alpha_mrloss:
             mr = pkg.get("mesh_restrict_loss")
             loss = loss + (mr if mr is not None else
                            mesh_restrict_loss(pkg["scale"], pkg["vertex1"], pkg["vertex2"], pkg["vertex3"], weight=self.opt.alpha_mrloss))
         loss.backward()
+        return loss, pkg
+
+    def step(self, camera, gt_image, background):
+        """One iteration; returns (loss tensor, render package).  Host synchronisation: the rasterizer's instance-count
+        read-back, or with sync_free only the (long completed) status words of the forward."""
+        from . import rasterizer
+        self.iteration += 1
+        self.update_learning_rate()
+        rasterizer.set_sync_free_training(self.sync_free)
+        try:
+            loss, pkg = self._forward_backward(camera, gt_image, background)
+            if self.sync_free and not rasterizer.verify_sync_free():
+                self.redone += 1                 # image was the background: same iteration again with the enlarged buffer
+                self.optimizer.zero_grad(set_to_none=True)
+                loss, pkg = self._forward_backward(camera, gt_image, background)
+                rasterizer.verify_sync_free()
+        finally:
+            rasterizer.set_sync_free_training(False)
+        if self.densify_stats:
+            from .model_ops import densify_stats
+            N = self.max_radii2D.shape[0]
+            densify_stats(pkg["radii"][:N], self.g.screenspace_points.grad, self.max_radii2D, self.bc_gradient_accum, self.denom)
         self.optimizer.step()
         self.optimizer.zero_grad(set_to_none=True)
         return loss.detach(), pkg

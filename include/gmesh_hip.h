@@ -282,6 +282,12 @@ int gm_adam_step(int count, float* const* params, const float* const* grads, flo
                  const uint64_t* sizes, const float* lr, const float* lr_rest, const uint32_t* period, const uint32_t* split,
                  float beta1, float beta2, float eps, int step, void* stream);
 
+/* Densification statistics of a training iteration in one pass (train_mesh_gaussian.py:119-126 and
+ * scene/mesh_based_gaussian_model.py:587-589): for every Gaussian with radii[i] > 0 (render()'s visibility_filter)
+ *   max_radii2D[i] = max(max_radii2D[i], radii[i]);  grad_accum[i] += |viewspace_grad[i, 0:2]|;  denom[i] += 1.
+ * radii int32 [N]; viewspace_grad float [N,3] (the gradient of means2D); the three accumulators float [N]. */
+int gm_densify_stats(int N, const int* radii, const float* viewspace_grad, float* max_radii2D, float* grad_accum, float* denom, void* stream);
+
 /* Per-stage GPU timing (HIP events recorded on `stream` around each kernel group).  Off by default.
  * gm_profile_enable(1) starts collecting, gm_profile_read synchronises the recorded events and returns
  * accumulated milliseconds and launch count for a stage name ("preprocess","depth_sort","scan",

@@ -54,3 +54,70 @@ def test_training_iterations_reduce_the_loss():
     for name in ("_bc", "_distance", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
         assert not torch.equal(getattr(student, name), getattr(fresh, name)), name
     assert tr.optimizer.param_groups[0]["lr"] < tr.opt.position_lr_init          # schedule is applied
+
+
+def test_trainer_sync_free_densify_stats_and_background_cloud():
+    """Trainer(sync_free=True, densify_stats=True, bg_gaussian=...): the same parameter trajectory as the exact-count
+    trainer (bit-identical images and losses: the instance count only sizes a buffer), the densification statistics of
+    train_mesh_gaussian.py:119-126 against their torch statement, and an overflowing iteration is redone, not lost."""
+    from gpu_utils import T
+    from gaussianmesh_amd import rasterizer as Rz, scenes
+    from gaussianmesh_amd.renderer import Camera, MeshBoundGaussians
+    from gaussianmesh_amd.train import FrozenGaussians, Trainer
+    verts, faces = scenes.torus_mesh(24, 16)
+    N = 4000
+
+    def build():
+        cl = scenes.bind_cloud_to_mesh(N, verts, faces, seed=2)
+        tri = faces[cl["fid"]]
+        v1, v2, v3 = (T(verts[tri[:, k]].astype(np.float32)) for k in range(3))
+        nrm = torch.nn.functional.normalize(torch.cross(v2 - v1, v3 - v1, dim=1), dim=1)
+        rad = (((v2 - v1).norm(dim=1) + (v3 - v2).norm(dim=1) + (v1 - v3).norm(dim=1)) / 3)[:, None]
+        return MeshBoundGaussians(torch.log(T(cl["weights"]).clamp_min(1e-6)), torch.zeros((N, 1), device="cuda"), T(cl["shs"][:, :1]),
+                                  T(cl["shs"][:, 1:]), torch.log(T(cl["scales"] * 4)), T(cl["rots"]), torch.logit(T(cl["opac"]).reshape(-1, 1)),
+                                  v1, v2, v3, nrm, rad).cuda()
+    b = scenes.make_cloud(500, seed=9, scale_lo=0.05, scale_hi=0.3)
+    nb = np.linalg.norm(b["means"], axis=1, keepdims=True) + 1e-6
+    bg = FrozenGaussians(T(b["means"] / nb * (4 + nb)), T(b["scales"]), torch.nn.functional.normalize(T(b["rots"])), T(b["opac"]).reshape(-1, 1), T(b["shs"]))
+    cams = [Camera(scenes.orbit_camera(k, 5, 160, 96, radius=6.5), "cuda") for k in range(5)]
+    gt = torch.rand((3, 96, 160), device="cuda")
+    zero = torch.zeros(3, device="cuda")
+    ta = Trainer(build(), densify_stats=True, sync_free=False, bg_gaussian=bg)
+    tb = Trainer(build(), densify_stats=True, sync_free=True, bg_gaussian=bg)
+    max_r = torch.zeros(N, device="cuda"); acc = torch.zeros((N, 1), device="cuda"); den = torch.zeros((N, 1), device="cuda")
+    for i in range(6):
+        if i == 4:
+            Rz._sync_free["capacity"][torch.device("cuda", 0)] = 64          # far too small: iteration 4 of tb must be redone
+        la, pa = ta.step(cams[i % 5], gt, zero)
+        vs_grad = ta.g.screenspace_points.grad                                # cleared at the start of the next step only
+        lb, pb = tb.step(cams[i % 5], gt, zero)
+        if i == 0:                      # same parameters: bit-identical image (the instance count only sizes a buffer) ...
+            assert torch.equal(pa["render"], pb["render"]) and torch.equal(la, lb)
+        else:                           # ... afterwards the two runs differ by the float-atomic summation order of their backward passes
+            assert (pa["render"] - pb["render"]).abs().max() <= 2e-2 and abs(float(la) - float(lb)) <= 1e-3 * abs(float(la)), i
+        vis = pa["radii"][:N] > 0
+        max_r[vis] = torch.maximum(max_r[vis], pa["radii"][:N][vis].float())
+    assert tb.redone == 1 and ta.redone == 0
+    for p, q in zip(ta.g.parameters(), tb.g.parameters()):
+        assert (p - q).abs().max() <= 5e-3 * max(float(p.abs().max()), 1.0)
+    assert torch.equal(ta.max_radii2D, max_r)
+    assert (ta.max_radii2D - tb.max_radii2D).abs().max() <= 1 and (ta.denom - tb.denom).abs().max() <= 1      # radii may flip by one
+    assert ta.denom.max() <= 6 and ta.denom.sum() > 0
+    assert torch.isfinite(ta.bc_gradient_accum).all() and (ta.bc_gradient_accum[ta.denom > 0] >= 0).all()
+    assert pa["radii"].shape[0] == N + 500 and pa["scale"].shape[0] == N
+
+
+def test_densify_stats_kernel_matches_the_reference_statements():
+    from gaussianmesh_amd.model_ops import densify_stats
+    g = torch.Generator(device="cuda").manual_seed(0)
+    N = 10007
+    radii = torch.randint(-2, 40, (N,), device="cuda", generator=g, dtype=torch.int32)
+    grad = torch.randn((N, 3), device="cuda", generator=g)
+    mr = torch.rand(N, device="cuda", generator=g) * 30; acc = torch.rand((N, 1), device="cuda", generator=g); den = torch.zeros((N, 1), device="cuda")
+    mr0, acc0, den0 = mr.clone(), acc.clone(), den.clone()
+    densify_stats(radii, grad, mr, acc, den)
+    vis = radii > 0
+    mr0[vis] = torch.maximum(mr0[vis], radii[vis].float())                    # train_mesh_gaussian.py:123
+    acc0[vis] += torch.norm(grad[vis, :2], dim=-1, keepdim=True)               # mesh_based_gaussian_model.py:588
+    den0[vis] += 1
+    assert torch.equal(mr, mr0) and torch.equal(den, den0) and (acc - acc0).abs().max() <= 1e-6
