@@ -108,268 +108,20 @@ int launch_sh_colors(int N, int deg, int M, const float* pos, const float* campo
 
 // ---------------------------------------------------------------------------------------------
 // Fused edit-loop kernel: deform + view-dependent colour in one pass (what ObjectVisualTool.render_gaussian needs per
-// frame: means3D = x', colors_precomp, cov3D_precomp = strip_symmetric(Sigma'); edittool/__init__.py:421-472).
-// Reads 264 B and writes 48 B per Gaussian (+72 B if the caller also wants Sigma' and rot), against
-// 72+108 (deform) + 240+12 (colour) for the two separate kernels.  SH and covariance rows go through LDS
-// (gm_stage.h), results leave through LDS as coalesced 16-byte stores.
+// frame: means3D = x', colors_precomp, cov3D_precomp = strip_symmetric(Sigma'); edittool/__init__.py:421-472), and with PRE
+// also the forward preprocess of the Gaussian it just produced.
+// Reads 264 B and writes 48 B per Gaussian (+72 B if the caller also wants Sigma' and rot), against 72+108 (deform) +
+// 240+12 (colour) for the two separate kernels.
+// One-wave workgroups of 64 Gaussians.  The block's SH and covariance rows come into LDS by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no ds_write pass, and the loads are in flight while the wave gathers
+// its vertices): per wave the dependent memory rounds are two (ids -> {rows DMA, vertex gathers}).  The LDS image is the
+// linear image of the rows (a DMA instruction writes wave-uniform base + lane x 16 B); the 192-byte row stride makes the
+// per-thread b128 reads bank-conflicted, which is immaterial next to the memory latency this kernel is bound by.
+// Results leave through LDS as coalesced 16-byte stores.
 // PACKED: dV points at the per-vertex table written by pack_mesh_state_kernel (6 float4 per vertex:
 // {dV,0} {R0..3} {R4..7} {R8,S0,S1,S2} {S3..6} {S7,S8,0,0}); the three vertex gathers of a Gaussian are then 18 16-byte
 // loads instead of 63 4-byte ones (Rv / Sv unused).
-template <int DS_THREADS, bool PACKED = false>
-__global__ __launch_bounds__(DS_THREADS) void deform_shade_kernel(int N, int deg, const int* __restrict__ tri, const float* __restrict__ w,
-                                                                  const float* __restrict__ dV, const float* __restrict__ Rv,
-                                                                  const float* __restrict__ Sv, const float* __restrict__ cov,
-                                                                  const float* __restrict__ pos, const float* __restrict__ shs,
-                                                                  const float* __restrict__ campos, float* __restrict__ pos_out,
-                                                                  float* __restrict__ cov6_out, float* __restrict__ rgb_out,
-                                                                  float* __restrict__ cov_out, float* __restrict__ rot_out) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float4* l_sh = reinterpret_cast<float4*>(lds);   // [DS_THREADS][13] granules (12 used): SH rows, conflict-free b128 access
-  float* l_cov = lds + DS_THREADS * 52;            // [DS_THREADS][9] linear image of the covariance rows
-  const size_t row0 = (size_t)blockIdx.x * DS_THREADS;
-  const int nrows = min(DS_THREADS, N - (int)row0);
-  stage_rows16<12, 13, DS_THREADS>(shs, row0, nrows, l_sh);
-  stage_linear<DS_THREADS>(cov + row0 * 9, nrows * 9, l_cov);
-  const int t = threadIdx.x;
-  const size_t i = row0 + t;
-  const bool live = t < nrows;
-  float O[9], Rt[9], npos[3], col[3];
-  int t0 = 0, t1 = 0, t2 = 0; float w0 = 0.f, w1 = 0.f, w2 = 0.f, p0 = 0.f, p1 = 0.f, p2 = 0.f;
-  if (live) {
-    t0 = tri[3 * i]; t1 = tri[3 * i + 1]; t2 = tri[3 * i + 2];
-    w0 = w[3 * i]; w1 = w[3 * i + 1]; w2 = w[3 * i + 2];
-    p0 = pos[3 * i]; p1 = pos[3 * i + 1]; p2 = pos[3 * i + 2];
-  }
-  float d[3], Rb[9], Sb[9];
-  if (PACKED) {
-    const float4* tab = reinterpret_cast<const float4*>(dV);
-    float va[24], vb[24], vc[24];
-#pragma unroll
-    for (int q = 0; q < 6; q++) {
-      const float4 a = tab[6 * (size_t)t0 + q], b = tab[6 * (size_t)t1 + q], c = tab[6 * (size_t)t2 + q];
-      va[4 * q] = a.x; va[4 * q + 1] = a.y; va[4 * q + 2] = a.z; va[4 * q + 3] = a.w;
-      vb[4 * q] = b.x; vb[4 * q + 1] = b.y; vb[4 * q + 2] = b.z; vb[4 * q + 3] = b.w;
-      vc[4 * q] = c.x; vc[4 * q + 1] = c.y; vc[4 * q + 2] = c.z; vc[4 * q + 3] = c.w;
-    }
-#pragma unroll
-    for (int k = 0; k < 3; k++) d[k] = (w0 * va[k] + w1 * vb[k]) + w2 * vc[k];
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-      Rb[k] = (w0 * va[4 + k] + w1 * vb[4 + k]) + w2 * vc[4 + k];
-      Sb[k] = (w0 * va[13 + k] + w1 * vb[13 + k]) + w2 * vc[13 + k];
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < 3; k++) d[k] = (w0 * dV[3 * (size_t)t0 + k] + w1 * dV[3 * (size_t)t1 + k]) + w2 * dV[3 * (size_t)t2 + k];
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-      Rb[k] = (w0 * Rv[9 * (size_t)t0 + k] + w1 * Rv[9 * (size_t)t1 + k]) + w2 * Rv[9 * (size_t)t2 + k];
-      Sb[k] = (w0 * Sv[9 * (size_t)t0 + k] + w1 * Sv[9 * (size_t)t1 + k]) + w2 * Sv[9 * (size_t)t2 + k];
-    }
-  }
-  __syncthreads();
-  {
-    float RS[9], A[9], C[9];
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-      for (int b = 0; b < 3; b++) Rt[3 * a + b] = Rb[3 * b + a];
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-      for (int b = 0; b < 3; b++) RS[3 * a + b] = (Rt[3 * a] * Sb[b] + Rt[3 * a + 1] * Sb[3 + b]) + Rt[3 * a + 2] * Sb[6 + b];
-#pragma unroll
-    for (int k = 0; k < 9; k++) C[k] = l_cov[t * 9 + k];
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-      for (int b = 0; b < 3; b++) A[3 * a + b] = (RS[3 * a] * C[b] + RS[3 * a + 1] * C[3 + b]) + RS[3 * a + 2] * C[6 + b];
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-      for (int b = 0; b < 3; b++) O[3 * a + b] = (A[3 * a] * RS[3 * b] + A[3 * a + 1] * RS[3 * b + 1]) + A[3 * a + 2] * RS[3 * b + 2];
-    npos[0] = p0 + d[0]; npos[1] = p1 + d[1]; npos[2] = p2 + d[2];
-    float dx = npos[0] - campos[0], dy = npos[1] - campos[1], dz = npos[2] - campos[2];
-    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-    dx = dx / len; dy = dy / len; dz = dz / len;
-    // dir_rot = rot^T dir with rot = Rt
-    const float x = (Rt[0] * dx + Rt[3] * dy) + Rt[6] * dz;
-    const float y = (Rt[1] * dx + Rt[4] * dy) + Rt[7] * dz;
-    const float z = (Rt[2] * dx + Rt[5] * dy) + Rt[8] * dz;
-    float sh[48];
-#pragma unroll
-    for (int c = 0; c < 12; c++) {
-      const float4 v = l_sh[t * 13 + c];
-      sh[4 * c] = v.x; sh[4 * c + 1] = v.y; sh[4 * c + 2] = v.z; sh[4 * c + 3] = v.w;
-    }
-#pragma unroll
-    for (int ch = 0; ch < 3; ch++) {
-      const float r = sh_channel(deg, [&](int k) { return sh[3 * k + ch]; }, x, y, z);
-      col[ch] = fmaxf(r + 0.5f, 0.0f);
-    }
-  }
-  __syncthreads();                               // everyone is done reading the staged inputs: reuse LDS for the outputs
-  float* o_pos = lds;                            // [256][3]
-  float* o_rgb = lds + DS_THREADS * 3;           // [256][3]
-  float* o_c6 = lds + DS_THREADS * 6;            // [256][6]  (stride 7 to stay conflict-free)
-  float* o_cov = lds + DS_THREADS * 13;          // [256][9]
-  float* o_rot = lds + DS_THREADS * 22;          // [256][9]
-#pragma unroll
-  for (int k = 0; k < 3; k++) { o_pos[t * 3 + k] = npos[k]; o_rgb[t * 3 + k] = col[k]; }
-  o_c6[t * 7 + 0] = O[0]; o_c6[t * 7 + 1] = O[1]; o_c6[t * 7 + 2] = O[2]; o_c6[t * 7 + 3] = O[4]; o_c6[t * 7 + 4] = O[5]; o_c6[t * 7 + 5] = O[8];
-  if (cov_out) {
-#pragma unroll
-    for (int k = 0; k < 9; k++) { o_cov[t * 9 + k] = O[k]; o_rot[t * 9 + k] = Rt[k]; }
-  }
-  __syncthreads();
-  unstage_rows<3, 3, DS_THREADS>(pos_out, row0, nrows, o_pos);
-  unstage_rows<3, 3, DS_THREADS>(rgb_out, row0, nrows, o_rgb);
-  unstage_rows<6, 7, DS_THREADS>(cov6_out, row0, nrows, o_c6);
-  if (cov_out) {
-    unstage_rows<9, 9, DS_THREADS>(cov_out, row0, nrows, o_cov);
-    unstage_rows<9, 9, DS_THREADS>(rot_out, row0, nrows, o_rot);
-  }
-}
-
-// One-wave variant that brings the block's SH and covariance rows into LDS with the LDS-DMA path
-// (global_load_lds_dwordx4: no staging registers, no ds_write pass, and the loads are in flight while the wave gathers
-// its vertices): per wave the dependent memory rounds drop from three (rows -> ids -> vertex gathers) to two
-// (ids -> {rows DMA, vertex gathers}).  The LDS image is the linear image of the rows (a DMA instruction writes
-// wave-uniform base + lane x 16 B); the 192-byte row stride makes the per-thread b128 reads bank-conflicted, which is
-// immaterial next to the memory latency this kernel is bound by.
-template <bool PACKED>
-__global__ __launch_bounds__(64) void deform_shade_dma_kernel(int N, int deg, const int* __restrict__ tri, const float* __restrict__ w,
-                                                                  const float* __restrict__ dV, const float* __restrict__ Rv,
-                                                                  const float* __restrict__ Sv, const float* __restrict__ cov,
-                                                                  const float* __restrict__ pos, const float* __restrict__ shs,
-                                                                  const float* __restrict__ campos, float* __restrict__ pos_out,
-                                                                  float* __restrict__ cov6_out, float* __restrict__ rgb_out,
-                                                                  float* __restrict__ cov_out, float* __restrict__ rot_out) {
-  constexpr int DS_THREADS = 64;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float4* l_sh = reinterpret_cast<float4*>(lds);   // [64][12] granules: linear image of the block's SH rows (12 KiB)
-  float* l_cov = lds + DS_THREADS * 48;            // [64][9] linear image of the covariance rows (2.25 KiB)
-  const size_t row0 = (size_t)blockIdx.x * DS_THREADS;
-  const int nrows = min(DS_THREADS, N - (int)row0);
-  const int t = threadIdx.x;
-  const size_t i = row0 + t;
-  const bool live = t < nrows;
-  float O[9], Rt[9], npos[3], col[3];
-  int t0 = 0, t1 = 0, t2 = 0; float w0 = 0.f, w1 = 0.f, w2 = 0.f, p0 = 0.f, p1 = 0.f, p2 = 0.f;
-  if (live) {
-    t0 = tri[3 * i]; t1 = tri[3 * i + 1]; t2 = tri[3 * i + 2];
-    w0 = w[3 * i]; w1 = w[3 * i + 1]; w2 = w[3 * i + 2];
-    p0 = pos[3 * i]; p1 = pos[3 * i + 1]; p2 = pos[3 * i + 2];
-  }
-  // ids are in (first use below waits for them); now start the row DMA, then the vertex gathers behind it
-  __builtin_amdgcn_sched_barrier(0);
-  if (nrows == DS_THREADS) {
-    const char* gsh = reinterpret_cast<const char*>(shs + row0 * 48) + t * 16;
-#pragma unroll
-    for (int q = 0; q < 12; q++) dma16(gsh + q * 1024, reinterpret_cast<char*>(l_sh) + q * 1024);
-    const char* gcv = reinterpret_cast<const char*>(cov + row0 * 9) + t * 16;
-    dma16(gcv, reinterpret_cast<char*>(l_cov));
-    dma16(gcv + 1024, reinterpret_cast<char*>(l_cov) + 1024);
-    if (t < 16) dma16(gcv + 2048, reinterpret_cast<char*>(l_cov) + 2048);
-  } else if (live) {                               // last, partial block: plain copies of the thread's own rows
-#pragma unroll
-    for (int c = 0; c < 12; c++) l_sh[t * 12 + c] = reinterpret_cast<const float4*>(shs)[i * 12 + c];
-#pragma unroll
-    for (int c = 0; c < 9; c++) l_cov[t * 9 + c] = cov[i * 9 + c];
-  }
-  float d[3], Rb[9], Sb[9];
-  if (PACKED) {
-    const float4* tab = reinterpret_cast<const float4*>(dV);
-    float va[24], vb[24], vc[24];
-#pragma unroll
-    for (int q = 0; q < 6; q++) {
-      const float4 a = tab[6 * (size_t)t0 + q], b = tab[6 * (size_t)t1 + q], c = tab[6 * (size_t)t2 + q];
-      va[4 * q] = a.x; va[4 * q + 1] = a.y; va[4 * q + 2] = a.z; va[4 * q + 3] = a.w;
-      vb[4 * q] = b.x; vb[4 * q + 1] = b.y; vb[4 * q + 2] = b.z; vb[4 * q + 3] = b.w;
-      vc[4 * q] = c.x; vc[4 * q + 1] = c.y; vc[4 * q + 2] = c.z; vc[4 * q + 3] = c.w;
-    }
-#pragma unroll
-    for (int k = 0; k < 3; k++) d[k] = (w0 * va[k] + w1 * vb[k]) + w2 * vc[k];
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-      Rb[k] = (w0 * va[4 + k] + w1 * vb[4 + k]) + w2 * vc[4 + k];
-      Sb[k] = (w0 * va[13 + k] + w1 * vb[13 + k]) + w2 * vc[13 + k];
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < 3; k++) d[k] = (w0 * dV[3 * (size_t)t0 + k] + w1 * dV[3 * (size_t)t1 + k]) + w2 * dV[3 * (size_t)t2 + k];
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-      Rb[k] = (w0 * Rv[9 * (size_t)t0 + k] + w1 * Rv[9 * (size_t)t1 + k]) + w2 * Rv[9 * (size_t)t2 + k];
-      Sb[k] = (w0 * Sv[9 * (size_t)t0 + k] + w1 * Sv[9 * (size_t)t1 + k]) + w2 * Sv[9 * (size_t)t2 + k];
-    }
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): the DMA has landed
-  __syncthreads();
-  {
-    float RS[9], A[9], C[9];
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-      for (int b = 0; b < 3; b++) Rt[3 * a + b] = Rb[3 * b + a];
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-      for (int b = 0; b < 3; b++) RS[3 * a + b] = (Rt[3 * a] * Sb[b] + Rt[3 * a + 1] * Sb[3 + b]) + Rt[3 * a + 2] * Sb[6 + b];
-#pragma unroll
-    for (int k = 0; k < 9; k++) C[k] = l_cov[t * 9 + k];
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-      for (int b = 0; b < 3; b++) A[3 * a + b] = (RS[3 * a] * C[b] + RS[3 * a + 1] * C[3 + b]) + RS[3 * a + 2] * C[6 + b];
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-      for (int b = 0; b < 3; b++) O[3 * a + b] = (A[3 * a] * RS[3 * b] + A[3 * a + 1] * RS[3 * b + 1]) + A[3 * a + 2] * RS[3 * b + 2];
-    npos[0] = p0 + d[0]; npos[1] = p1 + d[1]; npos[2] = p2 + d[2];
-    float dx = npos[0] - campos[0], dy = npos[1] - campos[1], dz = npos[2] - campos[2];
-    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-    dx = dx / len; dy = dy / len; dz = dz / len;
-    // dir_rot = rot^T dir with rot = Rt
-    const float x = (Rt[0] * dx + Rt[3] * dy) + Rt[6] * dz;
-    const float y = (Rt[1] * dx + Rt[4] * dy) + Rt[7] * dz;
-    const float z = (Rt[2] * dx + Rt[5] * dy) + Rt[8] * dz;
-    float sh[48];
-#pragma unroll
-    for (int c = 0; c < 12; c++) {
-      const float4 v = l_sh[t * 12 + c];
-      sh[4 * c] = v.x; sh[4 * c + 1] = v.y; sh[4 * c + 2] = v.z; sh[4 * c + 3] = v.w;
-    }
-#pragma unroll
-    for (int ch = 0; ch < 3; ch++) {
-      const float r = sh_channel(deg, [&](int k) { return sh[3 * k + ch]; }, x, y, z);
-      col[ch] = fmaxf(r + 0.5f, 0.0f);
-    }
-  }
-  __syncthreads();                               // everyone is done reading the staged inputs: reuse LDS for the outputs
-  float* o_pos = lds;                            // [256][3]
-  float* o_rgb = lds + DS_THREADS * 3;           // [256][3]
-  float* o_c6 = lds + DS_THREADS * 6;            // [256][6]  (stride 7 to stay conflict-free)
-  float* o_cov = lds + DS_THREADS * 13;          // [256][9]
-  float* o_rot = lds + DS_THREADS * 22;          // [256][9]
-#pragma unroll
-  for (int k = 0; k < 3; k++) { o_pos[t * 3 + k] = npos[k]; o_rgb[t * 3 + k] = col[k]; }
-  o_c6[t * 7 + 0] = O[0]; o_c6[t * 7 + 1] = O[1]; o_c6[t * 7 + 2] = O[2]; o_c6[t * 7 + 3] = O[4]; o_c6[t * 7 + 4] = O[5]; o_c6[t * 7 + 5] = O[8];
-  if (cov_out) {
-#pragma unroll
-    for (int k = 0; k < 9; k++) { o_cov[t * 9 + k] = O[k]; o_rot[t * 9 + k] = Rt[k]; }
-  }
-  __syncthreads();
-  unstage_rows<3, 3, DS_THREADS>(pos_out, row0, nrows, o_pos);
-  unstage_rows<3, 3, DS_THREADS>(rgb_out, row0, nrows, o_rgb);
-  unstage_rows<6, 7, DS_THREADS>(cov6_out, row0, nrows, o_c6);
-  if (cov_out) {
-    unstage_rows<9, 9, DS_THREADS>(cov_out, row0, nrows, o_cov);
-    unstage_rows<9, 9, DS_THREADS>(rot_out, row0, nrows, o_rot);
-  }
-}
-
-// Edit-loop fast path: deform_shade_dma_kernel<true> followed, in the same thread, by the forward preprocess of the
+// PRE (edit-loop fast path): followed, in the same thread, by the forward preprocess of the
 // Gaussian it just produced (gm_pre_body.h, the code preprocess_fwd_kernel runs on colors_precomp / cov3D_precomp
 // inputs).  The deformed position / covariance / colour never travel through HBM (48 B written + 48 B read per
 // Gaussian and one launch less per frame); pos_out / cov6_out / rgb_out are optional copies for callers that want them.
@@ -378,14 +130,14 @@ struct FusedPre {
   const float* opac;
   float4* splat; int* radii_int; int* radii_out; uint32_t* tiles; uint4* bin; uint32_t* counters; uint32_t* slots; uint8_t* clamped; uint32_t* depth_key;
 };
-__global__ __launch_bounds__(64) void deform_shade_pre_kernel(int N, int deg, const int* __restrict__ tri, const float* __restrict__ w,
-                                                              const float* __restrict__ dV, const float* __restrict__ cov,
-                                                              const float* __restrict__ pos, const float* __restrict__ shs,
-                                                              const float* __restrict__ campos, float* __restrict__ pos_out,
-                                                              float* __restrict__ cov6_out, float* __restrict__ rgb_out, const FusedPre fp) {
-  constexpr bool PACKED = true;
-  const float* Rv = nullptr; const float* Sv = nullptr;
-  float* cov_out = nullptr; float* rot_out = nullptr;
+template <bool PACKED, bool PRE>
+__global__ __launch_bounds__(64) void deform_shade_kernel(int N, int deg, const int* __restrict__ tri, const float* __restrict__ w,
+                                                          const float* __restrict__ dV, const float* __restrict__ Rv,
+                                                          const float* __restrict__ Sv, const float* __restrict__ cov,
+                                                          const float* __restrict__ pos, const float* __restrict__ shs,
+                                                          const float* __restrict__ campos, float* __restrict__ pos_out,
+                                                          float* __restrict__ cov6_out, float* __restrict__ rgb_out,
+                                                          float* __restrict__ cov_out, float* __restrict__ rot_out, const FusedPre fp) {
   constexpr int DS_THREADS = 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float4* l_sh = reinterpret_cast<float4*>(lds);   // [64][12] granules: linear image of the block's SH rows (12 KiB)
@@ -489,7 +241,7 @@ __global__ __launch_bounds__(64) void deform_shade_pre_kernel(int N, int deg, co
   }
   // ---- forward preprocess of the deformed Gaussian (colors_precomp / cov3D_precomp input mode)
   uint32_t tiles = 0, dkey = 0xFFFFFFFFu;
-  if (live) {
+  if (PRE && live) {
     int radius_i = 0;
     uint4 bin = make_uint4(0u, 0u, 0u, 0u);
     const V3 p = {npos[0], npos[1], npos[2]};
@@ -512,7 +264,7 @@ __global__ __launch_bounds__(64) void deform_shade_pre_kernel(int N, int deg, co
     fp.depth_key[i] = dkey;
     if (i == 0) fp.counters[GM_CNT_POLICY] = (uint32_t)fp.cam.tile_cull;
   }
-  slot_accumulate(fp.slots, tiles, dkey);
+  if (PRE) slot_accumulate(fp.slots, tiles, dkey);
   if (!pos_out) return;                          // wave-uniform
   __syncthreads();                               // everyone is done reading the staged inputs: reuse LDS for the outputs
   float* o_pos = lds;                            // [256][3]
@@ -571,12 +323,8 @@ int launch_deform_shade_packed(int N, int deg, int M, const int* tri, const floa
   }
   StageScope sc(ST_DEFORM, s);
   const size_t lds_bytes = sizeof(float) * 64 * (48 + 9);
-  if (getenv("GM_DS_NO_DMA"))
-    hipLaunchKernelGGL((deform_shade_kernel<64, true>), dim3((N + 63) / 64), dim3(64), sizeof(float) * 64 * (52 + 9), s, N, deg, tri, w, packed,
-                       nullptr, nullptr, cov, pos, shs, campos, pos_out, cov6_out, rgb_out, cov_out, rot_out);
-  else
-    hipLaunchKernelGGL((deform_shade_dma_kernel<true>), dim3((N + 63) / 64), dim3(64), lds_bytes, s, N, deg, tri, w, packed, nullptr, nullptr,
-                       cov, pos, shs, campos, pos_out, cov6_out, rgb_out, cov_out, rot_out);
+  hipLaunchKernelGGL((deform_shade_kernel<true, false>), dim3((N + 63) / 64), dim3(64), lds_bytes, s, N, deg, tri, w, packed, nullptr, nullptr,
+                     cov, pos, shs, campos, pos_out, cov6_out, rgb_out, cov_out, rot_out, FusedPre{});
   GM_HIP(hipGetLastError());
   return 0;
 }
@@ -599,8 +347,8 @@ int launch_deform_shade_pre(const RasterArgs& r, GeomState& g, int* radii, int d
   fp.splat = g.splat; fp.radii_int = g.radii; fp.radii_out = radii; fp.tiles = g.tiles_touched; fp.bin = g.bin; fp.counters = g.counters; fp.slots = g.slots;
   fp.clamped = g.clamped; fp.depth_key = g.depth_key;
   const size_t lds_bytes = sizeof(float) * 64 * (48 + 9);
-  hipLaunchKernelGGL(deform_shade_pre_kernel, dim3((N + 63) / 64), dim3(64), lds_bytes, r.stream, N, deg, tri, w, packed, cov, pos, shs,
-                     r.cam_pos, pos_out, cov6_out, rgb_out, fp);
+  hipLaunchKernelGGL((deform_shade_kernel<true, true>), dim3((N + 63) / 64), dim3(64), lds_bytes, r.stream, N, deg, tri, w, packed, nullptr,
+                     nullptr, cov, pos, shs, r.cam_pos, pos_out, cov6_out, rgb_out, nullptr, nullptr, fp);
   GM_LAUNCH_CHECK(r.debug, r.stream);
   return 0;
 }
@@ -617,20 +365,9 @@ int launch_deform_shade(int N, int deg, int M, const int* tri, const float* w, c
     return launch_sh_colors(N, deg, M, pos_out, campos, rot_out, shs, rgb_out, s);
   }
   StageScope sc(ST_DEFORM, s);
-  // 64 Gaussians per workgroup (one wave, 14.5 KiB of LDS): ~11 workgroups per CU sit in different phases
-  // (load / compute / store), which keeps far more bytes in flight than a few 256-thread groups in lock-step
-  const char* e = getenv("GM_DS_THREADS");
-  const int th = e ? atoi(e) : 64;
-  const size_t lds_bytes = sizeof(float) * th * (52 + 9);
-  if (th == 256)
-    hipLaunchKernelGGL(deform_shade_kernel<256>, dim3((N + 255) / 256), dim3(256), lds_bytes, s, N, deg, tri, w, dV, Rv, Sv, cov, pos,
-                       shs, campos, pos_out, cov6_out, rgb_out, cov_out, rot_out);
-  else if (th == 128)
-    hipLaunchKernelGGL(deform_shade_kernel<128>, dim3((N + 127) / 128), dim3(128), lds_bytes, s, N, deg, tri, w, dV, Rv, Sv, cov, pos,
-                       shs, campos, pos_out, cov6_out, rgb_out, cov_out, rot_out);
-  else
-    hipLaunchKernelGGL(deform_shade_kernel<64>, dim3((N + 63) / 64), dim3(64), lds_bytes, s, N, deg, tri, w, dV, Rv, Sv, cov, pos,
-                       shs, campos, pos_out, cov6_out, rgb_out, cov_out, rot_out);
+  const size_t lds_bytes = sizeof(float) * 64 * (48 + 9);
+  hipLaunchKernelGGL((deform_shade_kernel<false, false>), dim3((N + 63) / 64), dim3(64), lds_bytes, s, N, deg, tri, w, dV, Rv, Sv, cov, pos,
+                     shs, campos, pos_out, cov6_out, rgb_out, cov_out, rot_out, FusedPre{});
   GM_HIP(hipGetLastError());
   return 0;
 }

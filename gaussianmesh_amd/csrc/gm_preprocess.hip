@@ -32,10 +32,10 @@ struct PreArgs {
   float4* splat; int* radii_int; int* radii_out; uint32_t* tiles; uint4* bin; int tile_cull; uint32_t* counters; uint32_t* slots; float* cov3D; uint8_t* clamped; uint32_t* depth_key;
 };
 
-// STAGE_SH: the workgroup's 256 SH rows (192 B each, M == 16) are copied HBM -> LDS with consecutive lanes reading
-// consecutive 16 bytes (gm_stage.h) before the per-Gaussian work; otherwise each thread walks its own row.
-// DMA (one-wave workgroups of 64 Gaussians): the rows arrive by LDS-DMA as a linear image (row stride 12 granules), as in
-// gm_deform.hip's deform_shade_dma_kernel: more, smaller workgroups in different phases and no staging registers.
+// STAGE_SH + DMA (the instantiated fast path, SH input with M == 16): one-wave workgroups of 64 Gaussians whose SH rows
+// (192 B each) arrive in LDS by LDS-DMA as a linear image (row stride 12 granules), as in gm_deform.hip's
+// deform_shade_kernel: many small workgroups in different phases and no staging registers.  Without STAGE_SH (precomputed
+// colours, other M, unaligned rows) each thread walks its own row.
 template <bool STAGE_SH, int TH = 256, bool DMA = false>
 __global__ __launch_bounds__(TH) void preprocess_fwd_kernel(const PreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds_pre[];
@@ -151,10 +151,7 @@ int launch_preprocess(const RasterArgs& r, GeomState& g, int* radii) {
   a.clamped = g.clamped; a.depth_key = g.depth_key;
   if (r.P > 0) {
     if (a.shs && a.M == 16 && aligned16(a.shs)) {
-      if (getenv("GM_PRE_NO_DMA"))
-        hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3((r.P + 255) / 256), dim3(256), sizeof(float4) * 256 * 13, r.stream, a);
-      else
-        hipLaunchKernelGGL((preprocess_fwd_kernel<true, 64, true>), dim3((r.P + 63) / 64), dim3(64), sizeof(float4) * 64 * 12, r.stream, a);
+      hipLaunchKernelGGL((preprocess_fwd_kernel<true, 64, true>), dim3((r.P + 63) / 64), dim3(64), sizeof(float4) * 64 * 12, r.stream, a);
     }
     else
       hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3((r.P + 255) / 256), dim3(256), 0, r.stream, a);
@@ -476,10 +473,7 @@ int launch_preprocess_bwd(const RasterArgs& r, GeomState& g, const int* radii, f
   a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot;
   if (r.P > 0) {
     if (a.shs && a.M == 16 && aligned16(a.shs) && aligned16(a.dL_dsh)) {
-      if (getenv("GM_PRE_NO_DMA"))
-        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3((r.P + 255) / 256), dim3(256), sizeof(float4) * 256 * 13, r.stream, a);
-      else
-        hipLaunchKernelGGL((preprocess_bwd_kernel<true, 64, true>), dim3((r.P + 63) / 64), dim3(64), sizeof(float4) * 64 * 12, r.stream, a);
+      hipLaunchKernelGGL((preprocess_bwd_kernel<true, 64, true>), dim3((r.P + 63) / 64), dim3(64), sizeof(float4) * 64 * 12, r.stream, a);
     }
     else
       hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3((r.P + 255) / 256), dim3(256), 0, r.stream, a);
