@@ -369,6 +369,19 @@ def mark_visible(means3D, viewmatrix, projmatrix):
 _WORKSPACES = {}
 
 
+def _snapshot(path, args):
+    """torch.save of a failing call's arguments (tensors moved to the host when the device still answers)"""
+    def host(v):
+        try:
+            return v.detach().cpu() if isinstance(v, torch.Tensor) else v
+        except Exception:
+            return None
+    try:
+        torch.save({k: host(v) for k, v in args.items()}, path)
+    except Exception:
+        pass
+
+
 def _shared_workspace(device):
     """inference scratch of the autograd operator, one per (device, stream, thread)"""
     import threading
@@ -418,18 +431,29 @@ class _RasterizeGaussians(torch.autograd.Function):
         ws = None if needs_grad else _shared_workspace(means3D.device)   # inference: reuse scratch
         policy = get_default_emission_policy()
         cap = _sync_free["capacity"].get(means3D.device, 0) if (_sync_free["on"] and needs_grad) else 0
-        h = rasterize_forward_begin(rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
-                                    rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree,
-                                    rs.campos, rs.prefiltered, rs.debug, workspace=ws, emission_policy=policy, force_M=force_M)
-        if cap > 0:
-            num_rendered, color, radii, geom, binning, img = h.finish(sync_free=True, capacity=cap)
-            num_rendered = cap                        # the binning layout is that of the capacity
-            _sync_free["unchecked"].append(h)
-        else:
-            num_rendered, color, radii, geom, binning, img = h.finish()
-            if _sync_free["on"] and needs_grad:
-                key = means3D.device
-                _sync_free["capacity"][key] = max(_sync_free["capacity"].get(key, 0), int(num_rendered * _sync_free["growth"]) + 4096)
+        try:
+            h = rasterize_forward_begin(rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                                        rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
+                                        rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, workspace=ws, emission_policy=policy,
+                                        force_M=force_M)
+            if cap > 0:
+                num_rendered, color, radii, geom, binning, img = h.finish(sync_free=True, capacity=cap)
+                num_rendered = cap                        # the binning layout is that of the capacity
+                _sync_free["unchecked"].append(h)
+            else:
+                num_rendered, color, radii, geom, binning, img = h.finish()
+                if _sync_free["on"] and needs_grad:
+                    key = means3D.device
+                    _sync_free["capacity"][key] = max(_sync_free["capacity"].get(key, 0), int(num_rendered * _sync_free["growth"]) + 4096)
+        except Exception:
+            if rs.debug:       # the reference's debugging aid (diff_gaussian_rasterizater/__init__.py:61-67): keep the failing call's inputs
+                _snapshot("snapshot_fw.dump", dict(bg=rs.bg, means3D=means3D, colors_precomp=colors_precomp, opacities=opacities, scales=scales,
+                                                   rotations=rotations, scale_modifier=rs.scale_modifier, cov3Ds_precomp=cov3Ds_precomp,
+                                                   viewmatrix=rs.viewmatrix, projmatrix=rs.projmatrix, tanfovx=rs.tanfovx, tanfovy=rs.tanfovy,
+                                                   image_height=rs.image_height, image_width=rs.image_width, sh=sh, sh_degree=rs.sh_degree,
+                                                   campos=rs.campos, prefiltered=rs.prefiltered))
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+            raise
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.emission_policy = policy
@@ -442,10 +466,20 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, grad_out_color, _grad_radii):
         rs = ctx.raster_settings
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
-        g2d, gcol, gop, g3d, gcov, gsh, gsc, grot = rasterize_backward(
-            rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
-            rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos, geom, ctx.num_rendered,
-            binning, img, rs.debug, ctx.emission_policy)
+        try:
+            g2d, gcol, gop, g3d, gcov, gsh, gsc, grot = rasterize_backward(
+                rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+                rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos, geom, ctx.num_rendered,
+                binning, img, rs.debug, ctx.emission_policy)
+        except Exception:
+            if rs.debug:       # diff_gaussian_rasterizater/__init__.py:102-108
+                _snapshot("snapshot_bw.dump", dict(bg=rs.bg, means3D=means3D, radii=radii, colors_precomp=colors_precomp, scales=scales,
+                                                   rotations=rotations, scale_modifier=rs.scale_modifier, cov3Ds_precomp=cov3Ds_precomp,
+                                                   viewmatrix=rs.viewmatrix, projmatrix=rs.projmatrix, tanfovx=rs.tanfovx, tanfovy=rs.tanfovy,
+                                                   grad_out_color=grad_out_color, sh=sh, sh_degree=rs.sh_degree, campos=rs.campos,
+                                                   num_rendered=ctx.num_rendered))
+                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+            raise
         has = lambda t: t is not None and t.numel() > 0
         return (g3d, g2d, gsh if has(sh) else None, gcol if has(colors_precomp) else None, gop.reshape(ctx.opacity_shape),
                 gsc if has(scales) else None, grot if has(rotations) else None, gcov if has(cov3Ds_precomp) else None,

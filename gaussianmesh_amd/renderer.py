@@ -30,10 +30,42 @@ def strip_symmetric(cov):
     return torch.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], dim=1)
 
 
+_SH_C0 = 0.28209479177387814
+_SH_C1 = 0.4886025119029199
+_SH_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
+_SH_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658, 1.445305721320277,
+          -0.5900435899266435)
+
+
+def eval_sh_torch(deg, feats, dirs):
+    """Real spherical harmonics up to degree 3 as differentiable torch ops: feats [N,K,3] (coefficient-major, as the
+    rasterizer takes them), dirs [N,3] unit vectors -> [N,3].  Same basis and constants as the kernels (csrc/gm_sh.h;
+    the reference evaluates this in python with utils/sh_utils.py:57-112 eval_sh when pipe.convert_SHs_python is set)."""
+    x, y, z = dirs[:, 0:1], dirs[:, 1:2], dirs[:, 2:3]
+    r = _SH_C0 * feats[:, 0]
+    if deg > 0:
+        r = r - _SH_C1 * y * feats[:, 1] + _SH_C1 * z * feats[:, 2] - _SH_C1 * x * feats[:, 3]
+    if deg > 1:
+        xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+        r = (r + _SH_C2[0] * xy * feats[:, 4] + _SH_C2[1] * yz * feats[:, 5] + _SH_C2[2] * (2.0 * zz - xx - yy) * feats[:, 6] +
+             _SH_C2[3] * xz * feats[:, 7] + _SH_C2[4] * (xx - yy) * feats[:, 8])
+        if deg > 2:
+            r = (r + _SH_C3[0] * y * (3.0 * xx - yy) * feats[:, 9] + _SH_C3[1] * xy * z * feats[:, 10] +
+                 _SH_C3[2] * y * (4.0 * zz - xx - yy) * feats[:, 11] + _SH_C3[3] * z * (2.0 * zz - 3.0 * xx - 3.0 * yy) * feats[:, 12] +
+                 _SH_C3[4] * x * (4.0 * zz - xx - yy) * feats[:, 13] + _SH_C3[5] * z * (xx - yy) * feats[:, 14] +
+                 _SH_C3[6] * x * (xx - 3.0 * yy) * feats[:, 15])
+    return r
+
+
 def _python_sh_colors(pc, cam, xyz, feats):
-    # pipe.convert_SHs_python: colours from SH on the python side of the op (gaussian_renderer/__init__.py:84-89);
-    # here a HIP kernel, forward only (the reference's python path is differentiable; use shs= for training)
-    return sh_colors(xyz, cam.camera_center, feats, rot=None, deg=pc.active_sh_degree)
+    """pipe.convert_SHs_python: colours from SH on the python side of the op (gaussian_renderer/__init__.py:84-92),
+    differentiable with respect to the features AND the positions (through the view direction) like the reference's.
+    When no gradient can be asked for (inference), one forward-only HIP kernel does the same."""
+    if torch.is_grad_enabled() and (feats.requires_grad or xyz.requires_grad):
+        d = xyz - cam.camera_center.reshape(1, 3)
+        d = d / d.norm(dim=1, keepdim=True)
+        return torch.clamp_min(eval_sh_torch(pc.active_sh_degree, feats, d) + 0.5, 0.0)
+    return sh_colors(xyz.detach(), cam.camera_center, feats.detach(), rot=None, deg=pc.active_sh_degree)
 
 
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, bg_gaussian=None):
@@ -61,7 +93,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     shs = colors_precomp = None
     if override_color is None:
         if pipe.convert_SHs_python:
-            colors_precomp = _python_sh_colors(pc, viewpoint_camera, means3D.detach(), pc.get_features)
+            colors_precomp = _python_sh_colors(pc, viewpoint_camera, means3D, pc.get_features)
         else:
             shs = pc.get_features
     else:
@@ -114,7 +146,7 @@ def bg_render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, overri
     shs = colors_precomp = None
     if override_color is None:
         if pipe.convert_SHs_python:
-            colors_precomp = _python_sh_colors(pc, viewpoint_camera, means3D.detach(), pc.get_features)
+            colors_precomp = _python_sh_colors(pc, viewpoint_camera, means3D, pc.get_features)
         else:
             shs = pc.get_features
     else:

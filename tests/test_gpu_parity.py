@@ -670,3 +670,41 @@ def test_ordering_paths(oracle, case):
         else:
             assert np.array_equal(st["color"], ex["color"]) and np.array_equal(st["final_T"], ex["final_T"])
         assert_forward_gate(fw, st["color"], W, H, FWD_TOL, "%s policy %d" % (case, mode))
+
+
+def test_python_sh_route_is_differentiable_and_debug_snapshots(oracle, tmp_path, monkeypatch):
+    """pipe.convert_SHs_python (gaussian_renderer/__init__.py:84-92): same image and the same gradients - to the features and,
+    through the view direction, to the positions - as the in-op SH path; debug=True keeps the inputs of a failing call."""
+    from types import SimpleNamespace
+    from gpu_utils import T
+    from gaussianmesh_amd import scenes
+    from gaussianmesh_amd.renderer import Camera, render
+    N = 3000
+    cl = scenes.make_cloud(N, seed=6, scale_lo=0.03, scale_hi=0.3)
+    cam = Camera(scenes.orbit_camera(1, 6, 160, 96, radius=7.0), "cuda")
+    wgt = torch.randn((3, 96, 160), device="cuda")
+
+    def run(py):
+        pc = SimpleNamespace(get_xyz=T(cl["means"], True), get_opacity=T(cl["opac"]).reshape(-1, 1), get_scaling=T(cl["scales"]),
+                             get_rotation=torch.nn.functional.normalize(T(cl["rots"])), get_features=T(cl["shs"], True), active_sh_degree=3,
+                             max_sh_degree=3, screenspace_points=torch.zeros((N, 3), device="cuda", requires_grad=True))
+        pipe = SimpleNamespace(convert_SHs_python=py, compute_cov3D_python=False, debug=False)
+        out = render(cam, pc, pipe, torch.zeros(3, device="cuda"))
+        (out["render"] * wgt).sum().backward()
+        return out["render"].detach(), pc.get_xyz.grad, pc.get_features.grad
+    img_a, gx_a, gf_a = run(False)
+    img_b, gx_b, gf_b = run(True)
+    assert (img_a - img_b).abs().max() <= 2e-5
+    assert gf_b.abs().max() > 0 and (gf_a - gf_b).abs().max() <= 1e-3 * gf_a.abs().max()
+    assert (gx_a - gx_b).abs().max() <= 1e-3 * gx_a.abs().max()
+    # debug snapshot: an SH degree the library rejects, in debug mode -> snapshot_fw.dump next to the process
+    from gaussianmesh_amd import GaussianRasterizationSettings, GaussianRasterizer
+    monkeypatch.chdir(tmp_path)
+    c = scenes.orbit_camera(1, 6, 64, 48, radius=7.0)
+    rs = GaussianRasterizationSettings(48, 64, c["tanx"], c["tany"], torch.zeros(3, device="cuda"), 1.0, T(c["view"]), T(c["proj"]), 7,
+                                       T(c["campos"]), False, True)
+    with pytest.raises(Exception):
+        GaussianRasterizer(rs)(T(cl["means"]), torch.zeros((N, 3), device="cuda"), T(cl["opac"]).reshape(-1, 1), shs=T(cl["shs"]),
+                               scales=T(cl["scales"]), rotations=T(cl["rots"]))
+    snap = torch.load(str(tmp_path / "snapshot_fw.dump"))
+    assert snap["sh_degree"] == 7 and snap["means3D"].shape == (N, 3)
