@@ -49,3 +49,17 @@ def install(force=False, operators=True, edit_tool=False):
         ro.save_image = gio.save_image
         sys.modules["render_origin"] = ro
     return sys.modules["jittor"]
+
+
+def uninstall():
+    """Undo install(): restore torch.Tensor's own attributes (numpy() raises again for graph / device tensors) and drop the
+    module aliases this package registered."""
+    j = sys.modules.get("jittor")
+    if j is not None and getattr(j, "__gaussianmesh_compat__", False):
+        j._unpatch_tensor()
+        for k in [k for k in sys.modules if k == "jittor" or k.startswith("jittor.")]:
+            del sys.modules[k]
+    for k in ("gaussian_renderer.diff_gaussian_rasterizater", "scene.simple_knn", "edittool", "render_origin"):
+        m = sys.modules.get(k)
+        if m is not None and (getattr(m, "__name__", "").startswith("gaussianmesh_amd") or k == "render_origin"):
+            del sys.modules[k]

@@ -296,9 +296,31 @@ def _var_normalize(self, p=2, dim=1, eps=1e-12):
     return normalize(self, p=p, dim=dim, eps=eps)
 
 
+# Var methods Jittor code calls on tensors.  These are patched onto torch.Tensor for the whole process - that is what
+# compat.install() means (this module is imported by nothing else); compat.uninstall() restores torch's own attributes.
+# Note `numpy`: Jittor's Var.numpy() works on device / graph tensors, so the patched one detaches and copies to the host
+# where torch would raise.
+_PATCHED = getattr(_torch.Tensor, "_gm_compat_originals", None)           # survives a re-import of this module
+_first = _PATCHED is None
+if _first:
+    _PATCHED = {}
+    _torch.Tensor._gm_compat_originals = _PATCHED
+_torch_numpy = _PATCHED.get("numpy") or _torch_numpy
 for _name, _fn in (("stop_grad", _stop_grad), ("sync", _sync), ("update", _update), ("copy", _copy), ("numpy", _numpy),
                    ("normalize", _var_normalize)):
+    if _name not in _PATCHED:
+        _PATCHED[_name] = getattr(_torch.Tensor, _name, None)
     setattr(_torch.Tensor, _name, _fn)
+
+
+def _unpatch_tensor():
+    for name, orig in _PATCHED.items():
+        if orig is None:
+            if hasattr(_torch.Tensor, name):
+                delattr(_torch.Tensor, name)
+        else:
+            setattr(_torch.Tensor, name, orig)
+    _PATCHED.clear()
 
 from . import nn, linalg, init  # noqa: E402,F401
 

@@ -52,7 +52,15 @@ class _ParamList(list):
             return t
         if t.is_leaf and t.requires_grad:
             return t
-        return t.detach().clone().requires_grad_(True) if not t.is_leaf else t.requires_grad_(True)
+        if t.is_leaf:
+            return t.requires_grad_(True)
+        # A computed tensor cannot become a torch leaf: the group gets a trainable COPY.  Code that keeps using the object
+        # it passed in (instead of re-reading param_groups[i]["params"][0], as the reference's densifier does) would
+        # diverge from what is optimised, so say it once.
+        import warnings
+        warnings.warn("jittor compat: a non-leaf tensor was put into an optimizer group; the group holds a trainable copy - "
+                      "re-read it from param_groups[...]['params']", RuntimeWarning, stacklevel=3)
+        return t.detach().clone().requires_grad_(True)
 
     def __init__(self, it=()):
         super().__init__(self._leaf(t) for t in it)

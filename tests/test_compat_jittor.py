@@ -252,3 +252,16 @@ def test_reference_mesh_model_trains_and_densifies_on_the_subset(jt, ref_env):
     assert g.optimizer.param_groups[0]["m"][0].shape == (m + 9, 3)
     g.reset_viewspace_point()
     g.optimizer.backward((g.get_xyz ** 2).sum()); g.optimizer.step(); g.optimizer.zero_grad()
+
+
+def test_uninstall_restores_torch_tensor():
+    import torch
+    import gaussianmesh_amd.compat as compat
+    compat.install(force=True)
+    t = torch.ones(2, requires_grad=True)
+    assert t.numpy().tolist() == [1.0, 1.0] and hasattr(torch.Tensor, "stop_grad")          # Jittor semantics while installed
+    compat.uninstall()
+    assert not hasattr(torch.Tensor, "stop_grad")
+    with pytest.raises(RuntimeError):
+        t.numpy()                                                                          # torch's own behaviour is back
+    compat.install(force=True)                                                             # (other tests expect the shim)
