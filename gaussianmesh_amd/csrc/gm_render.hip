@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const uint2* __restrict
   float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f;
   uint32_t last = 0;
   float alive = inside ? 1.0f : 0.0f;            // 0 once the pixel has stopped (reference `done`): a factor of alpha, not a mask
-  int tr_iters = 0, tr_cand = 0, tr_surv = 0;    // (tools/wave_trace.py)
+  int tr_iters = 0, tr_cand = 0, tr_surv = 0, tr_useful = 0, tr_lanes = 0;    // (tools/wave_trace.py)
   if (n > 0) {
     // pixel-centre rectangle owned by this wave
     const float rx0 = (float)(tx * GM_TILE + (wave & 1) * 8), ry0 = (float)(ty * GM_TILE + (wave >> 1) * 8);
@@ -271,6 +271,7 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const uint2* __restrict
             T = stop ? T : t;
             Cr += RB[u].z * w; Cg += RB[u].w * w; Cb += RC[u].x * w;
             last = (w > 0.0f) ? __float_as_uint(RC[u].y) : last;
+            if (trace) { const unsigned long long hit = __ballot(w > 0.0f); tr_useful += hit != 0ull; tr_lanes += __popcll(hit); }
           }
           if (!__any(alive != 0.0f)) break;
         }
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const uint2* __restrict
   }
   if (trace && lane == 0) {
     unsigned long long* t = trace + 4 * ((size_t)blockIdx.x * 4 + wave);
-    t[0] = t_start; t[1] = wall_clock64(); t[2] = (unsigned long long)n;
+    t[0] = t_start; t[1] = wall_clock64(); t[2] = (unsigned long long)n | ((unsigned long long)tr_useful << 24) | ((unsigned long long)tr_lanes << 44);
     t[3] = (unsigned long long)tr_iters | ((unsigned long long)tr_cand << 16) | ((unsigned long long)tr_surv << 40);
   }
 }

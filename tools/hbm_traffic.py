@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""profiles/hbm_traffic.json from the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of a single-stream bench run
+(tools/pmc.sh <tag> FETCH_SIZE WRITE_SIZE with PMC_FILTER="").  Per stage: the kernels it consists of and the per-frame
+sums of their per-launch means, in KiB.  bench.py turns them into bytes as MI355X_MICROARCH.md prescribes for gfx950:
+bytes = 1024 * (2 * FETCH_SIZE + WRITE_SIZE)."""
+import json
+import re
+import sys
+
+STAGES = [  # stage, (kernel name fragment, launches per frame)
+    ("deform", [("pack_mesh_state_kernel", 1), ("deform_shade_kernel<true, true>", 1)]),
+    ("depth_sort", [("bk_hist_kernel<true, 11, 4>", 1), ("bk_scan_kernel<true, 11>", 1), ("bk_scatter_kernel<true, 11, 4>", 1), ("bucket_sort_kernel", 1)]),
+    ("duplicate", [("duplicate_kernel<1>", 1)]),
+    ("tile_sort", [("bk_hist_kernel<false, 11, 8>", 1), ("bk_scan_kernel<false, 11>", 1), ("bk_scatter_kernel<false, 11, 8>", 1)]),
+    ("ranges", [("tile_order_kernel", 1)]),
+    ("render", [("render_fwd_kernel", 1)]),
+]
+
+
+def parse(path):
+    """{counter: {kernel line: mean}} from tools/pmc_summary.py output"""
+    out, kernel = {}, None
+    for line in open(path):
+        if line.startswith("#"):
+            continue
+        m = re.match(r"\s+(\w+)\s+mean ([0-9.e+-]+)", line)
+        if m and kernel:
+            out.setdefault(m.group(1), {})[kernel] = float(m.group(2))
+        elif line.strip():
+            kernel = line.strip()
+    return out
+
+
+def main(pmc_txt, out_json, gaussians, width, height):
+    c = parse(pmc_txt)
+    stages = {}
+    for st, ks in STAGES:
+        f = w = 0.0
+        names = []
+        for frag, n in ks:
+            fk = [v for k, v in c.get("FETCH_SIZE", {}).items() if frag.replace(" ", "") in k.replace(" ", "")]
+            wk = [v for k, v in c.get("WRITE_SIZE", {}).items() if frag.replace(" ", "") in k.replace(" ", "")]
+            if not fk or not wk:
+                raise SystemExit("kernel %r not found in %s" % (frag, pmc_txt))
+            f += n * fk[0]; w += n * wk[0]
+            names.append(frag)
+        stages[st] = {"kernels": names, "fetch_kib": round(f, 1), "write_kib": round(w, 1)}
+    json.dump({"source": pmc_txt, "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
+               "`python bench.py --streams 1 --exact-count`; per-launch means in KiB; bytes = 1024 * (2 * FETCH_SIZE + WRITE_SIZE): "
+               "FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as reported",
+               "workload": {"gaussians": int(gaussians), "width": int(width), "height": int(height)}, "stages": stages},
+              open(out_json, "w"), indent=1)
+    print(json.dumps(stages, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:])

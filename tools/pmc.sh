@@ -13,6 +13,6 @@ for pass in "$@"; do
   rocprofv3 --kernel-trace --pmc $pass -d /tmp/pmc_${tag}_$i -o p -- python $root/bench.py --no-cpu-baseline ${PMC_BENCH_ARGS:---no-fwd-bwd} --streams 1 --exact-count --steps 6 --warmup 2 > /dev/null 2> /tmp/pmc_${tag}_$i.err
   db=$(find /tmp/pmc_${tag}_$i -name "*.db" | head -1)
   echo "# pass $i: $pass" >> $out
-  python $root/tools/pmc_summary.py $db ${PMC_FILTER:-render} >> $out 2>&1
+  python $root/tools/pmc_summary.py $db ${PMC_FILTER-render} >> $out 2>&1
 done
 cat $out

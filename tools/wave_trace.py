@@ -41,7 +41,8 @@ def main():
     t = buf.cpu().numpy().reshape(-1, 4)
     t = t[t[:, 0] > 0]
     t0 = t[:, 0].min()
-    start = (t[:, 0] - t0) / 100.0; end = (t[:, 1] - t0) / 100.0; n = t[:, 2]        # wall_clock64 ticks at 100 MHz -> microseconds
+    start = (t[:, 0] - t0) / 100.0; end = (t[:, 1] - t0) / 100.0; n = t[:, 2] & 0xFFFFFF        # wall_clock64 ticks at 100 MHz -> microseconds
+    useful = (t[:, 2] >> 24) & 0xFFFFF; lanes = t[:, 2] >> 44
     dur = end - start
     print("waves %d, kernel span %.1f us, sum of wave durations %.0f us (= %.1f us x 8192 resident slots)" % (len(t), end.max(), dur.sum(), dur.sum() / 8192))
     for q in (50, 90, 99, 99.9):
@@ -52,7 +53,8 @@ def main():
     late = np.argsort(-end)[:12]
     print("latest waves: end us / duration us / list length:", [(round(end[i], 1), round(dur[i], 1), int(n[i])) for i in late])
     iters = t[:, 3] & 0xFFFF; cand = (t[:, 3] >> 16) & 0xFFFFFF; surv = t[:, 3] >> 40
-    print("totals: iterations %d, candidates %d, survivors %d" % (iters.sum(), cand.sum(), surv.sum()))
+    print("totals: iterations %d, candidates %d, survivors %d, survivors some pixel accepts %d, accepting lanes per such survivor %.1f" %
+          (iters.sum(), cand.sum(), surv.sum(), useful.sum(), lanes.sum() / max(useful.sum(), 1)))
     print("latest waves: iterations / candidates / survivors:", [(int(iters[i]), int(cand[i]), int(surv[i])) for i in late])
     for lo, hi in ((0, 1), (1, 16), (16, 64), (64, 128), (128, 256), (256, 512), (512, 4096)):
         m = (surv >= lo) & (surv < hi)
