@@ -49,7 +49,7 @@ def build_scene(P, W, H, frames, seed=0):
         mesh[t, :, 0:3] = V1
         mesh[t, :, 3:12] = Rv.reshape(-1, 9)
         mesh[t, :, 12:21] = Sv.reshape(-1, 9)
-    return dict(verts=verts.astype(np.float32), tri=cl["tri"], weights=cl["weights"], pos=cl["means"], cov=cov,
+    return dict(verts=verts.astype(np.float32), faces=faces.astype(np.int32), tri=cl["tri"], weights=cl["weights"], pos=cl["means"], cov=cov,
                 opac=cl["opac"], shs=cl["shs"], scales=cl["scales"], rots=cl["rots"], mesh=mesh)
 
 
@@ -68,7 +68,7 @@ def algorithmic_bytes(stage, P, V, R, W, H, Vm, M=16, list_tiles=2040):
         "depth_sort": P * 8 + V * 8 + V * (8 + 4 + 4 + 4) + (P // 4096 + 1) * hist * 4,
         "duplicate": V * (4 + 4) + V * 16 + R * 8,                                  # counts + ids in order, bin records, (key, id) out
         "tile_sort": (R * (4 + 8 + 8) + (R // 4096 + 1) * hist * 4) * (1 if one_pass else 2) + list_tiles * 8,
-        "ranges": R * 4 + list_tiles * 8,
+        "ranges": list_tiles * 12,                                                  # tile_order_kernel: ranges in, dispatch order out
         "render": R * 40 + W * H * 12,
     }[stage]
 
@@ -170,6 +170,8 @@ def main():
                     "(gm_forward_1_geom's exact mode) instead of the sync-free mode")
     ap.add_argument("--check-dir", default=None, help="every rank saves the image of its last timed step (with the step, frame and "
                     "camera index) as <dir>/rank<r>.npz: lets a test verify that each rank rendered its own views")
+    ap.add_argument("--analytic-rs", action="store_true", help="take the per-vertex (R, S) of every animation frame from the analytic "
+                    "deformation (precomputed tables) instead of computing them from the deformed mesh inside the frame (gm_mesh_rs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fwd-bwd", action="store_true")
     args = ap.parse_args()
@@ -180,7 +182,7 @@ def main():
     import torch.distributed as dist
     from gaussianmesh_amd import _lib, multiview, scenes
     from gaussianmesh_amd import rasterizer as Rz
-    from gaussianmesh_amd.deform import deform_shade_packed, pack_mesh_state
+    from gaussianmesh_amd.deform import deform_shade_packed, mesh_rs, pack_mesh_state, vertex_face_adjacency
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -208,6 +210,7 @@ def main():
     shapes = dict(tri=((P, 3), torch.int32), weights=((P, 3), torch.float32), pos=((P, 3), torch.float32),
                   cov=((P, 3, 3), torch.float32), opac=((P, 1), torch.float32), shs=((P, 16, 3), torch.float32),
                   scales=((P, 3), torch.float32), rots=((P, 4), torch.float32), verts=((7500, 3), torch.float32),
+                  faces=((15000, 3), torch.int32),
                   mesh=((F, 7500, 21), torch.float32))
     g = {}
     if rank == 0:
@@ -220,6 +223,11 @@ def main():
     # the animation ("mesh") stays on rank 0; its frames are broadcast one at a time inside the timed loop
     multiview.broadcast_cloud({k: v for k, v in g.items() if k != "mesh"}, src=0)
     Vm = g["verts"].shape[0]
+    # per-frame ARAP-style deformation: (R, S) of every vertex come from the deformed mesh of that frame (gm_mesh_rs,
+    # the device counterpart of pyACAP.GetRS), on the rank that owns the animation
+    off, adj = vertex_face_adjacency(g["faces"], Vm)
+    adjacency = (torch.tensor(off, device=dev), torch.tensor(adj, device=dev))
+    v1_frames = g["mesh"][:, :, 0:3].contiguous()          # deformed vertex positions per animation frame
     cams = [scenes.orbit_camera(k, F, W, H) for k in range(F)]
     cam_t = [dict(view=torch.tensor(c["view"], device=dev), proj=torch.tensor(c["proj"], device=dev),
                   campos=torch.tensor(c["campos"], device=dev), tanx=c["tanx"], tany=c["tany"]) for c in cams]
@@ -270,12 +278,16 @@ def main():
 
     def step_on_stream(i, workspace, frame_buf, exchange=True, begin_only=False):
         t = i % F
+        def frame_state():                       # [Vm,21] = V1 | R | S of animation frame t
+            if args.analytic_rs:
+                return g["mesh"][t]
+            return mesh_rs(g["verts"], v1_frames[t], g["faces"], adjacency=adjacency, want_state=True)[2]
         if world > 1 and exchange:               # real exchange step: mesh state of frame t from rank 0 (RCCL)
             if rank == 0:
-                frame_buf.copy_(g["mesh"][t])
+                frame_buf.copy_(frame_state())
             ms = multiview.broadcast_mesh_state(frame_buf, src=0)
         else:
-            ms = g["mesh"][t]
+            ms = frame_state()
         packed = pack_mesh_state(ms, g["verts"])            # [Vm,21] frame state -> per-vertex gather table (one small kernel)
         c = cam_t[multiview.view_for_step(i, F, rank, world)]
         if begin_only and not args.unfused:      # one enqueue: deform + colour + preprocess + depth sort + instance count
@@ -365,7 +377,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "C3: %d Gaussians bound to 15k-face torus, per-frame mesh deform + SH colour + forward "
                                "render %dx%d, %d-camera orbit, views sharded by rank" % (P, W, H, F),
-                   "gaussians": P, "width": W, "height": H, "sh_degree": 3, "views_per_step_per_gpu": 1, "hip_streams": nstreams,
+                   "gaussians": P, "width": W, "height": H, "sh_degree": 3, "views_per_step_per_gpu": 1,
+                   "vertex_rs": "analytic tables" if args.analytic_rs else "gm_mesh_rs per frame", "hip_streams": nstreams,
                    "parallelism": "views x%d" % world},
     }
     if repeats:

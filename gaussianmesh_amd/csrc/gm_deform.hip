@@ -141,7 +141,6 @@ __global__ __launch_bounds__(64) void deform_shade_kernel(int N, int deg, const 
   constexpr int DS_THREADS = 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float4* l_sh = reinterpret_cast<float4*>(lds);   // [64][12] granules: linear image of the block's SH rows (12 KiB)
-  float* l_cov = lds + DS_THREADS * 48;            // [64][9] linear image of the covariance rows (2.25 KiB)
   const size_t row0 = (size_t)blockIdx.x * DS_THREADS;
   const int nrows = min(DS_THREADS, N - (int)row0);
   const int t = threadIdx.x;
@@ -160,16 +159,15 @@ __global__ __launch_bounds__(64) void deform_shade_kernel(int N, int deg, const 
     const char* gsh = reinterpret_cast<const char*>(shs + row0 * 48) + t * 16;
 #pragma unroll
     for (int q = 0; q < 12; q++) dma16(gsh + q * 1024, reinterpret_cast<char*>(l_sh) + q * 1024);
-    const char* gcv = reinterpret_cast<const char*>(cov + row0 * 9) + t * 16;
-    dma16(gcv, reinterpret_cast<char*>(l_cov));
-    dma16(gcv + 1024, reinterpret_cast<char*>(l_cov) + 1024);
-    if (t < 16) dma16(gcv + 2048, reinterpret_cast<char*>(l_cov) + 2048);
   } else if (live) {                               // last, partial block: plain copies of the thread's own rows
 #pragma unroll
     for (int c = 0; c < 12; c++) l_sh[t * 12 + c] = reinterpret_cast<const float4*>(shs)[i * 12 + c];
-#pragma unroll
-    for (int c = 0; c < 9; c++) l_cov[t * 9 + c] = cov[i * 9 + c];
   }
+  // the covariance row goes straight to registers (36 B per lane, the wave's 2304 B are contiguous): staging it as well
+  // would cost 2.25 KiB of LDS per wave, i.e. two resident waves per CU
+  float C[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) C[k] = live ? cov[i * 9 + k] : 0.f;
   float d[3], Rb[9], Sb[9];
   if (PACKED) {
     const float4* tab = reinterpret_cast<const float4*>(dV);
@@ -200,7 +198,7 @@ __global__ __launch_bounds__(64) void deform_shade_kernel(int N, int deg, const 
   __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): the DMA has landed
   __syncthreads();
   {
-    float RS[9], A[9], C[9];
+    float RS[9], A[9];
 #pragma unroll
     for (int a = 0; a < 3; a++)
 #pragma unroll
@@ -209,8 +207,6 @@ __global__ __launch_bounds__(64) void deform_shade_kernel(int N, int deg, const 
     for (int a = 0; a < 3; a++)
 #pragma unroll
       for (int b = 0; b < 3; b++) RS[3 * a + b] = (Rt[3 * a] * Sb[b] + Rt[3 * a + 1] * Sb[3 + b]) + Rt[3 * a + 2] * Sb[6 + b];
-#pragma unroll
-    for (int k = 0; k < 9; k++) C[k] = l_cov[t * 9 + k];
 #pragma unroll
     for (int a = 0; a < 3; a++)
 #pragma unroll
@@ -322,7 +318,7 @@ int launch_deform_shade_packed(int N, int deg, int M, const int* tri, const floa
     set_error("gm_deform_shade_packed: needs M == 16 and 16-byte aligned buffers"); return 1;
   }
   StageScope sc(ST_DEFORM, s);
-  const size_t lds_bytes = sizeof(float) * 64 * (48 + 9);
+  const size_t lds_bytes = sizeof(float) * 64 * 48;
   hipLaunchKernelGGL((deform_shade_kernel<true, false>), dim3((N + 63) / 64), dim3(64), lds_bytes, s, N, deg, tri, w, packed, nullptr, nullptr,
                      cov, pos, shs, campos, pos_out, cov6_out, rgb_out, cov_out, rot_out, FusedPre{});
   GM_HIP(hipGetLastError());
@@ -346,7 +342,7 @@ int launch_deform_shade_pre(const RasterArgs& r, GeomState& g, int* radii, int d
   fp.opac = r.opacities;
   fp.splat = g.splat; fp.radii_int = g.radii; fp.radii_out = radii; fp.tiles = g.tiles_touched; fp.bin = g.bin; fp.counters = g.counters; fp.slots = g.slots;
   fp.clamped = g.clamped; fp.depth_key = g.depth_key;
-  const size_t lds_bytes = sizeof(float) * 64 * (48 + 9);
+  const size_t lds_bytes = sizeof(float) * 64 * 48;
   hipLaunchKernelGGL((deform_shade_kernel<true, true>), dim3((N + 63) / 64), dim3(64), lds_bytes, r.stream, N, deg, tri, w, packed, nullptr,
                      nullptr, cov, pos, shs, r.cam_pos, pos_out, cov6_out, rgb_out, nullptr, nullptr, fp);
   GM_LAUNCH_CHECK(r.debug, r.stream);
@@ -365,7 +361,7 @@ int launch_deform_shade(int N, int deg, int M, const int* tri, const float* w, c
     return launch_sh_colors(N, deg, M, pos_out, campos, rot_out, shs, rgb_out, s);
   }
   StageScope sc(ST_DEFORM, s);
-  const size_t lds_bytes = sizeof(float) * 64 * (48 + 9);
+  const size_t lds_bytes = sizeof(float) * 64 * 48;
   hipLaunchKernelGGL((deform_shade_kernel<false, false>), dim3((N + 63) / 64), dim3(64), lds_bytes, s, N, deg, tri, w, dV, Rv, Sv, cov, pos,
                      shs, campos, pos_out, cov6_out, rgb_out, cov_out, rot_out, FusedPre{});
   GM_HIP(hipGetLastError());

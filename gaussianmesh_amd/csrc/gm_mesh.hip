@@ -69,16 +69,39 @@ __global__ __launch_bounds__(256) void mesh_rs_kernel(int Vm, const float* __res
   // at v with half the cotangent of the opposite angle (an interior edge gets both halves from its two faces)
   double M0[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, M1[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
   double nr[3] = {0, 0, 0}, nd[3] = {0, 0, 0}, wsum = 0.0;          // area-weighted normals (rest / deformed)
-  for (int k = adj_offsets[v]; k < adj_offsets[v + 1]; k++) {
-    const int f = adj_faces[k];
-    int iv[3] = {faces[3 * f], faces[3 * f + 1], faces[3 * f + 2]};
-    const int c0 = iv[0] == v ? 0 : (iv[1] == v ? 1 : 2);
-    const int ia = iv[(c0 + 1) % 3], ib = iv[(c0 + 2) % 3];
+  // The one-ring is read in chunks of RING faces with all loads of a level issued together (face ids -> corner ids ->
+  // positions: three dependent round trips per chunk instead of three per face; 7.5 k threads cannot hide latency otherwise).
+  constexpr int RING = 8;
+  const int k_begin = adj_offsets[v], k_end = adj_offsets[v + 1];
+  float p0[3], p1[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) { p0[j] = V0[3 * (size_t)v + j]; p1[j] = V1[3 * (size_t)v + j]; }
+  for (int kb = k_begin; kb < k_end; kb += RING) {
+    int fid[RING], ia_[RING], ib_[RING];
+#pragma unroll
+    for (int r = 0; r < RING; r++) fid[r] = adj_faces[min(kb + r, k_end - 1)];
+#pragma unroll
+    for (int r = 0; r < RING; r++) {
+      const int i0 = faces[3 * fid[r]], i1 = faces[3 * fid[r] + 1], i2 = faces[3 * fid[r] + 2];
+      ia_[r] = i0 == v ? i1 : (i1 == v ? i2 : i0);                  // the corner after v, the corner before v (orientation kept)
+      ib_[r] = i0 == v ? i2 : (i1 == v ? i0 : i1);
+    }
+    float qa0[RING][3], qb0[RING][3], qa1[RING][3], qb1[RING][3];
+#pragma unroll
+    for (int r = 0; r < RING; r++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        qa0[r][j] = V0[3 * (size_t)ia_[r] + j]; qb0[r][j] = V0[3 * (size_t)ib_[r] + j];
+        qa1[r][j] = V1[3 * (size_t)ia_[r] + j]; qb1[r][j] = V1[3 * (size_t)ib_[r] + j];
+      }
+#pragma unroll
+    for (int r = 0; r < RING; r++) {
+    if (kb + r >= k_end) continue;
     double ea[3], eb[3], da[3], db[3], ab[3];
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-      ea[j] = (double)V0[3 * ia + j] - V0[3 * v + j]; eb[j] = (double)V0[3 * ib + j] - V0[3 * v + j];
-      da[j] = (double)V1[3 * ia + j] - V1[3 * v + j]; db[j] = (double)V1[3 * ib + j] - V1[3 * v + j];
+      ea[j] = (double)qa0[r][j] - p0[j]; eb[j] = (double)qb0[r][j] - p0[j];
+      da[j] = (double)qa1[r][j] - p1[j]; db[j] = (double)qb1[r][j] - p1[j];
       ab[j] = eb[j] - ea[j];
     }
     double n0[3], n1[3];
@@ -99,6 +122,7 @@ __global__ __launch_bounds__(256) void mesh_rs_kernel(int Vm, const float* __res
 #pragma unroll
     for (int j = 0; j < 3; j++) { nr[j] += n0[j]; nd[j] += n1[j]; }
     wsum += l0;
+    }
   }
   double F[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
   bool have = false;
@@ -130,6 +154,61 @@ __global__ __launch_bounds__(256) void mesh_rs_kernel(int Vm, const float* __res
     }
   }
   double Q[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, S[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  // Common case - a proper, well-conditioned map (det F > 0, no direction collapsed by more than ~30x relative to the
+  // others): the orthogonal polar factor by Newton's iteration X <- (X + X^-T) / 2 (quadratic convergence, five or six
+  // steps of one cofactor matrix and one division each - a fifth of the Jacobi route's divisions and square roots).
+  // Reflections and near-singular maps take the eigen-decomposition route below, which fixes their conventions.
+  if (have) {
+    const double detF = F[0][0] * (F[1][1] * F[2][2] - F[1][2] * F[2][1]) - F[0][1] * (F[1][0] * F[2][2] - F[1][2] * F[2][0]) +
+                        F[0][2] * (F[1][0] * F[2][1] - F[1][1] * F[2][0]);
+    double fro = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) fro += F[i][j] * F[i][j];
+    if (detF > 0.0 && 27.0 * detF * detF > 1e-6 * fro * fro * fro) {
+      double X[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) X[i][j] = F[i][j];
+      bool converged = false;
+      for (int it = 0; it < 24 && !converged; it++) {
+        double Cf[3][3];                                            // cofactor matrix = det(X) X^-T
+        Cf[0][0] = X[1][1] * X[2][2] - X[1][2] * X[2][1]; Cf[0][1] = X[1][2] * X[2][0] - X[1][0] * X[2][2]; Cf[0][2] = X[1][0] * X[2][1] - X[1][1] * X[2][0];
+        Cf[1][0] = X[0][2] * X[2][1] - X[0][1] * X[2][2]; Cf[1][1] = X[0][0] * X[2][2] - X[0][2] * X[2][0]; Cf[1][2] = X[0][1] * X[2][0] - X[0][0] * X[2][1];
+        Cf[2][0] = X[0][1] * X[1][2] - X[0][2] * X[1][1]; Cf[2][1] = X[0][2] * X[1][0] - X[0][0] * X[1][2]; Cf[2][2] = X[0][0] * X[1][1] - X[0][1] * X[1][0];
+        const double d = X[0][0] * Cf[0][0] + X[0][1] * Cf[0][1] + X[0][2] * Cf[0][2];
+        const double hinv = 0.5 / d;
+        double delta = 0.0, mag = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            const double y = 0.5 * X[i][j] + hinv * Cf[i][j];
+            delta = fmax(delta, fabs(y - X[i][j])); mag = fmax(mag, fabs(y));
+            X[i][j] = y;
+          }
+        converged = delta <= 1e-14 * mag;
+      }
+      if (converged) {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) Q[i][j] = X[i][j];
+        double M[3][3];                                             // Q^T F, symmetric up to rounding
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) M[i][j] = X[0][i] * F[0][j] + X[1][i] * F[1][j] + X[2][i] * F[2][j];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) S[i][j] = 0.5 * (M[i][j] + M[j][i]);
+        have = false;                                               // done
+      }
+    }
+  }
   if (have) {
     double C[3][3], E[3][3];
 #pragma unroll

@@ -9,8 +9,8 @@
 // (and the colour from global memory).  Here a 16x16 tile is four independent wave64s, each owning one 8x8 pixel
 // quadrant (one pixel per lane, lane = y * 8 + x):
 //   * the workgroup walks the list of its PARENT tile (gm_common.h: emission policies); a two-stage front end (see
-//     WaveLds below) turns it into dense batches of up to 64 candidate records in LDS: a scan of the contiguous
-//     (key, id) stream picks the entries whose key carries the tile's child bit, their records arrive by LDS-DMA two
+//     WaveLds below) turns it into dense batches of up to 64 candidate records: a scan of the contiguous (key, id)
+//     stream picks the entries whose key carries the tile's child bit, their records are gathered into registers two
 //     iterations ahead of their use;
 //   * while lane j holds candidate j it tests, once per batch and for all 64 in parallel, whether the entry can reach
 //     alpha >= 1/255 anywhere inside the bounding box of the quadrant's still-live pixels (exact minimum of the conic's
@@ -125,11 +125,24 @@ struct WaveLds {                 // 3.9 KiB per wave
   // staged batch: the candidates that survive the cull, COMPACTED (entry k = k-th survivor in list order; 4 entries of
   // padding with opacity 0 behind the last one), conic pre-multiplied for the exp2 argument.  Survivors are re-read from
   // here as LDS broadcasts, consecutive entries at consecutive addresses: the loop over them needs no bit scanning.
-  float4 a[68];                  // x, y, conic.x', conic.y'
-  float4 b[68];                  // conic.z', opacity, r, g
+  float4 a[68];                  // x, y, conic.x', conic.z'
+  float4 b[68];                  // conic.y', opacity, r, g
   float2 cp[68];                 // b, list position (as bits; +1 in the forward kernel)
   uint32_t id[68];               // Gaussian id (backward kernel)
 };
+
+// exponent of one staged entry at one pixel, e = power * log2(e), on the packed-f32 pipe (v_pk_add / v_pk_mul operate on a
+// register PAIR in one issue slot): d = (x, y) - pix, q = (a', c') * d, q.x += b' d.y, e = q.x d.x + q.y d.y.
+// Staged record: RA = (x, y, a', c'), RB = (b', opacity, r, g) with a' = -log2e/2 conic.x, b' = -log2e conic.y, c' = -log2e/2 conic.z.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float staged_exponent(const float4& RA, float bq, v2f pix, v2f& d) {
+  const v2f xy = {RA.x, RA.y}, ac = {RA.z, RA.w};
+  d = xy - pix;
+  v2f q = ac * d;
+  q.x = __builtin_fmaf(bq, d.y, q.x);
+  const v2f r = q * d;
+  return r.x + r.y;
+}
 
 __device__ __forceinline__ Gather issue_gather(const float4* __restrict__ splat, uint2 cand) {
   Gather g;
@@ -139,17 +152,27 @@ __device__ __forceinline__ Gather issue_gather(const float4* __restrict__ splat,
   return g;
 }
 
-__global__ __launch_bounds__(256) void render_fwd_kernel(const uint2* __restrict__ ranges,
+#ifndef GM_RENDER_FWD_WPW
+#define GM_RENDER_FWD_WPW 1      // waves per workgroup of the forward blend: 4 (one workgroup per 16-px tile) or 1 (one per 8x8 quadrant)
+#endif
+template <bool TRACE>
+__global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(const uint2* __restrict__ ranges,
                                                                const uint2* __restrict__ pairs,
                                                                const float4* __restrict__ splat, int W, int H, TileMap tm,
                                                                const float* __restrict__ bg, float* __restrict__ out_color,
                                                                float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                                                                unsigned long long* __restrict__ trace) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned long long t_start = trace ? wall_clock64() : 0ull;      // tools/wave_trace.py: per-wave start / end / list length
+  // The four quadrant waves of a tile are independent.  As one-wave workgroups they are placed and retired one by one: a
+  // tile whose quadrants differ in length does not hold four wave slots (one per SIMD) until its longest wave is done.
+  // Workgroup ids 8 apart still share an XCD: id = ((tile slot j) * 4 + quadrant) * 8 + xcd.
+  constexpr int WPW = GM_RENDER_FWD_WPW;
+  const int lane = threadIdx.x & 63;
+  const int wave = WPW == 4 ? (int)(threadIdx.x >> 6) : (int)((blockIdx.x >> 3) & 3);
+  const int tile_block = WPW == 4 ? (int)blockIdx.x : (int)(((blockIdx.x >> 5) << 3) | (blockIdx.x & 7));
+  const unsigned long long t_start = TRACE ? wall_clock64() : 0ull;      // tools/wave_trace.py: per-wave start / end / list length
   int tx, ty, parent;
   uint32_t child_bit;
-  if (!tm.locate(blockIdx.x, tx, ty, parent, child_bit)) return;
+  if (!tm.locate(tile_block, tx, ty, parent, child_bit)) return;
   const uint2 range = ranges[parent];
   const int n = (int)(range.y - range.x);
   const uint2* list = pairs + range.x;           // (key, Gaussian id) per list entry
@@ -158,15 +181,19 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const uint2* __restrict
   const int py = ty * GM_TILE + (wave >> 1) * 8 + (lane >> 3);
   const float pixx = (float)px, pixy = (float)py;
   const bool inside = px < W && py < H;
-  float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f;
+  // T > 0: transmittance of a live pixel.  T < 0: the pixel has stopped (reference `done`) and |T| is its final transmittance - a
+  // stopped pixel then takes nothing with no extra state: T (1 - alpha) < 0 < 1e-4 is the stop test itself.
+  float T = inside ? 1.0f : -1.0f, Cb = 0.f;
+  v2f Crg = {0.f, 0.f};
+  const v2f pix = {pixx, pixy};
   uint32_t last = 0;
-  float alive = inside ? 1.0f : 0.0f;            // 0 once the pixel has stopped (reference `done`): a factor of alpha, not a mask
   int tr_iters = 0, tr_cand = 0, tr_surv = 0, tr_useful = 0, tr_lanes = 0;    // (tools/wave_trace.py)
+  int tr_tb = 0, tr_lr = 0, tr_q4 = 0, tr_steps = 0;                           // sum over batches of max(list length) under 2-way / 4-way pixel splits
   if (n > 0) {
     // pixel-centre rectangle owned by this wave
     const float rx0 = (float)(tx * GM_TILE + (wave & 1) * 8), ry0 = (float)(ty * GM_TILE + (wave >> 1) * 8);
-    __shared__ WaveLds l_w[4];
-    WaveLds& L = l_w[wave];
+    __shared__ WaveLds l_w[WPW];
+    WaveLds& L = l_w[WPW == 4 ? wave : 0];
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int nlast = n - 1;
     int kpos = 0;                                  // next list position to scan
@@ -199,8 +226,6 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const uint2* __restrict
       qa_head += (uint32_t)count; qa_cnt -= (uint32_t)count;
       return issue_gather(splat, cand);
     };
-    // Waves with long lists are the kernel's critical path (a 13 k-entry silhouette list takes a wave the whole launch when
-    // it shares its SIMD's issue slots evenly with five short-lived waves): they run at a higher priority from the start.
     load_keys();
     scan();                                        // (waits for the first keys)
     load_keys();
@@ -209,7 +234,7 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const uint2* __restrict
     // that is still being loaded makes the compiler wait for the load, i.e. vmcnt(0) at the end of every iteration.
     auto step = [&](Gather& cur, int& n0, const int n1, Gather& nxt, int& n2) -> bool {
       tr_iters++;
-      const unsigned long long live = __ballot(alive != 0.0f);
+      const unsigned long long live = __ballot(T > 0.0f);
       if (live == 0ull) return false;
       if (n0 == 0 && n1 == 0 && qa_cnt == 0u && kpos >= n) return false;
       // Entries are culled against the bounding box of the pixels that are still live, not the whole 8x8 quadrant (a
@@ -237,8 +262,8 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const uint2* __restrict
         }
         if (keep) {
           const int slot = __popcll(kb & lt_mask);
-          L.a[slot] = make_float4(cur.a.x, cur.a.y, (-0.5f * LOG2E) * cur.a.z, (-LOG2E) * cur.a.w);
-          L.b[slot] = make_float4((-0.5f * LOG2E) * cur.b.x, cur.b.y, cur.b.z, cur.b.w);
+          L.a[slot] = make_float4(cur.a.x, cur.a.y, (-0.5f * LOG2E) * cur.a.z, (-0.5f * LOG2E) * cur.b.x);
+          L.b[slot] = make_float4((-LOG2E) * cur.a.w, cur.b.y, cur.b.z, cur.b.w);
           L.cp[slot] = make_float2(cur.c, __uint_as_float(cur.pos + 1u));        // 1-based list position: n_contrib
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -248,6 +273,7 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const uint2* __restrict
         // RAST/forward.cu:336-352 is a select on a value (VCC only), never a combination of lane masks: the scalar unit, which
         // the four SIMDs of a CU share, was as busy as the vector units with the mask arithmetic of the first version
         // (21 scalar instructions per survivor).  Padding / skipped entries carry alpha 0 and change nothing.
+        int b_t = 0, b_b = 0, b_l = 0, b_r = 0, b_q[4] = {0, 0, 0, 0};
         for (int j = 0; j < ns; j += 4) {
           float4 RA[4], RB[4]; float2 RC[4];
 #pragma unroll
@@ -255,26 +281,33 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const uint2* __restrict
           float al[4];
 #pragma unroll
           for (int u = 0; u < 4; u++) {
-            const float dx = RA[u].x - pixx, dy = RA[u].y - pixy;
-            const float e = dx * (RA[u].z * dx + RA[u].w * dy) + (RB[u].x * dy) * dy;      // power * log2(e); same sign as power
+            v2f d;
+            const float e = staged_exponent(RA[u], RB[u].x, pix, d);                       // power * log2(e); same sign as power
             const float alpha = fminf(0.99f, RB[u].y * __builtin_amdgcn_exp2f(e));
             al[u] = (e <= 0.0f) ? alpha : 0.0f;                                           // skip power > 0
           }
 #pragma unroll
           for (int u = 0; u < 4; u++) {            // in list order
-            float a = al[u] * alive;                                                       // stopped pixels take nothing
-            a = (a >= 1.0f / 255.0f) ? a : 0.0f;                                          // skip alpha < 1/255
+            const float a = (al[u] >= 1.0f / 255.0f) ? al[u] : 0.0f;                      // skip alpha < 1/255
             const float wa = a * T, t = T - wa;                                           // weight alpha T; T (1 - alpha) as T - alpha T
-            const bool stop = t < 0.0001f;                                                // (t == T >= 1e-4 when a == 0)
-            alive = stop ? 0.0f : alive;                                                  // stop WITHOUT applying the entry
+            const bool stop = t < 0.0001f;                                                // (t == T >= 1e-4 when a == 0; t < 0 once stopped)
             const float w = stop ? 0.0f : wa;
-            T = stop ? T : t;
-            Cr += RB[u].z * w; Cg += RB[u].w * w; Cb += RC[u].x * w;
+            T = stop ? -__builtin_fabsf(T) : t;                                           // stop WITHOUT applying the entry
+            const v2f rg = {RB[u].z, RB[u].w}, ww = {w, w};
+            Crg = rg * ww + Crg; Cb += RC[u].x * w;
             last = (w > 0.0f) ? __float_as_uint(RC[u].y) : last;
-            if (trace) { const unsigned long long hit = __ballot(w > 0.0f); tr_useful += hit != 0ull; tr_lanes += __popcll(hit); }
+            if (TRACE) {
+              const unsigned long long hit = __ballot(w > 0.0f); tr_useful += hit != 0ull; tr_lanes += __popcll(hit);
+              const unsigned long long LM = 0x0F0F0F0F0F0F0F0Full;
+              b_t += (hit & 0xFFFFFFFFull) != 0; b_b += (hit >> 32) != 0; b_l += (hit & LM) != 0; b_r += (hit & ~LM) != 0;
+              b_q[0] += (hit & LM & 0xFFFFFFFFull) != 0; b_q[1] += (hit & ~LM & 0xFFFFFFFFull) != 0;
+              b_q[2] += ((hit & LM) >> 32) != 0; b_q[3] += ((hit & ~LM) >> 32) != 0;
+            }
           }
-          if (!__any(alive != 0.0f)) break;
+          if (TRACE) tr_steps++;
+          if (!__any(T > 0.0f)) break;
         }
+        if (TRACE) { tr_tb += max(b_t, b_b); tr_lr += max(b_l, b_r); tr_q4 += max(max(b_q[0], b_q[1]), max(b_q[2], b_q[3])); }
       }
       return true;
     };
@@ -288,16 +321,19 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const uint2* __restrict
   }
   if (inside) {
     const size_t HW = (size_t)H * W, pid = (size_t)W * py + px;
+    T = __builtin_fabsf(T);
     final_T[pid] = T;
     n_contrib[pid] = last;
-    out_color[pid] = Cr + T * bg[0];
-    out_color[HW + pid] = Cg + T * bg[1];
+    out_color[pid] = Crg.x + T * bg[0];
+    out_color[HW + pid] = Crg.y + T * bg[1];
     out_color[2 * HW + pid] = Cb + T * bg[2];
   }
-  if (trace && lane == 0) {
-    unsigned long long* t = trace + 4 * ((size_t)blockIdx.x * 4 + wave);
+  if (TRACE && lane == 0) {
+    unsigned long long* t = trace + 8 * ((size_t)tile_block * 4 + wave);
     t[0] = t_start; t[1] = wall_clock64(); t[2] = (unsigned long long)n | ((unsigned long long)tr_useful << 24) | ((unsigned long long)tr_lanes << 44);
     t[3] = (unsigned long long)tr_iters | ((unsigned long long)tr_cand << 16) | ((unsigned long long)tr_surv << 40);
+    t[4] = (unsigned long long)tr_tb | ((unsigned long long)tr_lr << 32);
+    t[5] = (unsigned long long)tr_q4 | ((unsigned long long)tr_steps << 32);
   }
 }
 
@@ -309,9 +345,15 @@ int launch_render_fwd(const GeomState& g, const uint2* pairs, ImageState& img, i
   StageScope sc(ST_RENDER, s);
   const TileGrid tg(W, H, mode);
   const TileMap tm{tg.gx, tg.gy, tg.pgx, tg.pgy, tg.s, img.tile_order};
-  if (tg.ptiles > 0)
-    hipLaunchKernelGGL(render_fwd_kernel, dim3(tm.blocks()), dim3(256), 0, s, img.ranges, pairs, g.splat, W, H, tm,
-                       background, out_color, img.final_T, img.n_contrib, g_render_trace);
+  if (tg.ptiles > 0) {
+    const dim3 grid(tm.blocks() * (4 / GM_RENDER_FWD_WPW)), block(64 * GM_RENDER_FWD_WPW);
+    if (g_render_trace)
+      hipLaunchKernelGGL(render_fwd_kernel<true>, grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
+                         background, out_color, img.final_T, img.n_contrib, g_render_trace);
+    else
+      hipLaunchKernelGGL(render_fwd_kernel<false>, grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
+                         background, out_color, img.final_T, img.n_contrib, nullptr);
+  }
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }
@@ -402,6 +444,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const uint2* __restrict
   const size_t pid = inside ? (size_t)W * py + px : 0;
   const float T_final = inside ? final_T[pid] : 0.f;
   float T = T_final;
+  const v2f pix = {pixx, pixy};
   const int last = inside ? (int)n_contrib[pid] : 0;
   const float dpr = inside ? dL_dpix[pid] : 0.f, dpg = inside ? dL_dpix[HW + pid] : 0.f, dpb = inside ? dL_dpix[2 * HW + pid] : 0.f;
   const float bg_dot = bg0 * dpr + bg1 * dpg + bg2 * dpb;
@@ -481,8 +524,8 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const uint2* __restrict
       const int ns = __popcll(kb);
       if (keep) {
         const int slot = __popcll(kb & lt_mask);
-        L.a[slot] = make_float4(cur.a.x, cur.a.y, (-0.5f * LOG2E) * cur.a.z, (-LOG2E) * cur.a.w);
-        L.b[slot] = make_float4((-0.5f * LOG2E) * cur.b.x, cur.b.y, cur.b.z, cur.b.w);
+        L.a[slot] = make_float4(cur.a.x, cur.a.y, (-0.5f * LOG2E) * cur.a.z, (-0.5f * LOG2E) * cur.b.x);
+        L.b[slot] = make_float4((-LOG2E) * cur.a.w, cur.b.y, cur.b.z, cur.b.w);
         L.cp[slot] = make_float2(cur.c, __uint_as_float(cur.pos));      // 0-based list position == reference `contributor`
         L.id[slot] = cur.id;
       }
@@ -491,9 +534,10 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const uint2* __restrict
       for (int j = 0; j < ns; j++) {
         const float4 RA = L.a[j], RB = L.b[j];
         const float2 RC = L.cp[j];
-        const float sx = RA.x, sy = RA.y, qa = RA.z, qb = RA.w, qc = RB.x, op = RB.y;
-        const float dx = sx - pixx, dy = sy - pixy;
-        const float e = dx * (qa * dx + qb * dy) + (qc * dy) * dy;      // power * log2(e); same sign as power
+        const float op = RB.y;
+        v2f dd;
+        const float e = staged_exponent(RA, RB.x, pix, dd);             // power * log2(e), evaluated exactly as in the forward kernel
+        const float dx = dd.x, dy = dd.y;
         const float G = __builtin_amdgcn_exp2f(e);
         const float alpha = fminf(0.99f, op * G);
         const int pos = (int)__float_as_uint(RC.y);

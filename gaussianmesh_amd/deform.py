@@ -154,8 +154,9 @@ def vertex_face_adjacency(faces, Vm):
 
 def mesh_rs(rest_vertices, deformed_vertices, faces, adjacency=None, want_state=False):
     """gm_mesh_rs: per-vertex (R, S) [Vm,3,3] of a deformed proxy mesh, the pair pyACAP.GetRS hands to
-    SingleObjectDeform.deform_gaussian (edittool/__init__.py:109-113): per-face TBN deformation gradients, rest-area
-    weighted per vertex, polar decomposition; R in pyACAP's row-vector convention (the transpose of the rotation).
+    SingleObjectDeform.deform_gaussian (edittool/__init__.py:109-113): cotangent-weighted one-ring least-squares
+    deformation gradient per vertex (ACAP / ARAP), polar decomposition; R in pyACAP's row-vector convention (the transpose
+    of the rotation).
     adjacency: (offsets, face ids) device int32 tensors from vertex_face_adjacency (built here when None).
     want_state: also return the frame record [Vm,21] = V1 | R | S that pack_mesh_state consumes."""
     lib = _lib.lib()

@@ -40,7 +40,7 @@ def test_bench_two_ranks_render_their_own_views(tmp_path):
     import bench
     from gpu_utils import T
     from gaussianmesh_amd import multiview, rasterizer as Rz, scenes
-    from gaussianmesh_amd.deform import pack_mesh_state
+    from gaussianmesh_amd.deform import mesh_rs, pack_mesh_state
     host = bench.build_scene(P, W, H, F)
     g = {k: T(host[k]) for k in ("weights", "pos", "cov", "opac", "shs", "verts")}
     g["tri"] = T(host["tri"], dtype=torch.int32)
@@ -53,7 +53,8 @@ def test_bench_two_ranks_render_their_own_views(tmp_path):
         views.add(v)
         cam = scenes.orbit_camera(v, F, W, H)
         ct = {n: T(cam[n]) for n in ("view", "proj", "campos")}
-        packed = pack_mesh_state(T(host["mesh"][last % F]), g["verts"])
+        state = mesh_rs(g["verts"], T(host["mesh"][last % F][:, 0:3]), T(host["faces"], dtype=torch.int32), want_state=True)[2]
+        packed = pack_mesh_state(state, g["verts"])
         _, color, *_ = Rz.forward_deformed_begin(torch.ones(3, device="cuda"), g["tri"], g["weights"], packed, g["cov"], g["pos"], g["shs"],
                                                  g["opac"], ct["view"], ct["proj"], cam["tanx"], cam["tany"], H, W, 3, ct["campos"]).finish()
         assert np.array_equal(d["image"], color.cpu().numpy()), "rank %d did not render view %d of frame %d" % (r, v, last % F)

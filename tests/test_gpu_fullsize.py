@@ -211,23 +211,31 @@ def test_c2_full_size_gradients_vs_oracle(oracle):
 
 def test_c3_bench_path_full_size_vs_oracle(oracle):
     """The exact path bench.py times (BASELINE config C3): bench.build_scene's 1 M-Gaussian torus cloud, 1920x1080,
-    gm_forward_0_deformed_async + gm_forward_1_geom, two frames / cameras.  Deformed cloud and colours vs the oracle's
+    per-vertex (R, S) of the frame from gm_mesh_rs (vs oracle/mesh_oracle.py), gm_forward_0_deformed_async +
+    gm_forward_1_geom, two frames / cameras.  Deformed cloud and colours vs the oracle's
     deform -> rotated SH colour (<= 1e-5 relative); then the oracle rasterizes the SAME deformed cloud: radii equal,
     num_rendered under the reference emission policy equal, sorted lists equal, strict image gate; the default policy's
     image is bit-identical to the reference policy's."""
     import bench
     from gpu_utils import T, set_policy
     from gaussianmesh_amd import rasterizer as Rz, scenes
-    from gaussianmesh_amd.deform import pack_mesh_state
+    from gaussianmesh_amd.deform import mesh_rs, pack_mesh_state
+    from oracle import mesh_oracle
     P, W, H, F = 1_000_000, 1920, 1080, 64
     host = bench.build_scene(P, W, H, F)
+    faces_t = T(host["faces"], dtype=torch.int32)
     g = {k: T(host[k]) for k in ("weights", "pos", "cov", "opac", "shs", "verts")}
     g["tri"] = T(host["tri"], dtype=torch.int32)
     bg = np.ones(3, np.float32)
     for t, k in ((3, 3), (40, 17)):
         cam = scenes.orbit_camera(k, F, W, H)
         ct = {n: T(cam[n]) for n in ("view", "proj", "campos")}
-        packed = pack_mesh_state(T(host["mesh"][t]), g["verts"])
+        state = mesh_rs(g["verts"], T(host["mesh"][t][:, 0:3]), faces_t, want_state=True)[2]      # as bench.py's frame_state()
+        ms = state.cpu().numpy()
+        Ro, So = mesh_oracle.mesh_rs(host["verts"], host["mesh"][t][:, 0:3], host["faces"])
+        assert np.abs(ms[:, 3:12].reshape(-1, 3, 3) - Ro).max() <= 5e-5 and np.abs(ms[:, 12:21].reshape(-1, 3, 3) - So).max() <= 5e-5
+        assert np.abs(ms[:, 3:21] - host["mesh"][t][:, 3:21]).max() <= 0.25       # sanity: first-order (edge length) approximation of the analytic Jacobian's factors
+        packed = pack_mesh_state(state, g["verts"])
         out = {}
         for mode in (0, 2):
             set_policy(mode)
@@ -244,7 +252,6 @@ def test_c3_bench_path_full_size_vs_oracle(oracle):
         assert np.array_equal(out[0][1], out[2][1]) and np.array_equal(out[0][2], out[2][2]) and out[2][0] < out[0][0]
         pos_d, cov6_d, rgb_d = out[2][3]
         # a20 / a21 against the oracle (float64 algebra, see gm_oracle.c orc_deform)
-        ms = host["mesh"][t]
         dV = ms[:, 0:3] - host["verts"]
         p_ref, c_ref, r_ref = oracle.deform(host["tri"], host["weights"], dV, ms[:, 3:12].reshape(-1, 3, 3), ms[:, 12:21].reshape(-1, 3, 3),
                                             host["cov"], host["pos"])

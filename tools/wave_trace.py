@@ -25,7 +25,7 @@ def main():
     fn = lib.gm_debug_render_trace
     fn.restype = None; fn.argtypes = [C.c_void_p]
     nblocks = 4 * 2048 * 4 + 64
-    buf = torch.zeros((nblocks * 4 * 4,), dtype=torch.int64, device=dev)
+    buf = torch.zeros((nblocks * 4 * 8,), dtype=torch.int64, device=dev)
     k = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     cam = scenes.orbit_camera(k, F, W, H)
     ct = {n: torch.tensor(cam[n], device=dev) for n in ("view", "proj", "campos")}
@@ -38,7 +38,7 @@ def main():
                                   cam["tanx"], cam["tany"], H, W, 3, ct["campos"]).finish()
         torch.cuda.synchronize()
     fn(None)
-    t = buf.cpu().numpy().reshape(-1, 4)
+    t = buf.cpu().numpy().reshape(-1, 8)
     t = t[t[:, 0] > 0]
     t0 = t[:, 0].min()
     start = (t[:, 0] - t0) / 100.0; end = (t[:, 1] - t0) / 100.0; n = t[:, 2] & 0xFFFFFF        # wall_clock64 ticks at 100 MHz -> microseconds
@@ -55,6 +55,9 @@ def main():
     iters = t[:, 3] & 0xFFFF; cand = (t[:, 3] >> 16) & 0xFFFFFF; surv = t[:, 3] >> 40
     print("totals: iterations %d, candidates %d, survivors %d, survivors some pixel accepts %d, accepting lanes per such survivor %.1f" %
           (iters.sum(), cand.sum(), surv.sum(), useful.sum(), lanes.sum() / max(useful.sum(), 1)))
+    tb = t[:, 4] & 0xFFFFFFFF; lr = t[:, 4] >> 32; q4 = t[:, 5] & 0xFFFFFFFF; steps = t[:, 5] >> 32
+    print("survivor-loop steps (4 survivors each) %d; ideal list entries to walk if the wave's pixels were split top/bottom %d, left/right %d, "
+          "in four 4x4 blocks %d (max over the parts per batch, entries some pixel of the part accepts)" % (steps.sum(), tb.sum(), lr.sum(), q4.sum()))
     print("latest waves: iterations / candidates / survivors:", [(int(iters[i]), int(cand[i]), int(surv[i])) for i in late])
     for lo, hi in ((0, 1), (1, 16), (16, 64), (64, 128), (128, 256), (256, 512), (512, 4096)):
         m = (surv >= lo) & (surv < hi)
