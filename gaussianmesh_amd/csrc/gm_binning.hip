@@ -52,9 +52,9 @@ __device__ __forceinline__ void get_rect(float px, float py, int r, int gx, int 
 }
 
 // Instance emission.  Workgroup b owns the sorted positions of depth bucket b (gm_bucket.hip), [bucket_start[b],
-// bucket_start[b + 1]), and walks them in chunks of 512: thread t owns 2 consecutive positions of a chunk, reads their
-// instance counts (cnt_sorted, coalesced) and gathers the bin records (candidate rectangle + emit mask, written by
-// preprocess) of the Gaussians that emit anything; the chunk scans the counts into output offsets; then instances are
+// bucket_start[b + 1]), and walks them in chunks of 512: thread t owns 2 consecutive positions of a chunk and reads their
+// emission records (candidate rectangle + instance count + emit mask, written by preprocess, brought into this order by
+// bucket_sort_kernel: coalesced); the chunk scans the counts into output offsets; then instances are
 // written (see (1) and (2) in the body).  The bucket's first output offset is the sum of the instance totals of the
 // buckets before it (bucket_inst, 2048 values, summed by every workgroup for itself).
 // Emitted order = Gaussian order (depth, id), then rectangle row-major - the reference's order
@@ -62,8 +62,8 @@ __device__ __forceinline__ void get_rect(float px, float py, int r, int gx, int 
 // S > 0: one instance per PARENT tile (2^S x 2^S tiles) that has a reached child; key = parent id | child mask << 16
 // (child bit = (row in parent) << S | column in parent).  S == 0: key = tile id | 1 << 16.
 template <int S>
-__global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* __restrict__ order, const uint32_t* __restrict__ cnt_sorted,
-                                                                const uint4* __restrict__ bins, const float4* __restrict__ splat,
+__global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles,
+                                                                const uint4* __restrict__ bin_sorted, const float4* __restrict__ splat,
                                                                 uint32_t* __restrict__ counters, const uint32_t* __restrict__ bucket_start,
                                                                 const uint32_t* __restrict__ bucket_inst, int gx, int pgx, int mode,
                                                                 uint32_t capacity, uint2* __restrict__ pairs_out,
@@ -102,12 +102,10 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
 #pragma unroll
   for (int i = 0; i < BN_PER_THREAD; i++) {
     const uint32_t s = base + i;
-    cnt[i] = s < P1 ? cnt_sorted[s] : 0u;
+    rc[i] = s < P1 ? bin_sorted[s] : make_uint4(0u, 0u, 0u, 0u);
+    cnt[i] = bin_count(rc[i]);
     gid[i] = (s < P1 && cnt[i]) ? order[s] : 0u;
-  }
-#pragma unroll
-  for (int i = 0; i < BN_PER_THREAD; i++) {
-    rc[i] = cnt[i] ? bins[gid[i]] : make_uint4(0u, 0u, 0u, 0u);
+    if (cnt[i] == GM_BIN_COUNT_SAT) cnt[i] = tiles[gid[i]];
     sum += cnt[i];
   }
   uint32_t total;
@@ -127,10 +125,10 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
   //     Gaussian.  The 4-byte stores of a lane go to its own run, neighbouring lanes' runs are adjacent.
 #pragma unroll
   for (int i = 0; i < BN_PER_THREAD; i++) {
-    const uint32_t w = rc[i].y & 0xFFFFu, h = rc[i].y >> 16, ncand = w * h;
+    const uint32_t w = bin_w(rc[i]), h = bin_h(rc[i]), ncand = w * h;
     const bool small = ncand <= 64 && (S == 0 || w <= 60);
     if (cnt[i] != 0 && small) {
-      const uint32_t x0 = rc[i].x & 0xFFFFu, y0 = rc[i].x >> 16;
+      const uint32_t x0 = bin_x0(rc[i]), y0 = bin_y0(rc[i]);
       unsigned long long m = ((unsigned long long)rc[i].w << 32) | rc[i].z;
       uint32_t pos = offs[i];
       if (S == 0) {
@@ -171,7 +169,7 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
   // (2) the other rectangles: the wave walks them one at a time, 64 candidate (parent) tiles per step
 #pragma unroll
   for (int i = 0; i < BN_PER_THREAD; i++) {
-    const uint32_t wi = rc[i].y & 0xFFFFu, nci = wi * (rc[i].y >> 16);
+    const uint32_t wi = bin_w(rc[i]), nci = wi * bin_h(rc[i]);
     unsigned long long todo = __ballot(cnt[i] != 0 && !(nci <= 64 && (S == 0 || wi <= 60)));
     while (todo) {
       const int j = __ffsll(todo) - 1;
@@ -180,7 +178,7 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
       const uint32_t rx = (uint32_t)__builtin_amdgcn_readlane((int)rc[i].x, j);
       const uint32_t ry = (uint32_t)__builtin_amdgcn_readlane((int)rc[i].y, j);
       const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)gid[i], j);
-      const uint32_t x0 = rx & 0xFFFFu, y0 = rx >> 16, w = ry & 0xFFFFu, h = ry >> 16;
+      const uint32_t x0 = rx & 0xFFFu, y0 = (rx >> 16) & 0xFFFu, w = ry & 0xFFFu, h = (ry >> 16) & 0xFFFu;
       const uint32_t px0 = x0 >> S, py0 = y0 >> S, pw = ((x0 + w - 1) >> S) - px0 + 1, ph = ((y0 + h - 1) >> S) - py0 + 1;
       const uint32_t ncand = pw * ph;
       const float inv_w = 1.0f / (float)pw;
@@ -235,7 +233,7 @@ int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, int mod
   const TileGrid tg(W, H, mode);
   const uint32_t cap = capacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)capacity;
   if (P > 0) {
-#define GM_DUP(SH) hipLaunchKernelGGL(duplicate_kernel<SH>, dim3(1 << GM_BUCKET_BITS), dim3(BN_THREADS), 0, s, g.order, g.cnt_sorted, g.bin, \
+#define GM_DUP(SH) hipLaunchKernelGGL(duplicate_kernel<SH>, dim3(1 << GM_BUCKET_BITS), dim3(BN_THREADS), 0, s, g.order, g.tiles_touched, g.bin_sorted, \
                                       g.splat, g.counters, g.bucket_start, g.bucket_inst, tg.gx, tg.pgx, mode, cap, b.pairs[0], b.acc, \
                                       (uint32_t)bk_acc_words(capacity))
     if (tg.s == 0) GM_DUP(0); else if (tg.s == 1) GM_DUP(1); else GM_DUP(2);

@@ -376,12 +376,12 @@ __global__ __launch_bounds__(WAVES * 64, 4) void bk_scatter_kernel(const void* _
 
 // ---------------------------------------------------------------------------------------------
 // One workgroup per bucket of the MSD partition: (key, id) pairs [start, end) of k1 / v1 -> final order.
-// Outputs: order0[start..end) = ids in (key, id) order, cnt_sorted[start..end) = tiles_touched of those ids,
+// Outputs: order0[start..end) = ids in (key, id) order, bin_sorted[start..end) = emission records of those ids,
 // bucket_inst[b] = their sum.  p0[start..end) is scratch for the slow path.
 __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t* __restrict__ slots, const uint32_t* __restrict__ bucket_start,
                                                                   uint2* __restrict__ p1, uint2* __restrict__ p0, uint32_t* __restrict__ order0,
-                                                                  const uint32_t* __restrict__ tiles, uint32_t* __restrict__ cnt_sorted,
-                                                                  uint32_t* __restrict__ bucket_inst) {
+                                                                  const uint32_t* __restrict__ tiles, const uint4* __restrict__ bins,
+                                                                  uint4* __restrict__ bin_sorted, uint32_t* __restrict__ bucket_inst) {
   __shared__ uint32_t wcnt[BK_WAVES][256];
   __shared__ uint32_t dstart[256];
   __shared__ uint32_t lkey[BS_CAP];
@@ -480,9 +480,12 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t*
       if ((uint32_t)r < rounds) {
         const uint32_t p = (wave * rounds + r) * 64u + lane;
         if (p < n) {
-          const uint32_t c = tiles[val[r]];
+          // the one random access per Gaussian of the whole ordering: its emission record travels to its sorted position
+          const uint4 rec = bins[val[r]];
+          uint32_t c = bin_count(rec);
+          if (c == GM_BIN_COUNT_SAT) c = tiles[val[r]];
           order0[start + p] = val[r];
-          cnt_sorted[start + p] = c;
+          bin_sorted[start + p] = rec;
           inst += c;
         }
       }
@@ -567,9 +570,11 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t*
     }
     for (uint32_t i = threadIdx.x; i < n; i += BK_THREADS) {
       const uint32_t id = sp[start + i].y;
-      const uint32_t c = tiles[id];
+      const uint4 rec = bins[id];
+      uint32_t c = bin_count(rec);
+      if (c == GM_BIN_COUNT_SAT) c = tiles[id];
       order0[start + i] = id;
-      cnt_sorted[start + i] = c;
+      bin_sorted[start + i] = rec;
       inst += c;
     }
   }
@@ -605,7 +610,7 @@ int launch_depth_order(GeomState& g, int P, int debug, hipStream_t s, int* num_r
                      g.slots, g.hist, nullptr, 0u);
   GM_LAUNCH_CHECK(debug, s);
   hipLaunchKernelGGL(bucket_sort_kernel, dim3(1 << DB), dim3(BK_THREADS), 0, s, g.slots, g.bucket_start, g.dpairs[1], g.dpairs[0], g.order,
-                     g.tiles_touched, g.cnt_sorted, g.bucket_inst);
+                     g.tiles_touched, g.bin, g.bin_sorted, g.bucket_inst);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }

@@ -85,18 +85,34 @@ static inline size_t bk_acc_words(size_t n) { return GM_ACC_SLOTS + (bk_chunks(n
 #define GM_CNT_COUNT 32
 #define GM_SLOTS 64                  // atomic slots {instance sum, max ~depth key, max depth key, -} filled by the preprocess kernel
 
+// Emission record of a Gaussian, 16 bytes: tile rectangle origin and size in 12 bits each (grids up to 4095 x 4095 tiles), the
+// instance count in the four spare nibbles (0xFFFF = "65535 or more: see tiles_touched"), 64-bit emit mask.
+#define GM_BIN_COUNT_SAT 0xFFFFu
+__host__ __device__ __forceinline__ uint4 bin_pack(uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t count, unsigned long long mask) {
+  const uint32_t c = count < GM_BIN_COUNT_SAT ? count : GM_BIN_COUNT_SAT;
+  return make_uint4(x0 | ((c & 0xFu) << 12) | (y0 << 16) | (((c >> 4) & 0xFu) << 28),
+                    w | (((c >> 8) & 0xFu) << 12) | (h << 16) | ((c >> 12) << 28), (uint32_t)mask, (uint32_t)(mask >> 32));
+}
+__host__ __device__ __forceinline__ uint32_t bin_x0(const uint4& b) { return b.x & 0xFFFu; }
+__host__ __device__ __forceinline__ uint32_t bin_y0(const uint4& b) { return (b.x >> 16) & 0xFFFu; }
+__host__ __device__ __forceinline__ uint32_t bin_w(const uint4& b) { return b.y & 0xFFFu; }
+__host__ __device__ __forceinline__ uint32_t bin_h(const uint4& b) { return (b.y >> 16) & 0xFFFu; }
+__host__ __device__ __forceinline__ uint32_t bin_count(const uint4& b) {       // GM_BIN_COUNT_SAT: look tiles_touched up
+  return ((b.x >> 12) & 0xFu) | ((b.x >> 28) << 4) | (((b.y >> 12) & 0xFu) << 8) | ((b.y >> 28) << 12);
+}
+
 struct GeomState {              // per-Gaussian state (P-sized)
   float4* splat;                // [P][3]: {x,y,con.x,con.y} {con.z,opacity,r,g} {b,depth,0,0}
   int* radii;                   // internal radii when the caller passes none
   uint32_t* tiles_touched;      // [P]
-  uint4* bin;                   // [P] {x0 | y0 << 16, width | height << 16, mask_lo, mask_hi}: candidate tile rectangle and, for
-                                //     rectangles of <= 64 tiles, the bit mask (row-major) of the tiles actually emitted
+  uint4* bin;                   // [P] emission record (bin_pack below): candidate tile rectangle, instance count and, for rectangles
+                                //     of <= 64 tiles, the bit mask (row-major) of the tiles actually emitted
   float* cov3D;                 // [P][6] (computed from scale/rot)
   uint8_t* clamped;             // [P] bit ch = SH colour channel ch was clamped at 0
   uint32_t* depth_key;          // [P] float bits of view z per Gaussian (0xFFFFFFFF = culled)
   uint2* dpairs[2];             // [P] (depth key, id): [1] partitioned into buckets, [0] scratch of an overfull bucket's sort
   uint32_t* order;              // [P] ids of the VISIBLE Gaussians in (depth, id) order
-  uint32_t* cnt_sorted;         // [P] tiles_touched in that order
+  uint4* bin_sorted;            // [P] the emission records in that order (duplicate_kernel reads them sequentially)
   uint32_t* hist;               // [bk_blocks(P)][2048] bucket histograms of the partition -> absolute output offsets
   uint32_t* bucket_start;       // [2049] first sorted position of each bucket (+ total)
   uint32_t* bucket_inst;        // [2048] instances emitted by each bucket
@@ -118,7 +134,7 @@ struct GeomState {              // per-Gaussian state (P-sized)
     g.dpairs[0] = carve<uint2>(p, P);
     g.dpairs[1] = carve<uint2>(p, P);
     g.order = carve<uint32_t>(p, P);
-    g.cnt_sorted = carve<uint32_t>(p, P);
+    g.bin_sorted = carve<uint4>(p, P);
     g.hist = carve<uint32_t>(p, ND * bk_blocks(P));
     g.bucket_start = carve<uint32_t>(p, ND + 1);
     g.bucket_inst = carve<uint32_t>(p, ND);

@@ -160,7 +160,7 @@ __device__ __forceinline__ void pre_emit(const PreCam& a, const PreGeom& g, floa
     if (s > 0) cnt += small ? parents_in_row(prow, x0, s) : (hull_hi >= 0 ? (uint32_t)((hull_hi >> s) - (hull_lo >> s) + 1) : 0u);
     tiles = cnt;
   }
-  bin = make_uint4((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)rw | ((uint32_t)rh << 16), (uint32_t)mask, (uint32_t)(mask >> 32));
+  bin = bin_pack((uint32_t)x0, (uint32_t)y0, (uint32_t)rw, (uint32_t)rh, tiles, mask);
 }
 
 // Per-wave partials of {instance total, max ~depth key, max depth key} of the visible Gaussians -> one of GM_SLOTS atomic

@@ -22,7 +22,7 @@ def test_scratch_sizes_scale_linearly():
     from gaussianmesh_amd import _lib
     l = _lib.lib()
     g1, g2 = l.gm_geom_bytes(1_000_000), l.gm_geom_bytes(2_000_000)
-    assert 130e6 < g1 < 180e6 and abs(g2 - 2 * g1) < 2e6       # ~175 B per Gaussian (incl. 48 B backward accumulators, ordering scratch and histograms)
+    assert 130e6 < g1 < 195e6 and abs(g2 - 2 * g1) < 2e6       # ~187 B per Gaussian (incl. 48 B backward accumulators, ordering scratch and histograms)
     b1 = l.gm_binning_bytes(8_000_000)
     assert 128e6 <= b1 < 150e6                                   # 16 B per instance + 2 B of histogram rows
     i1 = l.gm_image_bytes(1920, 1080)
