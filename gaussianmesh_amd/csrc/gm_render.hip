@@ -448,7 +448,10 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const uint2* __restrict
   const int last = inside ? (int)n_contrib[pid] : 0;
   const float dpr = inside ? dL_dpix[pid] : 0.f, dpg = inside ? dL_dpix[HW + pid] : 0.f, dpb = inside ? dL_dpix[2 * HW + pid] : 0.f;
   const float bg_dot = bg0 * dpr + bg1 * dpg + bg2 * dpb;
-  float last_alpha = 0.f, lcr = 0.f, lcg = 0.f, lcb = 0.f, arr = 0.f, arg_ = 0.f, arb = 0.f;
+  float last_alpha = 0.f, lcb = 0.f, arb = 0.f;
+  v2f lc_rg = {0.f, 0.f}, ar_rg = {0.f, 0.f};                 // last colour / accum_rec, (r, g) as a register pair
+  const v2f dp_rg = {dpr, dpg};
+  const float tf_bg = T_final * bg_dot;
   // entries at list positions >= max over the wave of n_contrib are never used: start there
   int max_last = last;
 #pragma unroll
@@ -537,39 +540,45 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const uint2* __restrict
         const float op = RB.y;
         v2f dd;
         const float e = staged_exponent(RA, RB.x, pix, dd);             // power * log2(e), evaluated exactly as in the forward kernel
-        const float dx = dd.x, dy = dd.y;
+        const float dy = dd.y;
         const float G = __builtin_amdgcn_exp2f(e);
         const float alpha = fminf(0.99f, op * G);
         const int pos = (int)__float_as_uint(RC.y);
         const bool valid = (pos < last) && (e <= 0.0f) && (alpha >= 1.0f / 255.0f);
         if (!__any(valid)) continue;
-        const float r = RB.z, g = RB.w, b = RC.x;
         const uint32_t gid = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.id[j]);
-        // per-lane partial sums of: dL/dcolor rgb (q0-2) and the six moments of h = G * dL/dG over the wave's pixels
-        // (q3 = sum h, q4 = sum h dx, q5 = sum h dy, q6 = sum h dx^2, q7 = sum h dx dy, q8 = sum h dy^2).
-        // preprocess_bwd_kernel turns the moments into dL/dopacity, dL/dmean2D and dL/dconic (backward.cu:538-554):
-        //   dL/dopacity = q3 / opacity, dL/dmean2D = -(W/2)(cx q4 + cy q5), -(H/2)(cz q5 + cy q4), dL/dconic = -q6/2, -q7/2, -q8/2
-        float q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, q8 = 0.f;
+        // The state of the walk (T, accum_rec, last colour / alpha: backward.cu:478-512) moves only on the lanes that take
+        // the entry; what leaves this block are the two per-lane factors every partial sum is a multiple of - the weight
+        // alpha T (dL/dcolour) and h = G dL/dG - both 0 on the other lanes, so the sums below need no masks.
+        float wv = 0.f, h = 0.f;
         if (valid) {
           const float inv = __builtin_amdgcn_rcpf(1.f - alpha);      // 1/(1-alpha): T recovery and the bg term
           T = T * inv;
-          const float dchannel_dcolor = alpha * T;
-          arr += last_alpha * (lcr - arr);                  // accum_rec = la*lc + (1-la)*accum_rec
-          arg_ += last_alpha * (lcg - arg_);
+          const v2f la2 = {last_alpha, last_alpha};
+          ar_rg = la2 * (lc_rg - ar_rg) + ar_rg;            // accum_rec = la*lc + (1-la)*accum_rec
           arb += last_alpha * (lcb - arb);
-          lcr = r; lcg = g; lcb = b;
-          float dL_dalpha = (r - arr) * dpr + (g - arg_) * dpg + (b - arb) * dpb;
-          q[0] += dchannel_dcolor * dpr; q[1] += dchannel_dcolor * dpg; q[2] += dchannel_dcolor * dpb;
+          const v2f rg = {RB.z, RB.w};
+          lc_rg = rg; lcb = RC.x;
+          const v2f t2 = (rg - ar_rg) * dp_rg;
+          float dL_dalpha = (t2.x + t2.y) + (RC.x - arb) * dpb;
           last_alpha = alpha;
-          dL_dalpha = dL_dalpha * T - (T_final * inv) * bg_dot;
-          const float h = (op * G) * dL_dalpha;                      // G * dL/dG with dL/dG = opacity * dL/dalpha
-          const float hx = h * dx, hy = h * dy;
-          q[3] += h; q[4] += hx; q[5] += hy;
-          q[6] += hx * dx; q[7] += hx * dy; q8 += hy * dy;
+          dL_dalpha = dL_dalpha * T - (tf_bg * inv);
+          wv = alpha * T;
+          h = (op * G) * dL_dalpha;                                  // G * dL/dG with dL/dG = opacity * dL/dalpha
         }
+        // per-lane partial sums of: dL/dcolor rgb (q0-2) and the six moments of h over the wave's pixels
+        // (q3 = sum h, q4 = sum h dx, q5 = sum h dy, q6 = sum h dx^2, q7 = sum h dx dy, q8 = sum h dy^2).
+        // preprocess_bwd_kernel turns the moments into dL/dopacity, dL/dmean2D and dL/dconic (backward.cu:538-554):
+        //   dL/dopacity = q3 / opacity, dL/dmean2D = -(W/2)(cx q4 + cy q5), -(H/2)(cz q5 + cy q4), dL/dconic = -q6/2, -q7/2, -q8/2
+        const v2f wv2 = {wv, wv}, h2 = {h, h};
+        const v2f c01 = wv2 * dp_rg, hxy = h2 * dd, m2 = hxy * dd;
+        float q[8] = {c01.x, c01.y, wv * dpb, h, hxy.x, hxy.y, m2.x, hxy.x * dy};
+        float q8 = m2.y;
         const float tot = reduce8(q, lane);
         q8 = wave_sum_to_lane63(q8);
         // eight totals sit in the lanes with (lane & 7) == 0, the ninth in lane 63: one atomic instruction commits all nine
+        // (measured and dropped: letting the ninth sum wait for the next entry's so that two share one tree - 13 % slower,
+        // the second code path costs more than the five DPP steps it saves)
         const bool last_lane = lane == 63;
         if (committer || last_lane)
           atomicAdd(grad_acc + (size_t)gid * GM_ACC_STRIDE + (last_lane ? 8 : my_slot), last_lane ? q8 : tot);
