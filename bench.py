@@ -182,7 +182,7 @@ def main():
     import torch.distributed as dist
     from gaussianmesh_amd import _lib, multiview, scenes
     from gaussianmesh_amd import rasterizer as Rz
-    from gaussianmesh_amd.deform import deform_shade_packed, mesh_rs, pack_mesh_state, vertex_face_adjacency
+    from gaussianmesh_amd.deform import deform_shade_packed, mesh_rs_packed, pack_mesh_state, vertex_face_adjacency
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -237,7 +237,7 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
     nws = nstreams + 2                          # frame i+1 is begun before frame i is completed, and frame i's status is read one frame later
     workspaces = [Rz.RasterWorkspace(growth=1.5) for _ in range(nws)]
-    frame_bufs = [torch.empty((Vm, 21), dtype=torch.float32, device=dev) for _ in range(nws)]
+    frame_bufs = [torch.empty((Vm, 24), dtype=torch.float32, device=dev) for _ in range(nws)]
     torch.cuda.synchronize()
 
     pending = {}
@@ -278,21 +278,21 @@ def main():
 
     def step_on_stream(i, workspace, frame_buf, exchange=True, begin_only=False):
         t = i % F
-        def frame_state():                       # [Vm,21] = V1 | R | S of animation frame t
+        def frame_table(out=None):               # per-vertex gather table [Vm,24] of animation frame t: dV | R | S
             if args.analytic_rs:
-                return g["mesh"][t]
-            return mesh_rs(g["verts"], v1_frames[t], g["faces"], adjacency=adjacency, want_state=True)[2]
-        if world > 1 and exchange:               # real exchange step: mesh state of frame t from rank 0 (RCCL)
+                return pack_mesh_state(g["mesh"][t], g["verts"])    # [Vm,21] frame state -> table (one small kernel)
+            return mesh_rs_packed(g["verts"], v1_frames[t], g["faces"], adjacency, out=out)
+        if world > 1 and exchange:               # real exchange step: the table of frame t from rank 0 (RCCL), 0.72 MB
             if rank == 0:
-                frame_buf.copy_(frame_state())
-            ms = multiview.broadcast_mesh_state(frame_buf, src=0)
+                frame_table(out=frame_buf) if not args.analytic_rs else frame_buf.copy_(frame_table())
+            packed = multiview.broadcast_mesh_state(frame_buf, src=0)
         else:
-            ms = frame_state()
-        packed = pack_mesh_state(ms, g["verts"])            # [Vm,21] frame state -> per-vertex gather table (one small kernel)
+            packed = frame_table()
         c = cam_t[multiview.view_for_step(i, F, rank, world)]
         if begin_only and not args.unfused:      # one enqueue: deform + colour + preprocess + depth sort + instance count
             return Rz.forward_deformed_begin(bg, g["tri"], g["weights"], packed, g["cov"], g["pos"], g["shs"], g["opac"], c["view"],
-                                             c["proj"], c["tanx"], c["tany"], H, W, 3, c["campos"], False, workspace=workspace)
+                                             c["proj"], c["tanx"], c["tany"], H, W, 3, c["campos"], False, workspace=workspace,
+                                             want_count=args.exact_count)
         if not args.unfused:                     # same path, completed at once (per-stage timing pass)
             nr, color, radii, _, _, _ = Rz.forward_deformed_begin(bg, g["tri"], g["weights"], packed, g["cov"], g["pos"], g["shs"], g["opac"],
                                                                   c["view"], c["proj"], c["tanx"], c["tany"], H, W, 3, c["campos"], False,
@@ -329,6 +329,10 @@ def main():
         torch.cuda.synchronize()
         assert nr_f == nr_u and torch.equal(rad_f, rad_u) and torch.equal(col_f, col_u), "fused frame differs from the unfused chain"
         del pos_u, cov6_u, rgb_u, col_u, col_f
+    # setup, not part of W: one pass over the camera orbit sizes every workspace's binning buffer for the largest instance count
+    # of the trajectory (the sync-free forward renders into a buffer of fixed capacity; a frame that outgrows it is redone)
+    for i in range(-F, 0):
+        step(i)
     for i in range(args.warmup):
         step(i)
     drain()

@@ -174,7 +174,8 @@ int gm_forward_0_deformed_async(int emission_policy, void* geom_buffer, int P, i
 }
 
 int gm_forward_1_geom(int emission_policy, void* geom_buffer, void* binning_buffer, void* image_buffer, int P, int num_rendered,
-                      int64_t binning_capacity, const float* background, int width, int height, float* out_color, int debug, void* stream) {
+                      int64_t binning_capacity, const float* background, int width, int height, float* out_color, int debug, void* stream,
+                      int* status_host) {
   if (int rc = check_policy(emission_policy)) return rc;
   if (P < 0 || width <= 0 || height <= 0) { set_error("invalid sizes P=%d W=%d H=%d", P, width, height); return GM_ERR_INVALID_ARG; }
   if (!image_buffer || !out_color || !background) { set_error("null image_buffer / out_color / background"); return GM_ERR_INVALID_ARG; }
@@ -190,16 +191,22 @@ int gm_forward_1_geom(int emission_policy, void* geom_buffer, void* binning_buff
   GeomState g = GeomState::from(geom_buffer, (size_t)(P > 0 ? P : 1));
   BinningState b = BinningState::from(binning_buffer, (size_t)cap);
   const int slot = sort_final_slot(tiles);
+  bool order_done = false;
   if (P > 0 && cap > 0) {
     if (int rc = launch_duplicate(g, b, P, width, height, mode, (size_t)cap, debug, st)) return rc;
-    if (int rc = launch_tile_sort(g, b, img, (size_t)cap, device_count ? g.counters + GM_CNT_RENDERED : nullptr, tiles, debug, st)) return rc;
+    if (int rc = launch_tile_sort(g, b, img, (size_t)cap, device_count ? g.counters + GM_CNT_RENDERED : nullptr, tiles, &order_done, debug, st)) return rc;
     if (slot == 0)
       if (int rc = launch_tile_ranges(g, b, slot, img, (int)cap, device_count ? g.counters + GM_CNT_RENDERED : nullptr, tiles, debug, st)) return rc;
   } else {
     GM_HIP(hipMemsetAsync(img.ranges, 0, sizeof(uint2) * (size_t)tiles, st));
   }
-  if (int rc = launch_tile_order(img, tiles, debug, st)) return rc;
-  return launch_render_fwd(g, b.pairs[slot], img, width, height, mode, background, out_color, debug, st);
+  if (!order_done)
+    if (int rc = launch_tile_order(img, tiles, debug, st)) return rc;
+  if (status_host && P == 0) {                       // no geometry state to report from
+    status_host[0] = 0; status_host[1] = 0; status_host[2] = mode; status_host[3] = 0;
+    status_host = nullptr;
+  }
+  return launch_render_fwd(g, b.pairs[slot], img, width, height, mode, background, out_color, status_host, debug, st);
 }
 
 int gm_forward_status_async(void* geom_buffer, int P, int* status_host, void* stream) {
@@ -243,7 +250,7 @@ int gm_forward_1(void* geom_buffer, void* binning_buffer, void* image_buffer, in
   (void)radii;
   if (num_rendered < 0) { set_error("negative num_rendered"); return GM_ERR_INVALID_ARG; }
   return gm_forward_1_geom(GM_POLICY_DEFAULT, geom_buffer, binning_buffer, image_buffer, P, num_rendered, 0, background, width, height, out_color,
-                           debug, stream);
+                           debug, stream, nullptr);
 }
 
 int gm_backward_p(int emission_policy, int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
@@ -381,7 +388,16 @@ int gm_mesh_rs(int Vm, int nfaces, const float* V0, const float* V1, const int* 
     set_error("gm_mesh_rs: bad args"); return GM_ERR_INVALID_ARG;
   }
   if ((R == nullptr) != (S == nullptr)) { set_error("gm_mesh_rs: pass R and S together"); return GM_ERR_INVALID_ARG; }
-  return launch_mesh_rs(Vm, V0, V1, faces, adj_offsets, adj_faces, R, S, state, reinterpret_cast<hipStream_t>(stream));
+  return launch_mesh_rs(Vm, V0, V1, faces, adj_offsets, adj_faces, R, S, state, nullptr, reinterpret_cast<hipStream_t>(stream));
+}
+
+int gm_mesh_rs_packed(int Vm, int nfaces, const float* V0, const float* V1, const int* faces, const int* adj_offsets, const int* adj_faces,
+                      float* packed, void* stream) {
+  if (Vm < 0 || nfaces < 0 || (Vm > 0 && (!V0 || !V1 || !adj_offsets || !packed || (nfaces > 0 && (!faces || !adj_faces))))) {
+    set_error("gm_mesh_rs_packed: bad args"); return GM_ERR_INVALID_ARG;
+  }
+  if (reinterpret_cast<uintptr_t>(packed) & 15) { set_error("gm_mesh_rs_packed: packed must be 16-byte aligned"); return GM_ERR_INVALID_ARG; }
+  return launch_mesh_rs(Vm, V0, V1, faces, adj_offsets, adj_faces, nullptr, nullptr, nullptr, packed, reinterpret_cast<hipStream_t>(stream));
 }
 
 int gm_cov_to_scale_rot(int N, const float* cov, float* scales, float* rots, void* stream) {

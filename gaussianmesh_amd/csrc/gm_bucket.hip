@@ -41,6 +41,7 @@
 //               pairs stored one lane at a time (64 different lines per store instruction) run into the L2's transaction
 //               rate (25-34 us per pass); larger tiles make longer runs (tile / 2048 pairs per digit).
 #include "gm_common.h"
+#include "gm_tile_order.h"
 
 namespace gm {
 
@@ -244,8 +245,16 @@ template <bool MSD, int DB, int WAVES>
 __global__ __launch_bounds__(WAVES * 64, 4) void bk_scatter_kernel(const void* __restrict__ in, uint2* __restrict__ out,
                                                                  uint32_t n_host, const uint32_t* __restrict__ n_dev, DigitSpec ds,
                                                                  const uint32_t* __restrict__ slots, const uint32_t* __restrict__ hist,
-                                                                 uint32_t* __restrict__ zero_acc, uint32_t zero_words) {
+                                                                 uint32_t* __restrict__ zero_acc, uint32_t zero_words,
+                                                                 const uint2* __restrict__ ord_ranges, int ord_tiles,
+                                                                 uint32_t* __restrict__ ord_out) {
   constexpr int ND = 1 << DB, THREADS = WAVES * 64, TILE = WAVES * BK_ROUNDS * 64;
+  if (!MSD && ord_out && blockIdx.x == gridDim.x - 1) {      // the launch's extra workgroup: dispatch order of the blend kernels
+    __shared__ uint32_t o_cnt[256];                          // from the ranges the scan kernel has just published
+    __shared__ uint32_t o_wsum[WAVES];
+    tile_order_block<THREADS>(ord_ranges, ord_tiles, ord_out, o_cnt, o_wsum);
+    return;
+  }
   // wcnt: per-wave running digit counts (<= 1024) -> per-wave exclusive offsets (< TILE <= 16384); once every key knows its
   // position in the digit-sorted tile the same memory stages the tile (one 8-byte pair per key)
   constexpr int SMEM = (WAVES * ND * 2 > TILE * 8) ? WAVES * ND * 2 : TILE * 8;
@@ -607,7 +616,7 @@ int launch_depth_order(GeomState& g, int P, int debug, hipStream_t s, int* num_r
                      g.slots, g.acc, g.bucket_start, g.counters, nullptr, 0u);
   GM_LAUNCH_CHECK(debug, s);
   hipLaunchKernelGGL((bk_scatter_kernel<true, DB, WAVES>), dim3(nblk), dim3(WAVES * 64), 0, s, g.depth_key, g.dpairs[1], (uint32_t)P, nullptr, ds,
-                     g.slots, g.hist, nullptr, 0u);
+                     g.slots, g.hist, nullptr, 0u, nullptr, 0, nullptr);
   GM_LAUNCH_CHECK(debug, s);
   hipLaunchKernelGGL(bucket_sort_kernel, dim3(1 << DB), dim3(BK_THREADS), 0, s, g.slots, g.bucket_start, g.dpairs[1], g.dpairs[0], g.order,
                      g.tiles_touched, g.bin, g.bin_sorted, g.bucket_inst);
@@ -618,7 +627,7 @@ int launch_depth_order(GeomState& g, int P, int debug, hipStream_t s, int* num_r
 // One stable pass over the pair stream b.pairs[from] -> b.pairs[from ^ 1].  b.acc must be zero on entry.
 template <int DB, int WAVES>
 static int tile_pass(BinningState& b, GeomState& g, int from, uint32_t n, const uint32_t* n_dev, DigitSpec ds, uint2* ranges, uint32_t nranges,
-                     bool zero_acc_after, int debug, hipStream_t s) {
+                     bool zero_acc_after, uint32_t* order_out, int debug, hipStream_t s) {
   constexpr uint32_t TILE = WAVES * BK_ROUNDS * 64;
   const uint32_t nblk = (n + TILE - 1) / TILE;
   const uint32_t nchunks = (nblk + BK_CHUNK - 1) / BK_CHUNK;
@@ -628,8 +637,9 @@ static int tile_pass(BinningState& b, GeomState& g, int from, uint32_t n, const 
   hipLaunchKernelGGL((bk_scan_kernel<false, DB>), dim3(nchunks ? nchunks : 1, (1 << DB) / 256), dim3(BK_THREADS), 0, s, b.hist, TILE, n, n_dev, nullptr,
                      b.acc, nullptr, g.counters, ranges, nranges);
   GM_LAUNCH_CHECK(debug, s);
-  hipLaunchKernelGGL((bk_scatter_kernel<false, DB, WAVES>), dim3(nblk), dim3(WAVES * 64), 0, s, b.pairs[from], b.pairs[from ^ 1], n, n_dev, ds, nullptr,
-                     b.hist, zero_acc_after ? b.acc : nullptr, (uint32_t)bk_acc_words(n));
+  hipLaunchKernelGGL((bk_scatter_kernel<false, DB, WAVES>), dim3(nblk + (order_out ? 1u : 0u)), dim3(WAVES * 64), 0, s, b.pairs[from],
+                     b.pairs[from ^ 1], n, n_dev, ds, nullptr, b.hist, zero_acc_after ? b.acc : nullptr, (uint32_t)bk_acc_words(n), ranges,
+                     (int)nranges, order_out);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }
@@ -637,8 +647,10 @@ static int tile_pass(BinningState& b, GeomState& g, int from, uint32_t n, const 
 // Tile sort of the instance stream b.pairs[0] (n instances; n_dev != nullptr: the count is read on the device and n is the
 // capacity).  tiles <= 2048: one 11-bit pass, result in pairs[1], ranges written by the scan.  Otherwise two 8-bit
 // passes, result in pairs[0], ranges by tile_ranges_kernel (caller).  duplicate_kernel has zeroed b.acc.
-int launch_tile_sort(GeomState& g, BinningState& b, ImageState& img, size_t n, const uint32_t* n_dev, int tiles, int debug, hipStream_t s) {
+int launch_tile_sort(GeomState& g, BinningState& b, ImageState& img, size_t n, const uint32_t* n_dev, int tiles, bool* order_done, int debug,
+                     hipStream_t s) {
   StageScope sc(ST_TILE_SORT, s);
+  *order_done = false;
   if (n == 0) {
     GM_HIP(hipMemsetAsync(img.ranges, 0, sizeof(uint2) * (size_t)tiles, s));
     return 0;
@@ -646,14 +658,15 @@ int launch_tile_sort(GeomState& g, BinningState& b, ImageState& img, size_t n, c
   if (n > 0xFFFFF000ull) { set_error("tile sort: too many instances"); return 1; }
   // below ~0.5 M instances 16-wave workgroups would leave most of the chip idle: 4-wave ones
   if (tiles <= (1 << GM_BUCKET_BITS)) {
+    *order_done = true;                 // the scatter launch carries the dispatch-order workgroup
     if (n <= (size_t(1) << 19))
       return tile_pass<GM_BUCKET_BITS, 4>(b, g, 0, (uint32_t)n, n_dev, DigitSpec{0u, 0u, (1u << GM_BUCKET_BITS) - 1u}, img.ranges, (uint32_t)tiles,
-                                          false, debug, s);
+                                          false, img.tile_order, debug, s);
     return tile_pass<GM_BUCKET_BITS, GM_TILE_PASS_WAVES>(b, g, 0, (uint32_t)n, n_dev, DigitSpec{0u, 0u, (1u << GM_BUCKET_BITS) - 1u}, img.ranges, (uint32_t)tiles,
-                                         false, debug, s);
+                                         false, img.tile_order, debug, s);
   }
-  if (int rc = tile_pass<8, 4>(b, g, 0, (uint32_t)n, n_dev, DigitSpec{0u, 0u, 0xFFu}, nullptr, 0u, true, debug, s)) return rc;
-  return tile_pass<8, 4>(b, g, 1, (uint32_t)n, n_dev, DigitSpec{0u, 8u, 0xFFu}, nullptr, 0u, false, debug, s);
+  if (int rc = tile_pass<8, 4>(b, g, 0, (uint32_t)n, n_dev, DigitSpec{0u, 0u, 0xFFu}, nullptr, 0u, true, nullptr, debug, s)) return rc;
+  return tile_pass<8, 4>(b, g, 1, (uint32_t)n, n_dev, DigitSpec{0u, 8u, 0xFFu}, nullptr, 0u, false, nullptr, debug, s);
 }
 
 }  // namespace gm

@@ -246,11 +246,12 @@ int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], uint32_t* hist, uint3
 int launch_depth_order(GeomState& g, int P, int debug, hipStream_t s, int* num_rendered_host, hipEvent_t count_event);
 int launch_arm_counters(GeomState& g, hipStream_t s);                               // zero slots + counters (first launch of a forward)
 int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, int tile_cull, size_t capacity, int debug, hipStream_t s);
-int launch_tile_sort(GeomState& g, BinningState& b, ImageState& img, size_t n, const uint32_t* n_dev, int tiles, int debug, hipStream_t s);
+int launch_tile_sort(GeomState& g, BinningState& b, ImageState& img, size_t n, const uint32_t* n_dev, int tiles, bool* order_done, int debug,
+                     hipStream_t s);      // order_done: img.tile_order was written too (one-pass case)
 int launch_tile_ranges(const GeomState& g, BinningState& b, int slot, ImageState& img, int R, const uint32_t* R_dev, int tiles, int debug, hipStream_t s);
 int launch_tile_order(ImageState& img, int tiles, int debug, hipStream_t s);          // ranges -> tile_order
 int launch_render_fwd(const GeomState& g, const uint2* pairs, ImageState& img, int W, int H, int mode,
-                      const float* background, float* out_color, int debug, hipStream_t s);
+                      const float* background, float* out_color, int* status_host, int debug, hipStream_t s);
 int launch_render_bwd(const GeomState& g, const uint2* pairs, ImageState& img, int W, int H, int mode,
                       const float* background, const float* dL_dpix, int debug, hipStream_t s);   // accumulates into g.grad_acc
 
@@ -270,7 +271,7 @@ int launch_deform_shade_packed(int N, int deg, int M, const int* tri, const floa
                                float* rgb_out, float* cov_out, float* rot_out, hipStream_t s);
 int launch_cov_to_scale_rot(int N, const float* cov, float* scales, float* rots, hipStream_t s);
 int launch_mesh_rs(int Vm, const float* V0, const float* V1, const int* faces, const int* adj_offsets, const int* adj_faces, float* R,
-                   float* S, float* state, hipStream_t s);
+                   float* S, float* state, float* packed, hipStream_t s);
 int launch_ssim_fwd(const float* img1, const float* img2, int planes, int H, int W, float* d_mu1, float* d_e11, float* d_e12,
                     float* partial, hipStream_t s);
 int launch_ssim_bwd(const float* img1, const float* img2, const float* d_mu1, const float* d_e11, const float* d_e12, int planes,

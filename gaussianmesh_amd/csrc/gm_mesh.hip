@@ -62,7 +62,8 @@ __device__ __forceinline__ void jacobi3(double A[3][3], double V[3][3]) {
 __global__ __launch_bounds__(256) void mesh_rs_kernel(int Vm, const float* __restrict__ V0, const float* __restrict__ V1,
                                                       const int* __restrict__ faces, const int* __restrict__ adj_offsets,
                                                       const int* __restrict__ adj_faces, float* __restrict__ R_out,
-                                                      float* __restrict__ S_out, float* __restrict__ state_out) {
+                                                      float* __restrict__ S_out, float* __restrict__ state_out,
+                                                      float4* __restrict__ packed_out) {
   const int v = blockIdx.x * 256 + threadIdx.x;
   if (v >= Vm) return;
   // M0 = sum c e e^T (symmetric), M1 = sum c e' e^T over the one-ring edges; every incident face contributes its two edges
@@ -277,13 +278,27 @@ __global__ __launch_bounds__(256) void mesh_rs_kernel(int Vm, const float* __res
   if (state_out)
 #pragma unroll
     for (int j = 0; j < 3; j++) state_out[21 * (size_t)v + j] = V1[3 * (size_t)v + j];
+  if (packed_out) {          // the gather table of deform_shade_kernel<true, .> (what pack_mesh_state_kernel makes of `state`)
+    const float r[9] = {(float)Q[0][0], (float)Q[1][0], (float)Q[2][0], (float)Q[0][1], (float)Q[1][1], (float)Q[2][1],
+                        (float)Q[0][2], (float)Q[1][2], (float)Q[2][2]};
+    const float t[9] = {(float)S[0][0], (float)S[0][1], (float)S[0][2], (float)S[1][0], (float)S[1][1], (float)S[1][2],
+                        (float)S[2][0], (float)S[2][1], (float)S[2][2]};
+    float4* o = packed_out + 6 * (size_t)v;
+    o[0] = make_float4(p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2], 0.f);
+    o[1] = make_float4(r[0], r[1], r[2], r[3]);
+    o[2] = make_float4(r[4], r[5], r[6], r[7]);
+    o[3] = make_float4(r[8], t[0], t[1], t[2]);
+    o[4] = make_float4(t[3], t[4], t[5], t[6]);
+    o[5] = make_float4(t[7], t[8], 0.f, 0.f);
+  }
 }
 
 int launch_mesh_rs(int Vm, const float* V0, const float* V1, const int* faces, const int* adj_offsets, const int* adj_faces, float* R,
-                   float* S, float* state, hipStream_t s) {
+                   float* S, float* state, float* packed, hipStream_t s) {
   if (Vm <= 0) return 0;
   StageScope sc(ST_DEFORM, s);
-  hipLaunchKernelGGL(mesh_rs_kernel, dim3((Vm + 255) / 256), dim3(256), 0, s, Vm, V0, V1, faces, adj_offsets, adj_faces, R, S, state);
+  hipLaunchKernelGGL(mesh_rs_kernel, dim3((Vm + 255) / 256), dim3(256), 0, s, Vm, V0, V1, faces, adj_offsets, adj_faces, R, S, state,
+                     reinterpret_cast<float4*>(packed));
   GM_HIP(hipGetLastError());
   return 0;
 }

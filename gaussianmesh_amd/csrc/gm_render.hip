@@ -27,6 +27,7 @@
 // tolerance argument.
 #include "gm_common.h"
 #include "gm_cull.h"
+#include "gm_tile_order.h"
 #include <cstdlib>
 
 namespace gm {
@@ -59,33 +60,11 @@ struct TileMap {
   int blocks() const { return ((pgx * pgy + 7) / 8) * 8 << (2 * s); }
 };
 
-// Dispatch order of the blend kernels: list tiles by descending list length, so that the workgroups with the most work
-// start first and the launch does not end on waves that were dispatched last AND have long lists (longest-processing-time
-// first; with index order the last 40 % of the forward kernel ran on a few hundred late starters).  One workgroup:
-// counting sort on min(length, 8191) / 32.
+// Dispatch order of the blend kernels (gm_tile_order.h) as a launch of its own: only when the tile pass did not produce it.
 __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restrict__ ranges, int tiles, uint32_t* __restrict__ order) {
   __shared__ uint32_t cnt[256];
   __shared__ uint32_t wsum[16];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x < 256) cnt[threadIdx.x] = 0;
-  __syncthreads();
-  auto bucket = [&](int t) { const uint2 r = ranges[t]; return 255u - min((r.y - r.x) >> 5, 255u); };   // bucket 0 = longest
-  for (int t = threadIdx.x; t < tiles; t += 1024) atomicAdd(&cnt[bucket(t)], 1u);
-  __syncthreads();
-  uint32_t v = threadIdx.x < 256 ? cnt[threadIdx.x] : 0u, incl = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t u = __shfl_up(incl, d);
-    if (lane >= d) incl += u;
-  }
-  if (lane == 63) wsum[wave] = incl;
-  __syncthreads();
-  uint32_t woff = 0;
-  for (int w = 0; w < wave; w++) woff += wsum[w];
-  __syncthreads();
-  if (threadIdx.x < 256) cnt[threadIdx.x] = woff + incl - v;          // exclusive start of each bucket
-  __syncthreads();
-  for (int t = threadIdx.x; t < tiles; t += 1024) order[atomicAdd(&cnt[bucket(t)], 1u)] = (uint32_t)t;
+  tile_order_block<1024>(ranges, tiles, order, cnt, wsum);
 }
 
 int launch_tile_order(ImageState& img, int tiles, int debug, hipStream_t s) {
@@ -161,7 +140,8 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
                                                                const float4* __restrict__ splat, int W, int H, TileMap tm,
                                                                const float* __restrict__ bg, float* __restrict__ out_color,
                                                                float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                               unsigned long long* __restrict__ trace) {
+                                                               unsigned long long* __restrict__ trace,
+                                                               const uint32_t* __restrict__ counters, int* __restrict__ status_host) {
   // The four quadrant waves of a tile are independent.  As one-wave workgroups they are placed and retired one by one: a
   // tile whose quadrants differ in length does not hold four wave slots (one per SIMD) until its longest wave is done.
   // Workgroup ids 8 apart still share an XCD: id = ((tile slot j) * 4 + quadrant) * 8 + xcd.
@@ -170,7 +150,9 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
   const int wave = WPW == 4 ? (int)(threadIdx.x >> 6) : (int)((blockIdx.x >> 3) & 3);
   const int tile_block = WPW == 4 ? (int)blockIdx.x : (int)(((blockIdx.x >> 5) << 3) | (blockIdx.x & 7));
   const unsigned long long t_start = TRACE ? wall_clock64() : 0ull;      // tools/wave_trace.py: per-wave start / end / list length
-  int tx, ty, parent;
+  if (status_host && blockIdx.x == 0 && threadIdx.x < 4)                 // the frame's status words {num_rendered, -, policy, refused}
+    __hip_atomic_store(status_host + threadIdx.x, (int)counters[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // straight into
+  int tx, ty, parent;                                                    // the caller's page-locked words: no copy launch behind the frame
   uint32_t child_bit;
   if (!tm.locate(tile_block, tx, ty, parent, child_bit)) return;
   const uint2 range = ranges[parent];
@@ -341,7 +323,7 @@ static unsigned long long* g_render_trace = nullptr;      // debugging aid (tool
 extern "C" void gm_debug_render_trace(void* buffer) { g_render_trace = reinterpret_cast<unsigned long long*>(buffer); }
 
 int launch_render_fwd(const GeomState& g, const uint2* pairs, ImageState& img, int W, int H, int mode,
-                      const float* background, float* out_color, int debug, hipStream_t s) {
+                      const float* background, float* out_color, int* status_host, int debug, hipStream_t s) {
   StageScope sc(ST_RENDER, s);
   const TileGrid tg(W, H, mode);
   const TileMap tm{tg.gx, tg.gy, tg.pgx, tg.pgy, tg.s, img.tile_order};
@@ -349,10 +331,12 @@ int launch_render_fwd(const GeomState& g, const uint2* pairs, ImageState& img, i
     const dim3 grid(tm.blocks() * (4 / GM_RENDER_FWD_WPW)), block(64 * GM_RENDER_FWD_WPW);
     if (g_render_trace)
       hipLaunchKernelGGL(render_fwd_kernel<true>, grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
-                         background, out_color, img.final_T, img.n_contrib, g_render_trace);
+                         background, out_color, img.final_T, img.n_contrib, g_render_trace, g.counters, status_host);
     else
       hipLaunchKernelGGL(render_fwd_kernel<false>, grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
-                         background, out_color, img.final_T, img.n_contrib, nullptr);
+                         background, out_color, img.final_T, img.n_contrib, nullptr, g.counters, status_host);
+  } else if (status_host) {
+    GM_HIP(hipMemcpyAsync(status_host, g.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   }
   GM_LAUNCH_CHECK(debug, s);
   return 0;

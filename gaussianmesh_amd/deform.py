@@ -152,6 +152,24 @@ def vertex_face_adjacency(faces, Vm):
     return offsets.astype(np.int32), fid[order].astype(np.int32)
 
 
+def mesh_rs_packed(rest_vertices, deformed_vertices, faces, adjacency, out=None):
+    """gm_mesh_rs_packed: the per-vertex gather table [Vm,24] of the fused deformation kernels, straight from the deformed
+    mesh (= pack_mesh_state(mesh_rs(..., want_state=True)[2], rest_vertices), bit for bit, in one launch)."""
+    lib = _lib.lib()
+    device = rest_vertices.device
+    if device.type != "cuda":
+        raise _lib.GmeshError("mesh_rs_packed needs tensors on a HIP (cuda) device; there is no CPU path")
+    V0, V1 = _f(rest_vertices), _f(deformed_vertices)
+    Vm = V0.shape[0]
+    faces = faces.detach().contiguous().to(torch.int32)
+    off, adj = adjacency
+    packed = out if out is not None else torch.empty((Vm, 24), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        _lib.check(lib.gm_mesh_rs_packed(Vm, faces.shape[0], V0.data_ptr(), V1.data_ptr(), faces.data_ptr(), off.data_ptr(), adj.data_ptr(),
+                                         packed.data_ptr(), torch.cuda.current_stream(device).cuda_stream))
+    return packed
+
+
 def mesh_rs(rest_vertices, deformed_vertices, faces, adjacency=None, want_state=False):
     """gm_mesh_rs: per-vertex (R, S) [Vm,3,3] of a deformed proxy mesh, the pair pyACAP.GetRS hands to
     SingleObjectDeform.deform_gaussian (edittool/__init__.py:109-113): cotangent-weighted one-ring least-squares

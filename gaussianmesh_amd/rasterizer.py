@@ -125,12 +125,14 @@ class PendingForward:
         self.__dict__.update(kw)
         self.status_event = None
         self.result = None
+        self.known_count = None
 
-    def _geom(self, binning, num_rendered, capacity):
+    def _geom(self, binning, num_rendered, capacity, status=None):
         lib = _lib.lib()
         a = self.args
         _lib.check(lib.gm_forward_1_geom(self.policy, _ptr(self.geom), _ptr(binning), _ptr(self.img), a["P"], num_rendered, capacity,
-                                         _ptr(a["bg"]), a["W"], a["H"], _ptr(self.color), a["debug"], self.stream.cuda_stream))
+                                         _ptr(a["bg"]), a["W"], a["H"], _ptr(self.color), a["debug"], self.stream.cuda_stream,
+                                         None if status is None else status.data_ptr()))
 
     def finish(self, sync_free=False, capacity=0):
         """capacity (sync_free without a workspace): instances the freshly allocated binning buffer shall hold."""
@@ -141,9 +143,8 @@ class PendingForward:
         with torch.cuda.device(device), torch.cuda.stream(self.stream):
             if sync_free and ws is None and capacity > 0 and a["P"] > 0 and self.status_event is None:
                 binning = torch.empty((lib.gm_binning_bytes(capacity),), dtype=torch.uint8, device=device)
-                self._geom(binning, -1, capacity)
                 self.status_host = _PINNED_STATUS.pop() if _PINNED_STATUS else torch.zeros((4,), dtype=torch.int32).pin_memory()
-                _lib.check(lib.gm_forward_status_async(_ptr(self.geom), a["P"], self.status_host.data_ptr(), self.stream.cuda_stream))
+                self._geom(binning, -1, capacity, self.status_host)      # the blend kernel writes the status words itself
                 self.status_event = torch.cuda.Event()
                 self.status_event.record(self.stream)
                 self.capacity = capacity
@@ -151,22 +152,28 @@ class PendingForward:
                 return self.result
             if sync_free and ws is not None and ws.capacity > 0 and a["P"] > 0 and self.status_event is None:
                 binning = ws.get("binning", lib.gm_binning_bytes(ws.capacity), device)
-                self._geom(binning, -1, ws.capacity)
-                st = ws.pinned_status()
-                _lib.check(lib.gm_forward_status_async(_ptr(self.geom), a["P"], st.data_ptr(), self.stream.cuda_stream))
+                self._geom(binning, -1, ws.capacity, ws.pinned_status())
                 self.status_event = torch.cuda.Event()
                 self.status_event.record(self.stream)
                 self.binning = binning
                 self.result = (-1, self.color, self.radii, self.geom, binning, self.img)
                 return self.result
-            self.event.synchronize()
-            num_rendered = int(self.count_host[0])
+            if self.count_host is not None:
+                self.event.synchronize()
+                num_rendered = int(self.count_host[0])
+            elif self.known_count is not None:                       # begun without the count copy; check() has read the status
+                num_rendered = self.known_count
+            else:                                                    # begun without the count copy and never checked: fetch it now
+                st = torch.zeros((4,), dtype=torch.int32).pin_memory()
+                _lib.check(lib.gm_forward_status_async(_ptr(self.geom), a["P"], st.data_ptr(), self.stream.cuda_stream))
+                self.stream.synchronize()
+                num_rendered = int(st[0])
             if ws is not None:
                 ws.capacity = max(ws.capacity, int(num_rendered * ws.growth) + 1024)
                 binning = ws.get("binning", lib.gm_binning_bytes(ws.capacity), device)
             else:
                 binning = torch.empty((lib.gm_binning_bytes(num_rendered),), dtype=torch.uint8, device=device)
-                if len(_PINNED_POOL) < 64:
+                if self.count_host is not None and len(_PINNED_POOL) < 64:
                     _PINNED_POOL.append(self.count_host)
             self._geom(binning, num_rendered, 0)
             self.status_event = None
@@ -184,11 +191,13 @@ class PendingForward:
         if self.workspace is None:
             st = self.status_host
             nr, refused = int(st[0]), int(st[3])
+            self.known_count = nr
             if len(_PINNED_STATUS) < 64:
                 _PINNED_STATUS.append(st)
             return (not refused), nr
         st = self.workspace.pinned_status()
         nr, refused = int(st[0]), int(st[3])
+        self.known_count = nr
         if refused:
             return False, nr
         self.workspace.release(self)
@@ -275,12 +284,13 @@ def rasterize_forward(bg, means3D, colors, opacity, scales, rotations, scale_mod
 
 def forward_deformed_begin(bg, tri, weights, packed, cov, pos, shs, opacity, viewmatrix, projmatrix, tan_fovx, tan_fovy,
                            image_height, image_width, degree, campos, debug=False, workspace=None, want_deformed=False,
-                           emission_policy=None):
+                           emission_policy=None, want_count=True):
     """Edit-loop frame, first half (gm_forward_0_deformed_async): mesh-driven deformation + rotated-direction SH colour +
     forward preprocess + depth order + instance count in one enqueue, no host synchronisation.  `packed` is
     deform.pack_mesh_state() of the frame.  Returns a PendingForward; .finish() completes the frame
     (gm_forward_1_geom) and returns (num_rendered, color, radii, geom, binning, img).  With want_deformed the handle
-    also carries .deformed = (pos' [N,3], cov6 [N,6], rgb [N,3])."""
+    also carries .deformed = (pos' [N,3], cov6 [N,6], rgb [N,3]).  want_count=False (loops that complete their frames with
+    finish(sync_free=True)): the 4-byte copy of the instance count to the host is not enqueued either."""
     lib = _lib.lib()
     device = pos.device
     if device.type != "cuda":
@@ -303,11 +313,15 @@ def forward_deformed_begin(bg, tri, weights, packed, cov, pos, shs, opacity, vie
             deformed = (torch.empty((P, 3), **f), torch.empty((P, 6), **f), torch.empty((P, 3), **f)) if want_deformed else None
             geom, img, count_host = _scratch(workspace, P, W, H, device)
             dp = [None, None, None] if deformed is None else [t.data_ptr() for t in deformed]
-            event = _count_event(stream)
+            event = _count_event(stream) if want_count else None
+            if not want_count:
+                count_host = None
             _lib.check(lib.gm_forward_0_deformed_async(policy, _ptr(geom), P, int(degree), M, W, H, _ptr(tri), _ptr(weights), _ptr(packed),
                                                        _ptr(cov), _ptr(pos), _ptr(shs), _ptr(opacity), _ptr(viewmatrix), _ptr(projmatrix),
                                                        _ptr(campos), float(tan_fovx), float(tan_fovy), dp[0], dp[1], dp[2], _ptr(radii),
-                                                       int(bool(debug)), stream.cuda_stream, count_host.data_ptr(), event.cuda_event))
+                                                       int(bool(debug)), stream.cuda_stream,
+                                                       None if count_host is None else count_host.data_ptr(),
+                                                       None if event is None else event.cuda_event))
     except Exception:
         if workspace is not None:
             workspace.release(h)

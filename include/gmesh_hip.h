@@ -210,24 +210,31 @@ int gm_forward_0_deformed_async(int emission_policy, void* geom_buffer, int P, i
  *                      gm_binning_bytes(binning_capacity); the kernels read the count on the device.  If it exceeds the
  *                      capacity nothing is emitted, the image is the background and the overflow is reported by
  *                      gm_forward_status_async (grow the buffer and render the frame again).
- * gm_forward_status_async copies {num_rendered, -, policy, refused} (4 x int32) of the forward that last used geom_buffer
- * into status_host (page-locked), stream-ordered; refused != 0: nothing was emitted (capacity overflow or policy mismatch). */
+ * status_host (page-locked, device-accessible host memory, 4 x int32; may be NULL) receives the frame's status words
+ * {num_rendered, -, policy, refused}, written by the blend kernel itself (no copy launch behind the frame); they are valid once
+ * the stream has passed this call.  refused != 0: nothing was emitted (capacity overflow or policy mismatch).
+ * gm_forward_status_async copies the same four words of the forward that last used geom_buffer, stream-ordered. */
 int gm_forward_1_geom(int emission_policy, void* geom_buffer, void* binning_buffer, void* image_buffer, int P, int num_rendered,
-                      int64_t binning_capacity, const float* background, int width, int height, float* out_color, int debug, void* stream);
+                      int64_t binning_capacity, const float* background, int width, int height, float* out_color, int debug, void* stream,
+                      int* status_host);
 int gm_forward_status_async(void* geom_buffer, int P, int* status_host, void* stream);
 
 /* Per-vertex rotation / stretch of a deformed proxy mesh: replaces pyACAP.GetRS(rest vertices, deformed vertices, ...) at
  * edittool/__init__.py:102, 109 (pyACAP is a binary missing from the reference tree, so the contract is the one its call
  * site implies).  V0 / V1 float [Vm,3] rest / deformed vertices, faces int32 [nfaces,3], adj_offsets int32 [Vm+1] and
  * adj_faces int32 [3 nfaces]: CSR list of the faces incident to each vertex (built once per mesh by the caller).
- * Per face the deformation gradient maps the rest TBN frame (two edges + unit normal) to the deformed one; per vertex the
- * rest-area-weighted average F of its faces' gradients is split by polar decomposition F = Q S (Q proper rotation, S
- * symmetric).  Outputs, row-major [Vm,3,3]: R = Q^T (the row-vector convention deform_gaussian expects: it uses
+ * Per vertex the affine map of its one-ring, T = argmin sum_j c_ij |(p'_i - p'_j) - T (p_i - p_j)|^2 with cotangent weights of
+ * the rest mesh (ACAP / ARAP deformation gradient), is split by polar decomposition T = Q S (Q proper rotation, S symmetric).
+ * Outputs, row-major [Vm,3,3]: R = Q^T (the row-vector convention deform_gaussian expects: it uses
  * gaussian_deform_rot = blend(R)^T and transforms covariances by R^T S, edittool/__init__.py:118-129) and S.
  * state (optional, float [Vm,21]) receives V1 | R | S per vertex - the frame record gm_pack_mesh_state consumes.
- * R and S: both or neither; at least one of (R, S) / state. */
+ * R and S: both or neither; at least one of (R, S) / state.
+ * gm_mesh_rs_packed writes, instead, the 96-byte-per-vertex gather table gm_pack_mesh_state would make of that record
+ * (float [Vm,24], 16-byte aligned): what gm_deform_shade_packed / gm_forward_0_deformed_async read - one launch per frame. */
 int gm_mesh_rs(int Vm, int nfaces, const float* V0, const float* V1, const int* faces, const int* adj_offsets, const int* adj_faces,
                float* R, float* S, float* state, void* stream);
+int gm_mesh_rs_packed(int Vm, int nfaces, const float* V0, const float* V1, const int* faces, const int* adj_offsets, const int* adj_faces,
+                      float* packed, void* stream);
 
 /* Covariance -> (scale, rotation): replaces the per-frame eigh + host-side det sign + sqrt + matrix->quaternion of
  * SceneVisualTool.render_gaussian (edittool/__init__.py:204-207, 23-38).  cov float [N,3,3] (symmetric),

@@ -65,6 +65,14 @@ def test_matches_numpy_oracle_on_random_deformations():
     assert np.abs(R - Ro).max() <= 2e-5 and np.abs(S - So).max() <= 2e-5
     assert np.array_equal(state[:, :3], V132.astype(np.float64)) and np.array_equal(state[:, 3:12], R.reshape(-1, 9))
     assert np.array_equal(state[:, 12:], S.reshape(-1, 9))
+    # the one-launch variant writes the deformation kernels' gather table directly: identical to state -> gm_pack_mesh_state
+    from gpu_utils import T
+    from gaussianmesh_amd.deform import mesh_rs, mesh_rs_packed, pack_mesh_state, vertex_face_adjacency
+    off, adj = vertex_face_adjacency(faces, verts32.shape[0])
+    adjacency = (torch.tensor(off, device="cuda"), torch.tensor(adj, device="cuda"))
+    ft = T(faces, dtype=torch.int32)
+    st = mesh_rs(T(verts32), T(V132), ft, adjacency=adjacency, want_state=True)[2]
+    assert torch.equal(mesh_rs_packed(T(verts32), T(V132), ft, adjacency), pack_mesh_state(st, T(verts32)))
     # a reflected neighbourhood (det F < 0) still gives a proper rotation, and degenerate faces / isolated vertices are inert
     V2 = V132.copy(); V2[:, 0] *= -1
     R2, S2 = _rs(verts32, V2, faces)
