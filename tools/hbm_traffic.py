@@ -8,11 +8,10 @@ import re
 import sys
 
 STAGES = [  # stage, (kernel name fragment, launches per frame)
-    ("deform", [("pack_mesh_state_kernel", 1), ("deform_shade_kernel<true, true>", 1)]),
+    ("deform", [("mesh_rs_kernel", 1), ("deform_shade_kernel<true, true>", 1)]),
     ("depth_sort", [("bk_hist_kernel<true, 11, 4>", 1), ("bk_scan_kernel<true, 11>", 1), ("bk_scatter_kernel<true, 11, 4>", 1), ("bucket_sort_kernel", 1)]),
     ("duplicate", [("duplicate_kernel<1>", 1)]),
     ("tile_sort", [("bk_hist_kernel<false, 11, 8>", 1), ("bk_scan_kernel<false, 11>", 1), ("bk_scatter_kernel<false, 11, 8>", 1)]),
-    ("ranges", [("tile_order_kernel", 1)]),
     ("render", [("render_fwd_kernel", 1)]),
 ]
 
