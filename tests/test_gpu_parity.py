@@ -496,6 +496,24 @@ def test_fused_deform_forward_equals_unfused_chain(oracle, N):
         assert nr1 == nr0 and torch.equal(radii1, radii0) and torch.equal(color1, color0)
         if want:
             assert torch.equal(h.deformed[0], pos) and torch.equal(h.deformed[1], cov6) and torch.equal(h.deformed[2], rgb)
+    # a frame begun without the count copy (what a sync-free loop does): completed exactly all the same (the count is fetched
+    # on demand), and after an overflow the status words supply it
+    fb = lambda **kw: Rz.forward_deformed_begin(bg, g["tri"], g["w"], packed, g["cov"], g["pos"], g["shs"], g["opac"], ct["view"], ct["proj"],
+                                                cam["tanx"], cam["tany"], H, W, 3, ct["campos"], want_count=False, **kw)
+    nr2, color2, *_ = fb().finish()
+    assert nr2 == nr0 and torch.equal(color2, color0)
+    ws = Rz.RasterWorkspace()
+    ws.capacity = 64                                    # far too small
+    h = fb(workspace=ws)
+    nr3, color3, *_ = h.finish(sync_free=True)
+    ok, count = h.check()                               # status words written by the blend kernel itself
+    assert nr3 == -1 and not ok and count == nr0 and torch.equal(color3, bg.view(3, 1, 1).expand(3, H, W))
+    nr4, color4, *_ = h.finish()
+    assert nr4 == nr0 and torch.equal(color4, color0)
+    h = fb(workspace=ws)                                # the workspace has grown: the same frame now fits
+    _, color5, *_ = h.finish(sync_free=True)
+    ok, count = h.check()
+    assert ok and count == nr0 and torch.equal(color5, color0)
     # against the oracle chain
     dV = (V1 - verts).astype(np.float32)
     p_ref, c_ref, r_ref = oracle.deform(cl["tri"], cl["weights"], dV, Rv, Sv, cov, cl["means"])
