@@ -230,10 +230,12 @@ int gm_forward_0(void* geom_buffer, int P, int D, int M, const float* background
                                   prefiltered, radii, debug, stream, nullptr, nullptr)) return rc;
   if (P == 0) return GM_OK;
   GeomState g = GeomState::from(geom_buffer, (size_t)P);
-  uint32_t r = 0;
+  uint32_t rw[2] = {0u, 0u};                 // {num_rendered, prefilter violation}
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  GM_HIP(hipMemcpyAsync(&r, g.counters + GM_CNT_RENDERED, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  GM_HIP(hipMemcpyAsync(rw, g.counters + GM_CNT_RENDERED, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   GM_HIP(hipStreamSynchronize(st));         // the one host sync of a forward (reference: rasterizer_impl.cu:411)
+  const uint32_t r = rw[0];
+  if (rw[1]) { set_error("Point is filtered although prefiltered is set. This shouldn't happen!"); return GM_ERR_INVALID_ARG; }   // auxiliary.h:157
   if (r > 0x7FFFFFFFu) { set_error("num_rendered overflows int32 (%u)", r); return GM_ERR_INVALID_ARG; }
   *num_rendered = (int)r;
   return GM_OK;

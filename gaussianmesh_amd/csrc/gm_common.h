@@ -78,6 +78,7 @@ static inline size_t bk_chunks(size_t n) { return (bk_blocks(n) + GM_BK_CHUNK - 
 static inline size_t bk_acc_words(size_t n) { return GM_ACC_SLOTS + (bk_chunks(n) << GM_BUCKET_BITS); }
 // device scalars (GeomState::counters)
 #define GM_CNT_RENDERED 0            // num_rendered (instance total of this forward)
+#define GM_CNT_PREFILTER 1        // set when a Gaussian was frustum-culled although the caller declared the cloud prefiltered
 #define GM_CNT_POLICY 2              // emission policy the counts were made under
 #define GM_CNT_REFUSED 3             // emission refused (policy mismatch / capacity overflow): every list stays empty
 #define GM_CNT_GROUP 8               // [8] digit-group totals of the scan in flight

@@ -177,6 +177,14 @@ class PendingForward:
                     _PINNED_POOL.append(self.count_host)
             self._geom(binning, num_rendered, 0)
             self.status_event = None
+            if a.get("prefiltered") and a["P"] > 0:         # the reference traps the kernel (auxiliary.h:155-159); here: an error
+                st = torch.zeros((4,), dtype=torch.int32).pin_memory()
+                _lib.check(lib.gm_forward_status_async(_ptr(self.geom), a["P"], st.data_ptr(), self.stream.cuda_stream))
+                self.stream.synchronize()
+                if int(st[1]):
+                    if ws is not None:
+                        ws.release(self)
+                    raise _lib.GmeshError(_PREFILTER_MESSAGE)
         if ws is not None:
             ws.release(self)
         self.result = (num_rendered, self.color, self.radii, self.geom, binning, self.img)
@@ -190,20 +198,26 @@ class PendingForward:
         self.status_event.synchronize()
         if self.workspace is None:
             st = self.status_host
-            nr, refused = int(st[0]), int(st[3])
+            nr, refused, violated = int(st[0]), int(st[3]), int(st[1])
             self.known_count = nr
             if len(_PINNED_STATUS) < 64:
                 _PINNED_STATUS.append(st)
+            if violated and self.args.get("prefiltered"):
+                raise _lib.GmeshError(_PREFILTER_MESSAGE)
             return (not refused), nr
         st = self.workspace.pinned_status()
         nr, refused = int(st[0]), int(st[3])
         self.known_count = nr
+        if int(st[1]) and self.args.get("prefiltered"):
+            self.workspace.release(self)
+            raise _lib.GmeshError(_PREFILTER_MESSAGE)
         if refused:
             return False, nr
         self.workspace.release(self)
         return True, nr
 
 
+_PREFILTER_MESSAGE = "Point is filtered although prefiltered is set. This shouldn't happen!"      # auxiliary.h:157
 _PINNED_POOL = []          # page-locked int32[1] counters of workspace-less forwards (allocating one per call costs ~0.1 ms)
 _PINNED_STATUS = []        # page-locked int32[4] status words of sync-free forwards without a workspace
 
@@ -265,7 +279,7 @@ def rasterize_forward_begin(bg, means3D, colors, opacity, scales, rotations, sca
         if workspace is not None:
             workspace.release(h)
         raise
-    h.args = dict(device=device, P=P, W=W, H=H, bg=bg, debug=int(bool(debug)),
+    h.args = dict(device=device, P=P, W=W, H=H, bg=bg, debug=int(bool(debug)), prefiltered=bool(prefiltered),
                   keep=(means3D, sh, colors, opacity, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos))
     h.geom, h.img, h.color, h.radii, h.count_host, h.event = geom, img, color, radii, count_host, event
     return h

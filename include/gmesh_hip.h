@@ -211,7 +211,7 @@ int gm_forward_0_deformed_async(int emission_policy, void* geom_buffer, int P, i
  *                      capacity nothing is emitted, the image is the background and the overflow is reported by
  *                      gm_forward_status_async (grow the buffer and render the frame again).
  * status_host (page-locked, device-accessible host memory, 4 x int32; may be NULL) receives the frame's status words
- * {num_rendered, -, policy, refused}, written by the blend kernel itself (no copy launch behind the frame); they are valid once
+ * {num_rendered, prefilter violation, policy, refused}, written by the blend kernel itself (no copy launch behind the frame); they are valid once
  * the stream has passed this call.  refused != 0: nothing was emitted (capacity overflow or policy mismatch).
  * gm_forward_status_async copies the same four words of the forward that last used geom_buffer, stream-ordered. */
 int gm_forward_1_geom(int emission_policy, void* geom_buffer, void* binning_buffer, void* image_buffer, int P, int num_rendered,

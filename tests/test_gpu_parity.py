@@ -278,6 +278,30 @@ def test_mark_visible(oracle):
     assert np.array_equal(vis, oracle.mark_visible(sc["means"], cam["view"], cam["proj"]))
 
 
+def test_prefiltered_contract(oracle):
+    """prefiltered=True promises that no Gaussian is frustum-culled; the reference traps the kernel when one is
+    (RAST/auxiliary.h:153-159).  Here the violation is an error with the reference's message, and a cloud that keeps the promise
+    renders exactly as with prefiltered=False."""
+    from gpu_utils import T
+    from gaussianmesh_amd import GaussianRasterizationSettings, GaussianRasterizer
+    from gaussianmesh_amd._lib import GmeshError
+    W, H = 48, 40
+    sc, cam = small_scene(P=400, W=W, H=H, behind=True)
+    def run(means, prefiltered):
+        rs = GaussianRasterizationSettings(H, W, cam["tanx"], cam["tany"], T(np.zeros(3)), 1.0, T(cam["view"]), T(cam["proj"]), 3,
+                                           T(cam["campos"]), prefiltered, False)
+        n = means.shape[0]
+        return GaussianRasterizer(rs)(T(means), torch.zeros((n, 3), device="cuda"), T(sc["opac"][:n]), shs=T(sc["shs"][:n]), scales=T(sc["scales"][:n]),
+                                      rotations=T(sc["rots"][:n]))
+    with pytest.raises(GmeshError, match="filtered although prefiltered"):
+        run(sc["means"], True)                                 # small_scene(behind=True) puts Gaussians behind the camera
+    vz = (np.c_[sc["means"], np.ones(len(sc["means"]))] @ cam["view"])[:, 2]
+    keep = np.nonzero(vz > 0.2)[0]
+    sc = {k: sc[k][keep] for k in ("means", "opac", "shs", "scales", "rots")}
+    a, b = run(sc["means"], True), run(sc["means"], False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
 def test_scale_modifier_and_debug(oracle):
     from gpu_utils import forward_state
     sc, cam = small_scene(P=300, W=48, H=48, seed=9)
