@@ -699,18 +699,25 @@ int64_t orc_forward(int P, int D, int M, const float* bg, int W, int H, const fl
                  campos, W, H, tanx, tany, radii, xy, depths, NULL, rgb, conic, tiles, clamped);
   /* count per tile */
   int64_t* tcount = (int64_t*)calloc((size_t)NT + 1, sizeof(int64_t));
+#pragma omp parallel for schedule(static)
   for (int i = 0; i < P; i++)
     if (radii[i] > 0) {
       int x0, y0, x1, y1;
       get_rect(xy[2 * (size_t)i], xy[2 * (size_t)i + 1], radii[i], gx, gy, &x0, &y0, &x1, &y1);
       for (int y = y0; y < y1; y++)
-        for (int x = x0; x < x1; x++) tcount[y * gx + x + 1]++;
+        for (int x = x0; x < x1; x++) {
+#pragma omp atomic
+          tcount[y * gx + x + 1]++;
+        }
     }
   for (int t = 0; t < NT; t++) tcount[t + 1] += tcount[t];
   const int64_t R = tcount[NT];
   uint64_t* comp = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(R ? R : 1));
   int64_t* cur = (int64_t*)malloc(sizeof(int64_t) * (size_t)NT);
   memcpy(cur, tcount, sizeof(int64_t) * (size_t)NT);
+  /* slots inside a tile are handed out in arrival order; the per-tile sort on the full (depth bits, id) key below makes
+   * the list independent of it */
+#pragma omp parallel for schedule(static)
   for (int i = 0; i < P; i++)
     if (radii[i] > 0) {
       int x0, y0, x1, y1;
@@ -718,7 +725,12 @@ int64_t orc_forward(int P, int D, int M, const float* bg, int W, int H, const fl
       uint32_t db;
       memcpy(&db, depths + i, 4);
       for (int y = y0; y < y1; y++)
-        for (int x = x0; x < x1; x++) comp[cur[y * gx + x]++] = ((uint64_t)db << 32) | (uint32_t)i;
+        for (int x = x0; x < x1; x++) {
+          int64_t pos;
+#pragma omp atomic capture
+          pos = cur[y * gx + x]++;
+          comp[pos] = ((uint64_t)db << 32) | (uint32_t)i;
+        }
     }
   uint32_t* plist = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(R ? R : 1));
   uint32_t* ranges = (uint32_t*)calloc((size_t)NT * 2, 4);
