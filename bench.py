@@ -212,6 +212,8 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     lib = _lib.lib()
+    if args.policy is not None:
+        Rz.set_default_emission_policy(args.policy)
 
     P, W, H, F = args.gaussians, args.width, args.height, args.cameras
     # ---- scene: rank 0 generates, everyone else receives it over RCCL (one-time broadcast of the shared cloud)
@@ -392,6 +394,7 @@ def main():
                                "render %dx%d, %d-camera orbit, views sharded by rank" % (P, W, H, F),
                    "gaussians": P, "width": W, "height": H, "sh_degree": 3, "views_per_step_per_gpu": 1,
                    "vertex_rs": "analytic tables" if args.analytic_rs else "gm_mesh_rs per frame", "hip_streams": nstreams,
+                   "emission_policy": Rz.get_default_emission_policy(),
                    "parallelism": "views x%d" % world},
     }
     if repeats:
