@@ -52,12 +52,13 @@ __device__ __forceinline__ void get_rect(float px, float py, int r, int gx, int 
   y1 = min(gy, max(0, (int)((py + r + GM_TILE - 1) / GM_TILE)));
 }
 
-// Instance emission.  Workgroup b owns the sorted positions of depth bucket b (gm_bucket.hip), [bucket_start[b],
-// bucket_start[b + 1]), and walks them in chunks of 512: thread t owns 2 consecutive positions of a chunk and reads their
+// Instance emission.  Workgroup r owns the run of sorted positions [512 r, 512 r + 512) (gm_bucket.hip leaves the instance
+// total of every run in chunk_inst; the work does not depend on how the depth buckets came out): thread t owns 2 consecutive
+// positions and reads their
 // emission records (candidate rectangle + instance count + emit mask, written by preprocess, brought into this order by
 // bucket_sort_kernel: coalesced); the chunk scans the counts into output offsets; then instances are
-// written (see (1) and (2) in the body).  The bucket's first output offset is the sum of the instance totals of the
-// buckets before it (bucket_inst, 2048 values, summed by every workgroup for itself).
+// written (see (1) and (2) in the body).  The run's first output offset is the sum of the instance totals of the runs before
+// it (chunk_inst, summed by every workgroup for itself).
 // Emitted order = Gaussian order (depth, id), then rectangle row-major - the reference's order
 // (RAST/rasterizer_impl.cu:98-109) restricted to the emitted tiles.
 // S > 0: one instance per PARENT tile (2^S x 2^S tiles) that has a reached child; key = parent id | child mask << 16
@@ -65,8 +66,8 @@ __device__ __forceinline__ void get_rect(float px, float py, int r, int gx, int 
 template <int S>
 __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles,
                                                                 const uint4* __restrict__ bin_sorted, const float4* __restrict__ splat,
-                                                                uint32_t* __restrict__ counters, const uint32_t* __restrict__ bucket_start,
-                                                                const uint32_t* __restrict__ bucket_inst, int gx, int pgx, int mode,
+                                                                uint32_t* __restrict__ counters, const uint32_t* __restrict__ chunk_inst,
+                                                                int gx, int pgx, int mode,
                                                                 uint32_t capacity, uint2* __restrict__ pairs_out,
                                                                 uint32_t* __restrict__ acc, uint32_t acc_words) {
   __shared__ uint32_t wsum[BN_THREADS / 64];
@@ -84,13 +85,14 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
   constexpr int M = (1 << S) - 1;
   const int lane = threadIdx.x & 63;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  const uint32_t bkt = blockIdx.x;
-  const uint32_t P0 = bucket_start[bkt], P1 = bucket_start[bkt + 1];
+  const uint32_t run = blockIdx.x;
+  const uint32_t V = counters[GM_CNT_VISIBLE];
+  const uint32_t P0 = min(run * (uint32_t)GM_SCAN_ITEMS, V), P1 = min(P0 + (uint32_t)GM_SCAN_ITEMS, V);
   if (P0 == P1) return;
   uint32_t ibase;
   {
     uint32_t part = 0;
-    for (uint32_t k = threadIdx.x; k < bkt; k += BN_THREADS) part += bucket_inst[k];
+    for (uint32_t k = threadIdx.x; k < run; k += BN_THREADS) part += chunk_inst[k];
     uint32_t tot;
     block_exclusive_scan(part, wsum, tot);
     ibase = tot;
@@ -234,8 +236,8 @@ int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, int mod
   const TileGrid tg(W, H, mode);
   const uint32_t cap = capacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)capacity;
   if (P > 0) {
-#define GM_DUP(SH) hipLaunchKernelGGL(duplicate_kernel<SH>, dim3(1 << GM_BUCKET_BITS), dim3(BN_THREADS), 0, s, g.order, g.tiles_touched, g.bin_sorted, \
-                                      g.splat, g.counters, g.bucket_start, g.bucket_inst, tg.gx, tg.pgx, mode, cap, b.pairs[0], b.acc, \
+#define GM_DUP(SH) hipLaunchKernelGGL(duplicate_kernel<SH>, dim3((P + GM_SCAN_ITEMS - 1) / GM_SCAN_ITEMS), dim3(BN_THREADS), 0, s, g.order, g.tiles_touched, \
+                                      g.bin_sorted, g.splat, g.counters, g.chunk_inst, tg.gx, tg.pgx, mode, cap, b.pairs[0], b.acc, \
                                       (uint32_t)bk_acc_words(capacity))
     if (tg.s == 0) GM_DUP(0); else if (tg.s == 1) GM_DUP(1); else GM_DUP(2);
 #undef GM_DUP

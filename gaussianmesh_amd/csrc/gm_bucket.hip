@@ -67,26 +67,6 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
   return v;
 }
 
-// Every thread of the workgroup calls this.  Reduces the 64 slots {instance sum, max ~key, max key} the preprocess
-// kernel filled: returns the bucket mapping (sub = kmin, shift), the number of buckets in use (0: nothing visible) and
-// the instance total.  s_tmp: 4 shared words.
-__device__ __forceinline__ uint32_t block_msd_params(const uint32_t* __restrict__ slots, uint32_t* s_tmp, DigitSpec& ds, uint32_t& total) {
-  if (threadIdx.x < 64) {
-    const uint4 s = reinterpret_cast<const uint4*>(slots)[threadIdx.x];
-    const uint32_t sum = wave_sum_u32(s.x), nkmin = wave_max_u32(s.y), kmax = wave_max_u32(s.z);
-    if (threadIdx.x == 0) { s_tmp[0] = sum; s_tmp[1] = ~nkmin; s_tmp[2] = kmax; }
-  }
-  __syncthreads();
-  total = s_tmp[0];
-  const uint32_t kmin = s_tmp[1], kmax = s_tmp[2];
-  ds.sub = kmin; ds.mask = 0xFFFFFFFFu; ds.shift = 0;
-  if (kmin > kmax) return 0u;                         // no visible key was recorded (slots still hold max(~key) = max(key) = 0)
-  const uint32_t range = kmax - kmin;
-  const int bits = range ? 32 - __clz((int)range) : 0;
-  ds.shift = (uint32_t)max(0, bits - GM_BUCKET_BITS);
-  return (range >> ds.shift) + 1u;                    // <= 2^GM_BUCKET_BITS
-}
-
 __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* wsum /*[4] shared*/, uint32_t& total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t incl = v;
@@ -108,6 +88,138 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
   return woff + incl - v;
 }
 
+// Depth-bucket mapping (gm_common.h, GM_COARSE_*): coarse bin c = key >> 20 owns buckets [base[c], base[c] + nb[c]) and
+// subdivides its 2^20 key values linearly among them.  Monotone in the key, so (bucket, key inside the bucket, id) order is
+// (key, id) order.
+struct DepthMap { uint16_t base[GM_COARSE_BINS]; uint16_t nb[GM_COARSE_BINS]; };     // 8 KiB of LDS
+__device__ __forceinline__ uint32_t depth_bucket(const DepthMap& m, uint32_t key) {
+  const uint32_t c = (key >> GM_COARSE_SHIFT) & (GM_COARSE_BINS - 1);
+  return (uint32_t)m.base[c] + (((key & ((1u << GM_COARSE_SHIFT) - 1u)) * (uint32_t)m.nb[c]) >> GM_COARSE_SHIFT);
+}
+// Built by every workgroup of the partition's histogram launch (256 threads; workgroup 0 also publishes it: dmap[c] = base <<
+// 16 | nb, bmap[bucket] = c, counters[VISIBLE / NBUCKETS / RENDERED]).  Each non-empty coarse bin gets
+// max(1, count * GM_BUCKET_BUDGET / visible) buckets; should more than 2048 come out (hundreds of sparsely filled bins), every
+// non-empty bin gets exactly one.  Returns the number of buckets (0: nothing visible).
+__device__ __forceinline__ uint32_t block_build_depth_map(const uint32_t* __restrict__ slots, const uint32_t* __restrict__ coarse, DepthMap& m,
+                                                          uint32_t* wsum /*[4]*/, uint32_t* s_tmp /*[4]*/, uint32_t* __restrict__ dmap,
+                                                          uint32_t* __restrict__ bmap, uint32_t* __restrict__ counters, bool publish) {
+  constexpr int PER = GM_COARSE_BINS / BK_THREADS;                  // 8 consecutive coarse bins per thread
+  {                                    // instance total (num_rendered), visible count, first / last coarse bin in use from the slots
+    static_assert(GM_SLOTS == BK_THREADS, "one slot per thread");
+    const uint4 sl = *reinterpret_cast<const uint4*>(slots + GM_SLOT_STRIDE * threadIdx.x);
+    const uint32_t inst = wave_sum_u32(sl.x), vis = wave_sum_u32(sl.y), ncmin = wave_max_u32(sl.z), cmax = wave_max_u32(sl.w);
+    uint4* part = reinterpret_cast<uint4*>(&m);                     // (the map's memory is free until the table is written)
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = make_uint4(inst, vis, ncmin, cmax);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint4 a = part[0], b = part[1], c = part[2], d = part[3];
+      s_tmp[0] = a.x + b.x + c.x + d.x; s_tmp[1] = a.y + b.y + c.y + d.y;
+      s_tmp[2] = (GM_COARSE_BINS - 1u) - max(max(a.z, b.z), max(c.z, d.z)); s_tmp[3] = max(max(a.w, b.w), max(c.w, d.w));
+    }
+  }
+  __syncthreads();
+  const uint32_t cmin = s_tmp[2], cmax = s_tmp[3];
+  uint32_t cnt[PER];
+#pragma unroll
+  for (int j = 0; j < PER; j++) cnt[j] = 0;
+  if (threadIdx.x * PER + PER > cmin && threadIdx.x * PER <= cmax) {   // only the threads whose bins can hold anything read the histogram
+#pragma unroll
+    for (int k = 0; k < GM_COARSE_COPIES; k++)
+#pragma unroll
+      for (int j = 0; j < PER; j++) cnt[j] += coarse[coarse_index(threadIdx.x * PER + j, k)];
+  }
+  // a bin next to an empty or much sparser one is usually only partly covered by the keys (the depth range of an object begins
+  // or ends inside it, and surfaces pile up at their depth extremes): its keys sit in a fraction of its range, so it gets four
+  // times its share.  Neighbour counts travel through the map's own memory.
+  uint32_t* scratch = reinterpret_cast<uint32_t*>(&m);
+#pragma unroll
+  for (int j = 0; j < PER; j++) scratch[threadIdx.x * PER + j] = cnt[j];
+  __syncthreads();
+  const uint32_t visible = s_tmp[1];
+  const uint32_t left = threadIdx.x ? scratch[threadIdx.x * PER - 1] : 0u;
+  const uint32_t right = threadIdx.x + 1 < BK_THREADS ? scratch[threadIdx.x * PER + PER] : 0u;
+  __syncthreads();                                                   // (the scratch is dead: the map may be written)
+  // share of the bucket budget in proportion to the weights: deterministic float arithmetic in a fixed order (every workgroup
+  // of every launch computes the same table)
+  float wgt[PER], wpart = 0.f;
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    const uint32_t lo = j ? cnt[j - 1] : left, hi = j + 1 < PER ? cnt[j + 1] : right;
+    wgt[j] = (float)cnt[j] * ((lo < cnt[j] / 8u || hi < cnt[j] / 8u) ? 4.0f : 1.0f);
+    wpart += wgt[j];
+  }
+  {
+    float ws = wpart;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) ws += __shfl_xor(ws, d);
+    if ((threadIdx.x & 63) == 0) reinterpret_cast<float*>(wsum)[threadIdx.x >> 6] = ws;
+  }
+  __syncthreads();
+  const float wtotal = ((reinterpret_cast<float*>(wsum)[0] + reinterpret_cast<float*>(wsum)[1]) + reinterpret_cast<float*>(wsum)[2]) +
+                       reinterpret_cast<float*>(wsum)[3];
+  __syncthreads();
+  const float scale = (float)GM_BUCKET_BUDGET / (wtotal > 0.f ? wtotal : 1.f);
+  uint32_t nbk[PER], nsum = 0, nonempty = 0;
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    nbk[j] = cnt[j] ? max(1u, (uint32_t)(wgt[j] * scale)) : 0u;
+    nsum += nbk[j]; nonempty += cnt[j] ? 1u : 0u;
+  }
+  (void)visible;
+  uint32_t total_b;
+  uint32_t excl = block_exclusive_scan_256(nsum, wsum, total_b);
+  __syncthreads();
+  if (total_b > (1u << GM_BUCKET_BITS)) {                            // (uniform) fall back to one bucket per non-empty coarse bin
+#pragma unroll
+    for (int j = 0; j < PER; j++) nbk[j] = cnt[j] ? 1u : 0u;
+    excl = block_exclusive_scan_256(nonempty, wsum, total_b);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    const uint32_t c = threadIdx.x * PER + j;
+    m.base[c] = (uint16_t)excl; m.nb[c] = (uint16_t)nbk[j];
+    if (publish) dmap[c] = (excl << 16) | nbk[j];
+    excl += nbk[j];
+  }
+  __syncthreads();
+  if (publish) {
+    // bucket -> coarse bin: the last bin whose first bucket is <= b (empty bins share their successor's first bucket)
+    for (uint32_t bk = threadIdx.x; bk < total_b; bk += BK_THREADS) {
+      uint32_t lo = 0, hi = GM_COARSE_BINS;                          // invariant: base[lo] <= bk, (hi == BINS or base[hi] > bk)
+      while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((uint32_t)m.base[mid] <= bk) lo = mid; else hi = mid;
+      }
+      // the bucket's key range: sub-range j of coarse bin lo, [lo << 20 | ceil(j 2^20 / nb), lo << 20 | ceil((j + 1) 2^20 / nb));
+      // bucket_sort_kernel sorts on (key - first key) with as many bits as the range needs
+      const uint32_t cn = max((uint32_t)m.nb[lo], 1u), j = bk - (uint32_t)m.base[lo];
+      const uint32_t k0 = (uint32_t)((((unsigned long long)j << GM_COARSE_SHIFT) + cn - 1u) / cn);
+      const uint32_t k1 = (uint32_t)((((unsigned long long)(j + 1u) << GM_COARSE_SHIFT) + cn - 1u) / cn);
+      const uint32_t width = k1 > k0 ? k1 - k0 : 1u;
+      reinterpret_cast<uint2*>(bmap)[bk] = make_uint2((lo << GM_COARSE_SHIFT) + k0, width > 1u ? 32u - (uint32_t)__clz((int)(width - 1u)) : 0u);
+    }
+    if (threadIdx.x == 0) {
+      counters[GM_CNT_VISIBLE] = visible; counters[GM_CNT_NBUCKETS] = total_b; counters[GM_CNT_RENDERED] = s_tmp[0];
+      counters[GM_CNT_CMIN] = cmin; counters[GM_CNT_CMAX] = cmax;
+    }
+  }
+  return visible ? total_b : 0u;
+}
+__device__ __forceinline__ void block_load_depth_map(const uint32_t* __restrict__ dmap, const uint32_t* __restrict__ counters, DepthMap& m) {
+  const uint32_t cmin = counters[GM_CNT_CMIN], cmax = min(counters[GM_CNT_CMAX], (uint32_t)GM_COARSE_BINS - 1u);
+  uint32_t* z = reinterpret_cast<uint32_t*>(&m);
+  for (uint32_t i = threadIdx.x; i < sizeof(DepthMap) / 4; i += blockDim.x) z[i] = 0u;     // (culled keys index the last bin: bucket 0, unused)
+  __syncthreads();
+  for (uint32_t c = cmin + threadIdx.x; c <= cmax; c += blockDim.x) {       // no visible key maps outside the bins in use
+    const uint32_t e = dmap[c];
+    m.base[c] = (uint16_t)(e >> 16); m.nb[c] = (uint16_t)(e & 0xFFFFu);
+  }
+  __syncthreads();
+}
+template <bool MSD> struct MapStorage { DepthMap m; };
+template <> struct MapStorage<false> { char unused; };
+
 // key of entry idx: MSD input is the plain key array of the preprocess kernel, everything else is a pair stream
 template <bool MSD>
 __device__ __forceinline__ uint32_t load_key(const void* __restrict__ in, uint32_t idx) {
@@ -123,19 +235,24 @@ template <bool MSD, int DB, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void bk_hist_kernel(const void* __restrict__ in, uint32_t n_host,
                                                               const uint32_t* __restrict__ n_dev, DigitSpec ds,
                                                               const uint32_t* __restrict__ slots, uint32_t* __restrict__ hist,
-                                                              uint32_t* __restrict__ acc, uint32_t* __restrict__ counters) {
+                                                              uint32_t* __restrict__ acc, uint32_t* __restrict__ counters,
+                                                              const uint32_t* __restrict__ coarse, uint32_t* __restrict__ dmap,
+                                                              uint32_t* __restrict__ bmap) {
   constexpr int ND = 1 << DB, THREADS = WAVES * 64, TILE = WAVES * BK_ROUNDS * 64;
   __shared__ uint32_t h[ND];
   __shared__ uint32_t s_tmp[4];
+  __shared__ uint32_t s_w[4];
+  __shared__ MapStorage<MSD> s_map;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t n = n_host;
   if (n_dev) n = min(n, *n_dev);
-  if (MSD) {
-    uint32_t total;
-    const uint32_t nb = block_msd_params(slots, s_tmp, ds, total);
-    if (blockIdx.x == 0 && threadIdx.x == 0) counters[GM_CNT_RENDERED] = total;   // num_rendered, for the host read-back
-    if (nb == 0u) return;
+  if constexpr (MSD) {               // (the launch's extra, last workgroup only publishes the mapping, the bucket count and num_rendered)
+    if (block_build_depth_map(slots, coarse, s_map.m, s_w, s_tmp, dmap, bmap, counters, blockIdx.x == gridDim.x - 1) == 0u) return;
   }
+  auto digit = [&](uint32_t key) -> uint32_t {
+    if constexpr (MSD) return depth_bucket(s_map.m, key);
+    else return ((key - ds.sub) >> ds.shift) & ds.mask;
+  };
   const uint32_t nblk = (n + TILE - 1) / TILE;
   if (blockIdx.x >= nblk) return;
   for (int d = threadIdx.x; d < ND; d += THREADS) h[d] = 0;
@@ -151,7 +268,7 @@ __global__ __launch_bounds__(WAVES * 64) void bk_hist_kernel(const void* __restr
   for (int r = 0; r < BK_ROUNDS; r++) {
     const uint32_t idx = wbase + r * 64 + lane;
     const bool valid = idx < n && (!MSD || k[r] != 0xFFFFFFFFu);
-    if (valid) atomicAdd(&h[((k[r] - ds.sub) >> ds.shift) & ds.mask], 1u);
+    if (valid) atomicAdd(&h[digit(k[r])], 1u);
   }
   __syncthreads();
   uint32_t* chunk_total = acc + GM_ACC_SLOTS + (size_t)(blockIdx.x / BK_CHUNK) * ND;
@@ -174,15 +291,11 @@ __global__ __launch_bounds__(BK_THREADS) void bk_scan_kernel(uint32_t* __restric
                                                               uint2* __restrict__ ranges_out, uint32_t nranges) {
   constexpr int ND = 1 << DB, NG = ND / 256;
   __shared__ uint32_t wsum[4];
-  __shared__ uint32_t s_tmp[4];
   __shared__ uint32_t gsum[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t n = n_host;
   if (n_dev) n = min(n, *n_dev);
-  if (MSD) {
-    DigitSpec ds; uint32_t total;
-    if (block_msd_params(slots, s_tmp, ds, total) == 0u) n = 0;
-  }
+  if (MSD && counters[GM_CNT_VISIBLE] == 0u) n = 0;          // (written by the histogram launch before this one)
   const uint32_t nblk = (n + tile - 1) / tile;
   const uint32_t nchunks = (nblk + BK_CHUNK - 1) / BK_CHUNK;
   const uint32_t c = blockIdx.x, g = blockIdx.y;
@@ -247,7 +360,8 @@ __global__ __launch_bounds__(WAVES * 64, 4) void bk_scatter_kernel(const void* _
                                                                  const uint32_t* __restrict__ slots, const uint32_t* __restrict__ hist,
                                                                  uint32_t* __restrict__ zero_acc, uint32_t zero_words,
                                                                  const uint2* __restrict__ ord_ranges, int ord_tiles,
-                                                                 uint32_t* __restrict__ ord_out) {
+                                                                 uint32_t* __restrict__ ord_out, const uint32_t* __restrict__ dmap,
+                                                                 const uint32_t* __restrict__ counters) {
   constexpr int ND = 1 << DB, THREADS = WAVES * 64, TILE = WAVES * BK_ROUNDS * 64;
   if (!MSD && ord_out && blockIdx.x == gridDim.x - 1) {      // the launch's extra workgroup: dispatch order of the blend kernels
     __shared__ uint32_t o_cnt[256];                          // from the ranges the scan kernel has just published
@@ -264,17 +378,21 @@ __global__ __launch_bounds__(WAVES * 64, 4) void bk_scatter_kernel(const void* _
   __shared__ uint32_t gbase[ND];             // first output position of each digit for this workgroup
   __shared__ uint16_t dstart[ND];            // start of each digit's run inside the digit-sorted tile (< TILE <= 16384)
   __shared__ uint32_t wsum[WAVES];
-  __shared__ uint32_t s_tmp[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   if (zero_acc)
     for (uint32_t i = blockIdx.x * THREADS + threadIdx.x; i < zero_words; i += gridDim.x * THREADS) zero_acc[i] = 0u;
   uint32_t n = n_host;
   if (n_dev) n = min(n, *n_dev);
-  if (MSD) {
-    uint32_t total;
-    if (block_msd_params(slots, s_tmp, ds, total) == 0u) return;
+  __shared__ MapStorage<MSD> s_map;
+  if constexpr (MSD) {
+    if (counters[GM_CNT_VISIBLE] == 0u) return;
+    block_load_depth_map(dmap, counters, s_map.m);
   }
+  auto digit = [&](uint32_t key) -> uint32_t {
+    if constexpr (MSD) return depth_bucket(s_map.m, key);
+    else return ((key - ds.sub) >> ds.shift) & ds.mask;
+  };
   const uint32_t nblk = (n + TILE - 1) / TILE;
   if (blockIdx.x >= nblk) return;
   for (int d = threadIdx.x; d < ND; d += THREADS) {
@@ -303,7 +421,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void bk_scatter_kernel(const void* _
     const uint32_t idx = wbase + r * 64 + lane;
     const bool valid = idx < n && (!MSD || key[r] != 0xFFFFFFFFu);
     vmask |= valid ? (1u << r) : 0u;
-    const uint32_t d = ((key[r] - ds.sub) >> ds.shift) & ds.mask;
+    const uint32_t d = digit(key[r]);
     uint64_t peers = __ballot(valid);          // match-any over the digit bits among the valid lanes
 #pragma unroll
     for (int b = 0; b < DB; b++) {
@@ -367,7 +485,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void bk_scatter_kernel(const void* _
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < BK_ROUNDS; r++) {        // position of each key inside the digit-sorted tile
-    const uint32_t d = ((key[r] - ds.sub) >> ds.shift) & ds.mask;
+    const uint32_t d = digit(key[r]);
     rank[r] += ((vmask >> r) & 1u) ? dstart[d] + wcnt[wave][d] : 0u;
   }
   __syncthreads();                             // wcnt is dead from here: its memory becomes the stage
@@ -378,7 +496,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void bk_scatter_kernel(const void* _
   // digit d's run goes to gbase[d] + (position in run): neighbouring lanes store neighbouring pairs
   for (uint32_t i = threadIdx.x; i < tile_n; i += THREADS) {
     const uint2 kv = stage[i];
-    const uint32_t d = ((kv.x - ds.sub) >> ds.shift) & ds.mask;
+    const uint32_t d = digit(kv.x);
     out[gbase[d] + (i - dstart[d])] = kv;
   }
 }
@@ -387,39 +505,55 @@ __global__ __launch_bounds__(WAVES * 64, 4) void bk_scatter_kernel(const void* _
 // One workgroup per bucket of the MSD partition: (key, id) pairs [start, end) of k1 / v1 -> final order.
 // Outputs: order0[start..end) = ids in (key, id) order, bin_sorted[start..end) = emission records of those ids,
 // bucket_inst[b] = their sum.  p0[start..end) is scratch for the slow path.
-__global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t* __restrict__ slots, const uint32_t* __restrict__ bucket_start,
+// Instances of 64 consecutive sorted positions (first one `pos0`, lane l holds position pos0 + l's count) into the per-run
+// totals duplicate_kernel builds its output offsets from: the 64 positions touch at most two runs of GM_SCAN_ITEMS.
+__device__ __forceinline__ void chunk_add(uint32_t* __restrict__ chunk_inst, uint32_t pos0, int lane, uint32_t count) {
+  const uint32_t ch0 = pos0 / GM_SCAN_ITEMS;
+  const bool first = (pos0 + (uint32_t)lane) / GM_SCAN_ITEMS == ch0;
+  const uint32_t s0 = wave_sum_u32(first ? count : 0u), s1 = wave_sum_u32(first ? 0u : count);
+  if (lane == 0) {
+    if (s0) atomicAdd(chunk_inst + ch0, s0);
+    if (s1) atomicAdd(chunk_inst + ch0 + 1, s1);
+  }
+}
+
+__global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t* __restrict__ counters, const uint32_t* __restrict__ dmap,
+                                                                  const uint32_t* __restrict__ bmap, const uint32_t* __restrict__ bucket_start,
                                                                   uint2* __restrict__ p1, uint2* __restrict__ p0, uint32_t* __restrict__ order0,
                                                                   const uint32_t* __restrict__ tiles, const uint4* __restrict__ bins,
-                                                                  uint4* __restrict__ bin_sorted, uint32_t* __restrict__ bucket_inst) {
+                                                                  uint4* __restrict__ bin_sorted, uint32_t* __restrict__ chunk_inst,
+                                                                  unsigned long long* __restrict__ trace) {
+  const unsigned long long t_begin = trace ? wall_clock64() : 0ull;
   __shared__ uint32_t wcnt[BK_WAVES][256];
   __shared__ uint32_t dstart[256];
-  __shared__ uint32_t lkey[BS_CAP];
-  __shared__ uint32_t lval[BS_CAP];
+  __shared__ uint32_t lkey[BS_CAP];                                 // (key - first key) << 12 | position in the bucket: 16 KiB
   __shared__ uint32_t wsum[4];
-  __shared__ uint32_t s_tmp[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  DigitSpec ds; uint32_t total;
-  const uint32_t nb = block_msd_params(slots, s_tmp, ds, total);
+  const uint32_t nb = counters[GM_CNT_VISIBLE] ? counters[GM_CNT_NBUCKETS] : 0u;
   const uint32_t b = blockIdx.x;
   uint32_t start = 0, end = 0;
   if (b < nb) { start = bucket_start[b]; end = bucket_start[b + 1]; }
   const uint32_t n = end - start;
-  if (n == 0u) { if (threadIdx.x == 0) bucket_inst[b] = 0u; return; }
-  const uint32_t low_bits = ds.shift;                 // bits of (key - kmin) below the bucket index
+  if (n == 0u) return;
+  const uint2 krange = reinterpret_cast<const uint2*>(bmap)[b];     // {first key of the bucket, bits of (key - first key) inside it}
+  DigitSpec ds;
+  ds.sub = krange.x; ds.shift = 0; ds.mask = 0xFFFFFFFFu;
+  const uint32_t low_bits = krange.y;
   const uint32_t npass = (low_bits + 7u) / 8u;
   const uint32_t pb = npass ? (low_bits + npass - 1u) / npass : 0u;
-  uint32_t inst = 0;
   if (n <= BS_CAP) {
     // wave w owns positions [w * rounds * 64, (w + 1) * rounds * 64) in rounds of 64: rank order == position order
     const uint32_t rounds = (n + 255u) / 256u;
-    uint32_t key[BK_ROUNDS], val[BK_ROUNDS], rank[BK_ROUNDS];
+    // What is sorted is ONE word per entry: the key relative to the bucket's first key (< 2^20: a bucket lies inside one coarse
+    // bin) above the entry's position in the bucket (< 4096).  Half the LDS and half the traffic of (key, id) pairs; the id is
+    // picked up from the bucket's own pair range at the end.  Equal keys keep their position order = ascending id.
+    uint32_t key[BK_ROUNDS], rank[BK_ROUNDS];
 #pragma unroll
     for (int r = 0; r < BK_ROUNDS; r++) {
       const uint32_t p = (wave * rounds + r) * 64u + lane;
       const bool valid = (uint32_t)r < rounds && p < n;
-      const uint2 kv = valid ? p1[start + p] : make_uint2(0u, 0u);
-      key[r] = kv.x; val[r] = kv.y;
+      key[r] = valid ? ((p1[start + p].x - ds.sub) << 12) | p : 0u;
     }
     for (uint32_t pass = 0; pass < npass; pass++) {
       const uint32_t lo = pass * pb, pmask = (1u << min(pb, low_bits - lo)) - 1u;
@@ -430,7 +564,7 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t*
         if ((uint32_t)r < rounds) {                   // wave-uniform
           const uint32_t p = (wave * rounds + r) * 64u + lane;
           const bool valid = p < n;
-          const uint32_t d = ((key[r] - ds.sub) >> lo) & pmask;
+          const uint32_t d = (key[r] >> (12u + lo)) & pmask;
           uint64_t peers = __ballot(valid);
 #pragma unroll
           for (int bb = 0; bb < 8; bb++) {
@@ -467,10 +601,9 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t*
         if ((uint32_t)r < rounds) {
           const uint32_t p = (wave * rounds + r) * 64u + lane;
           if (p < n) {
-            const uint32_t d = ((key[r] - ds.sub) >> lo) & pmask;
+            const uint32_t d = (key[r] >> (12u + lo)) & pmask;
             const uint32_t lp = dstart[d] + wcnt[wave][d] + rank[r];
             lkey[lp] = key[r];
-            lval[lp] = val[r];
           }
         }
       }
@@ -479,7 +612,7 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t*
       for (int r = 0; r < BK_ROUNDS; r++) {
         if ((uint32_t)r < rounds) {
           const uint32_t p = (wave * rounds + r) * 64u + lane;
-          if (p < n) { key[r] = lkey[p]; val[r] = lval[p]; }
+          if (p < n) key[r] = lkey[p];
         }
       }
       __syncthreads();
@@ -488,15 +621,18 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t*
     for (int r = 0; r < BK_ROUNDS; r++) {
       if ((uint32_t)r < rounds) {
         const uint32_t p = (wave * rounds + r) * 64u + lane;
+        uint32_t inst = 0;
         if (p < n) {
           // the one random access per Gaussian of the whole ordering: its emission record travels to its sorted position
-          const uint4 rec = bins[val[r]];
+          const uint32_t id = p1[start + (key[r] & 0xFFFu)].y;
+          const uint4 rec = bins[id];
           uint32_t c = bin_count(rec);
-          if (c == GM_BIN_COUNT_SAT) c = tiles[val[r]];
-          order0[start + p] = val[r];
+          if (c == GM_BIN_COUNT_SAT) c = tiles[id];
+          order0[start + p] = id;
           bin_sorted[start + p] = rec;
-          inst += c;
+          inst = c;
         }
+        chunk_add(chunk_inst, start + (wave * rounds + r) * 64u, lane, inst);
       }
     }
   } else {
@@ -577,22 +713,25 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t*
       __syncthreads();
       uint2* t = sp; sp = dp; dp = t;
     }
-    for (uint32_t i = threadIdx.x; i < n; i += BK_THREADS) {
-      const uint32_t id = sp[start + i].y;
-      const uint4 rec = bins[id];
-      uint32_t c = bin_count(rec);
-      if (c == GM_BIN_COUNT_SAT) c = tiles[id];
-      order0[start + i] = id;
-      bin_sorted[start + i] = rec;
-      inst += c;
+    for (uint32_t i0 = 0; i0 < n; i0 += BK_THREADS) {
+      const uint32_t i = i0 + threadIdx.x;
+      uint32_t c = 0;
+      if (i < n) {
+        const uint32_t id = sp[start + i].y;
+        const uint4 rec = bins[id];
+        c = bin_count(rec);
+        if (c == GM_BIN_COUNT_SAT) c = tiles[id];
+        order0[start + i] = id;
+        bin_sorted[start + i] = rec;
+      }
+      chunk_add(chunk_inst, start + i0 + wave * 64u, lane, c);
     }
   }
-  inst = wave_sum_u32(inst);
-  __syncthreads();
-  if (lane == 0) wsum[wave] = inst;
-  __syncthreads();
-  if (threadIdx.x == 0) bucket_inst[b] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  if (trace && threadIdx.x == 0) { trace[3 * b] = t_begin; trace[3 * b + 1] = wall_clock64(); trace[3 * b + 2] = n; }
 }
+
+static unsigned long long* g_bucket_trace = nullptr;      // debugging aid (tools/bucket_stats.py), never set by the package
+extern "C" void gm_debug_bucket_trace(void* buffer) { g_bucket_trace = reinterpret_cast<unsigned long long*>(buffer); }
 
 // ---------------------------------------------------------------------------------------------
 // host side
@@ -603,8 +742,8 @@ int launch_depth_order(GeomState& g, int P, int debug, hipStream_t s, int* num_r
   const DigitSpec ds{0u, 0u, 0xFFFFFFFFu};
   {
     StageScope sc(ST_DEPTH_SORT, s);
-    hipLaunchKernelGGL((bk_hist_kernel<true, DB, WAVES>), dim3(nblk), dim3(WAVES * 64), 0, s, g.depth_key, (uint32_t)P, nullptr, ds, g.slots, g.hist,
-                       g.acc, g.counters);
+    hipLaunchKernelGGL((bk_hist_kernel<true, DB, WAVES>), dim3(nblk + 1), dim3(WAVES * 64), 0, s, g.depth_key, (uint32_t)P, nullptr, ds, g.slots, g.hist,
+                       g.acc, g.counters, g.coarse, g.dmap, g.bmap);
     GM_LAUNCH_CHECK(debug, s);
   }
   if (num_rendered_host) {      // the instance total is known here; the rest of the ordering overlaps the host's wait for it
@@ -616,10 +755,10 @@ int launch_depth_order(GeomState& g, int P, int debug, hipStream_t s, int* num_r
                      g.slots, g.acc, g.bucket_start, g.counters, nullptr, 0u);
   GM_LAUNCH_CHECK(debug, s);
   hipLaunchKernelGGL((bk_scatter_kernel<true, DB, WAVES>), dim3(nblk), dim3(WAVES * 64), 0, s, g.depth_key, g.dpairs[1], (uint32_t)P, nullptr, ds,
-                     g.slots, g.hist, nullptr, 0u, nullptr, 0, nullptr);
+                     g.slots, g.hist, nullptr, 0u, nullptr, 0, nullptr, g.dmap, g.counters);
   GM_LAUNCH_CHECK(debug, s);
-  hipLaunchKernelGGL(bucket_sort_kernel, dim3(1 << DB), dim3(BK_THREADS), 0, s, g.slots, g.bucket_start, g.dpairs[1], g.dpairs[0], g.order,
-                     g.tiles_touched, g.bin, g.bin_sorted, g.bucket_inst);
+  hipLaunchKernelGGL(bucket_sort_kernel, dim3(1 << DB), dim3(BK_THREADS), 0, s, g.counters, g.dmap, g.bmap, g.bucket_start, g.dpairs[1], g.dpairs[0], g.order,
+                     g.tiles_touched, g.bin, g.bin_sorted, g.chunk_inst, g_bucket_trace);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }
@@ -632,14 +771,14 @@ static int tile_pass(BinningState& b, GeomState& g, int from, uint32_t n, const 
   const uint32_t nblk = (n + TILE - 1) / TILE;
   const uint32_t nchunks = (nblk + BK_CHUNK - 1) / BK_CHUNK;
   hipLaunchKernelGGL((bk_hist_kernel<false, DB, WAVES>), dim3(nblk), dim3(WAVES * 64), 0, s, b.pairs[from], n, n_dev, ds, nullptr, b.hist, b.acc,
-                     g.counters);
+                     g.counters, nullptr, nullptr, nullptr);
   GM_LAUNCH_CHECK(debug, s);
   hipLaunchKernelGGL((bk_scan_kernel<false, DB>), dim3(nchunks ? nchunks : 1, (1 << DB) / 256), dim3(BK_THREADS), 0, s, b.hist, TILE, n, n_dev, nullptr,
                      b.acc, nullptr, g.counters, ranges, nranges);
   GM_LAUNCH_CHECK(debug, s);
   hipLaunchKernelGGL((bk_scatter_kernel<false, DB, WAVES>), dim3(nblk + (order_out ? 1u : 0u)), dim3(WAVES * 64), 0, s, b.pairs[from],
                      b.pairs[from ^ 1], n, n_dev, ds, nullptr, b.hist, zero_acc_after ? b.acc : nullptr, (uint32_t)bk_acc_words(n), ranges,
-                     (int)nranges, order_out);
+                     (int)nranges, order_out, nullptr, nullptr);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }

@@ -76,15 +76,33 @@ static inline size_t bk_blocks(size_t n) { return (n + GM_BK_TILE - 1) / GM_BK_T
 static inline size_t bk_chunks(size_t n) { return (bk_blocks(n) + GM_BK_CHUNK - 1) / GM_BK_CHUNK; }
 #define GM_ACC_SLOTS 512             // accumulators of a pass: [8 digit groups][64] group-sum slots, then chunk_total [chunks][2048]
 static inline size_t bk_acc_words(size_t n) { return GM_ACC_SLOTS + (bk_chunks(n) << GM_BUCKET_BITS); }
+// Depth buckets that follow the data: a coarse histogram of the visible depth keys (float bits >> 20: eight bins per octave
+// of z, 2048 bins cover every positive float) is accumulated by the preprocess kernel; each coarse bin then gets a share of
+// the <= 2048 buckets in proportion to its count and is subdivided linearly (gm_bucket.hip, DepthMap).  A background far
+// behind (or a floater right in front of) a dense object no longer squeezes the object into a few hundred buckets.
+#define GM_COARSE_SHIFT 20
+#define GM_COARSE_BINS 2048
+#define GM_COARSE_COPIES 8           // copies of the coarse histogram the atomics are spread over (copy = workgroup & 7)
+// word of (coarse bin, copy): neighbouring bins - the ones a launch hammers - lie 512 bytes apart and the copies of a bin too, so
+// that their atomics do not queue up behind each other on one cache line (bins 16 apart share a line)
+__host__ __device__ __forceinline__ uint32_t coarse_index(uint32_t bin, uint32_t copy) {
+  return ((bin & 15u) * GM_COARSE_COPIES + copy) * (GM_COARSE_BINS / 16u) + (bin >> 4);
+}
+#define GM_BUCKET_BUDGET 1792        // buckets handed out in proportion to the bins' weights; every non-empty coarse bin gets at least one
 // device scalars (GeomState::counters)
 #define GM_CNT_RENDERED 0            // num_rendered (instance total of this forward)
 #define GM_CNT_PREFILTER 1        // set when a Gaussian was frustum-culled although the caller declared the cloud prefiltered
 #define GM_CNT_POLICY 2              // emission policy the counts were made under
 #define GM_CNT_REFUSED 3             // emission refused (policy mismatch / capacity overflow): every list stays empty
+#define GM_CNT_VISIBLE 4             // Gaussians with a depth key (written by the depth partition's histogram launch)
+#define GM_CNT_NBUCKETS 5            // depth buckets in use
+#define GM_CNT_CMIN 6                // first / last coarse bin that holds a visible key
+#define GM_CNT_CMAX 7
 #define GM_CNT_GROUP 8               // [8] digit-group totals of the scan in flight
 #define GM_CNT_DONE 16               // [9] arrival counters of the scan in flight (re-armed by its last workgroup)
 #define GM_CNT_COUNT 32
-#define GM_SLOTS 64                  // atomic slots {instance sum, max ~depth key, max depth key, -} filled by the preprocess kernel
+#define GM_SLOTS 256                 // atomic slots {instance sum, visible count, 2047 - first coarse bin, last coarse bin} filled by the preprocess kernel
+#define GM_SLOT_STRIDE 32            // words between slots: one 128-byte line each (atomics on one line serialise in the memory-side atomic unit)
 
 // Emission record of a Gaussian, 16 bytes: tile rectangle origin and size in 12 bits each (grids up to 4095 x 4095 tiles), the
 // instance count in the four spare nibbles (0xFFFF = "65535 or more: see tiles_touched"), 64-bit emit mask.
@@ -116,8 +134,11 @@ struct GeomState {              // per-Gaussian state (P-sized)
   uint4* bin_sorted;            // [P] the emission records in that order (duplicate_kernel reads them sequentially)
   uint32_t* hist;               // [bk_blocks(P)][2048] bucket histograms of the partition -> absolute output offsets
   uint32_t* bucket_start;       // [2049] first sorted position of each bucket (+ total)
-  uint32_t* bucket_inst;        // [2048] instances emitted by each bucket
-  uint32_t* slots;              // [GM_SLOTS][4]; slots, counters and acc are contiguous: one memset re-arms all three
+  uint32_t* chunk_inst;         // [P / GM_SCAN_ITEMS + 1] instances emitted by each run of GM_SCAN_ITEMS sorted positions (zeroed with the slots)
+  uint32_t* dmap;               // [GM_COARSE_BINS] coarse bin -> first bucket << 16 | buckets (written by the partition's histogram launch)
+  uint32_t* bmap;               // [2048][2] bucket -> {first key, bits of (key - first key) inside the bucket}
+  uint32_t* slots;              // [GM_SLOTS][GM_SLOT_STRIDE] (4 words used); slots, counters, coarse and acc are contiguous: one memset re-arms all of them
+  uint32_t* coarse;             // [GM_COARSE_COPIES][GM_COARSE_BINS] coarse histogram of the visible depth keys
   uint32_t* counters;           // [GM_CNT_COUNT] device scalars
   uint32_t* acc;                // [bk_acc_words(P)] accumulators of the partition pass
   float* grad_acc;              // [P][12] backward accumulators: dcolor rgb | dmean2D xy | dconic x,y,w | dopacity | pad
@@ -138,11 +159,15 @@ struct GeomState {              // per-Gaussian state (P-sized)
     g.bin_sorted = carve<uint4>(p, P);
     g.hist = carve<uint32_t>(p, ND * bk_blocks(P));
     g.bucket_start = carve<uint32_t>(p, ND + 1);
-    g.bucket_inst = carve<uint32_t>(p, ND);
-    g.slots = carve<uint32_t>(p, 4 * GM_SLOTS + GM_CNT_COUNT + bk_acc_words(P));
-    g.counters = g.slots + 4 * GM_SLOTS;
-    g.acc = g.counters + GM_CNT_COUNT;
-    g.arm_words = 4 * GM_SLOTS + GM_CNT_COUNT + bk_acc_words(P);
+    g.dmap = carve<uint32_t>(p, GM_COARSE_BINS);
+    g.bmap = carve<uint32_t>(p, 2 * ND);
+    const size_t nchunk = (P / GM_SCAN_ITEMS + 1 + 63) & ~size_t(63);      // (the armed block stays a multiple of 256 bytes: one fill kernel)
+    g.slots = carve<uint32_t>(p, GM_SLOT_STRIDE * GM_SLOTS + GM_CNT_COUNT + GM_COARSE_COPIES * GM_COARSE_BINS + bk_acc_words(P) + nchunk);
+    g.counters = g.slots + GM_SLOT_STRIDE * GM_SLOTS;
+    g.coarse = g.counters + GM_CNT_COUNT;
+    g.acc = g.coarse + GM_COARSE_COPIES * GM_COARSE_BINS;
+    g.chunk_inst = g.acc + bk_acc_words(P);
+    g.arm_words = GM_SLOT_STRIDE * GM_SLOTS + GM_CNT_COUNT + GM_COARSE_COPIES * GM_COARSE_BINS + bk_acc_words(P) + nchunk;
     g.grad_acc = carve<float>(p, 12 * P);
     g.end = p;
     return g;

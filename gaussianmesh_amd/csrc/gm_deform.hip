@@ -128,7 +128,7 @@ int launch_sh_colors(int N, int deg, int M, const float* pos, const float* campo
 struct FusedPre {
   PreCam cam;
   const float* opac;
-  float4* splat; int* radii_int; int* radii_out; uint32_t* tiles; uint4* bin; uint32_t* counters; uint32_t* slots; uint8_t* clamped; uint32_t* depth_key;
+  float4* splat; int* radii_int; int* radii_out; uint32_t* tiles; uint4* bin; uint32_t* counters; uint32_t* slots; uint32_t* coarse; uint8_t* clamped; uint32_t* depth_key;
 };
 template <bool PACKED, bool PRE>
 __global__ __launch_bounds__(64) void deform_shade_kernel(int N, int deg, const int* __restrict__ tri, const float* __restrict__ w,
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64) void deform_shade_kernel(int N, int deg, const 
     fp.depth_key[i] = dkey;
     if (i == 0) fp.counters[GM_CNT_POLICY] = (uint32_t)fp.cam.tile_cull;
   }
-  if (PRE) slot_accumulate(fp.slots, tiles, dkey);
+  if (PRE) slot_accumulate(fp.slots, fp.coarse, tiles, dkey);
   if (!pos_out) return;                          // wave-uniform
   __syncthreads();                               // everyone is done reading the staged inputs: reuse LDS for the outputs
   float* o_pos = lds;                            // [256][3]
@@ -340,7 +340,7 @@ int launch_deform_shade_pre(const RasterArgs& r, GeomState& g, int* radii, int d
   fp.cam.tanx = r.tan_fovx; fp.cam.tany = r.tan_fovy;
   fp.cam.fy = r.H / (2.0f * r.tan_fovy); fp.cam.fx = r.W / (2.0f * r.tan_fovx);   // rasterizer_impl.cu:359-360
   fp.opac = r.opacities;
-  fp.splat = g.splat; fp.radii_int = g.radii; fp.radii_out = radii; fp.tiles = g.tiles_touched; fp.bin = g.bin; fp.counters = g.counters; fp.slots = g.slots;
+  fp.splat = g.splat; fp.radii_int = g.radii; fp.radii_out = radii; fp.tiles = g.tiles_touched; fp.bin = g.bin; fp.counters = g.counters; fp.slots = g.slots; fp.coarse = g.coarse;
   fp.clamped = g.clamped; fp.depth_key = g.depth_key;
   const size_t lds_bytes = sizeof(float) * 64 * 48;
   hipLaunchKernelGGL((deform_shade_kernel<true, true>), dim3((N + 63) / 64), dim3(64), lds_bytes, r.stream, N, deg, tri, w, packed, nullptr,

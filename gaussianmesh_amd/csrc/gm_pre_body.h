@@ -163,23 +163,40 @@ __device__ __forceinline__ void pre_emit(const PreCam& a, const PreGeom& g, floa
   bin = bin_pack((uint32_t)x0, (uint32_t)y0, (uint32_t)rw, (uint32_t)rh, tiles, mask);
 }
 
-// Per-wave partials of {instance total, max ~depth key, max depth key} of the visible Gaussians -> one of GM_SLOTS atomic
-// slots (GeomState::slots).  Every lane of the wave must call this (culled / out-of-range lanes with tiles = 0,
-// dkey = 0xFFFFFFFF).  The ordering kernels (gm_bucket.hip) reduce the slots to num_rendered and the depth range.
-__device__ __forceinline__ void slot_accumulate(uint32_t* __restrict__ slots, uint32_t tiles, uint32_t dkey) {
+// Per-wave partials of the instance total, the visible count and the range of coarse bins in use -> one of GM_SLOTS atomic slots (GeomState::slots), and the wave's visible depth keys
+// into the coarse histogram (GeomState::coarse; one atomic per distinct coarse bin of the wave, spread over GM_COARSE_COPIES
+// copies by workgroup id so that no address sees more than a few thousand atomics per launch).  Every lane of the wave must
+// call this (culled / out-of-range lanes with tiles = 0, dkey = 0xFFFFFFFF).  The ordering kernels (gm_bucket.hip) reduce
+// the slots to num_rendered and turn the histogram into the depth-bucket mapping.
+__device__ __forceinline__ void slot_accumulate(uint32_t* __restrict__ slots, uint32_t* __restrict__ coarse, uint32_t tiles, uint32_t dkey) {
   const bool vis = dkey != 0xFFFFFFFFu;
-  uint32_t s = tiles, nk = vis ? ~dkey : 0u, mk = vis ? dkey : 0u;
+  const int lane = threadIdx.x & 63;
+  uint32_t s = tiles;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) s += (uint32_t)__shfl_xor((int)s, d);
+  const unsigned long long visb = __ballot(vis);
+  const uint32_t c = (dkey >> GM_COARSE_SHIFT) & (GM_COARSE_BINS - 1);          // (keys are positive float bits: < 2^31)
+  uint32_t ncmin = vis ? (GM_COARSE_BINS - 1u) - c : 0u, cmax = vis ? c : 0u;   // wave extremes of the coarse bin (as two maxima)
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
-    s += (uint32_t)__shfl_xor((int)s, d);
-    nk = max(nk, (uint32_t)__shfl_xor((int)nk, d));
-    mk = max(mk, (uint32_t)__shfl_xor((int)mk, d));
+    ncmin = max(ncmin, (uint32_t)__shfl_xor((int)ncmin, d));
+    cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, d));
   }
-  if ((threadIdx.x & 63) == 0 && (mk | nk) != 0u) {
-    uint32_t* slot = slots + 4 * ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (GM_SLOTS - 1));
-    if (s) atomicAdd(slot, s);
-    atomicMax(slot + 1, nk);
-    atomicMax(slot + 2, mk);
+  if (lane == 0 && visb) {
+    uint32_t* slot = slots + GM_SLOT_STRIDE * ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (GM_SLOTS - 1));
+    if (s) atomicAdd(slot, s);                                         // instances
+    atomicAdd(slot + 1, (uint32_t)__popcll(visb));                     // visible Gaussians
+    atomicMax(slot + 2, ncmin);                                        // 2047 - (first coarse bin in use)
+    atomicMax(slot + 3, cmax);                                         // last coarse bin in use
+  }
+  const uint32_t copy = blockIdx.x & (GM_COARSE_COPIES - 1);
+  unsigned long long todo = visb;
+  while (todo) {                                                       // wave-uniform loop over the distinct coarse bins
+    const int l = __ffsll(todo) - 1;
+    const uint32_t cl = (uint32_t)__builtin_amdgcn_readlane((int)c, l);
+    const unsigned long long same = __ballot(vis && c == cl);
+    if (lane == l) atomicAdd(coarse + coarse_index(cl, copy), (uint32_t)__popcll(same));
+    todo &= ~same;
   }
 }
 

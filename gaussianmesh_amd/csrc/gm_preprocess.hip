@@ -29,7 +29,7 @@ struct PreArgs {
   int P, D, M, W, H, gx, gy;
   const float *means, *scales, *rots, *opac, *shs, *cov3D_pre, *colors_pre, *view, *proj, *campos;
   float mod, tanx, tany, fx, fy;
-  float4* splat; int* radii_int; int* radii_out; uint32_t* tiles; uint4* bin; int tile_cull; int prefiltered; uint32_t* counters; uint32_t* slots; float* cov3D; uint8_t* clamped; uint32_t* depth_key;
+  float4* splat; int* radii_int; int* radii_out; uint32_t* tiles; uint4* bin; int tile_cull; int prefiltered; uint32_t* counters; uint32_t* slots; uint32_t* coarse; float* cov3D; uint8_t* clamped; uint32_t* depth_key;
 };
 
 // STAGE_SH + DMA (the instantiated fast path, SH input with M == 16): one-wave workgroups of 64 Gaussians whose SH rows
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(TH) void preprocess_fwd_kernel(const PreArgs a) {
     a.bin[idx] = bin;
     a.depth_key[idx] = dkey;
   }
-  slot_accumulate(a.slots, tiles, dkey);
+  slot_accumulate(a.slots, a.coarse, tiles, dkey);
 }
 
 int launch_preprocess(const RasterArgs& r, GeomState& g, int* radii) {
@@ -152,7 +152,7 @@ int launch_preprocess(const RasterArgs& r, GeomState& g, int* radii) {
   a.cov3D_pre = r.cov3D_precomp; a.colors_pre = r.colors_precomp; a.view = r.viewmatrix; a.proj = r.projmatrix;
   a.campos = r.cam_pos; a.mod = r.scale_modifier; a.tanx = r.tan_fovx; a.tany = r.tan_fovy;
   a.fy = r.H / (2.0f * r.tan_fovy); a.fx = r.W / (2.0f * r.tan_fovx);   // rasterizer_impl.cu:359-360
-  a.splat = g.splat; a.radii_int = g.radii; a.radii_out = radii; a.tiles = g.tiles_touched; a.bin = g.bin; a.tile_cull = r.tile_cull; a.prefiltered = r.prefiltered; a.counters = g.counters; a.slots = g.slots; a.cov3D = g.cov3D;
+  a.splat = g.splat; a.radii_int = g.radii; a.radii_out = radii; a.tiles = g.tiles_touched; a.bin = g.bin; a.tile_cull = r.tile_cull; a.prefiltered = r.prefiltered; a.counters = g.counters; a.slots = g.slots; a.coarse = g.coarse; a.cov3D = g.cov3D;
   a.clamped = g.clamped; a.depth_key = g.depth_key;
   if (r.P > 0) {
     if (a.shs && a.M == 16 && aligned16(a.shs)) {

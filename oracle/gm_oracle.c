@@ -697,41 +697,57 @@ int64_t orc_forward(int P, int D, int M, const float* bg, int W, int H, const fl
   uint8_t* clamped = (uint8_t*)calloc((size_t)P * 3, 1);
   orc_preprocess(P, D, M, means, scales, mod, rots, opac, shs, cov3D_precomp, colors_precomp, view, proj,
                  campos, W, H, tanx, tany, radii, xy, depths, NULL, rgb, conic, tiles, clamped);
-  /* count per tile */
+  /* count per tile: every thread takes a contiguous slice of the Gaussians and counts into its own row; the rows then become
+   * each thread's first slot per tile, so the fill below needs no atomics.  Slots inside a tile are in (thread, id) order here;
+   * the per-tile sort on the full (depth bits, id) key makes the list independent of it. */
   int64_t* tcount = (int64_t*)calloc((size_t)NT + 1, sizeof(int64_t));
-#pragma omp parallel for schedule(static)
-  for (int i = 0; i < P; i++)
-    if (radii[i] > 0) {
-      int x0, y0, x1, y1;
-      get_rect(xy[2 * (size_t)i], xy[2 * (size_t)i + 1], radii[i], gx, gy, &x0, &y0, &x1, &y1);
-      for (int y = y0; y < y1; y++)
-        for (int x = x0; x < x1; x++) {
-#pragma omp atomic
-          tcount[y * gx + x + 1]++;
-        }
-    }
-  for (int t = 0; t < NT; t++) tcount[t + 1] += tcount[t];
+  int nth = 1;
+#ifdef _OPENMP
+  nth = omp_get_max_threads();
+#endif
+  int64_t* local = (int64_t*)calloc((size_t)nth * NT, sizeof(int64_t));
+#pragma omp parallel num_threads(nth)
+  {
+    int th = 0;
+#ifdef _OPENMP
+    th = omp_get_thread_num();
+#endif
+    const int i0 = (int)((int64_t)P * th / nth), i1 = (int)((int64_t)P * (th + 1) / nth);
+    int64_t* row = local + (size_t)th * NT;
+    for (int i = i0; i < i1; i++)
+      if (radii[i] > 0) {
+        int x0, y0, x1, y1;
+        get_rect(xy[2 * (size_t)i], xy[2 * (size_t)i + 1], radii[i], gx, gy, &x0, &y0, &x1, &y1);
+        for (int y = y0; y < y1; y++)
+          for (int x = x0; x < x1; x++) row[y * gx + x]++;
+      }
+  }
+  for (int t = 0; t < NT; t++) {               /* exclusive offsets: tile-major, thread-minor */
+    int64_t run = tcount[t];
+    for (int th = 0; th < nth; th++) { const int64_t c = local[(size_t)th * NT + t]; local[(size_t)th * NT + t] = run; run += c; }
+    tcount[t + 1] = run;
+  }
   const int64_t R = tcount[NT];
   uint64_t* comp = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(R ? R : 1));
-  int64_t* cur = (int64_t*)malloc(sizeof(int64_t) * (size_t)NT);
-  memcpy(cur, tcount, sizeof(int64_t) * (size_t)NT);
-  /* slots inside a tile are handed out in arrival order; the per-tile sort on the full (depth bits, id) key below makes
-   * the list independent of it */
-#pragma omp parallel for schedule(static)
-  for (int i = 0; i < P; i++)
-    if (radii[i] > 0) {
-      int x0, y0, x1, y1;
-      get_rect(xy[2 * (size_t)i], xy[2 * (size_t)i + 1], radii[i], gx, gy, &x0, &y0, &x1, &y1);
-      uint32_t db;
-      memcpy(&db, depths + i, 4);
-      for (int y = y0; y < y1; y++)
-        for (int x = x0; x < x1; x++) {
-          int64_t pos;
-#pragma omp atomic capture
-          pos = cur[y * gx + x]++;
-          comp[pos] = ((uint64_t)db << 32) | (uint32_t)i;
-        }
-    }
+  int64_t* cur = local;                         /* (freed below under the name the rest of the function uses) */
+#pragma omp parallel num_threads(nth)
+  {
+    int th = 0;
+#ifdef _OPENMP
+    th = omp_get_thread_num();
+#endif
+    const int i0 = (int)((int64_t)P * th / nth), i1 = (int)((int64_t)P * (th + 1) / nth);
+    int64_t* row = local + (size_t)th * NT;
+    for (int i = i0; i < i1; i++)
+      if (radii[i] > 0) {
+        int x0, y0, x1, y1;
+        get_rect(xy[2 * (size_t)i], xy[2 * (size_t)i + 1], radii[i], gx, gy, &x0, &y0, &x1, &y1);
+        uint32_t db;
+        memcpy(&db, depths + i, 4);
+        for (int y = y0; y < y1; y++)
+          for (int x = x0; x < x1; x++) comp[row[y * gx + x]++] = ((uint64_t)db << 32) | (uint32_t)i;
+      }
+  }
   uint32_t* plist = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(R ? R : 1));
   uint32_t* ranges = (uint32_t*)calloc((size_t)NT * 2, 4);
 #pragma omp parallel for schedule(dynamic, 8)
