@@ -10,14 +10,16 @@
 // sort of instances emitted in id order gives) is produced exactly; tests compare point_list bit for bit.
 //
 // A. Depth order of the P Gaussians (keys = float bits of view-space z, 0xFFFFFFFF for culled ones):
-//    the preprocess kernel leaves min / max of the visible keys and the instance total in 64 atomic slots
-//    (GeomState::slots; one slot per 64th of the workgroups, so no address sees more than a few hundred atomics);
-//    1. MSD partition by bucket = (key - kmin) >> shift, shift chosen on the device so that the occupied range maps onto
-//       <= 2048 buckets: bk_hist -> bk_scan -> bk_scatter (stable, visible keys only);
-//    2. bucket_sort_kernel: one workgroup per bucket sorts its few hundred to few thousand (key, id) pairs by the
-//       remaining low bits entirely in LDS (stable LSD passes of <= 8 bits on registers + one LDS copy), writes the final
-//       order, the instance count of every Gaussian in that order and the bucket's instance total.  A bucket that does not
-//       fit (a pile-up of equal depths) takes a slow, still exact, path through global memory.
+//    the preprocess kernel leaves the instance total, the visible count, the range of coarse bins in use (256 atomic slots,
+//    one per cache line) and a coarse histogram of the visible keys (key >> 20; GeomState::coarse);
+//    1. MSD partition into <= 2048 buckets through a table built from that histogram (DepthMap below: buckets in proportion
+//       to the keys a coarse bin holds, so the partition stays balanced when a background or a floater stretches the depth
+//       range): bk_hist -> bk_scan -> bk_scatter (stable, visible keys only);
+//    2. bucket_sort_kernel: one workgroup per bucket sorts its few hundred to few thousand entries by the key bits inside
+//       the bucket entirely in LDS (stable LSD passes of <= 8 bits on registers + one LDS copy; one word per entry), writes
+//       the final order and the emission records in that order and adds the instance counts to the per-run totals the
+//       emission reads.  A bucket that does not fit (a pile-up of equal depths) takes a slow, still exact, path through
+//       global memory.
 //    Four launches and two passes over 8 B/Gaussian instead of twelve launches and four passes.
 // B. Instances (emitted by duplicate_kernel in that order, keyed by list tile id | child mask << 16):
 //    list tiles <= 2048 (1080p with 32-px parents: 2040; 4K with 64-px parents: 2040): ONE stable pass on an 11-bit digit,
@@ -502,9 +504,6 @@ __global__ __launch_bounds__(WAVES * 64, 4) void bk_scatter_kernel(const void* _
 }
 
 // ---------------------------------------------------------------------------------------------
-// One workgroup per bucket of the MSD partition: (key, id) pairs [start, end) of k1 / v1 -> final order.
-// Outputs: order0[start..end) = ids in (key, id) order, bin_sorted[start..end) = emission records of those ids,
-// bucket_inst[b] = their sum.  p0[start..end) is scratch for the slow path.
 // Instances of 64 consecutive sorted positions (first one `pos0`, lane l holds position pos0 + l's count) into the per-run
 // totals duplicate_kernel builds its output offsets from: the 64 positions touch at most two runs of GM_SCAN_ITEMS.
 __device__ __forceinline__ void chunk_add(uint32_t* __restrict__ chunk_inst, uint32_t pos0, int lane, uint32_t count) {
@@ -517,6 +516,9 @@ __device__ __forceinline__ void chunk_add(uint32_t* __restrict__ chunk_inst, uin
   }
 }
 
+// One workgroup per bucket of the MSD partition: (key, id) pairs [start, end) of p1 -> final order.
+// Outputs: order0[start..end) = ids in (key, id) order, bin_sorted[start..end) = emission records of those ids,
+// chunk_inst[run] += instance counts of the sorted positions of that run.  p0[start..end) is scratch for the slow path.
 __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t* __restrict__ counters, const uint32_t* __restrict__ dmap,
                                                                   const uint32_t* __restrict__ bmap, const uint32_t* __restrict__ bucket_start,
                                                                   uint2* __restrict__ p1, uint2* __restrict__ p0, uint32_t* __restrict__ order0,
