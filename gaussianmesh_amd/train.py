@@ -71,6 +71,9 @@ class Trainer:
         self.opt = SimpleNamespace(**o)
         self.g = gaussians
         self.bg_gaussian = bg_gaussian
+        if bg_gaussian is not None and hasattr(gaussians, "_features") and gaussians._features.is_cuda:
+            from .renderer import share_feature_storage
+            share_feature_storage(gaussians, bg_gaussian)        # before the optimizer captures the parameter
         s = spatial_lr_scale
         # the reference's seven groups; "f_dc" (coefficient 0) and "f_rest" are the two learning rates of the one SH tensor
         groups = [
