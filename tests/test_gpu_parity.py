@@ -278,6 +278,28 @@ def test_mark_visible(oracle):
     assert np.array_equal(vis, oracle.mark_visible(sc["means"], cam["view"], cam["proj"]))
 
 
+def test_large_splats_match_the_oracle(oracle):
+    """Splats whose tile rectangle holds more than 64 tiles take the wave-wide emission path (gm_binning.hip, (2)): instance
+    count and image against the oracle under the reference policy, images identical under the others."""
+    from gpu_utils import T
+    from gaussianmesh_amd import rasterizer as Rz
+    W, H = 400, 240
+    sc, cam = small_scene(P=600, W=W, H=H, seed=12, scale_lo=0.05, scale_hi=0.6, behind=False)
+    sc["scales"][:120] *= 8.0                                    # 120 splats that cover a good part of the screen
+    bg = np.array([0.2, 0.1, 0.3], np.float32)
+    ct = {n: T(cam[n]) for n in ("view", "proj", "campos")}
+    args = (T(bg), T(sc["means"]), None, T(sc["opac"]), T(sc["scales"]), T(sc["rots"]), 1.0, None, ct["view"], ct["proj"], cam["tanx"], cam["tany"],
+            H, W, T(sc["shs"]), 3, ct["campos"])
+    fw = oracle.forward_full(sc, cam, bg, D=3)
+    assert (fw["geo"]["radii"] > 56).sum() >= 100
+    ref = Rz.rasterize_forward(*args, False, False, emission_policy=0)
+    assert ref[0] == fw["bins"]["R"] and np.array_equal(ref[2].cpu().numpy(), fw["geo"]["radii"])
+    assert_forward_gate(fw, ref[1].cpu().numpy(), W, H, FWD_TOL, "large splats")
+    for pol in (1, 2, 3):
+        out = Rz.rasterize_forward(*args, False, False, emission_policy=pol)
+        assert torch.equal(out[1], ref[1]) and out[0] < ref[0]
+
+
 def test_prefiltered_contract(oracle):
     """prefiltered=True promises that no Gaussian is frustum-culled; the reference traps the kernel when one is
     (RAST/auxiliary.h:153-159).  Here the violation is an error with the reference's message, and a cloud that keeps the promise
