@@ -15,7 +15,6 @@
 namespace gm {
 
 #define BN_THREADS 256
-#define BN_PER_THREAD (GM_SCAN_ITEMS / BN_THREADS)   // 2
 #define DUP_STAGE 2048                               // instances a block can assemble in LDS (2 x 8 KB; 4096 is no faster alone and makes the
                                                      // workgroup harder to place next to other frames' blend kernels: 4350 -> 4400 frames/s)
 
@@ -63,7 +62,7 @@ __device__ __forceinline__ void get_rect(float px, float py, int r, int gx, int 
 // (RAST/rasterizer_impl.cu:98-109) restricted to the emitted tiles.
 // S > 0: one instance per PARENT tile (2^S x 2^S tiles) that has a reached child; key = parent id | child mask << 16
 // (child bit = (row in parent) << S | column in parent).  S == 0: key = tile id | 1 << 16.
-template <int S>
+template <int S, int BN_PER_THREAD>
 __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles,
                                                                 const uint4* __restrict__ bin_sorted, const float4* __restrict__ splat,
                                                                 uint32_t* __restrict__ counters, const uint32_t* __restrict__ chunk_inst,
@@ -87,18 +86,20 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const uint32_t run = blockIdx.x;
   const uint32_t V = counters[GM_CNT_VISIBLE];
-  const uint32_t P0 = min(run * (uint32_t)GM_SCAN_ITEMS, V), P1 = min(P0 + (uint32_t)GM_SCAN_ITEMS, V);
+  constexpr uint32_t RUN = BN_PER_THREAD * BN_THREADS;                  // sorted positions of this workgroup: 1 or 2 entries of chunk_inst
+  static_assert(RUN % GM_SCAN_ITEMS == 0, "a workgroup takes whole runs");
+  const uint32_t P0 = min(run * RUN, V), P1 = min(P0 + RUN, V);
   if (P0 == P1) return;
   uint32_t ibase;
   {
     uint32_t part = 0;
-    for (uint32_t k = threadIdx.x; k < run; k += BN_THREADS) part += chunk_inst[k];
+    for (uint32_t k = threadIdx.x; k < run * (RUN / GM_SCAN_ITEMS); k += BN_THREADS) part += chunk_inst[k];
     uint32_t tot;
     block_exclusive_scan(part, wsum, tot);
     ibase = tot;
     __syncthreads();
   }
-  for (uint32_t c0 = P0; c0 < P1; c0 += GM_SCAN_ITEMS) {
+  for (uint32_t c0 = P0; c0 < P1; c0 += RUN) {
   const uint32_t base = c0 + threadIdx.x * BN_PER_THREAD;
   uint32_t gid[BN_PER_THREAD], cnt[BN_PER_THREAD], offs[BN_PER_THREAD], sum = 0;
   uint4 rc[BN_PER_THREAD];
@@ -236,10 +237,14 @@ int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, int mod
   const TileGrid tg(W, H, mode);
   const uint32_t cap = capacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)capacity;
   if (P > 0) {
-#define GM_DUP(SH) hipLaunchKernelGGL(duplicate_kernel<SH>, dim3((P + GM_SCAN_ITEMS - 1) / GM_SCAN_ITEMS), dim3(BN_THREADS), 0, s, g.order, g.tiles_touched, \
-                                      g.bin_sorted, g.splat, g.counters, g.chunk_inst, tg.gx, tg.pgx, mode, cap, b.pairs[0], b.acc, \
-                                      (uint32_t)bk_acc_words(capacity))
-    if (tg.s == 0) GM_DUP(0); else if (tg.s == 1) GM_DUP(1); else GM_DUP(2);
+    // two Gaussians per thread while a workgroup's instances still fit its LDS stage (a run of 512 at C3's ~3 instances per
+    // Gaussian), one when the cloud emits more per Gaussian (4K, near cameras): unstaged runs store partial lines
+    const bool two = capacity <= (size_t)P * 5;
+#define GM_DUP(SH, PER) hipLaunchKernelGGL((duplicate_kernel<SH, PER>), dim3((P + PER * BN_THREADS - 1) / (PER * BN_THREADS)), dim3(BN_THREADS), 0, s, g.order, \
+                                           g.tiles_touched, g.bin_sorted, g.splat, g.counters, g.chunk_inst, tg.gx, tg.pgx, mode, cap, b.pairs[0], b.acc, \
+                                           (uint32_t)bk_acc_words(capacity))
+    if (two) { if (tg.s == 0) GM_DUP(0, 2); else if (tg.s == 1) GM_DUP(1, 2); else GM_DUP(2, 2); }
+    else { if (tg.s == 0) GM_DUP(0, 1); else if (tg.s == 1) GM_DUP(1, 1); else GM_DUP(2, 1); }
 #undef GM_DUP
   }
   GM_LAUNCH_CHECK(debug, s);

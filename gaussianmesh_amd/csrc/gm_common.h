@@ -54,7 +54,7 @@ static inline T* carve(char*& p, size_t count) {
 }
 
 #define GM_SORT_ITEMS 4096      // keys per workgroup per radix pass (256 threads x 16)
-#define GM_SCAN_ITEMS 512       // Gaussians per workgroup in the tiles_touched scan / instance emission (256 threads x 2)
+#define GM_SCAN_ITEMS 256       // sorted positions per entry of GeomState::chunk_inst; an emission workgroup takes one or two such runs
 
 #define GM_SORT_SMALL_N (3u << 19)   // up to this many keys (1.5 M) the radix sort uses 1024-key tiles (more workgroups),
 #define GM_SORT_MID_N (4u << 20)     // up to this many 2048-key tiles, 4096-key tiles above
