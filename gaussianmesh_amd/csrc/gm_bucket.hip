@@ -288,7 +288,7 @@ __global__ __launch_bounds__(WAVES * 64) void bk_hist_kernel(const void* __restr
 // {first, one past last} per digit value, {0, 0} for an empty one.
 template <bool MSD, int DB>
 __global__ __launch_bounds__(BK_THREADS) void bk_scan_kernel(uint32_t* __restrict__ hist, uint32_t tile, uint32_t n_host, const uint32_t* __restrict__ n_dev,
-                                                              const uint32_t* __restrict__ slots, const uint32_t* __restrict__ acc,
+                                                              const uint32_t* __restrict__ acc,
                                                               uint32_t* __restrict__ base_out, const uint32_t* __restrict__ counters,
                                                               uint2* __restrict__ ranges_out, uint32_t nranges) {
   constexpr int ND = 1 << DB, NG = ND / 256;
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(BK_THREADS) void bk_scan_kernel(uint32_t* __restric
 template <bool MSD, int DB, int WAVES>
 __global__ __launch_bounds__(WAVES * 64, 4) void bk_scatter_kernel(const void* __restrict__ in, uint2* __restrict__ out,
                                                                  uint32_t n_host, const uint32_t* __restrict__ n_dev, DigitSpec ds,
-                                                                 const uint32_t* __restrict__ slots, const uint32_t* __restrict__ hist,
+                                                                 const uint32_t* __restrict__ hist,
                                                                  uint32_t* __restrict__ zero_acc, uint32_t zero_words,
                                                                  const uint2* __restrict__ ord_ranges, int ord_tiles,
                                                                  uint32_t* __restrict__ ord_out, const uint32_t* __restrict__ dmap,
@@ -519,7 +519,7 @@ __device__ __forceinline__ void chunk_add(uint32_t* __restrict__ chunk_inst, uin
 // One workgroup per bucket of the MSD partition: (key, id) pairs [start, end) of p1 -> final order.
 // Outputs: order0[start..end) = ids in (key, id) order, bin_sorted[start..end) = emission records of those ids,
 // chunk_inst[run] += instance counts of the sorted positions of that run.  p0[start..end) is scratch for the slow path.
-__global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t* __restrict__ counters, const uint32_t* __restrict__ dmap,
+__global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t* __restrict__ counters,
                                                                   const uint32_t* __restrict__ bmap, const uint32_t* __restrict__ bucket_start,
                                                                   uint2* __restrict__ p1, uint2* __restrict__ p0, uint32_t* __restrict__ order0,
                                                                   const uint32_t* __restrict__ tiles, const uint4* __restrict__ bins,
@@ -754,12 +754,12 @@ int launch_depth_order(GeomState& g, int P, int debug, hipStream_t s, int* num_r
   }
   StageScope sc(ST_DEPTH_SORT, s);
   hipLaunchKernelGGL((bk_scan_kernel<true, DB>), dim3(nchunks, (1 << DB) / 256), dim3(BK_THREADS), 0, s, g.hist, (uint32_t)TILE, (uint32_t)P, nullptr,
-                     g.slots, g.acc, g.bucket_start, g.counters, nullptr, 0u);
+                     g.acc, g.bucket_start, g.counters, nullptr, 0u);
   GM_LAUNCH_CHECK(debug, s);
   hipLaunchKernelGGL((bk_scatter_kernel<true, DB, WAVES>), dim3(nblk), dim3(WAVES * 64), 0, s, g.depth_key, g.dpairs[1], (uint32_t)P, nullptr, ds,
-                     g.slots, g.hist, nullptr, 0u, nullptr, 0, nullptr, g.dmap, g.counters);
+                     g.hist, nullptr, 0u, nullptr, 0, nullptr, g.dmap, g.counters);
   GM_LAUNCH_CHECK(debug, s);
-  hipLaunchKernelGGL(bucket_sort_kernel, dim3(1 << DB), dim3(BK_THREADS), 0, s, g.counters, g.dmap, g.bmap, g.bucket_start, g.dpairs[1], g.dpairs[0], g.order,
+  hipLaunchKernelGGL(bucket_sort_kernel, dim3(1 << DB), dim3(BK_THREADS), 0, s, g.counters, g.bmap, g.bucket_start, g.dpairs[1], g.dpairs[0], g.order,
                      g.tiles_touched, g.bin, g.bin_sorted, g.chunk_inst, g_bucket_trace);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
@@ -775,11 +775,11 @@ static int tile_pass(BinningState& b, GeomState& g, int from, uint32_t n, const 
   hipLaunchKernelGGL((bk_hist_kernel<false, DB, WAVES>), dim3(nblk), dim3(WAVES * 64), 0, s, b.pairs[from], n, n_dev, ds, nullptr, b.hist, b.acc,
                      g.counters, nullptr, nullptr, nullptr);
   GM_LAUNCH_CHECK(debug, s);
-  hipLaunchKernelGGL((bk_scan_kernel<false, DB>), dim3(nchunks ? nchunks : 1, (1 << DB) / 256), dim3(BK_THREADS), 0, s, b.hist, TILE, n, n_dev, nullptr,
+  hipLaunchKernelGGL((bk_scan_kernel<false, DB>), dim3(nchunks ? nchunks : 1, (1 << DB) / 256), dim3(BK_THREADS), 0, s, b.hist, TILE, n, n_dev,
                      b.acc, nullptr, g.counters, ranges, nranges);
   GM_LAUNCH_CHECK(debug, s);
   hipLaunchKernelGGL((bk_scatter_kernel<false, DB, WAVES>), dim3(nblk + (order_out ? 1u : 0u)), dim3(WAVES * 64), 0, s, b.pairs[from],
-                     b.pairs[from ^ 1], n, n_dev, ds, nullptr, b.hist, zero_acc_after ? b.acc : nullptr, (uint32_t)bk_acc_words(n), ranges,
+                     b.pairs[from ^ 1], n, n_dev, ds, b.hist, zero_acc_after ? b.acc : nullptr, (uint32_t)bk_acc_words(n), ranges,
                      (int)nranges, order_out, nullptr, nullptr);
   GM_LAUNCH_CHECK(debug, s);
   return 0;

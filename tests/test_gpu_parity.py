@@ -685,14 +685,17 @@ def test_emission_policies_agree_on_random_scenes(seed):
         assert np.array_equal(cu["color"], ref["color"]), mode
 
 
-@pytest.mark.parametrize("case", ["equal_depths", "depth_pileup", "many_tiles", "tiny"])
+@pytest.mark.parametrize("case", ["equal_depths", "depth_pileup", "many_tiles", "tiny", "twenty_octaves", "object_and_background"])
 def test_ordering_paths(oracle, case):
     """gm_bucket.hip's special paths against the oracle's (tile, depth, id) stable sort, lists bit-exact:
     equal_depths: every Gaussian at the same view depth (one bucket, no low bits: order by id, bucket larger than the LDS);
     depth_pileup: 12k Gaussians inside a few ulps of one depth plus a sparse spread (one overfull bucket WITH low bits: the
                   global-memory slow path of bucket_sort_kernel, several passes);
     many_tiles:   more than 2048 list tiles (two 8-bit tile passes + tile_ranges_kernel), reference and default policy;
-    tiny:         3 Gaussians."""
+    tiny:         3 Gaussians;
+    twenty_octaves: depths from 0.3 to 3e5 around the optical axis - 160 sparsely filled coarse depth bins;
+    object_and_background: a dense cluster in a tenth of a depth unit in front of a sparse background and behind a few
+                  floaters (the proportional bucket table: most buckets go to the cluster)."""
     from gpu_utils import forward_state
     from gaussianmesh_amd import scenes
     rng = np.random.default_rng(5)
@@ -713,12 +716,29 @@ def test_ordering_paths(oracle, case):
         sc = scenes.make_cloud(3000, seed=8, scale_lo=0.01, scale_hi=0.3)
         cam = scenes.orbit_camera(2, 9, W, H, radius=7.0)
         modes = (0, 1, 2)
+    elif case in ("twenty_octaves", "object_and_background"):
+        P = 6000 if case == "twenty_octaves" else 20000
+        sc = scenes.make_cloud(P, seed=4, scale_lo=0.004, scale_hi=0.03)
+        cam = scenes.look_at_camera((0.0, 0.0, -6.0), (0.0, 0.0, 0.0), W, H)
+        if case == "twenty_octaves":
+            z = (0.3 * 2.0 ** (20.0 * np.arange(P) / P)).astype(np.float32)
+            sc["means"] = (rng.uniform(-0.05, 0.05, (P, 3)) * z[:, None]).astype(np.float32)     # inside the frustum at every depth
+            sc["means"][:, 2] = rng.permutation(z) - 6.0
+            sc["scales"] = (sc["scales"] * z[:, None] / 6.0).astype(np.float32)
+        else:
+            sc["means"][:17000, 2] = rng.uniform(0.0, 0.1, 17000).astype(np.float32)              # the object: view depth 6.0 .. 6.1
+            sc["means"][17000:19900, 2] = rng.uniform(20.0, 900.0, 2900).astype(np.float32)       # background
+            sc["means"][19900:, 2] = rng.uniform(-5.6, -5.0, 100).astype(np.float32)              # floaters right in front of the camera
+            sc["means"][17000:, :2] *= 0.2
+        modes = (0, 2)
     else:
         sc = scenes.make_cloud(3, seed=1, scale_lo=0.05, scale_hi=0.3)
         cam = scenes.orbit_camera(0, 4, W, H, radius=5.0)
         modes = (0, 2)
     bg = np.array([0.2, 0.3, 0.4], np.float32)
     fw = oracle.forward_full(sc, cam, bg, D=3)
+    if case in ("twenty_octaves", "object_and_background"):
+        assert (fw["geo"]["radii"] > 0).sum() > 0.5 * sc["means"].shape[0]
     ex = None
     for mode in modes:
         st = forward_state(sc, cam, bg, D=3, tile_cull=mode)

@@ -121,3 +121,37 @@ def test_densify_stats_kernel_matches_the_reference_statements():
     acc0[vis] += torch.norm(grad[vis, :2], dim=-1, keepdim=True)               # mesh_based_gaussian_model.py:588
     den0[vis] += 1
     assert torch.equal(mr, mr0) and torch.equal(den, den0) and (acc - acc0).abs().max() <= 1e-6
+
+
+def test_shared_feature_storage_equals_concatenation():
+    """render(..., bg_gaussian=...) with the SH parameter living in one buffer with the background's rows
+    (renderer.share_feature_storage: no per-iteration torch.cat) gives the image and the gradients of the concatenating path,
+    and an in-place optimizer step on the parameter is seen by the next render."""
+    from types import SimpleNamespace
+    from gpu_utils import T
+    from gaussianmesh_amd import scenes
+    from gaussianmesh_amd.renderer import Camera, render, share_feature_storage
+    from gaussianmesh_amd.train import FrozenGaussians
+    b = scenes.make_cloud(700, seed=4, scale_lo=0.05, scale_hi=0.3)
+    bg = FrozenGaussians(T(b["means"] * 1.5 + np.array([0, 0, 1.0], np.float32)), T(b["scales"]), torch.nn.functional.normalize(T(b["rots"])),
+                         T(b["opac"]).reshape(-1, 1), T(b["shs"]))
+    cam = Camera(scenes.orbit_camera(2, 7, 160, 96, radius=7.0), "cuda")
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
+    zero = torch.zeros(3, device="cuda")
+    w = torch.rand((3, 96, 160), device="cuda")
+    ma, mb = _model(1500, 0, perturb=False), _model(1500, 0, perturb=False)
+    share_feature_storage(mb, bg)
+    assert mb._features.is_leaf and mb._features.requires_grad and torch.equal(ma._features, mb._features)
+    outs = []
+    for m in (ma, mb):
+        img = render(cam, m, pipe, zero, bg_gaussian=bg)["render"]
+        (img * w).sum().backward()
+        outs.append((img.detach(), m._features.grad.clone(), m._opacity.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert (outs[0][1] - outs[1][1]).abs().max() <= 1e-5 * outs[0][1].abs().max() and (outs[0][2] - outs[1][2]).abs().max() <= 1e-5 * outs[0][2].abs().max()
+    with torch.no_grad():                                   # what an optimizer does
+        for m in (ma, mb):
+            m._features.add_(0.05)
+    ia = render(cam, ma, pipe, zero, bg_gaussian=bg)["render"]
+    ib = render(cam, mb, pipe, zero, bg_gaussian=bg)["render"]
+    assert torch.equal(ia, ib) and not torch.equal(ia.detach(), outs[0][0])
