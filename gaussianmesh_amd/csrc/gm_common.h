@@ -180,7 +180,9 @@ struct ImageState {             // per-pixel / per-tile state
   float* final_T;               // [H*W]
   uint32_t* n_contrib;          // [H*W]
   uint2* ranges;                // [tiles]
-  uint32_t* tile_order;         // [tiles] list tiles by descending list length (the blend kernels' dispatch order)
+  uint32_t* tile_order;         // [tiles] list tiles by descending list length (the forward blend's dispatch order)
+  uint32_t* tile_work;          // [tiles] deepest contributor (max n_contrib) among the pixels of a list tile's area
+  uint32_t* tile_order_bwd;     // [tiles] list tiles by descending tile_work (the backward blend's dispatch order)
   static ImageState from(void* buf, int W, int H) {
     char* p = reinterpret_cast<char*>(buf);
     const size_t N = (size_t)W * H;
@@ -190,6 +192,8 @@ struct ImageState {             // per-pixel / per-tile state
     s.n_contrib = carve<uint32_t>(p, N);
     s.ranges = carve<uint2>(p, T);
     s.tile_order = carve<uint32_t>(p, T);
+    s.tile_work = carve<uint32_t>(p, T);
+    s.tile_order_bwd = carve<uint32_t>(p, T);
     s.end = p;
     return s;
   }

@@ -67,6 +67,33 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restric
   tile_order_block<1024>(ranges, tiles, order, cnt, wsum);
 }
 
+// Dispatch order of the BACKWARD blend.  What a quadrant's wave has to walk is known exactly after the forward: the list
+// up to the deepest contributor of its pixels (n_contrib); list length says little (a 12 k-entry list that saturates after
+// 200 entries is cheap, a 1.5 k-entry silhouette list walked to the end is not).  One workgroup per list tile takes the maximum
+// of n_contrib over the tile's area, one workgroup sorts the tiles by it.
+__global__ __launch_bounds__(256) void tile_work_kernel(const uint32_t* __restrict__ n_contrib, int W, int H, int pgx, int shift,
+                                                        uint32_t* __restrict__ work) {
+  __shared__ uint32_t part[4];
+  const int p = blockIdx.x, py = p / pgx, px = p - py * pgx;
+  const int side = GM_TILE << shift;                          // 16, 32 or 64 pixels
+  const int x0 = px * side, y0 = py * side;
+  uint32_t m = 0;
+  for (int i = threadIdx.x; i < side * side; i += 256) {
+    const int x = x0 + (i & (side - 1)), y = y0 + (i >> (4 + shift));
+    if (x < W && y < H) m = max(m, n_contrib[(size_t)y * W + x]);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) work[p] = max(max(part[0], part[1]), max(part[2], part[3]));
+}
+__global__ __launch_bounds__(1024) void tile_order_work_kernel(const uint32_t* __restrict__ work, int tiles, uint32_t* __restrict__ order) {
+  __shared__ uint32_t cnt[256];
+  __shared__ uint32_t wsum[16];
+  tile_order_by<1024>([&](int t) { return work[t]; }, tiles, order, cnt, wsum);
+}
+
 int launch_tile_order(ImageState& img, int tiles, int debug, hipStream_t s) {
   StageScope sc(ST_RANGES, s);
   hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, img.ranges, tiles, img.tile_order);
@@ -583,7 +610,11 @@ int launch_render_bwd(const GeomState& g, const uint2* pairs, ImageState& img, i
                       const float* background, const float* dL_dpix, int debug, hipStream_t s) {
   StageScope sc(ST_RENDER_BWD, s);
   const TileGrid tg(W, H, mode);
-  const TileMap tm{tg.gx, tg.gy, tg.pgx, tg.pgy, tg.s, img.tile_order};
+  const TileMap tm{tg.gx, tg.gy, tg.pgx, tg.pgy, tg.s, img.tile_order_bwd};
+  if (tg.ptiles > 0) {
+    hipLaunchKernelGGL(tile_work_kernel, dim3(tg.ptiles), dim3(256), 0, s, img.n_contrib, W, H, tg.pgx, tg.s, img.tile_work);
+    hipLaunchKernelGGL(tile_order_work_kernel, dim3(1), dim3(1024), 0, s, img.tile_work, tg.ptiles, img.tile_order_bwd);
+  }
   if (tg.ptiles > 0)
     hipLaunchKernelGGL(render_bwd_kernel, dim3(tm.blocks()), dim3(256), 0, s, img.ranges, pairs, g.splat, W, H, tm,
                        background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc, g.counters, mode);
