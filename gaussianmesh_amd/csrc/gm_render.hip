@@ -429,18 +429,24 @@ __device__ __forceinline__ int reduce8_slot(int lane) {
 
 #define GM_ACC_STRIDE 12   // floats per Gaussian in grad_acc: dcolor rgb (0-2), moments of h: 1, dx, dy, dx^2, dx dy, dy^2 (3-8)
 
-__global__ __launch_bounds__(256) void render_bwd_kernel(const uint2* __restrict__ ranges,
+#ifndef GM_RENDER_BWD_WPW
+#define GM_RENDER_BWD_WPW 1      // waves per workgroup of the backward blend (as GM_RENDER_FWD_WPW)
+#endif
+__global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_kernel(const uint2* __restrict__ ranges,
                                                                const uint2* __restrict__ pairs,
                                                                const float4* __restrict__ splat, int W, int H, TileMap tm,
                                                                const float* __restrict__ bg, const float* __restrict__ final_T,
                                                                const uint32_t* __restrict__ n_contrib,
                                                                const float* __restrict__ dL_dpix, float* __restrict__ grad_acc,
                                                                const uint32_t* __restrict__ counters, int mode) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int WPW = GM_RENDER_BWD_WPW;
+  const int lane = threadIdx.x & 63;
+  const int wave = WPW == 4 ? (int)(threadIdx.x >> 6) : (int)((blockIdx.x >> 3) & 3);
+  const int tile_block = WPW == 4 ? (int)blockIdx.x : (int)(((blockIdx.x >> 5) << 3) | (blockIdx.x & 7));
   int tx, ty, parent;
   uint32_t child_bit;
   if ((int)counters[GM_CNT_POLICY] != mode || counters[GM_CNT_REFUSED] != 0u) return;   // lists were built under another emission policy: contribute nothing
-  if (!tm.locate(blockIdx.x, tx, ty, parent, child_bit)) return;
+  if (!tm.locate(tile_block, tx, ty, parent, child_bit)) return;
   const uint2 range = ranges[parent];
   const int n = (int)(range.y - range.x);
   if (n == 0) return;
@@ -473,8 +479,8 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const uint2* __restrict
   const int my_slot = reduce8_slot(lane);
   const bool committer = (lane & 7) == 0;
   const float rx0 = (float)(tx * GM_TILE + (wave & 1) * 8), ry0 = (float)(ty * GM_TILE + (wave >> 1) * 8);
-  __shared__ WaveLds l_w[4];
-  WaveLds& L = l_w[wave];
+  __shared__ WaveLds l_w[WPW];
+  WaveLds& L = l_w[WPW == 4 ? wave : 0];
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   // Same front end as render_fwd_kernel, walking the list back to front: chunk lane j <-> position start-1-kpos-j
   // (positions below 0 re-read entry 0 and are not "mine"); candidates enter the ring in descending list position.
@@ -616,7 +622,7 @@ int launch_render_bwd(const GeomState& g, const uint2* pairs, ImageState& img, i
     hipLaunchKernelGGL(tile_order_work_kernel, dim3(1), dim3(1024), 0, s, img.tile_work, tg.ptiles, img.tile_order_bwd);
   }
   if (tg.ptiles > 0)
-    hipLaunchKernelGGL(render_bwd_kernel, dim3(tm.blocks()), dim3(256), 0, s, img.ranges, pairs, g.splat, W, H, tm,
+    hipLaunchKernelGGL(render_bwd_kernel, dim3(tm.blocks() * (4 / GM_RENDER_BWD_WPW)), dim3(64 * GM_RENDER_BWD_WPW), 0, s, img.ranges, pairs, g.splat, W, H, tm,
                        background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc, g.counters, mode);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
