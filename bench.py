@@ -180,6 +180,9 @@ def main():
                     "camera index) as <dir>/rank<r>.npz: lets a test verify that each rank rendered its own views")
     ap.add_argument("--analytic-rs", action="store_true", help="take the per-vertex (R, S) of every animation frame from the analytic "
                     "deformation (precomputed tables) instead of computing them from the deformed mesh inside the frame (gm_mesh_rs)")
+    ap.add_argument("--backward-state", action="store_true", help="have the blend also write the per-pixel final transmittance / "
+                    "contributor count (the state only a backward pass reads); the edit loop is forward-only and renders "
+                    "with GM_FWD_IMAGE_ONLY by default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fwd-bwd", action="store_true")
     args = ap.parse_args()
@@ -198,6 +201,7 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    image_only = not args.backward_state
     # GM_BENCH_SHARE_DEVICE=1 + GM_BENCH_BACKEND=gloo: functional smoke test of the N>1 path on a one-GPU box
     # (RCCL refuses two ranks on one device); never used for measurements.
     if os.environ.get("GM_BENCH_SHARE_DEVICE") == "1":
@@ -269,12 +273,12 @@ def main():
         ok, nr = h.check()
         if not ok:                              # instance count outgrew the binning capacity: render that frame again, exactly
             stats["overflows"] += 1
-            nr = h.finish()[0]
+            nr = h.finish(image_only=image_only)[0]
         stats["R"] = nr
         stats["radii"] = h.radii
 
     def finish(h):
-        out = h.finish(sync_free=not args.exact_count)
+        out = h.finish(sync_free=not args.exact_count, image_only=image_only)
         stats["last_image"] = out[1]
         unchecked.append(h)
         while len(unchecked) > lag:
@@ -307,7 +311,7 @@ def main():
         if not args.unfused:                     # same path, completed at once (per-stage timing pass)
             nr, color, radii, _, _, _ = Rz.forward_deformed_begin(bg, g["tri"], g["weights"], packed, g["cov"], g["pos"], g["shs"], g["opac"],
                                                                   c["view"], c["proj"], c["tanx"], c["tany"], H, W, 3, c["campos"], False,
-                                                                  workspace=workspace).finish()
+                                                                  workspace=workspace).finish(image_only=image_only)
             stats["R"] = nr
             stats["radii"] = radii
             return color
@@ -333,7 +337,7 @@ def main():
         c = cam_t[multiview.view_for_step(0, F, rank, world)]
         pk = pack_mesh_state(g["mesh"][0], g["verts"])
         nr_f, col_f, rad_f, *_ = Rz.forward_deformed_begin(bg, g["tri"], g["weights"], pk, g["cov"], g["pos"], g["shs"], g["opac"], c["view"],
-                                                           c["proj"], c["tanx"], c["tany"], H, W, 3, c["campos"], False).finish()
+                                                           c["proj"], c["tanx"], c["tany"], H, W, 3, c["campos"], False).finish(image_only=image_only)
         pos_u, cov6_u, rgb_u = deform_shade_packed(g["tri"], g["weights"], pk, g["cov"], g["pos"], g["shs"], c["campos"], deg=3)
         nr_u, col_u, rad_u, *_ = Rz.rasterize_forward(bg, pos_u, rgb_u, g["opac"], None, None, 1.0, cov6_u, c["view"], c["proj"], c["tanx"],
                                                       c["tany"], H, W, None, 3, c["campos"], False, False)
@@ -394,7 +398,7 @@ def main():
                                "render %dx%d, %d-camera orbit, views sharded by rank" % (P, W, H, F),
                    "gaussians": P, "width": W, "height": H, "sh_degree": 3, "views_per_step_per_gpu": 1,
                    "vertex_rs": "analytic tables" if args.analytic_rs else "gm_mesh_rs per frame", "hip_streams": nstreams,
-                   "emission_policy": Rz.get_default_emission_policy(),
+                   "emission_policy": Rz.get_default_emission_policy(), "image_only": image_only,
                    "parallelism": "views x%d" % world},
     }
     if repeats:

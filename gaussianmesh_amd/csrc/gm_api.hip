@@ -175,8 +175,9 @@ int gm_forward_0_deformed_async(int emission_policy, void* geom_buffer, int P, i
 
 int gm_forward_1_geom(int emission_policy, void* geom_buffer, void* binning_buffer, void* image_buffer, int P, int num_rendered,
                       int64_t binning_capacity, const float* background, int width, int height, float* out_color, int debug, void* stream,
-                      int* status_host) {
+                      int* status_host, int flags) {
   if (int rc = check_policy(emission_policy)) return rc;
+  if (flags & ~GM_FWD_IMAGE_ONLY) { set_error("unknown flags 0x%x", flags); return GM_ERR_INVALID_ARG; }
   if (P < 0 || width <= 0 || height <= 0) { set_error("invalid sizes P=%d W=%d H=%d", P, width, height); return GM_ERR_INVALID_ARG; }
   if (!image_buffer || !out_color || !background) { set_error("null image_buffer / out_color / background"); return GM_ERR_INVALID_ARG; }
   const bool device_count = num_rendered < 0;          // sync-free: the count stays on the device, bounded by the capacity
@@ -206,7 +207,8 @@ int gm_forward_1_geom(int emission_policy, void* geom_buffer, void* binning_buff
     status_host[0] = 0; status_host[1] = 0; status_host[2] = mode; status_host[3] = 0;
     status_host = nullptr;
   }
-  return launch_render_fwd(g, b.pairs[slot], img, width, height, mode, background, out_color, status_host, debug, st);
+  return launch_render_fwd(g, b.pairs[slot], img, width, height, mode, background, out_color, status_host, (flags & GM_FWD_IMAGE_ONLY) != 0,
+                           debug, st);
 }
 
 int gm_forward_status_async(void* geom_buffer, int P, int* status_host, void* stream) {
@@ -252,7 +254,7 @@ int gm_forward_1(void* geom_buffer, void* binning_buffer, void* image_buffer, in
   (void)radii;
   if (num_rendered < 0) { set_error("negative num_rendered"); return GM_ERR_INVALID_ARG; }
   return gm_forward_1_geom(GM_POLICY_DEFAULT, geom_buffer, binning_buffer, image_buffer, P, num_rendered, 0, background, width, height, out_color,
-                           debug, stream, nullptr);
+                           debug, stream, nullptr, 0);
 }
 
 int gm_backward_p(int emission_policy, int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,

@@ -281,7 +281,7 @@ int launch_tile_sort(GeomState& g, BinningState& b, ImageState& img, size_t n, c
 int launch_tile_ranges(const GeomState& g, BinningState& b, int slot, ImageState& img, int R, const uint32_t* R_dev, int tiles, int debug, hipStream_t s);
 int launch_tile_order(ImageState& img, int tiles, int debug, hipStream_t s);          // ranges -> tile_order
 int launch_render_fwd(const GeomState& g, const uint2* pairs, ImageState& img, int W, int H, int mode,
-                      const float* background, float* out_color, int* status_host, int debug, hipStream_t s);
+                      const float* background, float* out_color, int* status_host, bool image_only, int debug, hipStream_t s);
 int launch_render_bwd(const GeomState& g, const uint2* pairs, ImageState& img, int W, int H, int mode,
                       const float* background, const float* dL_dpix, int debug, hipStream_t s);   // accumulates into g.grad_acc
 

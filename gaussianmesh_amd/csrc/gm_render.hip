@@ -161,7 +161,9 @@ __device__ __forceinline__ Gather issue_gather(const float4* __restrict__ splat,
 #ifndef GM_RENDER_FWD_WPW
 #define GM_RENDER_FWD_WPW 1      // waves per workgroup of the forward blend: 4 (one workgroup per 16-px tile) or 1 (one per 8x8 quadrant)
 #endif
-template <bool TRACE>
+// STATE = false: image-only frame (GM_FWD_IMAGE_ONLY) - final_T / n_contrib, which only a backward pass reads, are neither
+// tracked nor written.
+template <bool TRACE, bool STATE>
 __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(const uint2* __restrict__ ranges,
                                                                const uint2* __restrict__ pairs,
                                                                const float4* __restrict__ splat, int W, int H, TileMap tm,
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
             T = stop ? -__builtin_fabsf(T) : t;                                           // stop WITHOUT applying the entry
             const v2f rg = {RB[u].z, RB[u].w}, ww = {w, w};
             Crg = rg * ww + Crg; Cb += RC[u].x * w;
-            last = (w > 0.0f) ? __float_as_uint(RC[u].y) : last;
+            if (STATE) last = (w > 0.0f) ? __float_as_uint(RC[u].y) : last;
             if (TRACE) {
               const unsigned long long hit = __ballot(w > 0.0f); tr_useful += hit != 0ull; tr_lanes += __popcll(hit);
               const unsigned long long LM = 0x0F0F0F0F0F0F0F0Full;
@@ -331,8 +333,7 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
   if (inside) {
     const size_t HW = (size_t)H * W, pid = (size_t)W * py + px;
     T = __builtin_fabsf(T);
-    final_T[pid] = T;
-    n_contrib[pid] = last;
+    if (STATE) { final_T[pid] = T; n_contrib[pid] = last; }
     out_color[pid] = Crg.x + T * bg[0];
     out_color[HW + pid] = Crg.y + T * bg[1];
     out_color[2 * HW + pid] = Cb + T * bg[2];
@@ -350,17 +351,20 @@ static unsigned long long* g_render_trace = nullptr;      // debugging aid (tool
 extern "C" void gm_debug_render_trace(void* buffer) { g_render_trace = reinterpret_cast<unsigned long long*>(buffer); }
 
 int launch_render_fwd(const GeomState& g, const uint2* pairs, ImageState& img, int W, int H, int mode,
-                      const float* background, float* out_color, int* status_host, int debug, hipStream_t s) {
+                      const float* background, float* out_color, int* status_host, bool image_only, int debug, hipStream_t s) {
   StageScope sc(ST_RENDER, s);
   const TileGrid tg(W, H, mode);
   const TileMap tm{tg.gx, tg.gy, tg.pgx, tg.pgy, tg.s, img.tile_order};
   if (tg.ptiles > 0) {
     const dim3 grid(tm.blocks() * (4 / GM_RENDER_FWD_WPW)), block(64 * GM_RENDER_FWD_WPW);
     if (g_render_trace)
-      hipLaunchKernelGGL(render_fwd_kernel<true>, grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
+      hipLaunchKernelGGL((render_fwd_kernel<true, true>), grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
                          background, out_color, img.final_T, img.n_contrib, g_render_trace, g.counters, status_host);
+    else if (image_only)
+      hipLaunchKernelGGL((render_fwd_kernel<false, false>), grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
+                         background, out_color, img.final_T, img.n_contrib, nullptr, g.counters, status_host);
     else
-      hipLaunchKernelGGL(render_fwd_kernel<false>, grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
+      hipLaunchKernelGGL((render_fwd_kernel<false, true>), grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
                          background, out_color, img.final_T, img.n_contrib, nullptr, g.counters, status_host);
   } else if (status_host) {
     GM_HIP(hipMemcpyAsync(status_host, g.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));

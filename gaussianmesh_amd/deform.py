@@ -260,4 +260,4 @@ class SingleObjectDeform:
                                       self.gaussian_feature, self.gaussian_o, c.world_view_transform, c.full_proj_transform,
                                       math.tan(c.FoVx * 0.5), math.tan(c.FoVy * 0.5), c.image_height, c.image_width, 3, c.camera_center,
                                       workspace=workspace)
-        return h if begin_only else h.finish()[1]
+        return h if begin_only else h.finish(image_only=True)[1]          # forward-only: no backward state

@@ -126,16 +126,21 @@ class PendingForward:
         self.status_event = None
         self.result = None
         self.known_count = None
+        self.image_only = False
 
     def _geom(self, binning, num_rendered, capacity, status=None):
         lib = _lib.lib()
         a = self.args
         _lib.check(lib.gm_forward_1_geom(self.policy, _ptr(self.geom), _ptr(binning), _ptr(self.img), a["P"], num_rendered, capacity,
                                          _ptr(a["bg"]), a["W"], a["H"], _ptr(self.color), a["debug"], self.stream.cuda_stream,
-                                         None if status is None else status.data_ptr()))
+                                         None if status is None else status.data_ptr(), 1 if self.image_only else 0))
 
-    def finish(self, sync_free=False, capacity=0):
-        """capacity (sync_free without a workspace): instances the freshly allocated binning buffer shall hold."""
+    def finish(self, sync_free=False, capacity=0, image_only=False):
+        """capacity (sync_free without a workspace): instances the freshly allocated binning buffer shall hold.
+        image_only (GM_FWD_IMAGE_ONLY): a frame no backward pass follows - the blend writes the colour image and leaves the
+        per-pixel final transmittance / contributor count of the image state alone; the returned img must not be handed
+        to rasterize_backward."""
+        self.image_only = bool(image_only)
         lib = _lib.lib()
         a = self.args
         device = a["device"]

@@ -213,10 +213,14 @@ int gm_forward_0_deformed_async(int emission_policy, void* geom_buffer, int P, i
  * status_host (page-locked, device-accessible host memory, 4 x int32; may be NULL) receives the frame's status words
  * {num_rendered, prefilter violation, policy, refused}, written by the blend kernel itself (no copy launch behind the frame); they are valid once
  * the stream has passed this call.  refused != 0: nothing was emitted (capacity overflow or policy mismatch).
- * gm_forward_status_async copies the same four words of the forward that last used geom_buffer, stream-ordered. */
+ * gm_forward_status_async copies the same four words of the forward that last used geom_buffer, stream-ordered.
+ * flags: 0, or GM_FWD_IMAGE_ONLY for a frame no backward pass will follow (the edit / viewer loop): the blend writes out_color
+ * only - the per-pixel final transmittance and contributor count in image_buffer (forward.cu:369-370, read by
+ * backward.cu:444-447 alone) are left untouched, so gm_backward on that image_buffer is undefined. */
+#define GM_FWD_IMAGE_ONLY 1
 int gm_forward_1_geom(int emission_policy, void* geom_buffer, void* binning_buffer, void* image_buffer, int P, int num_rendered,
                       int64_t binning_capacity, const float* background, int width, int height, float* out_color, int debug, void* stream,
-                      int* status_host);
+                      int* status_host, int flags);
 int gm_forward_status_async(void* geom_buffer, int P, int* status_host, void* stream);
 
 /* Per-vertex rotation / stretch of a deformed proxy mesh: replaces pyACAP.GetRS(rest vertices, deformed vertices, ...) at

@@ -46,7 +46,7 @@ def test_argument_validation_happens_before_any_gpu_work():
     assert rc == 1
     rc = l.gm_forward_0_async(7, one, 10, 3, 16, one, 64, 64, one, one, None, one, one, 1.0, one, None, one, one, one, 0.5, 0.5, 0, None, 0, None, None, None)
     assert rc == 1 and b"emission policy" in l.gm_last_error()
-    assert l.gm_forward_1_geom(2, one, one, one, 10, -1, -5, one, 64, 64, one, 0, None, None) == 1          # negative capacity
+    assert l.gm_forward_1_geom(2, one, one, one, 10, -1, -5, one, 64, 64, one, 0, None, None, 0) == 1          # negative capacity
     assert l.gm_knn(5, None, None, None, 0, None) == 1
     assert l.gm_sh_colors(5, 4, 16, one, one, None, one, one, None) == 1
 

@@ -560,6 +560,21 @@ def test_fused_deform_forward_equals_unfused_chain(oracle, N):
     _, color5, *_ = h.finish(sync_free=True)
     ok, count = h.check()
     assert ok and count == nr0 and torch.equal(color5, color0)
+    # image-only frame (GM_FWD_IMAGE_ONLY): same image, and the backward state of the image buffer (final transmittance at the
+    # head of the buffer, contributor counts behind it) is left as it was
+    h = fb(workspace=ws)
+    img = h.img
+    img[:2 * 4 * H * W].fill_(0xA5)
+    snapshot = img[:2 * 4 * H * W].clone()
+    for sync_free in (True, False):
+        h = fb(workspace=ws) if h.result is not None else h
+        _, color6, *rest = h.finish(sync_free=sync_free, image_only=True)
+        assert h.check()[0]
+        torch.cuda.synchronize()
+        assert h.img.data_ptr() == img.data_ptr() and torch.equal(color6, color0) and torch.equal(img[:2 * 4 * H * W], snapshot)
+    _, color7, *rest = fb(workspace=ws).finish()
+    torch.cuda.synchronize()
+    assert torch.equal(color7, color0) and not torch.equal(img[:4 * H * W], snapshot[:4 * H * W])
     # against the oracle chain
     dV = (V1 - verts).astype(np.float32)
     p_ref, c_ref, r_ref = oracle.deform(cl["tri"], cl["weights"], dV, Rv, Sv, cov, cl["means"])
