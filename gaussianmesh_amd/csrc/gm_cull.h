@@ -108,6 +108,49 @@ __device__ __forceinline__ bool row_tiles(const TileCull& t, float sx, float sy,
   return ta <= tb;
 }
 
+// row_tiles for the two tile rows ty, ty + 1 at once, straight-line (no branch, the two rows' arithmetic side by side so that
+// the multiplies / adds pair up on the packed-f32 pipe): the per-row operations and their order are those of row_span /
+// row_tiles, so the spans are bit-identical.  A row without tiles comes back as the empty interval (GM_ROW_EMPTY_LO, -1).
+// Precondition: t.mode != 0.
+#define GM_ROW_EMPTY_LO 0x3fffffff
+typedef float cull_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cull_v2f v2_max(cull_v2f a, float b) { return cull_v2f{fmaxf(a.x, b), fmaxf(a.y, b)}; }
+__device__ __forceinline__ cull_v2f v2_min(cull_v2f a, float b) { return cull_v2f{fminf(a.x, b), fminf(a.y, b)}; }
+__device__ __forceinline__ cull_v2f v2_sqrt(cull_v2f a) { return cull_v2f{__builtin_amdgcn_sqrtf(a.x), __builtin_amdgcn_sqrtf(a.y)}; }
+__device__ __forceinline__ void row_tiles_pair(const TileCull& t, float sx, float sy, int ty, int x0, int x1, int* ta, int* tb) {
+#pragma clang fp contract(off)
+  const float al = t.a * t.lim, nb = -t.b;
+  const float p = (float)(ty * 16);
+  const cull_v2f py0 = {p, p + 16.f};                       // (exact: multiples of 16 far below 2^24)
+  const cull_v2f py1 = py0 + 15.f;
+  const cull_v2f dyl = v2_max(sy - py1, -t.dymax), dyh = v2_min(sy - py0, t.dymax);
+  const cull_v2f sl = v2_sqrt(v2_max(al - t.det * dyl * dyl, 0.f)), sh = v2_sqrt(v2_max(al - t.det * dyh * dyh, 0.f));
+  const cull_v2f bl = nb * dyl, bh = nb * dyh;
+  const cull_v2f hl = bl + sl, hh = bh + sh, ll = bl - sl, lh = bh - sh;
+  cull_v2f hi = cull_v2f{fmaxf(hl.x, hh.x), fmaxf(hl.y, hh.y)} * t.inv_a;
+  cull_v2f lo = cull_v2f{fminf(ll.x, lh.x), fminf(ll.y, lh.y)} * t.inv_a;
+  // dyl <= x <= dyh as med3(dyl, x, dyh) == x (a row with dyl > dyh is dropped below whatever this gives)
+  const float nd = -t.dystar;
+  if (__builtin_amdgcn_fmed3f(dyl.x, nd, dyh.x) == nd) hi.x = t.xext;
+  if (__builtin_amdgcn_fmed3f(dyl.y, nd, dyh.y) == nd) hi.y = t.xext;
+  if (__builtin_amdgcn_fmed3f(dyl.x, t.dystar, dyh.x) == t.dystar) lo.x = -t.xext;
+  if (__builtin_amdgcn_fmed3f(dyl.y, t.dystar, dyh.y) == t.dystar) lo.y = -t.xext;
+  hi = v2_min(hi, t.xext); lo = v2_max(lo, -t.xext);
+  const cull_v2f mag = {fabsf(hi.x) + fabsf(lo.x), fabsf(hi.y) + fabsf(lo.y)};
+  const cull_v2f eps = 2e-3f + 1e-4f * mag;
+  const cull_v2f A = sx - hi - eps, B = sx - lo + eps;
+  const cull_v2f fa = (A - 15.f) * 0.0625f, fb = B * 0.0625f;
+  const float fav[2] = {ceilf(fa.x), ceilf(fa.y)}, fbv[2] = {floorf(fb.x), floorf(fb.y)};
+  const bool in[2] = {dyl.x <= dyh.x, dyl.y <= dyh.y};
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    int a = max(x0, (int)fmaxf(fav[r], -1e9f)), b = min(x1 - 1, (int)fminf(fbv[r], 1e9f));
+    if (t.mode == 2) { a = x0; b = x1 - 1; }
+    const bool ok = t.mode == 2 || (in[r] && a <= b);
+    ta[r] = ok ? a : GM_ROW_EMPTY_LO; tb[r] = ok ? b : -1;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Parent tiles (2^s x 2^s tiles, s = 1 or 2).  `bits`: bit c = tile column x0 + c of one parent ROW is reached
 // (union over the row's child rows; at most 60 columns).  Returns the number of parent columns with a reached child.

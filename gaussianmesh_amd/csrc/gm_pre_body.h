@@ -140,6 +140,32 @@ __device__ __forceinline__ void pre_emit(const PreCam& a, const PreGeom& g, floa
     const int s = a.tile_cull >= 2 ? a.tile_cull - 1 : 0;
     const bool small = ncand <= 64 && rw <= 60;
     uint32_t cnt = 0;
+    if (s == 1) {
+      // 2 x 2-tile parents (the default policy): one iteration per parent row, its two tile rows evaluated side by side
+      // without a branch, and the two counting rules in interval arithmetic instead of 64-bit column masks:
+      //   small rectangles  parents with a reached child = |PA u PB| = |PA| + |PB| - |PA n PB|  (PA, PB: the rows' spans in parent columns)
+      //   others            the hull of the two spans
+      // (an empty span is (GM_ROW_EMPTY_LO, -1): every length below comes out <= 0 and clamps to 0).
+      const int pr_last = tc.mode != 0 ? (y1 - 1) >> 1 : (y0 >> 1) - 1;
+      for (int pr = y0 >> 1; pr <= pr_last; pr++) {
+        const int ty = 2 * pr;
+        int ta[2], tb[2];
+        row_tiles_pair(tc, g.pix, g.piy, ty, x0, x1, ta, tb);
+        if (ty < y0) { ta[0] = GM_ROW_EMPTY_LO; tb[0] = -1; }            // rows of the parent outside the rectangle
+        if (ty + 1 >= y1) { ta[1] = GM_ROW_EMPTY_LO; tb[1] = -1; }
+        const int la = ta[0] >> 1, ha = tb[0] >> 1, lb = ta[1] >> 1, hb = tb[1] >> 1;
+        const int uni = max(ha - la + 1, 0) + max(hb - lb + 1, 0) - max(min(ha, hb) - max(la, lb) + 1, 0);
+        const int hull = max((max(tb[0], tb[1]) >> 1) - (min(ta[0], ta[1]) >> 1) + 1, 0);
+        cnt += (uint32_t)(small ? uni : hull);
+#pragma unroll
+        for (int r = 0; r < 2; r++) {                                      // child mask of a rectangle of <= 64 tiles
+          const int len = max(tb[r] - ta[r] + 1, 0);
+          const unsigned long long run = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
+          mask |= run << (((ty + r - y0) * rw + (ta[r] - x0)) & 63);
+        }
+      }
+      if (ncand > 64) mask = 0ull;
+    } else {
     int cur_pr = -1, hull_lo = 0x7fffffff, hull_hi = -1;           // hull empty while hull_hi < 0
     unsigned long long prow = 0ull;
     for (int ry = 0; ry < rh; ry++) {            // per tile row: the span of tiles the alpha >= 1/255 region reaches
@@ -158,6 +184,7 @@ __device__ __forceinline__ void pre_emit(const PreCam& a, const PreGeom& g, floa
       else { hull_lo = min(hull_lo, ta); hull_hi = max(hull_hi, tb); }
     }
     if (s > 0) cnt += small ? parents_in_row(prow, x0, s) : (hull_hi >= 0 ? (uint32_t)((hull_hi >> s) - (hull_lo >> s) + 1) : 0u);
+    }
     tiles = cnt;
   }
   bin = bin_pack((uint32_t)x0, (uint32_t)y0, (uint32_t)rw, (uint32_t)rh, tiles, mask);

@@ -474,7 +474,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 num_rendered = cap                        # the binning layout is that of the capacity
                 _sync_free["unchecked"].append(h)
             else:
-                num_rendered, color, radii, geom, binning, img = h.finish()
+                num_rendered, color, radii, geom, binning, img = h.finish(image_only=not needs_grad)   # no backward will follow
                 if _sync_free["on"] and needs_grad:
                     key = means3D.device
                     _sync_free["capacity"][key] = max(_sync_free["capacity"].get(key, 0), int(num_rendered * _sync_free["growth"]) + 4096)
