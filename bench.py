@@ -180,6 +180,8 @@ def main():
                     "camera index) as <dir>/rank<r>.npz: lets a test verify that each rank rendered its own views")
     ap.add_argument("--analytic-rs", action="store_true", help="take the per-vertex (R, S) of every animation frame from the analytic "
                     "deformation (precomputed tables) instead of computing them from the deformed mesh inside the frame (gm_mesh_rs)")
+    ap.add_argument("--exchange-batch", type=int, default=8, help="N > 1: loop steps whose mesh tables travel in one broadcast "
+                    "(1 = a collective per frame)")
     ap.add_argument("--backward-state", action="store_true", help="have the blend also write the per-pixel final transmittance / "
                     "contributor count (the state only a backward pass reads); the edit loop is forward-only and renders "
                     "with GM_FWD_IMAGE_ONLY by default")
@@ -252,7 +254,6 @@ def main():
     lag = max(1, args.status_lag)
     nws = nstreams + 1 + lag                    # frame i+1 is begun before frame i is completed, and frame i's status is read `lag` frames later
     workspaces = [Rz.RasterWorkspace(growth=1.5) for _ in range(nws)]
-    frame_bufs = [torch.empty((Vm, 24), dtype=torch.float32, device=dev) for _ in range(nws)]
     torch.cuda.synchronize()
 
     pending = {}
@@ -265,7 +266,7 @@ def main():
         capacity, learned during warm-up), the host only reads frame i-2's status words, which landed long ago.
         --exact-count: the host waits for frame i-1's count (one 4-byte read-back, hidden behind frame i's first half)."""
         with torch.cuda.stream(streams[i % nstreams]):
-            pending[i] = step_on_stream(i, workspaces[i % nws], frame_bufs[i % nws], begin_only=True)
+            pending[i] = step_on_stream(i, workspaces[i % nws], begin_only=True)
         prev = pending.pop(i - 1, None)
         return finish(prev) if prev is not None else None
 
@@ -291,18 +292,23 @@ def main():
         while unchecked:
             verify(unchecked.pop(0))
 
-    def step_on_stream(i, workspace, frame_buf, exchange=True, begin_only=False):
+    def frame_table(t, out=None):                # per-vertex gather table [Vm,24] of animation frame t: dV | R | S
+        if args.analytic_rs:
+            tab = pack_mesh_state(g["mesh"][t], g["verts"])         # [Vm,21] frame state -> table (one small kernel)
+            return tab if out is None else out.copy_(tab.view(out.shape))
+        return mesh_rs_packed(g["verts"], v1_frames[t], g["faces"], adjacency, out=out)
+
+    # N > 1, the real exchange step: rank 0 owns the animation and produces the table of every loop step (0.72 MB); the
+    # tables of --exchange-batch consecutive steps travel in one RCCL broadcast, one batch ahead of their use, on the pipe's
+    # own stream (multiview.MeshStatePipe) - the render streams never wait on a collective.
+    pipe = None
+    if world > 1:
+        pipe = multiview.MeshStatePipe(lambda i, out: frame_table(i % F, out), (Vm, 24), args.exchange_batch, dev, src=0,
+                                       frames_in_flight=nstreams + lag + 1)
+
+    def step_on_stream(i, workspace, exchange=True, begin_only=False):
         t = i % F
-        def frame_table(out=None):               # per-vertex gather table [Vm,24] of animation frame t: dV | R | S
-            if args.analytic_rs:
-                return pack_mesh_state(g["mesh"][t], g["verts"])    # [Vm,21] frame state -> table (one small kernel)
-            return mesh_rs_packed(g["verts"], v1_frames[t], g["faces"], adjacency, out=out)
-        if world > 1 and exchange:               # real exchange step: the table of frame t from rank 0 (RCCL), 0.72 MB
-            if rank == 0:
-                frame_table(out=frame_buf) if not args.analytic_rs else frame_buf.copy_(frame_table())
-            packed = multiview.broadcast_mesh_state(frame_buf, src=0)
-        else:
-            packed = frame_table()
+        packed = pipe.frame(i) if (pipe is not None and exchange) else frame_table(t)
         c = cam_t[multiview.view_for_step(i, F, rank, world)]
         if begin_only and not args.unfused:      # one enqueue: deform + colour + preprocess + depth sort + instance count
             return Rz.forward_deformed_begin(bg, g["tri"], g["weights"], packed, g["cov"], g["pos"], g["shs"], g["opac"], c["view"],
@@ -383,7 +389,7 @@ def main():
         t1 = time.perf_counter()
         with torch.cuda.stream(streams[0]):
             for i in range(nlat):
-                step_on_stream(nxt + i, workspaces[0], frame_bufs[0], exchange=False)
+                step_on_stream(nxt + i, workspaces[0], exchange=False)
                 streams[0].synchronize()
         torch.cuda.synchronize()
         single_stream_ms = 1e3 * (time.perf_counter() - t1) / nlat
@@ -401,6 +407,7 @@ def main():
                                "render %dx%d, %d-camera orbit, views sharded by rank" % (P, W, H, F),
                    "gaussians": P, "width": W, "height": H, "sh_degree": 3, "views_per_step_per_gpu": 1,
                    "vertex_rs": "analytic tables" if args.analytic_rs else "gm_mesh_rs per frame", "hip_streams": nstreams,
+                   "exchange": None if pipe is None else {"steps_per_broadcast": pipe.batch, "bytes_per_step": Vm * 96, "broadcasts": pipe.broadcasts},
                    "emission_policy": Rz.get_default_emission_policy(), "image_only": image_only,
                    "parallelism": "views x%d" % world},
     }
@@ -420,7 +427,7 @@ def main():
         list_tiles = ((gx16 + 1) // 2) * ((gy16 + 1) // 2) if Rz.get_default_emission_policy() == 2 else gx16 * gy16
         with torch.cuda.stream(streams[0]):
             for i in range(nprof):
-                step_on_stream(args.warmup + i, workspaces[0], frame_bufs[0], exchange=False)   # rank 0 only: no collective here
+                step_on_stream(args.warmup + i, workspaces[0], exchange=False)   # rank 0 only: no collective here
         torch.cuda.synchronize()
         lib.gm_profile_enable(0)
         import ctypes as C

@@ -7,6 +7,8 @@ collective inside a frame.  The only exchange steps are
   * broadcast_mesh_state(): per deformation frame, the proxy-mesh state (V1, R, S) = 84 B per vertex
                             (0.63 MB for 7.5k vertices) -- every rank then runs the deform kernel locally,
                             instead of shipping the 36-48 MB deformed cloud.
+  * MeshStatePipe:          the same exchange for a pipelined frame loop: the states of several consecutive frames in one
+                            broadcast, one batch ahead of their use, on a stream of its own.
 Both are torch.distributed broadcasts: RCCL over xGMI with backend "nccl" on the GPUs, gloo in the CPU tests.
 """
 import torch
@@ -71,6 +73,68 @@ def broadcast_mesh_state(state, src=0):
     if ws > 1:
         _broadcast(state, src)
     return state
+
+
+class MeshStatePipe:
+    """Per-frame mesh states of a frame loop, exchanged in batches, one batch ahead of their use.
+
+    Rank `src` owns the animation: produce(i, out) writes the state of loop step i into `out` (rank src only; on a GPU it
+    enqueues on the current stream).  frame(i) returns the state of step i on every rank.  Steps must be requested in
+    non-decreasing order, by all ranks alike.  The states of `batch` consecutive steps travel in ONE broadcast, issued (on the
+    pipe's own stream) when the batch before it is first used, so the collective and the producer kernels of batch b+1 overlap
+    the rendering of batch b and a frame costs 1/batch of a collective.  The only wait is on the host - for an event recorded
+    a whole batch earlier - so the render streams carry no cross-stream dependency.  batch = 1 is a broadcast per frame (an
+    interactive editor: no look-ahead).
+
+    frames_in_flight bounds how many steps after frame(i) the device may still be reading the state of step i (the caller's
+    pipelining depth); a slot is overwritten only after that many further steps have been requested."""
+
+    def __init__(self, produce, frame_shape, batch, device, src=0, frames_in_flight=1, dtype=torch.float32):
+        self.produce, self.batch, self.src = produce, max(1, int(batch)), src
+        self.rank, self.ws = world()
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.slots = -(-int(frames_in_flight) // self.batch) + 2          # in use + being filled + still read by frames in flight
+        self.bufs = [torch.empty((self.batch,) + tuple(frame_shape), dtype=dtype, device=self.device) for _ in range(self.slots)]
+        self.stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self.ready = {}                                                   # batch index -> event (None on the CPU)
+        self.last = None
+        self.broadcasts = 0
+
+    def _issue(self, b):
+        buf = self.bufs[b % self.slots]
+
+        def fill():
+            if self.rank == self.src:
+                for j in range(self.batch):
+                    self.produce(b * self.batch + j, buf[j])
+            if self.ws > 1:
+                _broadcast(buf, self.src)
+                self.broadcasts += 1
+        if self.cuda:
+            with torch.cuda.stream(self.stream):
+                fill()
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+            self.ready[b] = ev
+        else:
+            fill()
+            self.ready[b] = None
+
+    def frame(self, i):
+        b, j = divmod(i, self.batch)
+        if self.last is not None and b < self.last:
+            raise ValueError("MeshStatePipe: steps must be requested in non-decreasing order")
+        if b not in self.ready:
+            self._issue(b)
+        if b + 1 not in self.ready:
+            self._issue(b + 1)                                            # one batch ahead
+        if self.ready[b] is not None:
+            self.ready[b].synchronize()                                   # host-side; recorded a batch ago, normally long complete
+        for k in [k for k in self.ready if k < b]:
+            del self.ready[k]
+        self.last = b
+        return self.bufs[b % self.slots][j]
 
 
 def unpack_mesh_state(state):

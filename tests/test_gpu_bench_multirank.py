@@ -1,6 +1,6 @@
 """-m gpu: bench.py's N>1 branch executed for real - two ranks launched by torch.distributed.run on the one GPU of the test
 box (GM_BENCH_SHARE_DEVICE=1, gloo instead of RCCL, which refuses two ranks on one device) on the HIP path: scene broadcast,
-per-frame mesh-state broadcast inside the multi-stream loop, view sharding, max-over-ranks timing, one JSON line from rank 0.
+mesh-state broadcasts (batched, one batch ahead: multiview.MeshStatePipe) inside the multi-stream loop, view sharding, max-over-ranks timing, one JSON line from rank 0.
 Each rank must have rendered ITS OWN view of the frame: the images equal a single-process render of those views bit for bit."""
 import json
 import os
@@ -21,19 +21,22 @@ def _free_port():
     return p
 
 
-def test_bench_two_ranks_render_their_own_views(tmp_path):
+@pytest.mark.parametrize("batch", [8, 1, 3])
+def test_bench_two_ranks_render_their_own_views(tmp_path, batch):
     P, W, H, F, steps, warm = 20000, 320, 200, 8, 4, 2
     env = dict(os.environ, GM_BENCH_SHARE_DEVICE="1", GM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", str(warm),
            "--gaussians", str(P), "--width", str(W), "--height", str(H), "--cameras", str(F), "--check-dir", str(tmp_path),
-           "--no-cpu-baseline", "--no-fwd-bwd"]
+           "--no-cpu-baseline", "--no-fwd-bwd", "--exchange-batch", str(batch)]
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == steps and out["scaling"] == "weak" and out["value"] > 0
+    ex = out["config"]["exchange"]                                      # mesh tables: `batch` loop steps per broadcast, one batch ahead
+    assert ex["steps_per_broadcast"] == batch and ex["broadcasts"] >= (3 * F + warm + steps) // batch
     assert abs(out["value"] - 2 * steps / (out["ms_per_step"] * 1e-3 * steps)) < 1e-6 * out["value"]        # frames of both ranks / max time
     # single-process render of the same frame for each rank's view
     sys.path.insert(0, ROOT)

@@ -89,3 +89,50 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     for k in s:
         assert np.array_equal(both[k], s[k]), k
         assert s[k].std() > 0                                    # something was actually rendered
+
+
+def _pipe_worker(rank, world, port, out_dir, batch, in_flight):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from gaussianmesh_amd import multiview
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    produced = []
+
+    def produce(i, out):                                        # rank 0 only: the state of loop step i
+        assert rank == 0
+        produced.append(i)
+        out.copy_(torch.full((5, 3), float(i)) + torch.arange(15, dtype=torch.float32).view(5, 3) / 100)
+
+    pipe = multiview.MeshStatePipe(produce, (5, 3), batch, "cpu", src=0, frames_in_flight=in_flight)
+    held = []                                                   # states a pipelined caller would still be reading
+    got = []
+    for i in range(-7, 30):                                     # (bench.py's loop starts below zero)
+        st = pipe.frame(i)
+        held.append((i, st))
+        held = held[-in_flight:]
+        for k, h in held:                                       # nothing in flight has been overwritten by a later batch
+            assert float(h[0, 0]) == float(k), (i, k, float(h[0, 0]))
+        got.append(st.clone())
+    with pytest.raises(ValueError):
+        pipe.frame(-7 - 2 * batch)                              # going back is refused
+    np.savez(os.path.join(out_dir, "pipe%d.npz" % rank), got=torch.stack(got).numpy(), broadcasts=pipe.broadcasts,
+             produced=np.array(produced, dtype=np.int64), slots=pipe.slots)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("batch,in_flight", [(8, 8), (1, 3), (3, 8)])
+def test_mesh_state_pipe_two_ranks(tmp_path, batch, in_flight):
+    """MeshStatePipe: every rank sees the state rank 0 produced for each step, in order, one broadcast per `batch` steps,
+    and a slot is not reused while a caller `in_flight` steps deep could still read it."""
+    mp.spawn(_pipe_worker, args=(2, _free_port(), str(tmp_path), batch, in_flight), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "pipe0.npz"), np.load(tmp_path / "pipe1.npz")
+    want = np.stack([np.full((5, 3), float(i), np.float32) + np.arange(15, dtype=np.float32).reshape(5, 3) / 100 for i in range(-7, 30)])
+    assert np.array_equal(r0["got"], want) and np.array_equal(r1["got"], want)
+    nb = int(r0["broadcasts"])
+    assert nb == int(r1["broadcasts"]) and nb == len(set(i // batch for i in range(-7, 30))) + 1       # (+1: the batch issued ahead)
+    assert len(r1["produced"]) == 0 and list(r0["produced"]) == sorted(r0["produced"]) and len(r0["produced"]) == nb * batch
+    assert int(r0["slots"]) == -(-in_flight // batch) + 2
