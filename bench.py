@@ -101,7 +101,8 @@ def run_c5(args):
     random target.  One JSON line: ms per iteration, peak device memory, instance counts."""
     import torch
     from gaussianmesh_amd import rasterizer as Rz, scenes
-    from gaussianmesh_amd.renderer import Camera, MeshBoundGaussians
+    from gaussianmesh_amd.renderer import Camera, MeshBoundGaussians, set_work_hints
+    set_work_hints(not args.no_work_hint)        # (per-camera work hints of the forward blend's dispatch order)
     from gaussianmesh_amd.train import FrozenGaussians, Trainer
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     dev = torch.device("cuda", 0)
@@ -180,6 +181,8 @@ def main():
                     "camera index) as <dir>/rank<r>.npz: lets a test verify that each rank rendered its own views")
     ap.add_argument("--analytic-rs", action="store_true", help="take the per-vertex (R, S) of every animation frame from the analytic "
                     "deformation (precomputed tables) instead of computing them from the deformed mesh inside the frame (gm_mesh_rs)")
+    ap.add_argument("--no-work-hint", action="store_true", help="dispatch the blend's tiles by list length instead of by what they cost "
+                    "in recent frames (gm_forward_1_geom's work_hint)")
     ap.add_argument("--exchange-batch", type=int, default=8, help="N > 1: loop steps whose mesh tables travel in one broadcast "
                     "(1 = a collective per frame)")
     ap.add_argument("--backward-state", action="store_true", help="have the blend also write the per-pixel final transmittance / "
@@ -256,6 +259,8 @@ def main():
     workspaces = [Rz.RasterWorkspace(growth=1.5) for _ in range(nws)]
     torch.cuda.synchronize()
 
+    # one work-hint buffer for the view stream of this rank: consecutive frames are neighbouring cameras of the orbit
+    hint = None if args.no_work_hint else Rz.new_work_hint(W, H, dev)
     pending = {}
     unchecked = []
     stats["overflows"] = 0
@@ -274,12 +279,12 @@ def main():
         ok, nr = h.check()
         if not ok:                              # instance count outgrew the binning capacity: render that frame again, exactly
             stats["overflows"] += 1
-            nr = h.finish(image_only=image_only)[0]
+            nr = h.finish(image_only=image_only, work_hint=hint)[0]
         stats["R"] = nr
         stats["radii"] = h.radii
 
     def finish(h):
-        out = h.finish(sync_free=not args.exact_count, image_only=image_only)
+        out = h.finish(sync_free=not args.exact_count, image_only=image_only, work_hint=hint)
         stats["last_image"] = out[1]
         unchecked.append(h)
         while len(unchecked) > lag:
@@ -317,7 +322,7 @@ def main():
         if not args.unfused:                     # same path, completed at once (per-stage timing pass)
             nr, color, radii, _, _, _ = Rz.forward_deformed_begin(bg, g["tri"], g["weights"], packed, g["cov"], g["pos"], g["shs"], g["opac"],
                                                                   c["view"], c["proj"], c["tanx"], c["tany"], H, W, 3, c["campos"], False,
-                                                                  workspace=workspace).finish(image_only=image_only)
+                                                                  workspace=workspace).finish(image_only=image_only, work_hint=hint)
             stats["R"] = nr
             stats["radii"] = radii
             return color
@@ -408,7 +413,7 @@ def main():
                    "gaussians": P, "width": W, "height": H, "sh_degree": 3, "views_per_step_per_gpu": 1,
                    "vertex_rs": "analytic tables" if args.analytic_rs else "gm_mesh_rs per frame", "hip_streams": nstreams,
                    "exchange": None if pipe is None else {"steps_per_broadcast": pipe.batch, "bytes_per_step": Vm * 96, "broadcasts": pipe.broadcasts},
-                   "emission_policy": Rz.get_default_emission_policy(), "image_only": image_only,
+                   "emission_policy": Rz.get_default_emission_policy(), "image_only": image_only, "work_hint": hint is not None,
                    "parallelism": "views x%d" % world},
     }
     if repeats:
@@ -461,7 +466,7 @@ def main():
         from gaussianmesh_amd import GaussianRasterizer, GaussianRasterizationSettings
         c = cam_t[0]
         rs = GaussianRasterizationSettings(H, W, c["tanx"], c["tany"], torch.zeros(3, device=dev), 1.0, c["view"], c["proj"], 3,
-                                           c["campos"], False, False)
+                                           c["campos"], False, False, None if args.no_work_hint else Rz.new_work_hint(W, H, dev))
         leaves = [g[k].clone().requires_grad_(True) for k in ("pos", "opac", "shs", "scales", "rots")]
         m2d = torch.zeros_like(leaves[0], requires_grad=True)
         wgt = torch.randn((3, H, W), device=dev)
@@ -529,7 +534,7 @@ def main():
         cam2 = _sc.orbit_camera(3, 64, W, H)
         t2 = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)
         rs2 = GaussianRasterizationSettings(H, W, cam2["tanx"], cam2["tany"], torch.zeros(3, device=dev), 1.0, t2(cam2["view"]), t2(cam2["proj"]),
-                                            3, t2(cam2["campos"]), False, False)
+                                            3, t2(cam2["campos"]), False, False, None if args.no_work_hint else Rz.new_work_hint(W, H, dev))
         rast2 = GaussianRasterizer(rs2)
         lv = [t2(c2[k]).requires_grad_(True) for k in ("means", "opac", "shs", "scales", "rots")]
         m2 = torch.zeros_like(lv[0], requires_grad=True)

@@ -22,6 +22,7 @@ SIGNATURES = {
     "gm_last_error": (C.c_char_p, []),
     "gm_geom_bytes": (sz, [i32]),
     "gm_image_bytes": (sz, [i32, i32]),
+    "gm_work_hint_bytes": (sz, [i32, i32]),
     "gm_binning_bytes": (sz, [i64]),
     "gm_forward_0": (i32, [vp, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, f32, f32, i32,
                            vp, i32, vp, C.POINTER(i32)]),
@@ -45,7 +46,7 @@ SIGNATURES = {
     "gm_pack_mesh_state": (i32, [i32, vp, vp, vp, vp]),
     "gm_forward_0_deformed_async": (i32, [i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp,
                                           i32, vp, vp, vp]),
-    "gm_forward_1_geom": (i32, [i32, vp, vp, vp, i32, i32, i64, vp, i32, i32, vp, i32, vp, vp, i32]),
+    "gm_forward_1_geom": (i32, [i32, vp, vp, vp, i32, i32, i64, vp, i32, i32, vp, i32, vp, vp, i32, vp]),
     "gm_forward_status_async": (i32, [vp, i32, vp, vp]),
     "gm_deform_shade_packed": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gm_cov_to_scale_rot": (i32, [i32, vp, vp, vp, vp]),

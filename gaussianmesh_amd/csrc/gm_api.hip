@@ -108,6 +108,10 @@ size_t gm_image_bytes(int W, int H) {
   ImageState s = ImageState::from(nullptr, W > 0 ? W : 1, H > 0 ? H : 1);
   return (size_t)s.end + 256;
 }
+size_t gm_work_hint_bytes(int W, int H) {          // frame counter + one word per list tile (at most one per 16-px tile)
+  const size_t T = (size_t)((W > 0 ? W : 1) + GM_TILE - 1) / GM_TILE * (size_t)(((H > 0 ? H : 1) + GM_TILE - 1) / GM_TILE);
+  return 4 * (T + 1);
+}
 size_t gm_binning_bytes(int64_t R) {
   BinningState b = BinningState::from(nullptr, (size_t)(R > 0 ? R : 1));
   return (size_t)b.end + 256;
@@ -175,7 +179,7 @@ int gm_forward_0_deformed_async(int emission_policy, void* geom_buffer, int P, i
 
 int gm_forward_1_geom(int emission_policy, void* geom_buffer, void* binning_buffer, void* image_buffer, int P, int num_rendered,
                       int64_t binning_capacity, const float* background, int width, int height, float* out_color, int debug, void* stream,
-                      int* status_host, int flags) {
+                      int* status_host, int flags, unsigned int* work_hint) {
   if (int rc = check_policy(emission_policy)) return rc;
   if (flags & ~GM_FWD_IMAGE_ONLY) { set_error("unknown flags 0x%x", flags); return GM_ERR_INVALID_ARG; }
   if (P < 0 || width <= 0 || height <= 0) { set_error("invalid sizes P=%d W=%d H=%d", P, width, height); return GM_ERR_INVALID_ARG; }
@@ -195,20 +199,20 @@ int gm_forward_1_geom(int emission_policy, void* geom_buffer, void* binning_buff
   bool order_done = false;
   if (P > 0 && cap > 0) {
     if (int rc = launch_duplicate(g, b, P, width, height, mode, (size_t)cap, debug, st)) return rc;
-    if (int rc = launch_tile_sort(g, b, img, (size_t)cap, device_count ? g.counters + GM_CNT_RENDERED : nullptr, tiles, &order_done, debug, st)) return rc;
+    if (int rc = launch_tile_sort(g, b, img, (size_t)cap, device_count ? g.counters + GM_CNT_RENDERED : nullptr, tiles, &order_done, work_hint, debug, st)) return rc;
     if (slot == 0)
       if (int rc = launch_tile_ranges(g, b, slot, img, (int)cap, device_count ? g.counters + GM_CNT_RENDERED : nullptr, tiles, debug, st)) return rc;
   } else {
     GM_HIP(hipMemsetAsync(img.ranges, 0, sizeof(uint2) * (size_t)tiles, st));
   }
   if (!order_done)
-    if (int rc = launch_tile_order(img, tiles, debug, st)) return rc;
+    if (int rc = launch_tile_order(img, tiles, work_hint, debug, st)) return rc;
   if (status_host && P == 0) {                       // no geometry state to report from
     status_host[0] = 0; status_host[1] = 0; status_host[2] = mode; status_host[3] = 0;
     status_host = nullptr;
   }
   return launch_render_fwd(g, b.pairs[slot], img, width, height, mode, background, out_color, status_host, (flags & GM_FWD_IMAGE_ONLY) != 0,
-                           debug, st);
+                           work_hint, debug, st);
 }
 
 int gm_forward_status_async(void* geom_buffer, int P, int* status_host, void* stream) {
@@ -254,7 +258,7 @@ int gm_forward_1(void* geom_buffer, void* binning_buffer, void* image_buffer, in
   (void)radii;
   if (num_rendered < 0) { set_error("negative num_rendered"); return GM_ERR_INVALID_ARG; }
   return gm_forward_1_geom(GM_POLICY_DEFAULT, geom_buffer, binning_buffer, image_buffer, P, num_rendered, 0, background, width, height, out_color,
-                           debug, stream, nullptr, 0);
+                           debug, stream, nullptr, 0, nullptr);
 }
 
 int gm_backward_p(int emission_policy, int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,

@@ -363,12 +363,13 @@ __global__ __launch_bounds__(WAVES * 64, 4) void bk_scatter_kernel(const void* _
                                                                  uint32_t* __restrict__ zero_acc, uint32_t zero_words,
                                                                  const uint2* __restrict__ ord_ranges, int ord_tiles,
                                                                  uint32_t* __restrict__ ord_out, const uint32_t* __restrict__ dmap,
-                                                                 const uint32_t* __restrict__ counters) {
+                                                                 const uint32_t* __restrict__ counters, uint32_t* __restrict__ ord_hint,
+                                                                 uint32_t* __restrict__ ord_epoch) {
   constexpr int ND = 1 << DB, THREADS = WAVES * 64, TILE = WAVES * BK_ROUNDS * 64;
   if (!MSD && ord_out && blockIdx.x == gridDim.x - 1) {      // the launch's extra workgroup: dispatch order of the blend kernels
     __shared__ uint32_t o_cnt[256];                          // from the ranges the scan kernel has just published
     __shared__ uint32_t o_wsum[WAVES];
-    tile_order_block<THREADS>(ord_ranges, ord_tiles, ord_out, o_cnt, o_wsum);
+    tile_order_block<THREADS>(ord_ranges, ord_tiles, ord_out, o_cnt, o_wsum, ord_hint, ord_epoch);
     return;
   }
   // wcnt: per-wave running digit counts (<= 1024) -> per-wave exclusive offsets (< TILE <= 16384); once every key knows its
@@ -757,7 +758,7 @@ int launch_depth_order(GeomState& g, int P, int debug, hipStream_t s, int* num_r
                      g.acc, g.bucket_start, g.counters, nullptr, 0u);
   GM_LAUNCH_CHECK(debug, s);
   hipLaunchKernelGGL((bk_scatter_kernel<true, DB, WAVES>), dim3(nblk), dim3(WAVES * 64), 0, s, g.depth_key, g.dpairs[1], (uint32_t)P, nullptr, ds,
-                     g.hist, nullptr, 0u, nullptr, 0, nullptr, g.dmap, g.counters);
+                     g.hist, nullptr, 0u, nullptr, 0, nullptr, g.dmap, g.counters, nullptr, nullptr);
   GM_LAUNCH_CHECK(debug, s);
   hipLaunchKernelGGL(bucket_sort_kernel, dim3(1 << DB), dim3(BK_THREADS), 0, s, g.counters, g.bmap, g.bucket_start, g.dpairs[1], g.dpairs[0], g.order,
                      g.tiles_touched, g.bin, g.bin_sorted, g.chunk_inst, g_bucket_trace);
@@ -768,7 +769,7 @@ int launch_depth_order(GeomState& g, int P, int debug, hipStream_t s, int* num_r
 // One stable pass over the pair stream b.pairs[from] -> b.pairs[from ^ 1].  b.acc must be zero on entry.
 template <int DB, int WAVES>
 static int tile_pass(BinningState& b, GeomState& g, int from, uint32_t n, const uint32_t* n_dev, DigitSpec ds, uint2* ranges, uint32_t nranges,
-                     bool zero_acc_after, uint32_t* order_out, int debug, hipStream_t s) {
+                     bool zero_acc_after, uint32_t* order_out, uint32_t* hint, uint32_t* epoch, int debug, hipStream_t s) {
   constexpr uint32_t TILE = WAVES * BK_ROUNDS * 64;
   const uint32_t nblk = (n + TILE - 1) / TILE;
   const uint32_t nchunks = (nblk + BK_CHUNK - 1) / BK_CHUNK;
@@ -780,7 +781,7 @@ static int tile_pass(BinningState& b, GeomState& g, int from, uint32_t n, const 
   GM_LAUNCH_CHECK(debug, s);
   hipLaunchKernelGGL((bk_scatter_kernel<false, DB, WAVES>), dim3(nblk + (order_out ? 1u : 0u)), dim3(WAVES * 64), 0, s, b.pairs[from],
                      b.pairs[from ^ 1], n, n_dev, ds, b.hist, zero_acc_after ? b.acc : nullptr, (uint32_t)bk_acc_words(n), ranges,
-                     (int)nranges, order_out, nullptr, nullptr);
+                     (int)nranges, order_out, nullptr, nullptr, hint, epoch);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }
@@ -788,8 +789,8 @@ static int tile_pass(BinningState& b, GeomState& g, int from, uint32_t n, const 
 // Tile sort of the instance stream b.pairs[0] (n instances; n_dev != nullptr: the count is read on the device and n is the
 // capacity).  tiles <= 2048: one 11-bit pass, result in pairs[1], ranges written by the scan.  Otherwise two 8-bit
 // passes, result in pairs[0], ranges by tile_ranges_kernel (caller).  duplicate_kernel has zeroed b.acc.
-int launch_tile_sort(GeomState& g, BinningState& b, ImageState& img, size_t n, const uint32_t* n_dev, int tiles, bool* order_done, int debug,
-                     hipStream_t s) {
+int launch_tile_sort(GeomState& g, BinningState& b, ImageState& img, size_t n, const uint32_t* n_dev, int tiles, bool* order_done,
+                     uint32_t* work_hint, int debug, hipStream_t s) {
   StageScope sc(ST_TILE_SORT, s);
   *order_done = false;
   if (n == 0) {
@@ -802,12 +803,12 @@ int launch_tile_sort(GeomState& g, BinningState& b, ImageState& img, size_t n, c
     *order_done = true;                 // the scatter launch carries the dispatch-order workgroup
     if (n <= (size_t(1) << 19))
       return tile_pass<GM_BUCKET_BITS, 4>(b, g, 0, (uint32_t)n, n_dev, DigitSpec{0u, 0u, (1u << GM_BUCKET_BITS) - 1u}, img.ranges, (uint32_t)tiles,
-                                          false, img.tile_order, debug, s);
+                                          false, img.tile_order, work_hint, img.epoch, debug, s);
     return tile_pass<GM_BUCKET_BITS, GM_TILE_PASS_WAVES>(b, g, 0, (uint32_t)n, n_dev, DigitSpec{0u, 0u, (1u << GM_BUCKET_BITS) - 1u}, img.ranges, (uint32_t)tiles,
-                                         false, img.tile_order, debug, s);
+                                         false, img.tile_order, work_hint, img.epoch, debug, s);
   }
-  if (int rc = tile_pass<8, 4>(b, g, 0, (uint32_t)n, n_dev, DigitSpec{0u, 0u, 0xFFu}, nullptr, 0u, true, nullptr, debug, s)) return rc;
-  return tile_pass<8, 4>(b, g, 1, (uint32_t)n, n_dev, DigitSpec{0u, 8u, 0xFFu}, nullptr, 0u, false, nullptr, debug, s);
+  if (int rc = tile_pass<8, 4>(b, g, 0, (uint32_t)n, n_dev, DigitSpec{0u, 0u, 0xFFu}, nullptr, 0u, true, nullptr, nullptr, nullptr, debug, s)) return rc;
+  return tile_pass<8, 4>(b, g, 1, (uint32_t)n, n_dev, DigitSpec{0u, 8u, 0xFFu}, nullptr, 0u, false, nullptr, nullptr, nullptr, debug, s);
 }
 
 }  // namespace gm

@@ -183,6 +183,7 @@ struct ImageState {             // per-pixel / per-tile state
   uint32_t* tile_order;         // [tiles] list tiles by descending list length (the forward blend's dispatch order)
   uint32_t* tile_work;          // [tiles] deepest contributor (max n_contrib) among the pixels of a list tile's area
   uint32_t* tile_order_bwd;     // [tiles] list tiles by descending tile_work (the backward blend's dispatch order)
+  uint32_t* epoch;              // [1] frame number of the work hint this frame's blend tags its entries with (gm_tile_order.h)
   static ImageState from(void* buf, int W, int H) {
     char* p = reinterpret_cast<char*>(buf);
     const size_t N = (size_t)W * H;
@@ -194,6 +195,7 @@ struct ImageState {             // per-pixel / per-tile state
     s.tile_order = carve<uint32_t>(p, T);
     s.tile_work = carve<uint32_t>(p, T);
     s.tile_order_bwd = carve<uint32_t>(p, T);
+    s.epoch = carve<uint32_t>(p, 1);
     s.end = p;
     return s;
   }
@@ -276,12 +278,13 @@ int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], uint32_t* hist, uint3
 int launch_depth_order(GeomState& g, int P, int debug, hipStream_t s, int* num_rendered_host, hipEvent_t count_event);
 int launch_arm_counters(GeomState& g, hipStream_t s);                               // zero slots + counters (first launch of a forward)
 int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, int tile_cull, size_t capacity, int debug, hipStream_t s);
-int launch_tile_sort(GeomState& g, BinningState& b, ImageState& img, size_t n, const uint32_t* n_dev, int tiles, bool* order_done, int debug,
-                     hipStream_t s);      // order_done: img.tile_order was written too (one-pass case)
+int launch_tile_sort(GeomState& g, BinningState& b, ImageState& img, size_t n, const uint32_t* n_dev, int tiles, bool* order_done,
+                     uint32_t* work_hint, int debug, hipStream_t s);      // order_done: img.tile_order was written too (one-pass case)
 int launch_tile_ranges(const GeomState& g, BinningState& b, int slot, ImageState& img, int R, const uint32_t* R_dev, int tiles, int debug, hipStream_t s);
-int launch_tile_order(ImageState& img, int tiles, int debug, hipStream_t s);          // ranges -> tile_order
+int launch_tile_order(ImageState& img, int tiles, uint32_t* work_hint, int debug, hipStream_t s);          // ranges -> tile_order
 int launch_render_fwd(const GeomState& g, const uint2* pairs, ImageState& img, int W, int H, int mode,
-                      const float* background, float* out_color, int* status_host, bool image_only, int debug, hipStream_t s);
+                      const float* background, float* out_color, int* status_host, bool image_only, uint32_t* work_hint, int debug,
+                      hipStream_t s);
 int launch_render_bwd(const GeomState& g, const uint2* pairs, ImageState& img, int W, int H, int mode,
                       const float* background, const float* dL_dpix, int debug, hipStream_t s);   // accumulates into g.grad_acc
 

@@ -61,10 +61,11 @@ struct TileMap {
 };
 
 // Dispatch order of the blend kernels (gm_tile_order.h) as a launch of its own: only when the tile pass did not produce it.
-__global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restrict__ ranges, int tiles, uint32_t* __restrict__ order) {
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restrict__ ranges, int tiles, uint32_t* __restrict__ order,
+                                                          uint32_t* __restrict__ hint, uint32_t* __restrict__ epoch) {
   __shared__ uint32_t cnt[256];
   __shared__ uint32_t wsum[16];
-  tile_order_block<1024>(ranges, tiles, order, cnt, wsum);
+  tile_order_block<1024>(ranges, tiles, order, cnt, wsum, hint, epoch);
 }
 
 // Dispatch order of the BACKWARD blend.  What a quadrant's wave has to walk is known exactly after the forward: the list
@@ -94,9 +95,9 @@ __global__ __launch_bounds__(1024) void tile_order_work_kernel(const uint32_t* _
   tile_order_by<1024>([&](int t) { return work[t]; }, tiles, order, cnt, wsum);
 }
 
-int launch_tile_order(ImageState& img, int tiles, int debug, hipStream_t s) {
+int launch_tile_order(ImageState& img, int tiles, uint32_t* work_hint, int debug, hipStream_t s) {
   StageScope sc(ST_RANGES, s);
-  hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, img.ranges, tiles, img.tile_order);
+  hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, img.ranges, tiles, img.tile_order, work_hint, img.epoch);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }
@@ -170,7 +171,8 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
                                                                const float* __restrict__ bg, float* __restrict__ out_color,
                                                                float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                                                                unsigned long long* __restrict__ trace,
-                                                               const uint32_t* __restrict__ counters, int* __restrict__ status_host) {
+                                                               const uint32_t* __restrict__ counters, int* __restrict__ status_host,
+                                                               uint32_t* __restrict__ hint, const uint32_t* __restrict__ epoch) {
   // The four quadrant waves of a tile are independent.  As one-wave workgroups they are placed and retired one by one: a
   // tile whose quadrants differ in length does not hold four wave slots (one per SIMD) until its longest wave is done.
   // Workgroup ids 8 apart still share an XCD: id = ((tile slot j) * 4 + quadrant) * 8 + xcd.
@@ -198,6 +200,7 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
   v2f Crg = {0.f, 0.f};
   const v2f pix = {pixx, pixy};
   uint32_t last = 0;
+  int work = 0;                                                               // entries this wave evaluated (wave-uniform): the work hint
   int tr_iters = 0, tr_cand = 0, tr_surv = 0, tr_useful = 0, tr_lanes = 0;    // (tools/wave_trace.py)
   int tr_tb = 0, tr_lr = 0, tr_q4 = 0, tr_steps = 0;                           // sum over batches of max(list length) under 2-way / 4-way pixel splits
   if (n > 0) {
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
         // per-survivor exponent is e = dx (a' dx + b' dy) + (c' dy) dy = power * log2(e): 5 instructions instead of 9
         const unsigned long long kb = __ballot(keep);
         const int ns = __popcll(kb);
-        tr_cand += n0; tr_surv += ns;
+        tr_cand += n0; tr_surv += ns; work += ns;
         if (lane < 4) {                             // padding behind the last survivor: opacity 0
           L.a[ns + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
           L.b[ns + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -330,6 +333,8 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
       if (!step(g2, n2, n0, g1, n1)) break;
     }
   }
+  if (hint && work > 0 && lane == 0)                                     // (gm_tile_order.h: the next frames' dispatch order)
+    atomicMax(&hint[1 + parent], (epoch[0] << 20) | min((uint32_t)work, GM_HINT_WORK_MASK));
   if (inside) {
     const size_t HW = (size_t)H * W, pid = (size_t)W * py + px;
     T = __builtin_fabsf(T);
@@ -351,7 +356,8 @@ static unsigned long long* g_render_trace = nullptr;      // debugging aid (tool
 extern "C" void gm_debug_render_trace(void* buffer) { g_render_trace = reinterpret_cast<unsigned long long*>(buffer); }
 
 int launch_render_fwd(const GeomState& g, const uint2* pairs, ImageState& img, int W, int H, int mode,
-                      const float* background, float* out_color, int* status_host, bool image_only, int debug, hipStream_t s) {
+                      const float* background, float* out_color, int* status_host, bool image_only, uint32_t* work_hint, int debug,
+                      hipStream_t s) {
   StageScope sc(ST_RENDER, s);
   const TileGrid tg(W, H, mode);
   const TileMap tm{tg.gx, tg.gy, tg.pgx, tg.pgy, tg.s, img.tile_order};
@@ -359,13 +365,13 @@ int launch_render_fwd(const GeomState& g, const uint2* pairs, ImageState& img, i
     const dim3 grid(tm.blocks() * (4 / GM_RENDER_FWD_WPW)), block(64 * GM_RENDER_FWD_WPW);
     if (g_render_trace)
       hipLaunchKernelGGL((render_fwd_kernel<true, true>), grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
-                         background, out_color, img.final_T, img.n_contrib, g_render_trace, g.counters, status_host);
+                         background, out_color, img.final_T, img.n_contrib, g_render_trace, g.counters, status_host, work_hint, img.epoch);
     else if (image_only)
       hipLaunchKernelGGL((render_fwd_kernel<false, false>), grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
-                         background, out_color, img.final_T, img.n_contrib, nullptr, g.counters, status_host);
+                         background, out_color, img.final_T, img.n_contrib, nullptr, g.counters, status_host, work_hint, img.epoch);
     else
       hipLaunchKernelGGL((render_fwd_kernel<false, true>), grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
-                         background, out_color, img.final_T, img.n_contrib, nullptr, g.counters, status_host);
+                         background, out_color, img.final_T, img.n_contrib, nullptr, g.counters, status_host, work_hint, img.epoch);
   } else if (status_host) {
     GM_HIP(hipMemcpyAsync(status_host, g.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   }

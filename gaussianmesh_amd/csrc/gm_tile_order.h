@@ -35,10 +35,41 @@ __device__ __forceinline__ void tile_order_by(Key key, int tiles, uint32_t* __re
   for (int t = threadIdx.x; t < tiles; t += THREADS) order[atomicAdd(&cnt[bucket(t)], 1u)] = (uint32_t)t;
 }
 
+// Work hint (optional, gm_forward_1_geom's work_hint): list length is a poor predictor of a tile's blend time - a 12 k-entry
+// list under an opaque surface saturates after ~200 entries while a 1.5 k-entry silhouette list is walked to its end - and
+// the launch ends on the heavy tiles that started late.  What a tile cost in a RECENT frame of the same view stream is a
+// good one.  hint[0] counts frames; hint[1 + t] = (frame & 0xFFF) << 20 | work of list tile t, written by the forward blend
+// with atomicMax (work = entries evaluated by the busiest of the tile's waves).  Entries older than GM_HINT_MAX_AGE frames are
+// ignored and cleared.  Frames in flight on other streams read and write the same buffer concurrently: whatever they see only
+// moves work in time.
+#define GM_HINT_MAX_AGE 64u
+#define GM_HINT_WORK_MASK 0xFFFFFu
 template <int THREADS>
 __device__ __forceinline__ void tile_order_block(const uint2* __restrict__ ranges, int tiles, uint32_t* __restrict__ order,
-                                                 uint32_t* cnt /*[256] shared*/, uint32_t* wsum /*[THREADS / 64] shared*/) {
-  tile_order_by<THREADS>([&](int t) { const uint2 r = ranges[t]; return r.y - r.x; }, tiles, order, cnt, wsum);
+                                                 uint32_t* cnt /*[256] shared*/, uint32_t* wsum /*[THREADS / 64] shared*/,
+                                                 uint32_t* __restrict__ hint = nullptr, uint32_t* __restrict__ epoch_out = nullptr) {
+  if (!hint) {
+    tile_order_by<THREADS>([&](int t) { const uint2 r = ranges[t]; return r.y - r.x; }, tiles, order, cnt, wsum);
+    return;
+  }
+  if (threadIdx.x == 0) wsum[0] = (atomicAdd(&hint[0], 1u) + 1u) & 0xFFFu;
+  __syncthreads();
+  const uint32_t now = wsum[0];
+  __syncthreads();
+  if (threadIdx.x == 0) *epoch_out = now;                    // the blend kernel of this frame tags its entries with it
+  for (int t = threadIdx.x; t < tiles; t += THREADS) {       // forget what is too old to mean anything
+    const uint32_t v = hint[1 + t];
+    if (v != 0u && ((now - (v >> 20)) & 0xFFFu) > GM_HINT_MAX_AGE) hint[1 + t] = 0u;
+  }
+  __syncthreads();
+  // key: 8 x (work + 1) for a tile with a hint (bucket = work / 4, saturating at ~1000 entries); min(length, 2040) without one
+  // (a tile that has just come into view: ranked like a tile of length / 8 entries of work)
+  tile_order_by<THREADS>([&](int t) -> uint32_t {
+    const uint2 r = ranges[t];
+    const uint32_t len = r.y - r.x, v = hint[1 + t];
+    if (len == 0u) return 0u;
+    return v != 0u ? min(((v & GM_HINT_WORK_MASK) + 1u) << 3, 8191u) : min(len, 2040u);
+  }, tiles, order, cnt, wsum);
 }
 
 }  // namespace gm

@@ -260,4 +260,7 @@ class SingleObjectDeform:
                                       self.gaussian_feature, self.gaussian_o, c.world_view_transform, c.full_proj_transform,
                                       math.tan(c.FoVx * 0.5), math.tan(c.FoVy * 0.5), c.image_height, c.image_width, 3, c.camera_center,
                                       workspace=workspace)
-        return h if begin_only else h.finish(image_only=True)[1]          # forward-only: no backward state
+        if begin_only:
+            return h
+        from .renderer import camera_work_hint
+        return h.finish(image_only=True, work_hint=camera_work_hint(c, dev))[1]          # forward-only: no backward state

@@ -19,7 +19,7 @@ from . import io as gio
 from .deform import SingleObjectDeform as _TensorObject
 from .deform import barycentric_weights, cov_to_scale_rot, mesh_rs, vertex_face_adjacency
 from .rasterizer import GaussianRasterizationSettings, NewGaussianRasterizer
-from .renderer import Camera, render_deformed
+from .renderer import Camera, camera_work_hint, render_deformed
 
 
 def _covariance(scaling_raw, rotation_raw):
@@ -188,7 +188,7 @@ class SceneVisualTool(ObjectVisualTool):
         new_s, new_q = cov_to_scale_rot(cov)
         rs = GaussianRasterizationSettings(int(c.image_height), int(c.image_width), math.tan(c.FoVx * 0.5), math.tan(c.FoVy * 0.5),
                                            torch.ones(3, device=self.device), 1, c.world_view_transform, c.full_proj_transform, 3,
-                                           c.camera_center, False, False)
+                                           c.camera_center, False, False, camera_work_hint(c, self.device))
         image, _ = NewGaussianRasterizer(rs)(means3D=means3D, means2D=torch.zeros_like(means3D), shs=shs, colors_precomp=None,
                                              opacities=opacity, scales=new_s, rotations=new_q, cov3D_precomp=None)
         return image

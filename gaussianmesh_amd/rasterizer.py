@@ -10,7 +10,7 @@ provided as an alias of forward.
 """
 import ctypes as C
 import os
-from typing import NamedTuple
+from typing import NamedTuple, Optional
 
 import torch
 from torch import nn
@@ -31,6 +31,8 @@ class GaussianRasterizationSettings(NamedTuple):
     campos: torch.Tensor
     prefiltered: bool
     debug: bool
+    work_hint: Optional[torch.Tensor] = None     # extension (new_work_hint()): per-tile cost memory of this camera / view stream
+
 
 
 def _ptr(t):
@@ -114,6 +116,11 @@ class RasterWorkspace:
             self.in_flight = None
 
 
+def new_work_hint(width, height, device):
+    """Zeroed work-hint buffer for PendingForward.finish(work_hint=...) / gm_forward_1_geom: one per view stream."""
+    return torch.zeros((_lib.lib().gm_work_hint_bytes(width, height) // 4,), dtype=torch.int32, device=device)
+
+
 class PendingForward:
     """Handle returned by rasterize_forward_begin() / forward_deformed_begin(): everything up to the instance count is
     enqueued.  finish() waits for the count (one 4-byte pinned-memory read-back, normally long complete), sizes the
@@ -127,20 +134,29 @@ class PendingForward:
         self.result = None
         self.known_count = None
         self.image_only = False
+        self.work_hint = None
 
     def _geom(self, binning, num_rendered, capacity, status=None):
         lib = _lib.lib()
         a = self.args
         _lib.check(lib.gm_forward_1_geom(self.policy, _ptr(self.geom), _ptr(binning), _ptr(self.img), a["P"], num_rendered, capacity,
                                          _ptr(a["bg"]), a["W"], a["H"], _ptr(self.color), a["debug"], self.stream.cuda_stream,
-                                         None if status is None else status.data_ptr(), 1 if self.image_only else 0))
+                                         None if status is None else status.data_ptr(), 1 if self.image_only else 0,
+                                         None if self.work_hint is None else self.work_hint.data_ptr()))
 
-    def finish(self, sync_free=False, capacity=0, image_only=False):
+    def finish(self, sync_free=False, capacity=0, image_only=False, work_hint=None):
         """capacity (sync_free without a workspace): instances the freshly allocated binning buffer shall hold.
         image_only (GM_FWD_IMAGE_ONLY): a frame no backward pass follows - the blend writes the colour image and leaves the
         per-pixel final transmittance / contributor count of the image state alone; the returned img must not be handed
-        to rasterize_backward."""
+        to rasterize_backward.
+        work_hint (new_work_hint()): per-tile cost memory shared by the consecutive frames of one view stream; the blend's
+        dispatch order then follows what tiles cost in recent frames.  Never changes an image."""
         self.image_only = bool(image_only)
+        if work_hint is not None:
+            need = _lib.lib().gm_work_hint_bytes(self.args["W"], self.args["H"])
+            if work_hint.dtype != torch.int32 or not work_hint.is_contiguous() or work_hint.numel() * 4 < need or work_hint.device != self.args["device"]:
+                raise _lib.GmeshError("work_hint: contiguous int32 tensor of gm_work_hint_bytes(W, H) bytes on the frame's device expected")
+        self.work_hint = work_hint
         lib = _lib.lib()
         a = self.args
         device = a["device"]
@@ -470,11 +486,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                                         rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, workspace=ws, emission_policy=policy,
                                         force_M=force_M)
             if cap > 0:
-                num_rendered, color, radii, geom, binning, img = h.finish(sync_free=True, capacity=cap)
+                num_rendered, color, radii, geom, binning, img = h.finish(sync_free=True, capacity=cap, work_hint=rs.work_hint)
                 num_rendered = cap                        # the binning layout is that of the capacity
                 _sync_free["unchecked"].append(h)
             else:
-                num_rendered, color, radii, geom, binning, img = h.finish(image_only=not needs_grad)   # no backward will follow
+                num_rendered, color, radii, geom, binning, img = h.finish(image_only=not needs_grad, work_hint=rs.work_hint)   # image_only: no backward will follow
                 if _sync_free["on"] and needs_grad:
                     key = means3D.device
                     _sync_free["capacity"][key] = max(_sync_free["capacity"].get(key, 0), int(num_rendered * _sync_free["growth"]) + 4096)

@@ -14,7 +14,34 @@ import math
 import torch
 
 from .deform import sh_colors
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, NewGaussianRasterizer
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, NewGaussianRasterizer, new_work_hint
+
+
+_WORK_HINTS = True
+
+
+def set_work_hints(on):
+    """render() / bg_render() keep a work-hint buffer (rasterizer.new_work_hint, 4 bytes per 16-px tile) on every camera object they
+    are called with: the forward blend then dispatches the tiles that were expensive the last time THIS camera was rendered
+    first.  A scheduling aid only - images and gradients do not depend on it.  set_work_hints(False) switches it off."""
+    global _WORK_HINTS
+    _WORK_HINTS = bool(on)
+
+
+def camera_work_hint(cam, device):
+    """The work-hint buffer riding on a camera object (created on first use; None when hints are off or the object takes no
+    attributes)."""
+    if not _WORK_HINTS or torch.device(device).type != "cuda":
+        return None
+    W, H = int(cam.image_width), int(cam.image_height)
+    h = getattr(cam, "_gm_work_hint", None)
+    if h is None or h[0] != (W, H) or h[1].device != torch.device(device):
+        try:
+            h = ((W, H), new_work_hint(W, H, device))
+            cam._gm_work_hint = h
+        except (AttributeError, TypeError):
+            return None
+    return h[1]
 
 
 def _settings(cam, bg_color, scaling_modifier, sh_degree, debug):
@@ -22,7 +49,7 @@ def _settings(cam, bg_color, scaling_modifier, sh_degree, debug):
         image_height=int(cam.image_height), image_width=int(cam.image_width),
         tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=bg_color, scale_modifier=scaling_modifier,
         viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=sh_degree,
-        campos=cam.camera_center, prefiltered=False, debug=debug)
+        campos=cam.camera_center, prefiltered=False, debug=debug, work_hint=camera_work_hint(cam, cam.world_view_transform.device))
 
 
 def strip_symmetric(cov):

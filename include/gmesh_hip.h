@@ -68,6 +68,7 @@ const char* gm_last_error(void);
  * (RAST/rasterizer_impl.h:67-73; python side rasterize_points.py:63-86). */
 size_t gm_geom_bytes(int P);
 size_t gm_image_bytes(int W, int H);
+size_t gm_work_hint_bytes(int W, int H);      /* gm_forward_1_geom's optional work_hint buffer */
 size_t gm_binning_bytes(int64_t num_rendered);
 
 /* Replaces CudaRasterizer::Rasterizer::forward_0 (RAST/rasterizer.h:31-51, rasterizer_impl.cu:338-413):
@@ -216,11 +217,17 @@ int gm_forward_0_deformed_async(int emission_policy, void* geom_buffer, int P, i
  * gm_forward_status_async copies the same four words of the forward that last used geom_buffer, stream-ordered.
  * flags: 0, or GM_FWD_IMAGE_ONLY for a frame no backward pass will follow (the edit / viewer loop): the blend writes out_color
  * only - the per-pixel final transmittance and contributor count in image_buffer (forward.cu:369-370, read by
- * backward.cu:444-447 alone) are left untouched, so gm_backward on that image_buffer is undefined. */
+ * backward.cu:444-447 alone) are left untouched, so gm_backward on that image_buffer is undefined.
+ * work_hint (may be NULL): device buffer of gm_work_hint_bytes(width, height) bytes, zeroed once by the caller and then handed
+ * to the consecutive frames of one view stream (an orbit, an edit session at one resolution and policy).  The blend leaves in
+ * it what each list tile cost; the next frames dispatch the tiles that were expensive first instead of the ones with the
+ * longest lists, which shortens the kernel's tail (list length says little: a long list under an opaque surface saturates
+ * early, a short one on a silhouette is walked to its end).  It only moves work in time: images are bit-identical with and
+ * without it, frames in flight on several streams may share one buffer. */
 #define GM_FWD_IMAGE_ONLY 1
 int gm_forward_1_geom(int emission_policy, void* geom_buffer, void* binning_buffer, void* image_buffer, int P, int num_rendered,
                       int64_t binning_capacity, const float* background, int width, int height, float* out_color, int debug, void* stream,
-                      int* status_host, int flags);
+                      int* status_host, int flags, unsigned int* work_hint);
 int gm_forward_status_async(void* geom_buffer, int P, int* status_host, void* stream);
 
 /* Per-vertex rotation / stretch of a deformed proxy mesh: replaces pyACAP.GetRS(rest vertices, deformed vertices, ...) at

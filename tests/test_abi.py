@@ -46,7 +46,7 @@ def test_argument_validation_happens_before_any_gpu_work():
     assert rc == 1
     rc = l.gm_forward_0_async(7, one, 10, 3, 16, one, 64, 64, one, one, None, one, one, 1.0, one, None, one, one, one, 0.5, 0.5, 0, None, 0, None, None, None)
     assert rc == 1 and b"emission policy" in l.gm_last_error()
-    assert l.gm_forward_1_geom(2, one, one, one, 10, -1, -5, one, 64, 64, one, 0, None, None, 0) == 1          # negative capacity
+    assert l.gm_forward_1_geom(2, one, one, one, 10, -1, -5, one, 64, 64, one, 0, None, None, 0, None) == 1          # negative capacity
     assert l.gm_knn(5, None, None, None, 0, None) == 1
     assert l.gm_sh_colors(5, 4, 16, one, one, None, one, one, None) == 1
 
@@ -82,5 +82,7 @@ def test_operator_argument_rules_match_reference():
             r(m, m, o, shs=sh, scales=s)
         with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
             r(m, m, o, shs=sh, scales=s, rotations=q, cov3D_precomp=torch.ones(4, 6))
-    assert GaussianRasterizationSettings._fields == ("image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier",
-                                                     "viewmatrix", "projmatrix", "sh_degree", "campos", "prefiltered", "debug")
+    # the reference's twelve fields in its order; one optional extension behind them (default None: reference call sites unchanged)
+    assert GaussianRasterizationSettings._fields[:12] == ("image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier",
+                                                          "viewmatrix", "projmatrix", "sh_degree", "campos", "prefiltered", "debug")
+    assert GaussianRasterizationSettings._fields[12:] == ("work_hint",) and rs.work_hint is None

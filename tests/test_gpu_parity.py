@@ -575,6 +575,20 @@ def test_fused_deform_forward_equals_unfused_chain(oracle, N):
     _, color7, *rest = fb(workspace=ws).finish()
     torch.cuda.synchronize()
     assert torch.equal(color7, color0) and not torch.equal(img[:4 * H * W], snapshot[:4 * H * W])
+    # work hint: the blend's dispatch order follows what tiles cost in earlier frames; images never change
+    hint = Rz.new_work_hint(W, H, color0.device)
+    for k in range(4):
+        h = fb(workspace=ws)
+        _, color8, *rest = h.finish(sync_free=bool(k & 1), image_only=bool(k & 2), work_hint=hint)
+        assert h.check()[0]
+        torch.cuda.synchronize()
+        assert torch.equal(color8, color0)
+        hv = hint.cpu().numpy().view(np.uint32)
+        assert int(hv[0]) == k + 1                                         # frames counted
+        entries = hv[1:][hv[1:] != 0]
+        assert entries.size > 0 and set((entries >> 20).tolist()) <= set(range(1, k + 2)) and (entries & 0xFFFFF).max() <= nr0
+    with pytest.raises(Exception):
+        fb(workspace=Rz.RasterWorkspace()).finish(work_hint=torch.zeros(4, dtype=torch.int32, device=color0.device))   # too small
     # against the oracle chain
     dV = (V1 - verts).astype(np.float32)
     p_ref, c_ref, r_ref = oracle.deform(cl["tri"], cl["weights"], dV, Rv, Sv, cov, cl["means"])
