@@ -183,8 +183,9 @@ def main():
                     "deformation (precomputed tables) instead of computing them from the deformed mesh inside the frame (gm_mesh_rs)")
     ap.add_argument("--no-work-hint", action="store_true", help="dispatch the blend's tiles by list length instead of by what they cost "
                     "in recent frames (gm_forward_1_geom's work_hint)")
-    ap.add_argument("--exchange-batch", type=int, default=8, help="N > 1: loop steps whose mesh tables travel in one broadcast "
-                    "(1 = a collective per frame)")
+    ap.add_argument("--exchange-batch", type=int, default=None, help="loop steps whose mesh tables are produced (and at N > 1 "
+                    "broadcast) together, one batch ahead of their use, on a stream of their own.  Default: 8 at N > 1 (1 = a "
+                    "collective per frame), 0 at N = 1 (computed on the frame's own stream)")
     ap.add_argument("--backward-state", action="store_true", help="have the blend also write the per-pixel final transmittance / "
                     "contributor count (the state only a backward pass reads); the edit loop is forward-only and renders "
                     "with GM_FWD_IMAGE_ONLY by default")
@@ -306,9 +307,13 @@ def main():
     # N > 1, the real exchange step: rank 0 owns the animation and produces the table of every loop step (0.72 MB); the
     # tables of --exchange-batch consecutive steps travel in one RCCL broadcast, one batch ahead of their use, on the pipe's
     # own stream (multiview.MeshStatePipe) - the render streams never wait on a collective.
+    # N = 1: the table is computed on the frame's own stream.  (Producing it ahead on a fifth stream - --exchange-batch B at
+    # N = 1 - would take a 12-us launch that lasts 38 us inside the pipelined loop off the frame's chain, and is 6 % slower:
+    # 4500 -> 4220 frames/s, as with any fifth stream next to the four.)
     pipe = None
-    if world > 1:
-        pipe = multiview.MeshStatePipe(lambda i, out: frame_table(i % F, out), (Vm, 24), args.exchange_batch, dev, src=0,
+    batch = args.exchange_batch if args.exchange_batch is not None else (8 if world > 1 else 0)
+    if world > 1 or batch > 0:
+        pipe = multiview.MeshStatePipe(lambda i, out: frame_table(i % F, out), (Vm, 24), max(1, batch), dev, src=0,
                                        frames_in_flight=nstreams + lag + 1)
 
     def step_on_stream(i, workspace, exchange=True, begin_only=False):

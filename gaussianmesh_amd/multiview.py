@@ -129,10 +129,11 @@ class MeshStatePipe:
             self._issue(b)
         if b + 1 not in self.ready:
             self._issue(b + 1)                                            # one batch ahead
-        if self.ready[b] is not None:
-            self.ready[b].synchronize()                                   # host-side; recorded a batch ago, normally long complete
-        for k in [k for k in self.ready if k < b]:
-            del self.ready[k]
+        if b != self.last:                                                # once per batch
+            if self.ready[b] is not None:
+                self.ready[b].synchronize()                               # host-side; recorded a batch ago, normally long complete
+            for k in [k for k in self.ready if k < b]:
+                del self.ready[k]
         self.last = b
         return self.bufs[b % self.slots][j]
 
