@@ -821,3 +821,31 @@ def test_python_sh_route_is_differentiable_and_debug_snapshots(oracle, tmp_path,
                                scales=T(cl["scales"]), rotations=T(cl["rots"]))
     snap = torch.load(str(tmp_path / "snapshot_fw.dump"))
     assert snap["sh_degree"] == 7 and snap["means3D"].shape == (N, 3)
+
+
+@pytest.mark.parametrize("W,H,policy", [(1600, 1000, 0), (1600, 1000, 2), (333, 211, 3)])
+def test_work_hint_never_changes_an_image(W, H, policy):
+    """gm_forward_1_geom's work_hint only reorders the blend's workgroups: images, final transmittance and contributor counts
+    are those of a frame without it, on the one-pass tile sort (order from the scatter launch) and on the two-pass one
+    (6300 list tiles: tile_order_kernel), frame after frame, with the camera moving under the same buffer."""
+    from gpu_utils import T
+    from gaussianmesh_amd import rasterizer as Rz, scenes
+    sc = scenes.make_cloud(4000, seed=8, scale_lo=0.01, scale_hi=0.3)
+    bg = T(np.array([0.2, 0.3, 0.4], np.float32))
+    hint = Rz.new_work_hint(W, H, bg.device)
+    lib = Rz._lib.lib()
+    for k in range(5):
+        cam = scenes.orbit_camera(k, 9, W, H, radius=7.0)
+        args = (bg, T(sc["means"]), None, T(sc["opac"]), T(sc["scales"]), T(sc["rots"]), 1.0, None, T(cam["view"]), T(cam["proj"]), cam["tanx"],
+                cam["tany"], H, W, T(sc["shs"]), 3, T(cam["campos"]), False, False)
+        nr0, c0, r0, _, _, img0 = Rz.rasterize_forward_begin(*args, emission_policy=policy).finish()
+        nr1, c1, r1, _, _, img1 = Rz.rasterize_forward_begin(*args, emission_policy=policy).finish(work_hint=hint)
+        torch.cuda.synchronize()
+        assert nr0 == nr1 and torch.equal(c0, c1) and torch.equal(r0, r1)
+        for plane in (b"final_T", b"n_contrib"):
+            o0 = lib.gm_image_field(img0.data_ptr(), W, H, plane) - img0.data_ptr()
+            o1 = lib.gm_image_field(img1.data_ptr(), W, H, plane) - img1.data_ptr()
+            assert torch.equal(img0[o0:o0 + 4 * W * H], img1[o1:o1 + 4 * W * H]), plane
+        hv = hint.cpu().numpy().view(np.uint32)
+        assert int(hv[0]) == k + 1 and (hv[1:] != 0).sum() > 0
+        assert hv.size * 4 == lib.gm_work_hint_bytes(W, H)
