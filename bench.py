@@ -482,10 +482,10 @@ def main():
                 l.grad = None
             color, _ = rast(leaves[0], m2d, leaves[1], shs=leaves[2], scales=leaves[3], rotations=leaves[4])
             (color * wgt).sum().backward()
-        for _ in range(3):
+        for _ in range(10):
             it()
         torch.cuda.synchronize()
-        nit = 40
+        nit = 100
         t1 = time.perf_counter()
         for _ in range(nit):
             it()
@@ -501,7 +501,7 @@ def main():
                 l.grad = None
             color, _ = rast(leaves[0], m2d, leaves[1], shs=leaves[2], scales=leaves[3], rotations=leaves[4])
             photometric_loss(color, gt, 0.2).backward()
-        for _ in range(3):
+        for _ in range(10):
             it_loss()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -524,7 +524,7 @@ def main():
         tr = Trainer(model)
         cam0 = Camera(cams[0], dev)
         zero_bg = torch.zeros(3, device=dev)
-        for _ in range(3):
+        for _ in range(10):
             tr.step(cam0, gt, zero_bg)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -549,7 +549,7 @@ def main():
                 l.grad = None
             color, _ = rast2(lv[0], m2, lv[1], shs=lv[2], scales=lv[3], rotations=lv[4])
             (color * wgt).sum().backward()
-        for _ in range(3):
+        for _ in range(10):
             it_c2()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
