@@ -315,6 +315,13 @@ void gm_profile_enable(int on);
 void gm_profile_reset(void);
 int gm_profile_read(const char* stage, double* total_ms, int64_t* launches);
 
+/* Debugging aids of the repository's tools, never called by the package: while a device buffer is registered the forward
+ * blend (tools/wave_trace.py: 8 x uint64 per wave - start / end clock, list length, entries evaluated ...) / the depth-bucket
+ * sort (tools/bucket_stats.py) write per-wave / per-bucket records into it; NULL switches the tracing kernels off again.
+ * Process-wide, not thread-safe. */
+void gm_debug_render_trace(void* buffer);
+void gm_debug_bucket_trace(void* buffer);
+
 #ifdef __cplusplus
 }
 #endif
