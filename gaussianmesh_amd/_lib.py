@@ -62,6 +62,8 @@ SIGNATURES = {
     "gm_profile_enable": (None, [i32]),
     "gm_profile_reset": (None, []),
     "gm_profile_read": (i32, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]),
+    "gm_debug_render_trace": (None, [vp]),
+    "gm_debug_bucket_trace": (None, [vp]),
 }
 
 
