@@ -148,7 +148,7 @@ def run_c5(args):
            "config": {"workload": "C5: %d mesh-bound + %d free Gaussians, %dx%d, render + L1/SSIM/mesh-restrict loss + backward + FusedAdam + "
                                   "densification statistics, 32-camera orbit, fixed random target" % (Nfg, Nbg, W, H),
                       "gaussians": Nfg + Nbg, "width": W, "height": H, "sh_degree": 3, "sync_free": not args.exact_count,
-                      "emission_policy": Rz.get_default_emission_policy()},
+                      "emission_policy": Rz.get_default_emission_policy(W, H)},
            "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30, "iterations_redone": tr.redone,
            "visible": int((pkg["radii"] > 0).sum().item()), "final_loss": float(loss),
            "visited_fraction": float((tr.denom > 0).float().mean().item())}
@@ -418,7 +418,7 @@ def main():
                    "gaussians": P, "width": W, "height": H, "sh_degree": 3, "views_per_step_per_gpu": 1,
                    "vertex_rs": "analytic tables" if args.analytic_rs else "gm_mesh_rs per frame", "hip_streams": nstreams,
                    "exchange": None if pipe is None else {"steps_per_broadcast": pipe.batch, "bytes_per_step": Vm * 96, "broadcasts": pipe.broadcasts},
-                   "emission_policy": Rz.get_default_emission_policy(), "image_only": image_only, "work_hint": hint is not None,
+                   "emission_policy": Rz.get_default_emission_policy(W, H), "image_only": image_only, "work_hint": hint is not None,
                    "parallelism": "views x%d" % world},
     }
     if repeats:
@@ -434,7 +434,8 @@ def main():
         lib.gm_profile_reset(); lib.gm_profile_enable(1)
         nprof = min(args.steps, 50)
         gx16, gy16 = (W + 15) // 16, (H + 15) // 16
-        list_tiles = ((gx16 + 1) // 2) * ((gy16 + 1) // 2) if Rz.get_default_emission_policy() == 2 else gx16 * gy16
+        psh = max(Rz.get_default_emission_policy(W, H) - 1, 0)                   # lists per 2^psh x 2^psh tiles
+        list_tiles = ((gx16 + (1 << psh) - 1) >> psh) * ((gy16 + (1 << psh) - 1) >> psh)
         with torch.cuda.stream(streams[0]):
             for i in range(nprof):
                 step_on_stream(args.warmup + i, workspaces[0], exchange=False)   # rank 0 only: no collective here
