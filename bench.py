@@ -173,8 +173,9 @@ def main():
     ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams the frame loop alternates over (frame i runs on stream i %% streams): consecutive frames are "
                          "independent, so frame i+1's per-Gaussian stages overlap the low-occupancy tail of frame i's blend")
-    ap.add_argument("--status-lag", type=int, default=3, help="sync-free loop: the host reads a frame's status words this many frames "
-                    "after completing it (how far the host may run ahead of the GPU)")
+    ap.add_argument("--status-lag", type=int, default=6, help="sync-free loop: the host reads a frame's status words this many frames "
+                    "after completing it (how far the host may run ahead of the GPU).  With four frames in flight a lag of 3 still "
+                    "makes the host wait for a frame that is running (4470 frames/s); 6 or more never does (4550-4570)")
     ap.add_argument("--exact-count", action="store_true", help="complete every frame with the instance count read back by the host "
                     "(gm_forward_1_geom's exact mode) instead of the sync-free mode")
     ap.add_argument("--check-dir", default=None, help="every rank saves the image of its last timed step (with the step, frame and "
