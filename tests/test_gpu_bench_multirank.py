@@ -21,14 +21,15 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("batch", [8, 1, 3])
+@pytest.mark.parametrize("batch", [None, 1, 3])          # None: bench.py's own default at N > 1 (8)
 def test_bench_two_ranks_render_their_own_views(tmp_path, batch):
     P, W, H, F, steps, warm = 20000, 320, 200, 8, 4, 2
     env = dict(os.environ, GM_BENCH_SHARE_DEVICE="1", GM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", str(warm),
            "--gaussians", str(P), "--width", str(W), "--height", str(H), "--cameras", str(F), "--check-dir", str(tmp_path),
-           "--no-cpu-baseline", "--no-fwd-bwd", "--exchange-batch", str(batch)]
+           "--no-cpu-baseline", "--no-fwd-bwd"] + ([] if batch is None else ["--exchange-batch", str(batch)])
+    batch = 8 if batch is None else batch
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
