@@ -420,6 +420,7 @@ def main():
                    "vertex_rs": "analytic tables" if args.analytic_rs else "gm_mesh_rs per frame", "hip_streams": nstreams,
                    "exchange": None if pipe is None else {"steps_per_broadcast": pipe.batch, "bytes_per_step": Vm * 96, "broadcasts": pipe.broadcasts},
                    "emission_policy": Rz.get_default_emission_policy(W, H), "image_only": image_only, "work_hint": hint is not None,
+                   "frames_redone": stats["overflows"],          # sync-free frames that outgrew their binning buffer (rendered again, exactly)
                    "parallelism": "views x%d" % world},
     }
     if repeats:
