@@ -71,7 +71,8 @@ def algorithmic_bytes(stage, P, V, R, W, H, Vm, M=16, list_tiles=2040):
         "sh_colors": P * (12 + 36 + 12 * M) + P * 12,
         "preprocess": P * (12 + 24 + 4 + 12) + V * 48,
         # bucket partition (key read twice, (key, id) written once) + in-LDS bucket sort ((key, id) in; id, count out; count gather)
-        "depth_sort": P * 8 + V * 8 + V * (8 + 4 + 4 + 4) + (P // 4096 + 1) * hist * 4,
+        # + the move of every visible Gaussian's 16-byte emission record into depth order (read + write): DESIGN.md section 3's 76 MB
+        "depth_sort": P * 8 + V * 8 + V * (8 + 4 + 4 + 4) + V * 32 + (P // 4096 + 1) * hist * 4,
         "duplicate": V * (4 + 4) + V * 16 + R * 8,                                  # counts + ids in order, bin records, (key, id) out
         "tile_sort": (R * (4 + 8 + 8) + (R // 4096 + 1) * hist * 4) * (1 if one_pass else 2) + list_tiles * 8,
         "ranges": list_tiles * 12,                                                  # tile_order_kernel: ranges in, dispatch order out
@@ -94,24 +95,19 @@ def measured_traffic(stage, P, W, H):
     return int(1024 * (2 * e["fetch_kib"] + e["write_kib"]))
 
 
-def run_c5(args):
-    """BASELINE config C5 on this package's training harness: 3 M Gaussians (2 M bound to the 15 k-face torus + 1 M free
-    "background" Gaussians in a shell of radius 6-12), 3840x2160, iterations of {render, L1 + SSIM + mesh-restrict loss,
-    backward, FusedAdam on the six parameter groups, densification statistics} with cameras cycling over 32 poses and a fixed
-    random target.  One JSON line: ms per iteration, peak device memory, instance counts."""
+def build_c5(Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, dev=None, sync_free=True, ncams=32, seed=0):
+    """BASELINE config C5 on this package's training harness: Nfg Gaussians bound to the 15 k-face torus + Nbg free, frozen
+    "background" Gaussians in a shell of radius 6-12 that contains the cameras, W x H, a Trainer with FusedAdam on the six
+    parameter groups, densification statistics, sync-free forward, and `ncams` orbit cameras with one fixed random target
+    (SURVEY.md 8d).  Returns (trainer, cameras, target, background colour).  Also used by tests/test_gpu_fullsize.py."""
     import torch
-    from gaussianmesh_amd import rasterizer as Rz, scenes
-    from gaussianmesh_amd.renderer import Camera, MeshBoundGaussians, set_work_hints
-    set_work_hints(not args.no_work_hint)        # (per-camera work hints of the forward blend's dispatch order)
+    from gaussianmesh_amd import scenes
+    from gaussianmesh_amd.renderer import Camera, MeshBoundGaussians
     from gaussianmesh_amd.train import FrozenGaussians, Trainer
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(dev)
-    W, H = args.width if args.width != 1920 else 3840, args.height if args.height != 1080 else 2160
-    Nfg, Nbg = (2 * args.gaussians) // 3 if args.gaussians != 1_000_000 else 2_000_000, args.gaussians // 3 if args.gaussians != 1_000_000 else 1_000_000
+    dev = dev or torch.device("cuda", 0)
     t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)
     verts, faces = scenes.torus_mesh(100, 75)
-    cl = scenes.bind_cloud_to_mesh(Nfg, verts, faces, seed=0)
+    cl = scenes.bind_cloud_to_mesh(Nfg, verts, faces, seed=seed)
     perm = np.argsort(cl["fid"], kind="stable")
     tri = cl["tri"][perm]
     v1, v2, v3 = (t(verts[tri[:, k]]) for k in range(3))
@@ -120,38 +116,68 @@ def run_c5(args):
     shs = t(cl["shs"][perm])
     model = MeshBoundGaussians(torch.log(t(cl["weights"][perm]).clamp_min(1e-6)), torch.zeros((Nfg, 1), device=dev), shs[:, :1].clone(),
                                shs[:, 1:].clone(), torch.log(t(cl["scales"][perm])), t(cl["rots"][perm]),
-                               torch.logit(t(cl["opac"][perm]).reshape(-1, 1).clamp(1e-4, 1 - 1e-4)), v1, v2, v3, nrm, rad).to(dev)
-    b = scenes.make_cloud(Nbg, seed=1, extent=1.0)
+                               torch.logit(t(cl["opac"][perm]).reshape(-1, 1).clamp(1e-4, 1 - 1e-4)), v1, v2, v3, nrm, rad,
+                               fid=torch.tensor(cl["fid"][perm].astype(np.int32), device=dev)).to(dev)
+    b = scenes.make_cloud(Nbg, seed=seed + 1, extent=1.0)
     nb = np.linalg.norm(b["means"], axis=1, keepdims=True) + 1e-6
     bg = FrozenGaussians(t(b["means"] / nb * (6 + 6 * nb)), t(b["scales"]), torch.nn.functional.normalize(t(b["rots"])), t(b["opac"]).reshape(-1, 1),
                          t(b["shs"]))
-    if args.policy is not None:
-        Rz.set_default_emission_policy(args.policy)
-    cams = [Camera(scenes.orbit_camera(k, 32, W, H), dev) for k in range(32)]
-    target = torch.rand((3, H, W), device=dev)
-    zero_bg = torch.zeros(3, device=dev)
-    tr = Trainer(model, densify_stats=True, sync_free=not args.exact_count, bg_gaussian=bg)
-    steps = args.steps if args.steps != 300 else 1000
-    warm = max(args.warmup, 5)
+    cams = [Camera(scenes.orbit_camera(k, ncams, W, H), dev) for k in range(ncams)]
+    target = torch.rand((3, H, W), device=dev, generator=torch.Generator(device=dev).manual_seed(seed))
+    tr = Trainer(model, densify_stats=True, sync_free=sync_free, bg_gaussian=bg)
+    return tr, cams, target, torch.zeros(3, device=dev)
+
+
+def c5_leg(steps, warm, Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, sync_free=True, policy=None, work_hint=True, dev=None):
+    """Times `steps` Trainer.step iterations of the C5 workload (after `warm` untimed ones); returns the "c5" object of the bench line."""
+    import torch
+    from gaussianmesh_amd import rasterizer as Rz
+    from gaussianmesh_amd.renderer import set_work_hints
+    set_work_hints(work_hint)                    # (per-camera work hints of the forward blend's dispatch order)
+    dev = dev or torch.device("cuda", 0)
+    if policy is not None:
+        Rz.set_default_emission_policy(policy)
+    tr, cams, target, zero_bg = build_c5(Nfg, Nbg, W, H, dev, sync_free)
+    nc = len(cams)
+    losses = []
     for i in range(warm):
-        tr.step(cams[i % 32], target, zero_bg)
+        losses.append(tr.step(cams[i % nc], target, zero_bg)[0])
     torch.cuda.synchronize()
     torch.cuda.reset_peak_memory_stats(dev)
+    redone0 = tr.redone
     t0 = time.perf_counter()
     for i in range(steps):
-        loss, pkg = tr.step(cams[(warm + i) % 32], target, zero_bg)
+        loss, pkg = tr.step(cams[(warm + i) % nc], target, zero_bg)
+        if i % 50 == 0 or i == steps - 1:
+            losses.append(loss)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    out = {"metric": "ms/iter (fwd+bwd+optimizer), 3M Gaussians @4K training loop", "value": 1e3 * el / steps, "unit": "ms/iter", "n_gpus": 1,
-           "steps": steps, "warmup": warm, "ms_per_step": 1e3 * el / steps, "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "C5: %d mesh-bound + %d free Gaussians, %dx%d, render + L1/SSIM/mesh-restrict loss + backward + FusedAdam + "
-                                  "densification statistics, 32-camera orbit, fixed random target" % (Nfg, Nbg, W, H),
-                      "gaussians": Nfg + Nbg, "width": W, "height": H, "sh_degree": 3, "sync_free": not args.exact_count,
-                      "emission_policy": Rz.get_default_emission_policy(W, H)},
-           "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30, "iterations_redone": tr.redone,
-           "visible": int((pkg["radii"] > 0).sum().item()), "final_loss": float(loss),
-           "visited_fraction": float((tr.denom > 0).float().mean().item())}
+    out = {"ms_per_iter": 1e3 * el / steps, "iters": steps, "warmup": warm, "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
+           "iterations_redone": tr.redone - redone0, "gaussians": Nfg + Nbg, "trainable": Nfg, "width": W, "height": H,
+           "visible": int((pkg["radii"] > 0).sum().item()), "emission_policy": Rz.get_default_emission_policy(W, H), "sync_free": bool(sync_free),
+           "loss_first": float(losses[0]), "loss_last": float(losses[-1]),
+           "workload": "C5: %d mesh-bound + %d frozen free Gaussians, %dx%d, render + L1/SSIM/mesh-restrict loss + backward + FusedAdam + "
+                       "densification statistics, %d orbit cameras, fixed random target" % (Nfg, Nbg, W, H, nc)}
+    del tr, cams, target, pkg
+    torch.cuda.empty_cache()
+    return out
+
+
+def run_c5(args):
+    """`bench.py --config c5`: the C5 training loop as the headline of its own JSON line (ms per iteration)."""
+    import torch
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(0)
+    W, H = args.width if args.width != 1920 else 3840, args.height if args.height != 1080 else 2160
+    Nfg, Nbg = ((2 * args.gaussians) // 3, args.gaussians // 3) if args.gaussians != 1_000_000 else (2_000_000, 1_000_000)
+    steps = args.steps if args.steps != 300 else 1000
+    c5 = c5_leg(steps, max(args.warmup, 5), Nfg, Nbg, W, H, sync_free=not args.exact_count, policy=args.policy, work_hint=not args.no_work_hint)
+    out = {"metric": "ms/iter (fwd+bwd+optimizer), 3M Gaussians @4K training loop", "value": c5["ms_per_iter"], "unit": "ms/iter", "n_gpus": 1,
+           "steps": steps, "warmup": c5["warmup"], "ms_per_step": c5["ms_per_iter"], "higher_is_better": False, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": c5["workload"], "gaussians": Nfg + Nbg, "trainable": Nfg, "width": W, "height": H, "sh_degree": 3,
+                      "emission_policy": c5["emission_policy"], "sync_free": c5["sync_free"], "iterations_redone": c5["iterations_redone"]},
+           "peak_memory_gb": c5["peak_memory_gb"], "visible": c5["visible"], "loss_first": c5["loss_first"], "loss_last": c5["loss_last"]}
     print(json.dumps(out))
 
 
@@ -192,6 +218,8 @@ def main():
                     "with GM_FWD_IMAGE_ONLY by default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fwd-bwd", action="store_true")
+    ap.add_argument("--no-c5", action="store_true", help="leave out the bounded C5 leg (200 iterations of the 3 M-Gaussian 4K training loop)")
+    ap.add_argument("--c5-iters", type=int, default=200)
     args = ap.parse_args()
     if args.config == "c5":
         return run_c5(args)
@@ -495,6 +523,48 @@ def main():
         torch.cuda.synchronize()
         out["fwd_bwd"] = {"ms_per_iter": 1e3 * (time.perf_counter() - t1) / nit, "iters": nit,
                           "config": "%d Gaussians, %dx%d, SH3 + scale/rot inputs, loss = sum(w*image)" % (P, W, H)}
+        # roofline of the other half of the metric: per-stage HIP events (torch's current stream IS the stream the operator
+        # launches on) over a second pass of the same iteration; algorithmic bytes of THIS algorithm for forward (training
+        # input mode, backward state written) + backward (SURVEY.md 8d A_fwd(training) + A_bwd restated for the record layout
+        # of DESIGN.md section 3); dominant kernel = the backward blend
+        lib.gm_profile_reset(); lib.gm_profile_enable(1)
+        nprof_fb = 20
+        for _ in range(nprof_fb):
+            it()
+        torch.cuda.synchronize()
+        lib.gm_profile_enable(0)
+        per_fb = {}
+        for st_name in ("preprocess", "depth_sort", "duplicate", "tile_sort", "ranges", "render", "render_bwd", "preprocess_bwd"):
+            ms = C.c_double(0); n = C.c_int64(0)
+            lib.gm_profile_read(st_name.encode(), C.byref(ms), C.byref(n))
+            if n.value:
+                per_fb[st_name] = ms.value / nprof_fb
+        st_img = torch.zeros((4,), dtype=torch.int32).pin_memory()
+        with torch.no_grad():
+            nr_fb, _, rad_fb, *_ = Rz.rasterize_forward(rs.bg, g["pos"], None, g["opac"], g["scales"], g["rots"], 1.0, None, c["view"], c["proj"],
+                                                        c["tanx"], c["tany"], H, W, g["shs"], 3, c["campos"], False, False)
+        Vf = int((rad_fb > 0).sum().item()); Rf = int(nr_fb)
+        fb_bytes = {
+            "preprocess": P * (12 + 12 + 16 + 4) + Vf * 12 * 16 + Vf * 48 + P * 28 + Vf * 27,     # inputs, SH rows, splat record, radius/count/bin/key, cov3D + clamped
+            "depth_sort": algorithmic_bytes("depth_sort", P, Vf, Rf, W, H, Vm, list_tiles=list_tiles),
+            "duplicate": algorithmic_bytes("duplicate", P, Vf, Rf, W, H, Vm, list_tiles=list_tiles),
+            "tile_sort": algorithmic_bytes("tile_sort", P, Vf, Rf, W, H, Vm, list_tiles=list_tiles),
+            "ranges": algorithmic_bytes("ranges", P, Vf, Rf, W, H, Vm, list_tiles=list_tiles),
+            "render": Rf * 40 + W * H * (12 + 8),                                                  # + final_T, n_contrib
+            "render_bwd": Rf * 40 + W * H * 20 + Vf * 48,                                           # lists + records, dL/dpixel + T + n_contrib, grad_acc record
+            "preprocess_bwd": Vf * 559,                                                              # 303 read + 256 written per visible Gaussian
+        }
+        tot_fb = sum(fb_bytes[k] for k in per_fb)
+        sec = out["fwd_bwd"]["ms_per_iter"] * 1e-3
+        ach_b = fb_bytes["render_bwd"] / (per_fb["render_bwd"] * 1e-3) / 1e9
+        out["fwd_bwd"]["stage_ms"] = {k: round(v, 4) for k, v in per_fb.items()}
+        out["fwd_bwd"]["scene"] = {"P": P, "V": Vf, "R": Rf}
+        out["fwd_bwd"]["roofline"] = {"bound": "hbm", "kernel": "render_bwd", "achieved": ach_b, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": ach_b / HBM_PEAK_GBS, "algorithmic_bytes": fb_bytes["render_bwd"], "avg_ms": per_fb["render_bwd"],
+                                      "traffic": None,
+                                      "note": "the backward blend is bound by vector-ALU issue (DESIGN.md section 4), not by HBM"}
+        out["fwd_bwd"]["iteration_roofline"] = {"algorithmic_bytes": tot_fb, "achieved": tot_fb / sec / 1e9, "frac": tot_fb / sec / 1e9 / HBM_PEAK_GBS,
+                                                "unit": "GB/s", "sum_of_stage_ms": sum(per_fb.values())}
         # the same iteration with the training loop's photometric loss (L1 + SSIM, gm_ssim_fwd/bwd) on the rendered image
         from gaussianmesh_amd.loss import photometric_loss
         gt = torch.rand((3, H, W), device=dev)
@@ -561,12 +631,24 @@ def main():
         torch.cuda.synchronize()
         out["fwd_bwd"]["c2_500k_ms_per_iter"] = 1e3 * (time.perf_counter() - t1) / nit
 
+    if rank == 0 and world == 1 and not args.no_fwd_bwd and not args.no_c5:
+        # ---- bounded C5 leg: BASELINE config C5 (3 M Gaussians, 3840x2160, the train_mesh_gaussian.py iteration) on the same box,
+        # --c5-iters iterations of Trainer.step; `python bench.py --config c5` runs the 1000 iterations of the config as a line of its own
+        host_keep = {k: g[k].cpu() for k in ("tri", "weights", "pos", "cov", "opac", "shs", "verts")} if not args.no_cpu_baseline else None
+        mesh_keep = g["mesh"][:24].cpu() if not args.no_cpu_baseline else None
+        g.clear(); workspaces.clear(); pending.clear()
+        del lv, m2, rast2, rs2, wgt, gt, rast, rs, v1_frames, hint, adjacency, stats      # C3 / C2 state: not part of C5's peak memory
+        torch.cuda.empty_cache()
+        out["c5"] = c5_leg(max(1, args.c5_iters), 10, policy=args.policy, work_hint=not args.no_work_hint, dev=dev)
+    else:
+        host_keep = mesh_keep = None
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # ---- CPU baseline: the oracle port (plain C + OpenMP) on the host cores, bounded sample of the same workload
         from oracle import oracle as orc
         nfr_max, budget_s = 24, 10.0                # bounded sample: at least 2 frames, then until ~10 s of host work
-        hp = {k: g[k].cpu().numpy() for k in ("tri", "weights", "pos", "cov", "opac", "shs", "verts")}
-        mesh0 = g["mesh"][:nfr_max].cpu().numpy()
+        hp = {k: (host_keep[k] if host_keep is not None else g[k].cpu()).numpy() for k in ("tri", "weights", "pos", "cov", "opac", "shs", "verts")}
+        mesh0 = (mesh_keep if mesh_keep is not None else g["mesh"][:nfr_max].cpu()).numpy()
         tc = time.perf_counter()
         nfr = 0
         for t in range(min(nfr_max, mesh0.shape[0])):

@@ -44,10 +44,15 @@ def install(force=False, operators=True, edit_tool=False):
     if edit_tool:
         import types
         from .. import edittool, io as gio
-        sys.modules["edittool"] = edittool
-        ro = types.ModuleType("render_origin")
-        ro.save_image = gio.save_image
-        sys.modules["render_origin"] = ro
+        # never swap a module somebody else already imported under these names (the reference's own edittool package, a real
+        # render_origin) unless force=True - same rule as for the jittor subset and the operator aliases above
+        if force or "edittool" not in sys.modules:
+            sys.modules["edittool"] = edittool
+        if force or "render_origin" not in sys.modules:
+            ro = types.ModuleType("render_origin")
+            ro.save_image = gio.save_image
+            ro.__gaussianmesh_compat__ = True
+            sys.modules["render_origin"] = ro
     return sys.modules["jittor"]
 
 
@@ -61,5 +66,5 @@ def uninstall():
             del sys.modules[k]
     for k in ("gaussian_renderer.diff_gaussian_rasterizater", "scene.simple_knn", "edittool", "render_origin"):
         m = sys.modules.get(k)
-        if m is not None and (getattr(m, "__name__", "").startswith("gaussianmesh_amd") or k == "render_origin"):
-            del sys.modules[k]
+        if m is not None and (getattr(m, "__name__", "").startswith("gaussianmesh_amd") or getattr(m, "__gaussianmesh_compat__", False)):
+            del sys.modules[k]            # only what install() put there

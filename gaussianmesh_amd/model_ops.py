@@ -88,6 +88,78 @@ class FusedAdam:
         if len(self.param_groups) > 8:
             raise ValueError("FusedAdam: at most 8 groups per optimizer")
 
+    # ---- topology changes: the optimizer state follows the parameter rows (scene/mesh_based_gaussian_model.py:411-480)
+    def resize(self, keep=None, new_rows=None):
+        """Row surgery on every group in ONE pass per tensor: rows selected by `keep` (bool mask [N] or int64 index tensor; None =
+        all) stay in their order - parameter and both Adam moments move together, as _prune_optimizer (:425-438) does - and the
+        rows of `new_rows[group name]` are appended behind them with ZERO moments, as cat_tensors_to_optimizer (:465-483) does.
+        `new_rows` may name the SH group by its own name or give "f_dc" [n,1,3] and "f_rest" [n,15,3].  Every group's parameter
+        becomes a new leaf torch.nn.Parameter (the old one, and any .grad on it, is dropped); returns {group name: parameter}."""
+        out = {}
+        idx = None
+        if keep is not None:
+            idx = keep.nonzero(as_tuple=False).reshape(-1) if keep.dtype == torch.bool else keep.reshape(-1).long()
+        for g in self.param_groups:
+            p = g["params"][0]
+            ext = None
+            if new_rows is not None:
+                if g["name"] in new_rows:
+                    ext = new_rows[g["name"]]
+                elif g["name"] == "f_dc+f_rest" and "f_dc" in new_rows:
+                    ext = torch.cat((new_rows["f_dc"], new_rows["f_rest"]), dim=1)
+                else:
+                    raise KeyError("FusedAdam.resize: no new rows for group %r" % g["name"])
+            nk = p.shape[0] if idx is None else idx.numel()
+            nn_ = 0 if ext is None else ext.shape[0]
+            if ext is not None and tuple(ext.shape[1:]) != tuple(p.shape[1:]):
+                raise ValueError("FusedAdam.resize: new rows of group %r have shape %s, parameter rows %s"
+                                 % (g["name"], tuple(ext.shape[1:]), tuple(p.shape[1:])))
+            with torch.no_grad():
+                np_, nm, nv = (torch.empty((nk + nn_,) + tuple(p.shape[1:]), dtype=p.dtype, device=p.device) for _ in range(3))
+                for dst, src in ((np_, p.detach()), (nm, g["m"][0]), (nv, g["values"][0])):
+                    if idx is None:
+                        dst[:nk].copy_(src)
+                    elif nk:
+                        torch.index_select(src, 0, idx, out=dst[:nk])
+                if nn_:
+                    np_[nk:].copy_(ext.detach())
+                    nm[nk:].zero_()
+                    nv[nk:].zero_()
+            g["params"][0] = torch.nn.Parameter(np_, requires_grad=p.requires_grad)
+            g["m"][0], g["values"][0] = nm, nv
+            out[g["name"]] = g["params"][0]
+        return out
+
+    def prune(self, keep):
+        """_prune_optimizer(mask) (:425-438): keep the rows where `keep` is True."""
+        return self.resize(keep=keep)
+
+    def append(self, new_rows):
+        """cat_tensors_to_optimizer(tensors_dict) (:465-483)."""
+        return self.resize(new_rows=new_rows)
+
+    def replace(self, name, tensor):
+        """replace_tensor_to_optimizer(tensor, name) (:411-423): new values for one group, both moments reset to zero."""
+        for g in self.param_groups:
+            if g["name"] == name:
+                old = g["params"][0]
+                g["params"][0] = torch.nn.Parameter(tensor.detach().clone().contiguous().float(), requires_grad=old.requires_grad)
+                g["m"][0] = torch.zeros_like(g["params"][0])
+                g["values"][0] = torch.zeros_like(g["params"][0])
+                return {name: g["params"][0]}
+        raise KeyError(name)
+
+    def rebind(self, name, param):
+        """Point group `name` at `param` (same shape and values expected, e.g. after renderer.share_feature_storage moved the SH
+        rows into a shared buffer); the moments are kept."""
+        for g in self.param_groups:
+            if g["name"] == name:
+                if tuple(param.shape) != tuple(g["params"][0].shape):
+                    raise ValueError("FusedAdam.rebind: shape %s != %s" % (tuple(param.shape), tuple(g["params"][0].shape)))
+                g["params"][0] = param
+                return
+        raise KeyError(name)
+
     def zero_grad(self, set_to_none=True):
         for g in self.param_groups:
             p = g["params"][0]

@@ -167,6 +167,16 @@ class PendingForward:
                                          None if self.work_hint is None else self.work_hint.data_ptr()))
 
     def finish(self, sync_free=False, capacity=0, image_only=False, work_hint=None):
+        """See _finish().  A failure anywhere in here (allocation, a C-side error) releases the workspace: one failed frame must
+        not leave it marked in flight for ever."""
+        try:
+            return self._finish(sync_free, capacity, image_only, work_hint)
+        except Exception:
+            if self.workspace is not None:
+                self.workspace.release(self)
+            raise
+
+    def _finish(self, sync_free=False, capacity=0, image_only=False, work_hint=None):
         """capacity (sync_free without a workspace): instances the freshly allocated binning buffer shall hold.
         image_only (GM_FWD_IMAGE_ONLY): a frame no backward pass follows - the blend writes the colour image and leaves the
         per-pixel final transmittance / contributor count of the image state alone; the returned img must not be handed
@@ -225,8 +235,6 @@ class PendingForward:
                 _lib.check(lib.gm_forward_status_async(_ptr(self.geom), a["P"], st.data_ptr(), self.stream.cuda_stream))
                 self.stream.synchronize()
                 if int(st[1]):
-                    if ws is not None:
-                        ws.release(self)
                     raise _lib.GmeshError(_PREFILTER_MESSAGE)
         if ws is not None:
             ws.release(self)
@@ -468,6 +476,7 @@ def _shared_workspace(device):
 # verify_sync_free() - typically after backward() has been enqueued, so the host never idles the GPU - and an iteration
 # whose count outgrew its buffer (image = background, gradients = 0) is reported so the caller can redo it.
 _sync_free = {"on": False, "capacity": {}, "unchecked": [], "growth": 1.3}
+_SYNC_FREE_MAX_UNCHECKED = 64      # unverified sync-free forwards (each pins its geometry / binning / image buffers)
 
 
 def set_sync_free_training(on, growth=1.3):
@@ -510,6 +519,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             if cap > 0:
                 num_rendered, color, radii, geom, binning, img = h.finish(sync_free=True, capacity=cap, work_hint=rs.work_hint)
                 num_rendered = cap                        # the binning layout is that of the capacity
+                if len(_sync_free["unchecked"]) >= _SYNC_FREE_MAX_UNCHECKED:
+                    raise _lib.GmeshError("sync-free training: %d forwards were issued without verify_sync_free(); every unverified "
+                                          "forward keeps its scratch buffers alive - call verify_sync_free() once per iteration"
+                                          % _SYNC_FREE_MAX_UNCHECKED)
                 _sync_free["unchecked"].append(h)
             else:
                 num_rendered, color, radii, geom, binning, img = h.finish(image_only=not needs_grad, work_hint=rs.work_hint)   # image_only: no backward will follow

@@ -177,7 +177,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
                                        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
     out = {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
            "vertex1": getattr(pc, "vertex1", None), "vertex2": getattr(pc, "vertex2", None),
-           "vertex3": getattr(pc, "vertex3", None), "scale": scales if bg_gaussian is None else scales[:pc.screenspace_points.shape[0]]}
+           "vertex3": getattr(pc, "vertex3", None), "scale": scales if (bg_gaussian is None or scales is None) else scales[:pc.screenspace_points.shape[0]]}  # None on the compute_cov3D_python route (:143)
     if mrloss is not None:                       # extra key (pipe.mesh_restrict_weight set): the loss term of train_mesh_gaussian.py:93
         out["mesh_restrict_loss"] = mrloss
     return out
@@ -263,16 +263,29 @@ class MeshBoundGaussians(torch.nn.Module):
     alpha_distance = 4
 
     def __init__(self, bc, distance, features_dc, features_rest, scaling, rotation, opacity, vertex1, vertex2, vertex3, normal, r,
-                 sh_degree=3):
+                 sh_degree=3, fid=None, vertex_index=None, v=None):
+        """fid [N] (face of the ORIGINAL proxy mesh a Gaussian descends from), vertex_index [N,3] and v [Vm,3] (the refined
+        mesh the face splits build, :596-647) are optional bookkeeping: only the topology edits of train.Trainer move them."""
         super().__init__()
         P = torch.nn.Parameter
         self._bc, self._distance = P(bc), P(distance)
         self._features = P(torch.cat((features_dc, features_rest), dim=1).contiguous())
         self._scaling, self._rotation, self._opacity = P(scaling), P(rotation), P(opacity)
-        for n, v in dict(vertex1=vertex1, vertex2=vertex2, vertex3=vertex3, normal=normal, r=r).items():
-            self.register_buffer(n, v)
+        for n, t in dict(vertex1=vertex1, vertex2=vertex2, vertex3=vertex3, normal=normal, r=r).items():
+            self.register_buffer(n, t)
+        self.register_buffer("fid", fid if fid is not None else torch.arange(bc.shape[0], device=bc.device, dtype=torch.int32))
+        self.register_buffer("vertex_index", vertex_index)
+        self.register_buffer("v", v)
         self.max_sh_degree = self.active_sh_degree = sh_degree
         self.screenspace_points = torch.zeros_like(vertex1, requires_grad=True)
+
+    @property
+    def get_number(self):
+        return self._bc.shape[0]
+
+    def oneupSHdegree(self):
+        if self.active_sh_degree < self.max_sh_degree:
+            self.active_sh_degree += 1
 
     @property
     def get_scaling(self):

@@ -5,9 +5,11 @@ package's operators (SURVEY.md 8f-3 "training loop harness"):
 
 `Trainer` keeps the per-group learning rates of MeshBasedGaussianModel.training_setup
 (scene/mesh_based_gaussian_model.py:242-263) and the exponential position schedule
-(utils/general_utils.py:28-62 get_expon_lr_func).  Densification / pruning are host-side bookkeeping of the reference
-model class (it runs unchanged on gaussianmesh_amd.compat); this harness is the fixed-topology loop used to time and
-test the GPU path end to end.
+(utils/general_utils.py:28-62 get_expon_lr_func).  Topology changes between iterations - the face splits and prunes of
+MeshBasedGaussianModel.densify_and_split / densify_and_split_for_init / densify_and_prune / prune_points / reset_opacity
+(scene/mesh_based_gaussian_model.py:334-339, 411-563, 596-647) - are Trainer.resize() and the methods built on it: the
+parameter rows, BOTH Adam moments, the per-face buffers, the densification statistics, the shared SH storage and the
+sync-free capacity all follow the new row set, so the HIP ops run on a cloud whose size changes between two iterations.
 """
 import math
 from types import SimpleNamespace
@@ -94,12 +96,150 @@ class Trainer:
         self.iteration = 0
         self.sync_free = bool(sync_free)
         self.redone = 0                          # iterations repeated because the instance count outgrew the binning buffer
+        self.resizes = 0                         # topology changes applied (resize and everything built on it)
         self.densify_stats = bool(densify_stats)
         if self.densify_stats:
             N, dev = gaussians._bc.shape[0], gaussians._bc.device
             self.max_radii2D = torch.zeros((N,), device=dev)
             self.bc_gradient_accum = torch.zeros((N, 1), device=dev)
             self.denom = torch.zeros((N, 1), device=dev)
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # topology changes (scene/mesh_based_gaussian_model.py:411-563, 596-647)
+    _PARAM_OF_GROUP = {"bc": "_bc", "distance": "_distance", "f_dc+f_rest": "_features", "opacity": "_opacity", "scaling": "_scaling",
+                       "rotation": "_rotation"}
+    _ROW_BUFFERS = ("vertex1", "vertex2", "vertex3", "normal", "r", "fid", "vertex_index")
+
+    def resize(self, keep_mask=None, new_rows=None, new_buffers=None):
+        """The one primitive under every topology edit.  Rows where keep_mask is True stay, in order (prune_points :440-463 with
+        mask = ~keep_mask); new_rows {"bc","distance","f_dc","f_rest" (or "f_dc+f_rest"),"opacity","scaling","rotation"} are
+        appended behind them (densification_postfix :485-506) together with new_buffers {"vertex1","vertex2","vertex3","normal",
+        "r"[,"fid","vertex_index"]}.  Adam moments of surviving rows move with their rows, appended rows start from zero
+        moments (FusedAdam.resize); max_radii2D / bc_gradient_accum / denom of survivors are kept when nothing is appended
+        (:452-455) and reset to zero when rows are (:503-505 followed by the prune of the split originals); the SH parameter
+        goes back into the storage it shares with the frozen background; screenspace_points is re-made; the sync-free binning
+        capacity is scaled with the row count (a too small guess only costs one redone iteration).  Returns the new row count."""
+        from . import rasterizer
+        g = self.g
+        n_old = g._bc.shape[0]
+        if keep_mask is not None and keep_mask.shape[0] != n_old:
+            raise ValueError("Trainer.resize: keep_mask has %d rows, the model %d" % (keep_mask.shape[0], n_old))
+        n_new = 0 if new_rows is None else int(next(iter(new_rows.values())).shape[0])
+        if n_new and (new_buffers is None or any(k not in new_buffers for k in ("vertex1", "vertex2", "vertex3", "normal", "r"))):
+            raise ValueError("Trainer.resize: appended rows need their vertex1/vertex2/vertex3/normal/r buffers")
+        idx = None if keep_mask is None else keep_mask.nonzero(as_tuple=False).reshape(-1)
+        params = self.optimizer.resize(keep=idx, new_rows=new_rows if n_new else None)
+        for name, attr in self._PARAM_OF_GROUP.items():
+            setattr(g, attr, params[name])
+        with torch.no_grad():
+            for b in self._ROW_BUFFERS:
+                old = getattr(g, b, None)
+                if old is None:
+                    continue
+                kept = old if idx is None else old.index_select(0, idx)
+                if n_new:
+                    ext = (new_buffers or {}).get(b)
+                    if ext is None:
+                        if b in ("fid", "vertex_index"):              # optional bookkeeping the caller did not extend: drop it
+                            setattr(g, b, None)
+                            continue
+                        raise ValueError("Trainer.resize: no new rows for buffer %r" % b)
+                    kept = torch.cat((kept, ext.to(kept.dtype).reshape((n_new,) + tuple(kept.shape[1:]))), dim=0)
+                setattr(g, b, kept.contiguous())
+            if new_buffers is not None and new_buffers.get("v") is not None and getattr(g, "v", None) is not None:
+                g.v = torch.cat((g.v, new_buffers["v"].to(g.v.dtype)), dim=0)
+        n = g._bc.shape[0]
+        g.screenspace_points = torch.zeros((n, 3), dtype=g._bc.dtype, device=g._bc.device, requires_grad=True)
+        if self.bg_gaussian is not None and g._features.is_cuda:
+            from .renderer import share_feature_storage
+            share_feature_storage(g, self.bg_gaussian)
+            self.optimizer.rebind("f_dc+f_rest", g._features)
+        if self.densify_stats:
+            if n_new:
+                dev = g._bc.device
+                self.max_radii2D = torch.zeros((n,), device=dev)
+                self.bc_gradient_accum = torch.zeros((n, 1), device=dev)
+                self.denom = torch.zeros((n, 1), device=dev)
+            elif idx is not None:
+                self.max_radii2D = self.max_radii2D.index_select(0, idx)
+                self.bc_gradient_accum = self.bc_gradient_accum.index_select(0, idx)
+                self.denom = self.denom.index_select(0, idx)
+        cap = rasterizer._sync_free["capacity"]
+        if n_old and n > n_old:
+            for k in list(cap):
+                cap[k] = int(cap[k] * n / n_old) + 4096
+        self.resizes += 1
+        return n
+
+    def prune_points(self, mask):
+        """prune_points(mask) (:440-463): remove the rows where mask is True."""
+        return self.resize(keep_mask=mask.logical_not())
+
+    def reset_opacity(self):
+        """reset_opacity (:334-339): opacity = min(opacity, 0.01), both Adam moments of the group zeroed."""
+        g = self.g
+        with torch.no_grad():
+            o = torch.clamp_max(torch.sigmoid(g._opacity), 0.01)
+            g._opacity = self.optimizer.replace("opacity", torch.log(o / (1.0 - o)))["opacity"]
+
+    def densify_and_split(self, selected, N=4):
+        """densify_and_split (:508-563) for an explicit selection: every selected row (a Gaussian on its triangle) is replaced by N
+        new rows on the sub-triangles of the midpoint split - N = 4: (a,ab,ac), (ab,b,bc), (ac,bc,c), (ab,bc,ac)
+        (utils/general_utils.py:133-170); N = 5 adds a copy on the parent triangle (:172-212) - with barycentrics (1/3,1/3,1/3),
+        zero normal offset, the parent's scale / (4 * 0.8), rotation, SH rows, opacity, normal, r and fid; the new rows are
+        appended, then the selected originals are pruned (:561-562).  Returns the new row count."""
+        if N not in (4, 5):
+            raise ValueError("densify_and_split: N must be 4 or 5")
+        g = self.g
+        if selected.dtype != torch.bool:
+            raise ValueError("densify_and_split: boolean selection mask expected")
+        ns = int(selected.sum().item())
+        if ns == 0:
+            return g._bc.shape[0]
+        with torch.no_grad():
+            rep = lambda t: t[selected].unsqueeze(1).repeat_interleave(N, dim=1).reshape((ns * N,) + tuple(t.shape[1:]))
+            a, b, c = g.vertex1[selected], g.vertex2[selected], g.vertex3[selected]
+            ab, ac, bc = (a + b) / 2, (a + c) / 2, (b + c) / 2
+            tri1 = [a, ab, ac, ab] + ([a] if N == 5 else [])
+            tri2 = [ab, b, bc, bc] + ([b] if N == 5 else [])
+            tri3 = [ac, bc, c, ac] + ([c] if N == 5 else [])
+            st = lambda xs: torch.stack(xs, dim=1).reshape(ns * N, 3)
+            new_buffers = {"vertex1": st(tri1), "vertex2": st(tri2), "vertex3": st(tri3), "normal": rep(g.normal), "r": rep(g.r)}
+            if getattr(g, "fid", None) is not None:
+                new_buffers["fid"] = rep(g.fid)
+            if getattr(g, "vertex_index", None) is not None and getattr(g, "v", None) is not None:
+                # three new mesh vertices per split face, numbered behind the existing ones (general_utils.py:153-168)
+                v0 = g.v.shape[0]
+                t = torch.arange(ns * 3, device=g.v.device, dtype=g.vertex_index.dtype).reshape(ns, 3) + v0
+                vi = g.vertex_index[selected]
+                ia, ib, ic = vi[:, 0], vi[:, 1], vi[:, 2]
+                rows = [torch.stack((ia, t[:, 0], t[:, 1]), 1), torch.stack((t[:, 0], ib, t[:, 2]), 1), torch.stack((t[:, 1], t[:, 2], ic), 1),
+                        torch.stack((t[:, 0], t[:, 2], t[:, 1]), 1)] + ([vi] if N == 5 else [])
+                new_buffers["vertex_index"] = torch.stack(rows, dim=1).reshape(ns * N, 3)
+                new_buffers["v"] = torch.stack((ab, ac, bc), dim=1).reshape(ns * 3, 3)
+            new_rows = {
+                "bc": torch.full((ns * N, 3), 1.0 / 3.0, dtype=g._bc.dtype, device=g._bc.device),
+                "distance": torch.zeros((ns * N, 1), dtype=g._bc.dtype, device=g._bc.device),
+                "f_dc+f_rest": rep(g._features.detach()),
+                "opacity": rep(g._opacity.detach()),
+                "scaling": torch.log(rep(torch.exp(g._scaling.detach())) / (4 * 0.8)),
+                "rotation": rep(g._rotation.detach()),
+            }
+        return self.resize(keep_mask=selected.logical_not(), new_rows=new_rows, new_buffers=new_buffers)
+
+    def densify_and_split_for_init(self, N=4):
+        """densify_and_split_for_init (:596-647): split every face (train_mesh_gaussian.py:60-61 repeats it until the model has
+        more than 100 000 Gaussians)."""
+        return self.densify_and_split(torch.ones((self.g._bc.shape[0],), dtype=torch.bool, device=self.g._bc.device), N)
+
+    def densify_and_prune(self, max_grad, min_opacity=0.005, extent=None, max_screen_size=None, N=4):
+        """densify_and_prune (:588-594): rows whose mean view-space gradient norm (bc_gradient_accum / denom, NaN -> 0) reaches
+        max_grad are split; as in the reference, min_opacity / extent / max_screen_size are accepted and unused."""
+        if not self.densify_stats:
+            raise ValueError("densify_and_prune needs Trainer(densify_stats=True)")
+        grads = self.bc_gradient_accum / self.denom
+        grads[grads.isnan()] = 0.0
+        return self.densify_and_split(grads.reshape(-1) >= max_grad, N)
 
     def update_learning_rate(self):
         lr = self.bc_lr(self.iteration)
@@ -130,11 +270,18 @@ class Trainer:
         rasterizer.set_sync_free_training(self.sync_free)
         try:
             loss, pkg = self._forward_backward(camera, gt_image, background)
-            if self.sync_free and not rasterizer.verify_sync_free():
-                self.redone += 1                 # image was the background: same iteration again with the enlarged buffer
+            attempts = 0
+            while self.sync_free and not rasterizer.verify_sync_free():
+                # the image was the background and the render gradients zero: the same iteration again, with the buffer
+                # verify_sync_free() just enlarged; the third attempt takes the exact-count path, which cannot overflow
+                attempts += 1
+                self.redone += 1
+                if attempts >= 2:
+                    rasterizer.set_sync_free_training(False)
                 self.optimizer.zero_grad(set_to_none=True)
                 loss, pkg = self._forward_backward(camera, gt_image, background)
-                rasterizer.verify_sync_free()
+                if attempts >= 2:
+                    break
         finally:
             rasterizer.set_sync_free_training(False)
         if self.densify_stats:

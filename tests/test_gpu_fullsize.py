@@ -160,29 +160,25 @@ def test_c2_backward_properties():
 
 
 def test_c5_scale_smoke():
-    """C5 shape: 3M Gaussians (2M cloud + 1M shell), 3840x2160, a few train-style iterations (render, L1, backward, Adam)."""
-    from gpu_utils import T, settings
-    from gaussianmesh_amd import GaussianRasterizer, scenes
-    W, H = 3840, 2160
-    a = scenes.make_cloud(2_000_000, seed=0)
-    b = scenes.make_cloud(1_000_000, seed=1, extent=1.0)
-    nb = np.linalg.norm(b["means"], axis=1, keepdims=True) + 1e-6
-    b["means"] = (b["means"] / nb * (6 + 6 * nb)).astype(np.float32)       # shell of radius 6..12
-    sc = {k: np.concatenate([a[k], b[k]], 0) for k in ("means", "opac", "shs", "scales", "rots")}
-    params = [T(sc[k], True) for k in ("means", "opac", "shs", "scales", "rots")]
-    opt = torch.optim.Adam(params, lr=1e-4)
-    target = torch.rand((3, H, W), device="cuda")
+    """C5 as bench.py times it (bench.build_c5): 2 M mesh-bound + 1 M frozen background Gaussians, 3840x2160, through
+    Trainer(sync_free=True, densify_stats=True, bg_gaussian=...) - fused activations, render with the shared SH storage,
+    L1 + SSIM + mesh-restrict loss, backward, FusedAdam, densification statistics.  Twelve iterations alternating over two
+    cameras: finite, the loss of each camera goes down, nothing is lost to an overflowing binning buffer, statistics fill."""
+    import bench
+    tr, cams, target, zero = bench.build_c5(ncams=32)
+    N = tr.g.get_number
     losses = []
-    for it in range(3):
-        cam = scenes.orbit_camera(it, 32, W, H)
-        rast = GaussianRasterizer(settings(cam, np.zeros(3, np.float32), 3))
-        m2d = torch.zeros_like(params[0], requires_grad=True)
-        color, radii = rast(params[0], m2d, params[1], shs=params[2], scales=params[3], rotations=params[4])
-        loss = (color - target).abs().mean()
-        opt.zero_grad(); loss.backward(); opt.step()
-        losses.append(float(loss))
-        assert torch.isfinite(color).all() and (radii > 0).sum() > 1_000_000
-    assert all(np.isfinite(losses))
+    for it in range(12):
+        loss, pkg = tr.step(cams[(it % 2) * 5], target, zero)
+        losses.append(loss)
+    losses = [float(l) for l in losses]
+    assert all(np.isfinite(losses)), losses
+    assert losses[10] < losses[0] and losses[11] < losses[1], losses              # per camera: later visits are cheaper
+    assert pkg["render"].shape == (3, 2160, 3840) and torch.isfinite(pkg["render"]).all()
+    assert pkg["radii"].shape[0] == 3_000_000 and int((pkg["radii"] > 0).sum()) > 1_000_000 and pkg["scale"].shape[0] == N
+    assert tr.optimizer.n_step == 12 and tr.redone <= 2                            # a redone iteration is repeated, never skipped
+    assert float(tr.denom.max()) == 12 and float((tr.denom > 0).float().mean()) > 0.3 and float(tr.max_radii2D.max()) > 0
+    assert torch.isfinite(tr.bc_gradient_accum).all()
 
 
 def test_c2_full_size_gradients_vs_oracle(oracle):

@@ -113,3 +113,56 @@ def test_closest_triangles_matches_point_by_point_search():
         d = ((samples - p) ** 2).sum(-1).min(1)                     # sampled distance to each triangle (upper bound, close)
         exact_got = d[got[i]]
         assert exact_got <= d.min() * 1.02 + 1e-4, i               # the chosen triangle is (one of) the closest
+
+
+# ---- fixtures generated by EXECUTING the reference's own code (tests/golden/make_golden_model.py) -----------------------------
+import os
+
+_GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_cameras_json_written_by_the_reference_serialiser():
+    """tests/golden/cameras.json is the output of utils/camera_utils.py:63-83 camera_to_JSON on three scene/cameras.py Camera
+    objects; cameras_expected.npz holds those cameras' (R, T, FoV) and the matrices the reference's Camera class derived from
+    them.  io.camera_to_json must write the same entries, io.load_cameras_json (edittool/__init__.py:547-584) must recover the
+    cameras."""
+    from gaussianmesh_amd import io
+    exp = np.load(os.path.join(_GOLD, "cameras_expected.npz"))
+    with open(os.path.join(_GOLD, "cameras.json")) as f:
+        entries = json.load(f)
+    assert len(entries) == 3
+    for k, e in enumerate(entries):
+        mine = io.camera_to_json(k, exp["R"][k], exp["T"][k], int(exp["W"][k]), int(exp["H"][k]), float(exp["FoVx"][k]), float(exp["FoVy"][k]),
+                                 e["img_name"])
+        assert set(mine) == set(e) and mine["id"] == e["id"] and mine["width"] == e["width"] and mine["height"] == e["height"]
+        assert mine["img_name"] == e["img_name"]
+        assert np.allclose(mine["position"], e["position"], rtol=0, atol=1e-12) and np.allclose(mine["rotation"], e["rotation"], rtol=0, atol=1e-12)
+        assert abs(mine["fx"] - e["fx"]) <= 1e-9 * e["fx"] and abs(mine["fy"] - e["fy"]) <= 1e-9 * e["fy"]
+    cams = io.load_cameras_json(os.path.join(_GOLD, "cameras.json"))
+    for k, c in enumerate(cams):
+        assert (c["W"], c["H"]) == (int(exp["W"][k]), int(exp["H"][k])) and c["img_name"] == entries[k]["img_name"]
+        assert abs(c["fovx"] - exp["FoVx"][k]) < 1e-9 and abs(c["fovy"] - exp["FoVy"][k]) < 1e-9
+        # the matrices of the reference's Camera class (world_view_transform, full_proj_transform, camera_center), float32
+        assert np.allclose(c["view"], exp["view"][k], atol=2e-6), k
+        assert np.allclose(c["proj"], exp["proj"][k], rtol=1e-5, atol=1e-5), k
+        assert np.allclose(c["campos"], exp["center"][k], atol=1e-5), k
+
+
+def test_mesh_ply_rows_assembled_by_the_reference_writer(tmp_path):
+    """tests/golden/mesh_ply.npz: `names` = construct_list_of_attributes() (scene/mesh_based_gaussian_model.py:290-303),
+    `elements` = the structured rows save_ply (:305-330) hands to plyfile for the model stored next to them, `loaded_*` = what
+    load_ply (:341-408) makes of those columns."""
+    from gaussianmesh_amd import io
+    fx = np.load(os.path.join(_GOLD, "mesh_ply.npz"))
+    names = [str(n) for n in fx["names"]]
+    assert io.attribute_names() == names and len(names) == 80
+    m = {k: fx[k] for k in ("xyz", "normal", "bc", "v1", "v2", "v3", "distance", "vertex_index", "radius", "fid", "features_dc", "features_rest",
+                             "opacity", "scaling", "rotation")}
+    p = tmp_path / "point_cloud.ply"
+    io.save_mesh_gaussians(str(p), m)
+    got_names, data = io.read_ply(str(p))
+    assert got_names == names and np.array_equal(data, fx["elements"])
+    back = io.load_mesh_gaussians(str(p), bc_from_xyz=True)            # the reference loader fills _bc from x, y, z (:392-393)
+    for k in ("bc", "features_dc", "features_rest", "opacity", "scaling", "rotation", "distance", "v1", "v2", "v3", "normal", "radius", "load_xyz"):
+        assert np.array_equal(back[k], fx["loaded_" + k]), k
+    assert np.array_equal(back["fid"].astype(np.float32).reshape(-1), fx["loaded_fid"].astype(np.float32).reshape(-1))
