@@ -293,6 +293,7 @@ def main():
     hint = None if args.no_work_hint else Rz.new_work_hint(W, H, dev)
     pending = {}
     unchecked = []
+    views_walked = []                            # camera index of every loop step this rank issued (--check-dir)
     stats["overflows"] = 0
 
     def step(i):
@@ -333,22 +334,40 @@ def main():
             return tab if out is None else out.copy_(tab.view(out.shape))
         return mesh_rs_packed(g["verts"], v1_frames[t], g["faces"], adjacency, out=out)
 
-    # N > 1, the real exchange step: rank 0 owns the animation and produces the table of every loop step (0.72 MB); the
-    # tables of --exchange-batch consecutive steps travel in one RCCL broadcast, one batch ahead of their use, on the pipe's
-    # own stream (multiview.MeshStatePipe) - the render streams never wait on a collective.
-    # N = 1: the table is computed on the frame's own stream.  (Producing it ahead on a fifth stream - --exchange-batch B at
-    # N = 1 - would take a 12-us launch that lasts 38 us inside the pipelined loop off the frame's chain, and is 6 % slower:
-    # 4500 -> 4220 frames/s, as with any fifth stream next to the four.)
+    # N > 1, the real exchange step: rank 0 owns the animation.  What travels is the DEFORMED VERTEX POSITIONS of every loop step
+    # (Vm x 12 B = 90 KB), --exchange-batch consecutive steps in one RCCL broadcast, one batch ahead of their use, on the pipe's
+    # own stream (multiview.MeshStatePipe) - the render streams never wait on a collective - and EVERY rank turns them into the
+    # per-vertex (R, S) gather table with gm_mesh_rs_packed on the frame's own stream, exactly as at N = 1: no rank runs a
+    # kernel the others do not (round 2 produced the 720-KB tables on rank 0 only, which made rank 0 the slowest rank of a
+    # max-over-ranks timing).  --analytic-rs (precomputed (R, S) that only rank 0 holds) still ships whole tables.
+    # N = 1: no pipe; the positions are read where they lie.
     pipe = None
     batch = args.exchange_batch if args.exchange_batch is not None else (8 if world > 1 else 0)
     if world > 1 or batch > 0:
-        pipe = multiview.MeshStatePipe(lambda i, out: frame_table(i % F, out), (Vm, 24), max(1, batch), dev, src=0,
-                                       frames_in_flight=nstreams + lag + 1)
+        if args.analytic_rs:
+            pipe = multiview.MeshStatePipe(lambda i, out: frame_table(i % F, out), (Vm, 24), max(1, batch), dev, src=0,
+                                           frames_in_flight=nstreams + lag + 1)
+        else:
+            def produce_positions(b, buf):           # one gather launch per batch on the pipe's stream (rank 0 only)
+                idx = (torch.arange(buf.shape[0], device=dev) + b * buf.shape[0]) % F
+                torch.index_select(v1_frames, 0, idx, out=buf)
+            pipe = multiview.MeshStatePipe(None, (Vm, 3), max(1, batch), dev, src=0, frames_in_flight=nstreams + lag + 1,
+                                           produce_batch=produce_positions)
+    exchange_bytes = Vm * (96 if args.analytic_rs else 12)
+
+    def table_for_step(i, exchange):
+        if pipe is None or not exchange:
+            return frame_table(i % F)
+        got = pipe.frame(i)
+        return got if args.analytic_rs else mesh_rs_packed(g["verts"], got, g["faces"], adjacency)
 
     def step_on_stream(i, workspace, exchange=True, begin_only=False):
         t = i % F
-        packed = pipe.frame(i) if (pipe is not None and exchange) else frame_table(t)
-        c = cam_t[multiview.view_for_step(i, F, rank, world)]
+        packed = table_for_step(i, exchange)
+        vi = multiview.view_for_step(i, F, rank, world)
+        if begin_only:
+            views_walked.append((i, vi))
+        c = cam_t[vi]
         if begin_only and not args.unfused:      # one enqueue: deform + colour + preprocess + depth sort + instance count
             return Rz.forward_deformed_begin(bg, g["tri"], g["weights"], packed, g["cov"], g["pos"], g["shs"], g["opac"], c["view"],
                                              c["proj"], c["tanx"], c["tany"], H, W, 3, c["campos"], False, workspace=workspace,
@@ -436,7 +455,8 @@ def main():
         last = args.warmup + args.steps - 1
         os.makedirs(args.check_dir, exist_ok=True)
         np.savez(os.path.join(args.check_dir, "rank%d.npz" % rank), step=last, frame=last % F, view=multiview.view_for_step(last, F, rank, world),
-                 image=stats["last_image"].cpu().numpy(), overflows=stats["overflows"])
+                 image=stats["last_image"].cpu().numpy(), overflows=stats["overflows"],
+                 views=np.array([v for (k, v) in views_walked if args.warmup <= k < args.warmup + args.steps], np.int64))   # timed steps only
 
     out = {
         "metric": "frames/sec (fwd), 1M Gaussians @1080p, deform+render", "value": fps, "unit": "frames/s",
@@ -446,7 +466,8 @@ def main():
                                "render %dx%d, %d-camera orbit, views sharded by rank" % (P, W, H, F),
                    "gaussians": P, "width": W, "height": H, "sh_degree": 3, "views_per_step_per_gpu": 1,
                    "vertex_rs": "analytic tables" if args.analytic_rs else "gm_mesh_rs per frame", "hip_streams": nstreams,
-                   "exchange": None if pipe is None else {"steps_per_broadcast": pipe.batch, "bytes_per_step": Vm * 96, "broadcasts": pipe.broadcasts},
+                   "exchange": None if pipe is None else {"steps_per_broadcast": pipe.batch, "bytes_per_step": exchange_bytes, "broadcasts": pipe.broadcasts,
+                                                          "payload": "per-vertex (R, S) tables" if args.analytic_rs else "deformed vertex positions; (R, S) by gm_mesh_rs on every rank"},
                    "emission_policy": Rz.get_default_emission_policy(W, H), "image_only": image_only, "work_hint": hint is not None,
                    "frames_redone": stats["overflows"],          # sync-free frames that outgrew their binning buffer (rendered again, exactly)
                    "parallelism": "views x%d" % world},

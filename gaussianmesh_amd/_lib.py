@@ -14,7 +14,7 @@ SO_PATH = os.path.join(CSRC, "libgmesh_hip.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "gmesh_hip.h")
 _lib = None
 
-vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+vp, i32, i64, f32, f64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
 
 # name -> (restype, argtypes); mirrors include/gmesh_hip.h one to one
 SIGNATURES = {
@@ -54,7 +54,7 @@ SIGNATURES = {
     "gm_mesh_rs_packed": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "gm_mesh_activate_fwd": (i32, [i32, f32] + [vp] * 10 + [vp] * 4 + [f32, vp] + [vp]),
     "gm_mesh_activate_bwd": (i32, [i32, f32] + [vp] * 10 + [vp] * 4 + [vp] * 5 + [f32, vp] + [vp]),
-    "gm_adam_step": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, i32, vp]),
+    "gm_adam_step": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, f64, f64, f64, i32, vp]),
     "gm_densify_stats": (i32, [i32, vp, vp, vp, vp, vp, vp]),
     "gm_ssim_partials": (i64, [i32, i32, i32]),
     "gm_ssim_fwd": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),

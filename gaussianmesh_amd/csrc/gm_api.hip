@@ -478,12 +478,13 @@ int gm_mesh_activate_bwd(int N, float alpha, const float* bc, const float* dist,
 
 int gm_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                  const uint64_t* sizes, const float* lr, const float* lr_rest, const uint32_t* period, const uint32_t* split,
-                 float beta1, float beta2, float eps, int step, void* stream) {
+                 double beta1, double beta2, double eps, int step, void* stream) {
   if (count < 0 || count > 8 || step < 1) { set_error("gm_adam_step: 0..8 tensors per call, step >= 1"); return GM_ERR_INVALID_ARG; }
   if (count > 0 && (!params || !grads || !exp_avg || !exp_avg_sq || !sizes || !lr)) { set_error("gm_adam_step: null table"); return GM_ERR_INVALID_ARG; }
   AdamTable tab;
-  tab.count = 0; tab.b1 = beta1; tab.b2 = beta2; tab.eps = eps;
-  const double corr = sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
+  tab.count = 0; tab.b1 = (float)beta1; tab.b2 = (float)beta2; tab.eps = (float)eps;
+  tab.omb1 = (float)(1.0 - beta1); tab.omb2 = (float)(1.0 - beta2);
+  const double corr = sqrt(1.0 - pow(beta2, (double)step)) / (1.0 - pow(beta1, (double)step));
   for (int i = 0; i < count; i++) {
     if (sizes[i] == 0) continue;
     if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i]) { set_error("gm_adam_step: null tensor %d", i); return GM_ERR_INVALID_ARG; }

@@ -320,7 +320,7 @@ struct AdamTensor {
   float step_lo, step_hi;      // lr * sqrt(1-b2^t)/(1-b1^t) for elements with (index % period) < split / the others
   unsigned period, split;      // period == 0: one rate (step_lo) for the whole tensor
 };
-struct AdamTable { AdamTensor t[8]; int count; float b1, b2, eps; };
+struct AdamTable { AdamTensor t[8]; int count; float b1, b2, eps, omb1, omb2; };   // omb = (float)(1 - beta), formed in double
 int launch_mesh_activate_fwd(const ActArgs& a, float* xyz, float* scales, float* rots, float* opac, float mr_weight, float* mr_partial,
                              hipStream_t s);
 int launch_mesh_activate_bwd(const ActArgs& a, const float* d_xyz, const float* d_scales, const float* d_rots, const float* d_opac,

@@ -135,7 +135,7 @@ int launch_mesh_activate_bwd(const ActArgs& a, const float* d_xyz, const float* 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(const AdamTable tab) {
   const AdamTensor t = tab.t[blockIdx.y];
-  const float b1 = tab.b1, b2 = tab.b2, eps = tab.eps;
+  const float b1 = tab.b1, b2 = tab.b2, eps = tab.eps, c1 = tab.omb1, c2 = tab.omb2;
   const unsigned long long n4 = t.n >> 2;
   for (unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (unsigned long long)gridDim.x * 256) {
     const float4 g = reinterpret_cast<const float4*>(t.g)[q];
@@ -145,8 +145,8 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable tab) {
 #pragma unroll
     for (int c = 0; c < 4; c++) {
       const float st = (t.period && in_period + c >= t.split) ? t.step_hi : t.step_lo;
-      mm[c] = b1 * mm[c] + (1.0f - b1) * gg[c];
-      vv[c] = b2 * vv[c] + (1.0f - b2) * gg[c] * gg[c];
+      mm[c] = b1 * mm[c] + c1 * gg[c];
+      vv[c] = b2 * vv[c] + c2 * gg[c] * gg[c];
       pp[c] -= st * mm[c] / (sqrtf(vv[c]) + eps);
     }
     reinterpret_cast<float4*>(t.p)[q] = p; reinterpret_cast<float4*>(t.m)[q] = m; reinterpret_cast<float4*>(t.v)[q] = v;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable tab) {
     const unsigned long long e = (n4 << 2) + threadIdx.x;
     const float st = (t.period && (unsigned)(e % t.period) >= t.split) ? t.step_hi : t.step_lo;
     const float g = t.g[e];
-    const float m = b1 * t.m[e] + (1.0f - b1) * g, v = b2 * t.v[e] + (1.0f - b2) * g * g;
+    const float m = b1 * t.m[e] + c1 * g, v = b2 * t.v[e] + c2 * g * g;
     t.m[e] = m; t.v[e] = v;
     t.p[e] -= st * m / (sqrtf(v) + eps);
   }

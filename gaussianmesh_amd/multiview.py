@@ -7,8 +7,10 @@ collective inside a frame.  The only exchange steps are
   * broadcast_mesh_state(): per deformation frame, the proxy-mesh state (V1, R, S) = 84 B per vertex
                             (0.63 MB for 7.5k vertices) -- every rank then runs the deform kernel locally,
                             instead of shipping the 36-48 MB deformed cloud.
-  * MeshStatePipe:          the same exchange for a pipelined frame loop: the states of several consecutive frames in one
-                            broadcast, one batch ahead of their use, on a stream of its own.
+  * MeshStatePipe:          the exchange of a pipelined frame loop: the per-frame state of several consecutive frames in one
+                            broadcast, one batch ahead of their use, on a stream of its own.  bench.py ships only the deformed
+                            VERTEX POSITIONS (12 B per vertex, 90 KB per frame) and lets every rank derive (R, S) itself
+                            (gm_mesh_rs_packed on the frame's stream, as at N = 1), so all ranks run the same kernels.
 Both are torch.distributed broadcasts: RCCL over xGMI with backend "nccl" on the GPUs, gloo in the CPU tests.
 """
 import torch
@@ -89,8 +91,10 @@ class MeshStatePipe:
     frames_in_flight bounds how many steps after frame(i) the device may still be reading the state of step i (the caller's
     pipelining depth); a slot is overwritten only after that many further steps have been requested."""
 
-    def __init__(self, produce, frame_shape, batch, device, src=0, frames_in_flight=1, dtype=torch.float32):
-        self.produce, self.batch, self.src = produce, max(1, int(batch)), src
+    def __init__(self, produce, frame_shape, batch, device, src=0, frames_in_flight=1, dtype=torch.float32, produce_batch=None):
+        """produce_batch(b, buf) (optional, instead of produce): fills all `batch` states of batch b at once - buf[j] is the state
+        of step b * batch + j - e.g. one gather launch instead of `batch` copies."""
+        self.produce, self.produce_batch, self.batch, self.src = produce, produce_batch, max(1, int(batch)), src
         self.rank, self.ws = world()
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
@@ -106,8 +110,11 @@ class MeshStatePipe:
 
         def fill():
             if self.rank == self.src:
-                for j in range(self.batch):
-                    self.produce(b * self.batch + j, buf[j])
+                if self.produce_batch is not None:
+                    self.produce_batch(b, buf)
+                else:
+                    for j in range(self.batch):
+                        self.produce(b * self.batch + j, buf[j])
             if self.ws > 1:
                 _broadcast(buf, self.src)
                 self.broadcasts += 1

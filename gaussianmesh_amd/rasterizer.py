@@ -138,6 +138,29 @@ class RasterWorkspace:
             self.in_flight = None
 
 
+_STREAMS_SEEN = set()
+_QUEUE_WARNED = [False]
+
+
+def _note_stream(stream):
+    """Frames pipelined over three or more HIP streams only overlap if the runtime has a hardware queue for each: HIP multiplexes
+    streams onto FOUR queues by default and streams that share one serialise (four streams: 3460 frames/s on 4 queues, 4350-4590
+    on 8).  GPU_MAX_HW_QUEUES is read when the HIP runtime starts, so a library cannot set it for its
+    caller: warn, once, when it sees the third stream and the variable is not set."""
+    if _QUEUE_WARNED[0]:
+        return
+    _STREAMS_SEEN.add(stream.cuda_stream)
+    if len(_STREAMS_SEEN) >= 3:
+        _QUEUE_WARNED[0] = True
+        import os
+        import warnings
+        if "GPU_MAX_HW_QUEUES" not in os.environ:
+            warnings.warn("gaussianmesh_amd: frames are being issued on %d HIP streams but GPU_MAX_HW_QUEUES is not set; the runtime "
+                          "multiplexes streams onto 4 hardware queues by default and streams sharing a queue serialise. Export "
+                          "GPU_MAX_HW_QUEUES=8 before the process starts HIP (before importing torch)." % len(_STREAMS_SEEN), RuntimeWarning,
+                          stacklevel=3)
+
+
 def new_work_hint(width, height, device):
     """Zeroed work-hint buffer for PendingForward.finish(work_hint=...) / gm_forward_1_geom: one per view stream."""
     return torch.zeros((_lib.lib().gm_work_hint_bytes(width, height) // 4,), dtype=torch.int32, device=device)
@@ -312,6 +335,7 @@ def rasterize_forward_begin(bg, means3D, colors, opacity, scales, rotations, sca
     if force_M is not None and sh is not None and M != force_M:
         raise ValueError("NewGaussianRasterizer expects shs of shape [P,%d,3]" % force_M)
     stream = torch.cuda.current_stream(device)
+    _note_stream(stream)
     h = PendingForward(policy=policy, workspace=workspace, stream=stream)
     if workspace is not None:
         workspace.acquire(h)
@@ -367,6 +391,7 @@ def forward_deformed_begin(bg, tri, weights, packed, cov, pos, shs, opacity, vie
     bg, viewmatrix, projmatrix, campos = (_prep(t, device) for t in (bg, viewmatrix, projmatrix, campos))
     H, W = int(image_height), int(image_width)
     stream = torch.cuda.current_stream(device)
+    _note_stream(stream)
     h = PendingForward(policy=policy, workspace=workspace, stream=stream)
     if workspace is not None:
         workspace.acquire(h)

@@ -295,10 +295,11 @@ int gm_mesh_activate_bwd(int N, float alpha, const float* bc, const float* dist,
  * The arrays are HOST arrays of `count` entries (device pointers, element counts, learning rates).  period/split/lr_rest
  * (may be NULL) give a tensor two rates: elements with (index % period) < split use lr, the others lr_rest - the SH
  * tensor [P,16,3] with period 48, split 3 is the reference's "f_dc" and "f_rest" groups without splitting the rows.
- * All tensors 16-byte aligned; gradients are read, not cleared. */
+ * All tensors 16-byte aligned; gradients are read, not cleared.  beta1 / beta2 / eps are doubles: Jittor forms (1 - beta) in
+ * python double precision before it meets the float32 tensors, and (1 - beta2) taken from a float32 0.999 is off by 1.3e-5. */
 int gm_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                  const uint64_t* sizes, const float* lr, const float* lr_rest, const uint32_t* period, const uint32_t* split,
-                 float beta1, float beta2, float eps, int step, void* stream);
+                 double beta1, double beta2, double eps, int step, void* stream);
 
 /* Densification statistics of a training iteration in one pass (train_mesh_gaussian.py:119-126 and
  * scene/mesh_based_gaussian_model.py:587-589): for every Gaussian with radii[i] > 0 (render()'s visibility_filter)

@@ -44,7 +44,10 @@ def account_outlier_pixels(fw, color, W, H, tol=1e-4):
         t1 = 0.5 * co[g, 0] * dx * dx; t2 = 0.5 * co[g, 2] * dy * dy; t3 = co[g, 1] * dx * dy
         power = -(t1 + t2) - t3
         mag = np.abs(t1) + np.abs(t2) + np.abs(t3)
-        d_pow = 8 * eps * (mag + 1.0) + 2e-6           # rounding distance of `power` (and of log alpha) for this entry
+        # rounding distance of `power` (and of log alpha) for this entry: eight float32 roundings of its cancelling terms
+        # (pre-multiplied conic, two differences, three products, two sums) plus eight for exp and the opacity product -
+        # no flat allowance on top
+        d_pow = 8 * eps * (mag + 1.0)
         op = co[g, 3]
         with np.errstate(over="ignore"):
             alpha = np.minimum(0.99, op * np.exp(np.minimum(power, 50.0)))
@@ -52,12 +55,16 @@ def account_outlier_pixels(fw, color, W, H, tol=1e-4):
         keep = np.where(acc, 1.0 - alpha, 1.0)
         T_before = np.concatenate([[1.0], np.cumprod(keep)[:-1]])
         test_T = T_before * (1.0 - alpha)
-        definite_stop = acc & (test_T < 1e-4 * (1 - 1e-3))
+        # rounding distance of log T at each entry: every accepted factor (1 - alpha) carries alpha / (1 - alpha) times the
+        # entry's own log-alpha distance plus one rounding of the running product - accumulated over the entries visited,
+        # instead of a blanket 1e-3 band around the 1e-4 threshold
+        d_T = np.cumsum(np.where(acc, alpha / (1.0 - alpha) * d_pow + eps, 0.0)) + eps
+        definite_stop = acc & (test_T < 1e-4 * np.exp(-d_T))
         n_vis = int(np.argmax(definite_stop)) + 1 if definite_stop.any() else len(g)
         v = slice(0, n_vis)
         amb_alpha = np.abs(np.log(np.maximum(alpha[v], 1e-300) * 255.0)) <= d_pow[v]
         amb_power = (np.abs(power[v]) <= d_pow[v]) & (op[v] >= 1.0 / 255.0 * 0.99)
-        amb_stop = acc[v] & (np.abs(np.log(np.maximum(test_T[v], 1e-300) / 1e-4)) <= 1e-3)
+        amb_stop = acc[v] & (np.abs(np.log(np.maximum(test_T[v], 1e-300) / 1e-4)) <= d_T[v])
         if (amb_alpha | amb_power | amb_stop).any():
             worst = max(worst, float(err[y, x]))
         else:
@@ -65,10 +72,29 @@ def account_outlier_pixels(fw, color, W, H, tol=1e-4):
     return len(ys), unexplained, worst
 
 
+GATE_LOG = []          # (what, W, H, outliers, unexplained, worst) of every gate evaluated in this process
+
+
+def assert_grads_elementwise(got, ref, what="", floor=1e-3, rtol=1e-2):
+    """Element-wise companion of the max-norm gradient gate (which a Gaussian with a small gradient can pass while being
+    entirely wrong): EVERY entry whose reference magnitude is at least `floor` x the tensor's maximum must agree to `rtol`
+    RELATIVE TO ITSELF.  Returns the number of entries checked."""
+    got = np.asarray(got, np.float64).reshape(-1); ref = np.asarray(ref, np.float64).reshape(-1)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    big = np.abs(ref) >= floor * max(np.abs(ref).max(), 1e-300)
+    rel = np.abs(got[big] - ref[big]) / np.abs(ref[big])
+    bad = int((rel > rtol).sum())
+    assert bad == 0, "%s: %d of %d entries above %g x max differ by more than %g relative (worst %.3g)" % (what, bad, int(big.sum()), floor, rtol,
+                                                                                                     rel.max())
+    return int(big.sum())
+
+
 def assert_forward_gate(fw, color, W, H, tol=1e-4, what=""):
     """The strict forward gate: every pixel within `tol` of the oracle, except pixels with a provable threshold flip
     (account_outlier_pixels), which are bounded by one flipped entry's weight: alpha * T * |colour| <= 2 / 255."""
     n_out, n_bad, worst = account_outlier_pixels(fw, color, W, H, tol)
+    GATE_LOG.append((what, W, H, n_out, n_bad, worst))
+    print("forward gate %-22s %dx%d: %d pixel(s) above %g, %d unexplained, worst explained %.3g" % (what, W, H, n_out, tol, n_bad, worst))
     assert n_bad == 0, "%s: %d of %d outlier pixels (> %g) have no entry at a decision threshold" % (what, n_bad, n_out, tol)
     assert n_out <= max(2, 1e-4 * W * H), "%s: %d outlier pixels" % (what, n_out)
     assert worst <= 2.0 / 255.0 + 1e-3, "%s: explained outlier of %g" % (what, worst)

@@ -21,23 +21,50 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("batch", [None, 1, 3])          # None: bench.py's own default at N > 1 (8)
-def test_bench_two_ranks_render_their_own_views(tmp_path, batch):
-    P, W, H, F, steps, warm = 20000, 320, 200, 8, 4, 2
-    env = dict(os.environ, GM_BENCH_SHARE_DEVICE="1", GM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", str(warm),
+def _launch(tmp_path, nproc, env_extra, P, W, H, F, steps, warm, batch=None, extra=()):
+    """`python -m torch.distributed.run --nproc-per-node nproc bench.py --gpus nproc ...` exactly as the driver launches it;
+    returns bench.py's JSON line."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", **env_extra)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", str(steps), "--warmup", str(warm),
            "--gaussians", str(P), "--width", str(W), "--height", str(H), "--cameras", str(F), "--check-dir", str(tmp_path),
-           "--no-cpu-baseline", "--no-fwd-bwd"] + ([] if batch is None else ["--exchange-batch", str(batch)])
-    batch = 8 if batch is None else batch
-    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+           "--no-cpu-baseline", "--no-fwd-bwd"] + ([] if batch is None else ["--exchange-batch", str(batch)]) + list(extra)
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout
-    out = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_bench_eight_ranks_walk_the_c4_view_split(tmp_path):
+    """BASELINE config C4's split - 64-camera trajectory, 8 views per rank - as bench.py shards it: `--gpus 8 --cameras 64`, eight
+    ranks on the one GPU of the test box (gloo; a dry run of the launch, the exchange and the sharding, not a measurement): over
+    eight loop steps rank r renders cameras 8r .. 8r+7 and nothing else; one broadcast carries eight steps of vertex positions."""
+    P, W, H, F, steps, warm = 2000, 96, 64, 64, 8, 0
+    out = _launch(tmp_path, 8, dict(GM_BENCH_SHARE_DEVICE="1", GM_BENCH_BACKEND="gloo"), P, W, H, F, steps, warm)
+    assert out["n_gpus"] == 8 and out["config"]["parallelism"] == "views x8" and out["value"] > 0
+    assert out["config"]["exchange"]["steps_per_broadcast"] == 8 and out["config"]["exchange"]["bytes_per_step"] == 7500 * 12
+    seen = set()
+    for r in range(8):
+        d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        assert d["views"].tolist() == list(range(8 * r, 8 * r + 8)), (r, d["views"].tolist())
+        assert int(d["overflows"]) == 0 and np.isfinite(d["image"]).all()
+        seen.update(d["views"].tolist())
+    assert seen == set(range(64))
+
+
+@pytest.mark.parametrize("batch", [None, 1, 3])          # None: bench.py's own default at N > 1 (8)
+def test_bench_two_ranks_render_their_own_views(tmp_path, batch):
+    _two_ranks(tmp_path, batch, dict(GM_BENCH_SHARE_DEVICE="1", GM_BENCH_BACKEND="gloo"))
+
+
+def _two_ranks(tmp_path, batch, env_extra):
+    P, W, H, F, steps, warm = 20000, 320, 200, 8, 4, 2
+    out = _launch(tmp_path, 2, env_extra, P, W, H, F, steps, warm, batch)
+    batch = 8 if batch is None else batch
     assert out["n_gpus"] == 2 and out["steps"] == steps and out["scaling"] == "weak" and out["value"] > 0
-    ex = out["config"]["exchange"]                                      # mesh tables: `batch` loop steps per broadcast, one batch ahead
-    assert ex["steps_per_broadcast"] == batch and ex["broadcasts"] >= (3 * F + warm + steps) // batch
+    ex = out["config"]["exchange"]                                      # vertex positions: `batch` loop steps per broadcast, one batch ahead
+    assert ex["steps_per_broadcast"] == batch and ex["broadcasts"] >= (3 * F + warm + steps) // batch and ex["bytes_per_step"] == 7500 * 12
     assert abs(out["value"] - 2 * steps / (out["ms_per_step"] * 1e-3 * steps)) < 1e-6 * out["value"]        # frames of both ranks / max time
     # single-process render of the same frame for each rank's view
     sys.path.insert(0, ROOT)

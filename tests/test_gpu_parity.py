@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import assert_forward_gate, small_scene
+from helpers import assert_forward_gate, assert_grads_elementwise, small_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -124,6 +124,13 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
+def _grad_gate(got, ref, what=""):
+    """max-norm gate (north_star: <= 1e-3 relative to the tensor's magnitude) AND the element-wise one: every entry of at least
+    1e-3 x max agrees to 1e-2 of itself"""
+    assert _rel(got, ref) <= GRAD_RTOL, (what, _rel(got, ref))
+    assert_grads_elementwise(got, ref, what)
+
+
 @pytest.mark.parametrize("mode", [0, 1, 3])
 def test_backward_under_every_emission_policy(oracle, mode):
     from gaussianmesh_amd import rasterizer
@@ -143,18 +150,18 @@ def test_backward_small(oracle, use_precomp_cov, use_precomp_color):
     color, radii, g = _grads_gpu(sc, cam, bg, dpix, D, use_precomp_cov, use_precomp_color)
     assert np.array_equal(radii, fw["geo"]["radii"])
     assert np.abs(color - fw["color"]).max() <= FWD_TOL
-    assert _rel(g["means"], bw["dmean3D"]) <= GRAD_RTOL
-    assert _rel(g["m2d"][:, :2], bw["dmean2D"][:, :2]) <= GRAD_RTOL
-    assert _rel(g["opac"].reshape(-1), bw["dopacity"]) <= GRAD_RTOL
+    _grad_gate(g["means"], bw["dmean3D"], 'g["means"]')
+    _grad_gate(g["m2d"][:, :2], bw["dmean2D"][:, :2], 'g["m2d"][:, :2]')
+    _grad_gate(g["opac"].reshape(-1), bw["dopacity"], 'g["opac"].reshape(-1)')
     if use_precomp_color:
-        assert _rel(g["colors"], bw["dcolor"]) <= GRAD_RTOL
+        _grad_gate(g["colors"], bw["dcolor"], 'g["colors"]')
     else:
-        assert _rel(g["shs"], bw["dsh"]) <= GRAD_RTOL
+        _grad_gate(g["shs"], bw["dsh"], 'g["shs"]')
     if use_precomp_cov:
-        assert _rel(g["cov"], bw["dcov3D"]) <= GRAD_RTOL
+        _grad_gate(g["cov"], bw["dcov3D"], 'g["cov"]')
     else:
-        assert _rel(g["scales"], bw["dscale"]) <= GRAD_RTOL
-        assert _rel(g["rots"], bw["drot"]) <= GRAD_RTOL
+        _grad_gate(g["scales"], bw["dscale"], 'g["scales"]')
+        _grad_gate(g["rots"], bw["drot"], 'g["rots"]')
 
 
 def test_backward_medium(oracle):
@@ -169,8 +176,8 @@ def test_backward_medium(oracle):
     color, radii, g = _grads_gpu(sc, cam, bg, dpix, D, False, False)
     assert np.array_equal(radii, fw["geo"]["radii"])
     for name, ref in [("means", bw["dmean3D"]), ("shs", bw["dsh"]), ("scales", bw["dscale"]), ("rots", bw["drot"])]:
-        assert _rel(g[name], ref) <= GRAD_RTOL, name
-    assert _rel(g["opac"].reshape(-1), bw["dopacity"]) <= GRAD_RTOL
+        _grad_gate(g[name], ref, name)
+    _grad_gate(g["opac"].reshape(-1), bw["dopacity"], 'g["opac"].reshape(-1)')
 
 
 @pytest.mark.parametrize("mode", [1, 2, 3])

@@ -18,10 +18,12 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("mode", ["sh_scale_rot", "precomp"])
-@pytest.mark.parametrize("seed,D", [(0, 3), (4, 1)])
-def test_oracle_vs_dense_autograd(oracle, mode, seed, D):
+@pytest.mark.parametrize("seed,D,P,W,H", [(0, 3, 160, 40, 36), (4, 1, 160, 40, 36), (9, 3, 2400, 128, 96)])
+def test_oracle_vs_dense_autograd(oracle, mode, seed, D, P, W, H):
+    """The third case is large enough for the tile machinery to matter: 2400 Gaussians on 48 tiles, lists of several hundred
+    entries (more than one 256-entry staging round of RAST/forward.cu:306-330 per tile), pixels that saturate and stop early."""
     from oracle import torch_dense as td
-    sc, cam = small_scene(P=160, W=40, H=36, seed=seed, D=D)
+    sc, cam = small_scene(P=P, W=W, H=H, seed=seed, D=D, scale_lo=0.05, scale_hi=0.6 if P < 1000 else 0.35)
     bg = np.array([0.2, 0.5, 0.9], np.float32)
     pre = mode == "precomp"
     fw = oracle.forward_full(sc, cam, bg, D=D, use_precomp_cov=pre, use_precomp_color=pre)
@@ -36,6 +38,10 @@ def test_oracle_vs_dense_autograd(oracle, mode, seed, D):
         kw = dict(shs=shs, scales=scales, rots=rots)
     out, aux = td.render(means, opac, _T(cam["view"]), _T(cam["proj"]), _T(cam["campos"]), cam["W"], cam["H"], cam["tanx"],
                          cam["tany"], _T(bg), D=D, means2D=m2d, **kw)
+    if P > 1000:
+        r = fw["bins"]["ranges"].astype(np.int64)
+        assert (r[:, 1] - r[:, 0]).max() > 256 and fw["n_contrib"].max() > 256          # multi-round tiles, deep contributors
+        assert (fw["final_T"] < 1e-3).any()                                                # some pixels saturate (early stop)
     assert np.array_equal(aux["radii"].numpy(), fw["geo"]["radii"])
     assert np.array_equal(aux["n_contrib"].numpy(), fw["n_contrib"].astype(np.int64))
     assert np.abs(out.detach().numpy() - fw["color"]).max() <= 2e-6
