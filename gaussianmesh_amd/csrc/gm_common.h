@@ -331,4 +331,10 @@ int launch_densify_stats(int N, const int* radii, const float* grad2d, float* ma
 int launch_knn(int P, const float* points, float* meanDists, void* ws, size_t ws_bytes, hipStream_t s);
 size_t knn_workspace_bytes(int P);
 
+// number of set bits of a wave-wide 64-bit mask (a ballot) at positions BELOW the calling lane: v_mbcnt_lo + v_mbcnt_hi, two
+// vector instructions and no per-lane mask registers (popcount(mask & lanes_lt) costs four and two registers)
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
 }  // namespace gm

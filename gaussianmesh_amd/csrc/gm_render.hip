@@ -208,7 +208,6 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
     const float rx0 = (float)(tx * GM_TILE + (wave & 1) * 8), ry0 = (float)(ty * GM_TILE + (wave >> 1) * 8);
     __shared__ WaveLds l_w[WPW];
     WaveLds& L = l_w[WPW == 4 ? wave : 0];
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int nlast = n - 1;
     int kpos = 0;                                  // next list position to scan
     uint32_t qa_head = 0, qa_cnt = 0;              // candidate ring (wave-uniform)
@@ -222,7 +221,7 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
           const int p = kpos + lane;
           const bool mine = p < n && (kv[k].x & child_bit) != 0u;
           const unsigned long long bal = __ballot(mine);
-          if (mine) L.qa[(qa_head + qa_cnt + (uint32_t)__popcll(bal & lt_mask)) & (RQ_QA - 1)] = make_uint2(kv[k].y, (uint32_t)p);
+          if (mine) L.qa[(qa_head + qa_cnt + lanes_below(bal)) & (RQ_QA - 1)] = make_uint2(kv[k].y, (uint32_t)p);
           qa_cnt += (uint32_t)__popcll(bal);
           kpos += 64;
         }
@@ -275,7 +274,7 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
           L.cp[ns + lane] = make_float2(0.f, 0.f);
         }
         if (keep) {
-          const int slot = __popcll(kb & lt_mask);
+          const int slot = (int)lanes_below(kb);
           L.a[slot] = make_float4(cur.a.x, cur.a.y, (-0.5f * LOG2E) * cur.a.z, (-0.5f * LOG2E) * cur.b.x);
           L.b[slot] = make_float4((-LOG2E) * cur.a.w, cur.b.y, cur.b.z, cur.b.w);
           L.cp[slot] = make_float2(cur.c, __uint_as_float(cur.pos + 1u));        // 1-based list position: n_contrib
@@ -442,7 +441,240 @@ __device__ __forceinline__ int reduce8_slot(int lane) {
 #ifndef GM_RENDER_BWD_WPW
 #define GM_RENDER_BWD_WPW 1      // waves per workgroup of the backward blend (as GM_RENDER_FWD_WPW)
 #endif
+
+// Backward blend, two phases per wave (round 3).
+//
+// Phase 1, lane = pixel: the walk of backward.cu:441-556 with everything that is not the per-pixel recurrence taken out.
+// Going back to front, with T_i the transmittance in front of entry i, w_i = alpha_i T_i and cd_i = c_i . dL/dpixel,
+//   dL/dalpha_i = T_i cd_i - (A_i + T_final bg . dL/dpixel) / (1 - alpha_i),   A_{i-1} = A_i + w_i cd_i
+// (the reference carries the three-channel `accum_rec` = A / T and the last colour / alpha for the same quantity: one
+// scalar recurrence instead of three vector ones).  An entry a lane does not take gets alpha = 0, which makes every update
+// the identity - no execution-mask juggling.  All an entry leaves behind per pixel are the two factors every gradient sum is
+// a multiple of: w (dL/dcolour) and h = G dL/dG.  They go to a row of an LDS matrix M[slot][pixel]; the entry's centre and
+// id are kept per slot.  Entries no pixel of the wave takes use no slot.
+// Phase 2, lane = (pixel row r, slot es), once per SEVEN used slots: each lane folds the eight pixels of its row into the nine
+// sums of its slot's Gaussian - dL/dcolour rgb and the six moments (1, dx, dy, dx^2, dx dy, dy^2) of h, dy being constant
+// along a row - six vector instructions per pixel, no cross-lane traffic; the eight row partials of a slot meet through LDS
+// (written [row][slot * 9 + value], read back by lane = slot * 9 + value: both conflict-free), and ONE atomic instruction
+// with 63 active lanes commits seven 36-byte records (one L2 transaction per record, as before).
+// Per entry: ~28 + ~9 vector instructions instead of ~44 + 28 for the per-entry cross-lane reduction of round 2
+// (v_permlane32/16_swap + DPP butterfly), which is gone.
+struct StagedB {                 // one survivor of the staged batch (one LDS address per entry in the walk)
+  float4 a;                      // x, y, conic.x', conic.z'   (as WaveLds::a)
+  float4 b;                      // conic.y', opacity, r, g
+  float4 c;                      // b, list position (bits), Gaussian id (bits), -
+};
+struct SlotB { float2 xy; uint32_t id, pad; };   // splat centre and id of a phase-2 slot
+struct BwdLds {                  // per wave: 7.5 KiB
+  uint2 qa[RQ_QA];               // candidate ring (front end, as WaveLds::qa)
+  StagedB st[64];                // staged batch
+  union {
+    float2 M[7][65];             // (w, h) per slot and pixel; row stride 65 keeps phase 2's row reads conflict-free
+    float part[8][72];           // phase 2: row partials [row][slot * 9 + value] (columns 63.. belong to the idle lanes)
+    struct { float2 rg[64]; float bl[64]; } dpt;   // kernel start only: dL/dpixel of every pixel
+  };
+  SlotB slot[8];
+};
+
+#ifdef GM_BWD_OCC4
+__attribute__((amdgpu_waves_per_eu(4, 8)))
+#endif
 __global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_kernel(const uint2* __restrict__ ranges,
+                                                               const uint2* __restrict__ pairs,
+                                                               const float4* __restrict__ splat, int W, int H, TileMap tm,
+                                                               const float* __restrict__ bg, const float* __restrict__ final_T,
+                                                               const uint32_t* __restrict__ n_contrib,
+                                                               const float* __restrict__ dL_dpix, float* __restrict__ grad_acc,
+                                                               const uint32_t* __restrict__ counters, int mode) {
+  constexpr int WPW = GM_RENDER_BWD_WPW;
+  const int lane = threadIdx.x & 63;
+  const int wave = WPW == 4 ? (int)(threadIdx.x >> 6) : (int)((blockIdx.x >> 3) & 3);
+  const int tile_block = WPW == 4 ? (int)blockIdx.x : (int)(((blockIdx.x >> 5) << 3) | (blockIdx.x & 7));
+  int tx, ty, parent;
+  uint32_t child_bit;
+  if ((int)counters[GM_CNT_POLICY] != mode || counters[GM_CNT_REFUSED] != 0u) return;   // lists were built under another emission policy: contribute nothing
+  if (!tm.locate(tile_block, tx, ty, parent, child_bit)) return;
+  const uint2 range = ranges[parent];
+  const int n = (int)(range.y - range.x);
+  if (n == 0) return;
+  const uint2* list = pairs + range.x;           // (key, Gaussian id) per list entry
+  const size_t HW = (size_t)H * W;
+
+  const int px = tx * GM_TILE + (wave & 1) * 8 + (lane & 7);
+  const int py = ty * GM_TILE + (wave >> 1) * 8 + (lane >> 3);
+  const bool inside = px < W && py < H;
+  const size_t pid = inside ? (size_t)W * py + px : 0;
+  const float T_final = inside ? final_T[pid] : 0.f;
+  float T = T_final;
+  const v2f pix = {(float)px, (float)py};
+  const int last = inside ? (int)n_contrib[pid] : 0;
+  const float dpr = inside ? dL_dpix[pid] : 0.f, dpg = inside ? dL_dpix[HW + pid] : 0.f, dpb = inside ? dL_dpix[2 * HW + pid] : 0.f;
+  float A = T_final * (bg[0] * dpr + bg[1] * dpg + bg[2] * dpb);      // A_i + T_final bg . dL/dpixel (see above)
+  // entries at list positions >= max over the wave of n_contrib are never used: start there
+  int max_last = last;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) max_last = max(max_last, __shfl_xor(max_last, d));
+  const int start = max_last;           // number of list entries this wave has to visit (positions start-1 .. 0)
+  if (start == 0) return;
+
+  const float rx0 = (float)(tx * GM_TILE + (wave & 1) * 8), ry0 = (float)(ty * GM_TILE + (wave >> 1) * 8);
+  __shared__ BwdLds l_b[WPW];
+  BwdLds& B = l_b[WPW == 4 ? wave : 0];
+  BwdLds& L = B;
+  // phase 2 geometry of this lane: slot es (7: idle), pixel row r; dL/dpixel of the row's eight pixels stays in registers
+  const int es = lane & 7, r = lane >> 3, esc = min(es, 6);
+  float2 dq[8]; float dqb[8];
+  B.dpt.rg[lane] = make_float2(dpr, dpg); B.dpt.bl[lane] = dpb;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int i = 0; i < 8; i++) { dq[i] = B.dpt.rg[r * 8 + i]; dqb[i] = B.dpt.bl[r * 8 + i]; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const float rowy = ry0 + (float)r;
+  const int cl = min(lane, 62), ce = cl / 9, ck = cl - 9 * ce;      // commit role of this lane: value ck of slot ce
+  int m = 0;                                                          // slots in use (wave-uniform)
+
+  auto phase2 = [&](const int cnt) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const float2 c = B.slot[esc].xy;
+    const float x0 = c.x - rx0, dy = c.y - rowy;
+    v2f s01 = {0.f, 0.f};
+    float s2 = 0.f, s3 = 0.f, s4 = 0.f, s6 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const float2 v = B.M[esc][r * 8 + i];                       // (w, h) of pixel i of this lane's row
+      const float dx = x0 - (float)i, hx = v.y * dx;
+      const v2f ww = {v.x, v.x}, drg = {dq[i].x, dq[i].y};
+      s3 += v.y; s4 += hx;
+      s6 = __builtin_fmaf(hx, dx, s6);
+      s01 = ww * drg + s01;
+      s2 = __builtin_fmaf(v.x, dqb[i], s2);
+    }
+    const v2f s34 = {s3, s4};
+    const float s5 = dy * s34.x, s7 = dy * s34.y, s8 = dy * s5;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // every lane has read M before `part` (same storage) is written
+    __builtin_amdgcn_wave_barrier();
+    float* prow = &B.part[r][es * 9];
+    prow[0] = s01.x; prow[1] = s01.y; prow[2] = s2; prow[3] = s34.x; prow[4] = s34.y; prow[5] = s5; prow[6] = s6; prow[7] = s7; prow[8] = s8;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; q++) tot += B.part[q][cl];
+    const uint32_t gid = B.slot[ce].id;
+    if (lane < 63 && ce < cnt) atomicAdd(grad_acc + (size_t)gid * GM_ACC_STRIDE + ck, tot);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // `part` has been read before phase 1 writes M again
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  // Same front end as render_fwd_kernel, walking the list back to front: chunk lane j <-> position start-1-kpos-j
+  // (positions below 0 re-read entry 0 and are not "mine"); candidates enter the ring in descending list position.
+  int kpos = 0;                                  // entries scanned so far (from the back)
+  uint32_t qa_head = 0, qa_cnt = 0;
+  uint2 kv[RQ_K];
+  auto scan = [&]() {
+    bool go = true;
+#pragma unroll
+    for (int k = 0; k < RQ_K; k++) {
+      go = go && kpos < start && qa_cnt + 64u <= (uint32_t)RQ_QA;
+      if (go) {
+        const int p = start - 1 - kpos - lane;
+        const bool mine = p >= 0 && (kv[k].x & child_bit) != 0u;
+        const unsigned long long bal = __ballot(mine);
+        if (mine) L.qa[(qa_head + qa_cnt + lanes_below(bal)) & (RQ_QA - 1)] = make_uint2(kv[k].y, (uint32_t)p);
+        qa_cnt += (uint32_t)__popcll(bal);
+        kpos += 64;
+      }
+    }
+  };
+  auto load_keys = [&]() {
+#pragma unroll
+    for (int k = 0; k < RQ_K; k++) kv[k] = list[max(start - 1 - kpos - k * 64 - lane, 0)];
+  };
+  auto pop = [&](int& count) {
+    count = (int)min(qa_cnt, 64u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint2 cand = lane < count ? L.qa[(qa_head + (uint32_t)lane) & (RQ_QA - 1)] : make_uint2(0u, 0u);
+    qa_head += (uint32_t)count; qa_cnt -= (uint32_t)count;
+    return issue_gather(splat, cand);
+  };
+  load_keys();
+  scan();
+  load_keys();
+  auto step = [&](Gather& cur, int& n0, const int n1, Gather& nxt, int& n2) -> bool {      // see render_fwd_kernel
+    if (n0 == 0 && n1 == 0 && qa_cnt == 0u && kpos >= start) return false;
+    __builtin_amdgcn_s_waitcnt(0x0F73);                                  // vmcnt(3)
+    scan();
+    load_keys();
+    nxt = pop(n2);
+    if (n0 > 0) {
+      // A pixel takes part in this batch only if its last contributor lies above the batch's lowest position: cull against
+      // the bounding box of those pixels (at the deep end of the walk only the few pixels that reached far into the list
+      // are still in play).  Lane = y * 8 + x.
+      const int pos_lo = __builtin_amdgcn_readlane((int)cur.pos, n0 - 1);
+      const unsigned long long live = __ballot(last > pos_lo);
+      float cx0 = rx0, cx1 = rx0 + 7.0f, cy0 = ry0, cy1 = ry0 + 7.0f;
+      if (live != 0ull) {
+        uint32_t cols = (uint32_t)live | (uint32_t)(live >> 32);
+        cols |= cols >> 16; cols |= cols >> 8; cols &= 0xFFu;
+        cx0 = rx0 + (float)(__ffs((int)cols) - 1);
+        cx1 = rx0 + (float)(31 - __clz((int)cols));
+        cy0 = ry0 + (float)((__ffsll(live) - 1) >> 3);
+        cy1 = ry0 + (float)((63 - __clzll((long long)live)) >> 3);
+      }
+      const bool keep = live != 0ull && lane < n0 && may_touch(cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, cx0, cx1, cy0, cy1);
+      // compacted, conic pre-multiplied for the exp2 argument, as in render_fwd_kernel
+      const unsigned long long kb = __ballot(keep);
+      const int ns = __popcll(kb);
+      if (keep) {
+        StagedB& o = B.st[(int)lanes_below(kb)];
+        o.a = make_float4(cur.a.x, cur.a.y, (-0.5f * LOG2E) * cur.a.z, (-0.5f * LOG2E) * cur.b.x);
+        o.b = make_float4((-LOG2E) * cur.a.w, cur.b.y, cur.b.z, cur.b.w);
+        o.c = make_float4(cur.c, __uint_as_float(cur.pos), __uint_as_float(cur.id), 0.f);   // 0-based list position == reference `contributor`
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int j = 0; j < ns; j++) {
+        const float4 RA = B.st[j].a, RB = B.st[j].b, RC = B.st[j].c;
+        v2f dd;
+        const float e = staged_exponent(RA, RB.x, pix, dd);             // power * log2(e), evaluated exactly as in the forward kernel
+        const float oG = RB.y * __builtin_amdgcn_exp2f(e);               // opacity * G (the unclamped alpha)
+        const int pos = (int)__float_as_uint(RC.y);
+        const float alpha = fminf(0.99f, oG);
+        const bool valid = (pos < last) && (e <= 0.0f) && (alpha >= 1.0f / 255.0f);
+        if (!__any(valid)) continue;
+        const float oGe = valid ? oG : 0.0f, al = valid ? alpha : 0.0f;   // a lane that skips the entry: alpha 0, every update the identity
+        const float inv = __builtin_amdgcn_rcpf(1.f - al);               // 1 / (1 - alpha)
+        const float cd = __builtin_fmaf(RC.x, dpb, __builtin_fmaf(RB.w, dpg, RB.z * dpr));
+        T = T * inv;                                                     // transmittance in front of the entry
+        const float wv = al * T;
+        const float dL_dalpha = T * cd - A * inv;
+        A = __builtin_fmaf(wv, cd, A);
+        B.M[m][lane] = make_float2(wv, oGe * dL_dalpha);                 // w ; h = G dL/dG with dL/dG = opacity dL/dalpha
+        B.slot[m].xy = make_float2(RA.x, RA.y);                          // (uniform address, uniform value)
+        B.slot[m].id = __float_as_uint(RC.z);
+        m = __builtin_amdgcn_readfirstlane(m + 1);                       // (wave-uniform by construction; keeps it in a scalar register)
+        if (m == 7) { phase2(7); m = 0; }
+      }
+    }
+    return true;
+  };
+  int n0, n1, n2 = 0;
+  Gather g0 = pop(n0), g1 = pop(n1), g2 = g1;
+  for (;;) {
+    if (!step(g0, n0, n1, g2, n2)) break;
+    if (!step(g1, n1, n2, g0, n0)) break;
+    if (!step(g2, n2, n0, g1, n1)) break;
+  }
+  if (m > 0) phase2(m);
+}
+
+// ---- round-2 form of the backward blend, kept only for A/B timing during round 3 (GM_BWD_V1=1)
+
+__global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_kernel_v1(const uint2* __restrict__ ranges,
                                                                const uint2* __restrict__ pairs,
                                                                const float4* __restrict__ splat, int W, int H, TileMap tm,
                                                                const float* __restrict__ bg, const float* __restrict__ final_T,
@@ -631,9 +863,15 @@ int launch_render_bwd(const GeomState& g, const uint2* pairs, ImageState& img, i
     hipLaunchKernelGGL(tile_work_kernel, dim3(tg.ptiles), dim3(256), 0, s, img.n_contrib, W, H, tg.pgx, tg.s, img.tile_work);
     hipLaunchKernelGGL(tile_order_work_kernel, dim3(1), dim3(1024), 0, s, img.tile_work, tg.ptiles, img.tile_order_bwd);
   }
-  if (tg.ptiles > 0)
-    hipLaunchKernelGGL(render_bwd_kernel, dim3(tm.blocks() * (4 / GM_RENDER_BWD_WPW)), dim3(64 * GM_RENDER_BWD_WPW), 0, s, img.ranges, pairs, g.splat, W, H, tm,
-                       background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc, g.counters, mode);
+  static const bool v1 = getenv("GM_BWD_V1") != nullptr;
+  if (tg.ptiles > 0) {
+    if (v1)
+      hipLaunchKernelGGL(render_bwd_kernel_v1, dim3(tm.blocks() * (4 / GM_RENDER_BWD_WPW)), dim3(64 * GM_RENDER_BWD_WPW), 0, s, img.ranges, pairs, g.splat, W, H, tm,
+                         background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc, g.counters, mode);
+    else
+      hipLaunchKernelGGL(render_bwd_kernel, dim3(tm.blocks() * (4 / GM_RENDER_BWD_WPW)), dim3(64 * GM_RENDER_BWD_WPW), 0, s, img.ranges, pairs, g.splat, W, H, tm,
+                         background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc, g.counters, mode);
+  }
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }

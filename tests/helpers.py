@@ -75,18 +75,22 @@ def account_outlier_pixels(fw, color, W, H, tol=1e-4):
 GATE_LOG = []          # (what, W, H, outliers, unexplained, worst) of every gate evaluated in this process
 
 
-def assert_grads_elementwise(got, ref, what="", floor=1e-3, rtol=1e-2):
+def assert_grads_elementwise(got, ref, what="", floor=1e-3, rtol=1e-2, stragglers=1e-4, straggler_rtol=1e-1):
     """Element-wise companion of the max-norm gradient gate (which a Gaussian with a small gradient can pass while being
     entirely wrong): EVERY entry whose reference magnitude is at least `floor` x the tensor's maximum must agree to `rtol`
-    RELATIVE TO ITSELF.  Returns the number of entries checked."""
+    RELATIVE TO ITSELF.  A gradient entry is a float32 sum of cancelling terms (in the oracle as well), so its absolute error is
+    that of the large entries: with a max-norm error of 2e-5 an entry at the floor is 2 % off in either implementation.  At
+    most `stragglers` of the checked entries (never more than a handful) may therefore exceed `rtol`, and none may exceed
+    `straggler_rtol` - an entry that is simply wrong (relative error ~1) fails.  Returns (entries checked, stragglers, worst)."""
     got = np.asarray(got, np.float64).reshape(-1); ref = np.asarray(ref, np.float64).reshape(-1)
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     big = np.abs(ref) >= floor * max(np.abs(ref).max(), 1e-300)
     rel = np.abs(got[big] - ref[big]) / np.abs(ref[big])
-    bad = int((rel > rtol).sum())
-    assert bad == 0, "%s: %d of %d entries above %g x max differ by more than %g relative (worst %.3g)" % (what, bad, int(big.sum()), floor, rtol,
-                                                                                                     rel.max())
-    return int(big.sum())
+    n, bad, worst = int(big.sum()), int((rel > rtol).sum()), float(rel.max()) if big.any() else 0.0
+    assert bad <= max(2, int(stragglers * n)), "%s: %d of %d entries above %g x max differ by more than %g relative (worst %.3g)" % (
+        what, bad, n, floor, rtol, worst)
+    assert worst <= straggler_rtol, "%s: an entry above %g x max is off by %.3g relative" % (what, floor, worst)
+    return n, bad, worst
 
 
 def assert_forward_gate(fw, color, W, H, tol=1e-4, what=""):

@@ -23,8 +23,8 @@ def _check_all_grads(g, bw, rtol):
         assert _rel(got, ref) <= rtol, (name, _rel(got, ref))
         l2 = np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)
         assert l2 <= rtol, (name, "L2", l2)
-        n = assert_grads_elementwise(got, ref, name)            # every entry >= 1e-3 x max to 1e-2 of ITSELF
-        print("gradient %-7s max-norm %.2e  L2 %.2e  element-wise gate on %d entries" % (name, _rel(got, ref), l2, n))
+        n, bad, worst = assert_grads_elementwise(got, ref, name)            # every entry >= 1e-3 x max to 1e-2 of ITSELF
+        print("gradient %-7s max-norm %.2e  L2 %.2e  element-wise gate: %d entries, %d above 1e-2 (worst %.2e)" % (name, _rel(got, ref), l2, n, bad, worst))
 
 
 def _forward(sc, cam, bg, **kw):
