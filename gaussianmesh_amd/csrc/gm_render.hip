@@ -165,7 +165,7 @@ __device__ __forceinline__ Gather issue_gather(const float4* __restrict__ splat,
 // STATE = false: image-only frame (GM_FWD_IMAGE_ONLY) - final_T / n_contrib, which only a backward pass reads, are neither
 // tracked nor written.
 template <bool TRACE, bool STATE>
-__global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(const uint2* __restrict__ ranges,
+__global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel_v1(const uint2* __restrict__ ranges,
                                                                const uint2* __restrict__ pairs,
                                                                const float4* __restrict__ splat, int W, int H, TileMap tm,
                                                                const float* __restrict__ bg, float* __restrict__ out_color,
@@ -351,6 +351,236 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Forward blend, round 3: the exponent of every (survivor, pixel) pair comes from the MATRIX core.
+//
+// With c = (cx, cy) the pixel's offset from the centre of its 8x4 half of the quadrant and (u, v) the splat centre's offset
+// from the same point, the exponent e = log2(e) * power is a quadratic polynomial in c whose six coefficients depend on the
+// survivor only:   e = a' cx^2 + b' cx cy + c' cy^2 + (-2a'u - b'v) cx + (-b'u - 2c'v) cy + (a'u^2 + b'uv + c'v^2).
+// For 16 survivors and the 64 pixels of the wave that is D[32 x 32] = A[32 x 6] B[6 x 32]: row (half h, survivor s) of A holds
+// survivor s's coefficients about the centre of half h, column j of B the six monomials of pixel j of a half - three chained
+// v_mfma_f32_32x32x2_f32.  Row 8 (s / 4) + 4 h + s % 4 lands in register s of the lanes of half h (tools/mfma_probe/probe32.hip),
+// i.e. lane = pixel ends up with the exponents of the 16 survivors in 16 registers, which is exactly what the per-pixel
+// recurrence wants.  The coefficients are computed once per candidate, lane-parallel, when the batch is staged, and fetched
+// as three 4-byte LDS reads per lane and group; what is still broadcast per survivor is (r, g, b, opacity).
+// Per survivor the vector ALU keeps exp, the opacity product, the two alpha decisions and the T / C recurrence: ~13
+// instructions instead of ~20, and the LDS return traffic drops from 40 to ~17 bytes per lane.  192 matrix cycles per 16
+// survivors ride beside ~800 vector cycles.
+// Arithmetic: the polynomial is evaluated about a point at most 3.5 / 1.5 pixels away from every pixel, so its terms are at most
+// a few tens for the narrowest splat the 0.3-px^2 low-pass filter allows; the matrix core sums the six products to within 2 ulp
+// of the largest (probe32: 1.2e-7 of the sum of magnitudes): |e - e_exact| <~ 1e-5, alpha to ~1e-5 relative (the pixel-relative
+// form of round 2: ~5e-7).  Because e now carries an absolute error, the reference's "skip when power > 0" (a guard against
+// rounding at the splat's own centre, where power = -0 +- 1e-7) becomes e := min(e, 0): skipping would drop a splat at its
+// brightest pixel whenever the polynomial came out at +1e-6.  The backward kernel clamps likewise.
+typedef float v16f __attribute__((ext_vector_type(16)));
+#ifndef GM_FWD_DB
+#define GM_FWD_DB 0
+#endif
+struct FwdLds {                  // per wave: 5.25 KiB
+  uint2 qa[RQ_QA];               // candidate ring: (Gaussian id, list position)
+  float ct[4 * 6 * 32];          // [group of 16 survivors][monomial][MFMA row]: lane l of MFMA step m reads ct[192 g + 64 m + l]
+  float4 sb[68];                 // (r, g, b, opacity) per survivor (+ 4 entries of padding with opacity 0 behind the last)
+  uint32_t sp[68];               // list position + 1 per survivor (n_contrib; STATE only)
+};
+
+template <bool STATE>
+#ifdef GM_FWD_OCC
+__attribute__((amdgpu_waves_per_eu(GM_FWD_OCC, 8)))
+#endif
+__global__ __launch_bounds__(64) void render_fwd_kernel(const uint2* __restrict__ ranges, const uint2* __restrict__ pairs,
+                                                        const float4* __restrict__ splat, int W, int H, TileMap tm,
+                                                        const float* __restrict__ bg, float* __restrict__ out_color,
+                                                        float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                                                        const uint32_t* __restrict__ counters, int* __restrict__ status_host,
+                                                        uint32_t* __restrict__ hint, const uint32_t* __restrict__ epoch) {
+  // One 8x8 pixel quadrant = one wave = one workgroup (placed and retired on its own); ids 8 apart share an XCD:
+  // id = ((tile slot j) * 4 + quadrant) * 8 + xcd.
+  const int lane = threadIdx.x & 63;
+  const int wave = (int)((blockIdx.x >> 3) & 3);
+  const int tile_block = (int)(((blockIdx.x >> 5) << 3) | (blockIdx.x & 7));
+  if (status_host && blockIdx.x == 0 && threadIdx.x < 4)                 // the frame's status words {num_rendered, -, policy, refused}
+    __hip_atomic_store(status_host + threadIdx.x, (int)counters[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // straight into
+  int tx, ty, parent;                                                    // the caller's page-locked words: no copy launch behind the frame
+  uint32_t child_bit;
+  if (!tm.locate(tile_block, tx, ty, parent, child_bit)) return;
+  const uint2 range = ranges[parent];
+  const int n = (int)(range.y - range.x);
+  const uint2* list = pairs + range.x;           // (key, Gaussian id) per list entry
+
+  const int px = tx * GM_TILE + (wave & 1) * 8 + (lane & 7);
+  const int py = ty * GM_TILE + (wave >> 1) * 8 + (lane >> 3);
+  const bool inside = px < W && py < H;
+  // T > 0: transmittance of a live pixel.  T < 0: the pixel has stopped (reference `done`) and |T| is its final transmittance - a
+  // stopped pixel then takes nothing with no extra state: T (1 - alpha) < 0 < 1e-4 is the stop test itself.
+  float T = inside ? 1.0f : -1.0f, Cb = 0.f;
+  v2f Crg = {0.f, 0.f};
+  uint32_t last = 0;
+  int work = 0;                                                               // entries this wave evaluated (wave-uniform): the work hint
+  if (n > 0) {
+    const float rx0 = (float)(tx * GM_TILE + (wave & 1) * 8), ry0 = (float)(ty * GM_TILE + (wave >> 1) * 8);
+    __shared__ FwdLds L;
+    // B operand of the three MFMA steps: monomials (cx^2, cx cy) / (cy^2, cx) / (cy, 1) of this lane's pixel column; k = lane / 32
+    const float ccx = (float)(lane & 7) - 3.5f, ccy = (float)((lane >> 3) & 3) - 1.5f;
+    const bool khi = lane >= 32;
+    const float B0 = khi ? ccx * ccy : ccx * ccx, B1 = khi ? ccx : ccy * ccy, B2 = khi ? 1.0f : ccy;
+    const float ucx = rx0 + 3.5f, vcy = ry0 + 1.5f;                            // centre of half 0 (half 1: + 4 rows)
+    // rows of a group that hold no survivor are multiplied all the same: they must be finite (their opacity is 0), so the table
+    // starts out as zeros and afterwards only ever holds coefficients of real entries
+#pragma unroll
+    for (int i = 0; i < 12; i++) L.ct[64 * i + lane] = 0.f;
+    const int nlast = n - 1;
+    int kpos = 0;                                  // next list position to scan
+    uint32_t qa_head = 0, qa_cnt = 0;              // candidate ring (wave-uniform)
+    uint2 kv[RQ_K];
+    auto scan = [&]() {                            // stage A: the chunks in kv, in order, while the ring has room
+      bool go = true;
+#pragma unroll
+      for (int k = 0; k < RQ_K; k++) {
+        go = go && kpos < n && qa_cnt + 64u <= (uint32_t)RQ_QA;
+        if (go) {
+          const int p = kpos + lane;
+          const bool mine = p < n && (kv[k].x & child_bit) != 0u;
+          const unsigned long long bal = __ballot(mine);
+          if (mine) L.qa[(qa_head + qa_cnt + lanes_below(bal)) & (RQ_QA - 1)] = make_uint2(kv[k].y, (uint32_t)p);
+          qa_cnt += (uint32_t)__popcll(bal);
+          kpos += 64;
+        }
+      }
+    };
+    auto load_keys = [&]() {
+#pragma unroll
+      for (int k = 0; k < RQ_K; k++) kv[k] = list[min(kpos + k * 64 + lane, nlast)];
+    };
+    auto pop = [&](int& count) {                   // stage B: up to 64 candidates, lane j <- candidate j, record loads issued
+      count = (int)min(qa_cnt, 64u);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const uint2 cand = lane < count ? L.qa[(qa_head + (uint32_t)lane) & (RQ_QA - 1)] : make_uint2(0u, 0u);
+      qa_head += (uint32_t)count; qa_cnt -= (uint32_t)count;
+      return issue_gather(splat, cand);
+    };
+    load_keys();
+    scan();                                        // (waits for the first keys)
+    load_keys();
+    auto step = [&](Gather& cur, int& n0, const int n1, Gather& nxt, int& n2) -> bool {      // register sets rotate by call site
+      const unsigned long long live = __ballot(T > 0.0f);
+      if (live == 0ull) return false;
+      if (n0 == 0 && n1 == 0 && qa_cnt == 0u && kpos >= n) return false;
+      // cull against the bounding box of the pixels that are still live (lane = y * 8 + x; scalar bit arithmetic)
+      uint32_t cols = (uint32_t)live | (uint32_t)(live >> 32);
+      cols |= cols >> 16; cols |= cols >> 8; cols &= 0xFFu;
+      const float cx0 = rx0 + (float)(__ffs((int)cols) - 1), cx1 = rx0 + (float)(31 - __clz((int)cols));
+      const float cy0 = ry0 + (float)((__ffsll(live) - 1) >> 3), cy1 = ry0 + (float)((63 - __clzll((long long)live)) >> 3);
+      __builtin_amdgcn_s_waitcnt(0x0F73);                                  // vmcnt(3): all but the gather issued last iteration
+      scan();
+      load_keys();
+      nxt = pop(n2);
+      if (n0 > 0) {
+        const bool keep = lane < n0 && may_touch(cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, cx0, cx1, cy0, cy1);
+        const unsigned long long kb = __ballot(keep);
+        const int ns = __popcll(kb);
+        work += ns;
+        // stage the survivors, compacted (slot = rank among the survivors, list order): polynomial coefficients about the two
+        // half centres into the MFMA's A layout, colour + opacity, list position
+        if (keep) {
+          const int slot = (int)lanes_below(kb), g = slot >> 4, sg = slot & 15;
+          const float a = (-0.5f * LOG2E) * cur.a.z, b = (-LOG2E) * cur.a.w, c = (-0.5f * LOG2E) * cur.b.x;
+          const float u = cur.a.x - ucx, v0 = cur.a.y - vcy, v1 = v0 - 4.0f;
+          const float au = a * u, bu = b * u;
+          float* row = &L.ct[192 * g + 8 * (sg >> 2) + (sg & 3)];         // row of (half 0, survivor sg); half 1: + 4
+          row[0] = a; row[4] = a; row[32] = b; row[36] = b; row[64] = c; row[68] = c;
+          row[96] = -2.0f * au - b * v0;  row[100] = -2.0f * au - b * v1;
+          row[128] = -bu - 2.0f * c * v0; row[132] = -bu - 2.0f * c * v1;
+          row[160] = u * (au + b * v0) + c * v0 * v0; row[164] = u * (au + b * v1) + c * v1 * v1;
+          L.sb[slot] = make_float4(cur.b.z, cur.b.w, cur.c, cur.b.y);
+          if (STATE) L.sp[slot] = cur.pos + 1u;                           // 1-based list position: n_contrib
+        }
+        if (lane < 4) L.sb[ns + lane] = make_float4(0.f, 0.f, 0.f, 0.f);    // survivors are taken four at a time: opacity 0 behind the last
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // groups of 16 survivors; the three MFMA steps of the NEXT group are issued before the current group's exponents are
+        // consumed (two accumulator sets alternate by call site), so a wave that runs alone does not sit out the matrix latency
+        auto exponents = [&](const int j) -> v16f {
+          const float* ctg = &L.ct[12 * j + lane];                        // 192 (j / 16) + lane
+          const float A0 = ctg[0], A1 = ctg[64], A2 = ctg[128];
+          v16f E = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          E = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, B0, E, 0, 0, 0);
+          E = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B1, E, 0, 0, 0);
+          E = __builtin_amdgcn_mfma_f32_32x32x2f32(A2, B2, E, 0, 0, 0);
+          return E;
+        };
+        auto blend16 = [&](const v16f& E, const int j) -> bool {          // false: every pixel of the wave has stopped
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            if (q > 0 && j + 4 * q >= ns) break;
+            float4 S[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) S[t] = L.sb[j + 4 * q + t];
+            uint32_t SP[4];
+            if (STATE) {
+#pragma unroll
+              for (int t = 0; t < 4; t++) SP[t] = L.sp[j + 4 * q + t];
+            }
+            float al[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+              const float G = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(E[4 * q + t]), 0.0f, 1.0f);   // G = min(2^e, 1): the exponent clamped
+              const float oG = S[t].w * G;                                                    // at 0 (see above) by v_exp_f32's clamp bit
+              al[t] = (oG >= 1.0f / 255.0f) ? fminf(0.99f, oG) : 0.0f;                        // skip alpha < 1/255; alpha = min(0.99, .)
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) {            // in list order
+              const float wa = al[t] * T, tt = T - wa;                                      // weight alpha T; T (1 - alpha) as T - alpha T
+              const bool stop = tt < 0.0001f;                                               // (tt == T >= 1e-4 when alpha == 0; tt < 0 once stopped)
+              const float w = stop ? 0.0f : wa;
+              T = stop ? -__builtin_fabsf(T) : tt;                                          // stop WITHOUT applying the entry
+              const v2f rg = {S[t].x, S[t].y}, ww = {w, w};
+              Crg = rg * ww + Crg; Cb += S[t].z * w;
+              if (STATE) last = (w > 0.0f) ? SP[t] : last;
+            }
+            if (!__any(T > 0.0f)) return false;
+          }
+          return true;
+        };
+#if GM_FWD_DB
+        v16f Ea = exponents(0), Eb = Ea;
+        for (int j = 0; j < ns; j += 32) {
+          if (j + 16 < ns) Eb = exponents(j + 16);
+          if (!blend16(Ea, j)) break;
+          if (j + 16 >= ns) break;
+          if (j + 32 < ns) Ea = exponents(j + 32);
+          if (!blend16(Eb, j + 16)) break;
+        }
+#else
+        for (int j = 0; j < ns; j += 16) {
+          const v16f E = exponents(j);
+          if (!blend16(E, j)) break;
+        }
+#endif
+      }
+      return true;
+    };
+    int n0, n1, n2 = 0;
+    Gather g0 = pop(n0), g1 = pop(n1), g2 = g1;
+    for (;;) {
+      if (!step(g0, n0, n1, g2, n2)) break;
+      if (!step(g1, n1, n2, g0, n0)) break;
+      if (!step(g2, n2, n0, g1, n1)) break;
+    }
+  }
+  if (hint && work > 0 && lane == 0)                                     // (gm_tile_order.h: the next frames' dispatch order)
+    atomicMax(&hint[1 + parent], (epoch[0] << 20) | min((uint32_t)work, GM_HINT_WORK_MASK));
+  if (inside) {
+    const size_t HW = (size_t)H * W, pid = (size_t)W * py + px;
+    T = __builtin_fabsf(T);
+    if (STATE) { final_T[pid] = T; n_contrib[pid] = last; }
+    out_color[pid] = Crg.x + T * bg[0];
+    out_color[HW + pid] = Crg.y + T * bg[1];
+    out_color[2 * HW + pid] = Cb + T * bg[2];
+  }
+}
+
 static unsigned long long* g_render_trace = nullptr;      // debugging aid (tools/wave_trace.py), never set by the package
 extern "C" void gm_debug_render_trace(void* buffer) { g_render_trace = reinterpret_cast<unsigned long long*>(buffer); }
 
@@ -360,17 +590,24 @@ int launch_render_fwd(const GeomState& g, const uint2* pairs, ImageState& img, i
   StageScope sc(ST_RENDER, s);
   const TileGrid tg(W, H, mode);
   const TileMap tm{tg.gx, tg.gy, tg.pgx, tg.pgy, tg.s, img.tile_order};
+  static const bool fwd_v1 = getenv("GM_FWD_V1") != nullptr;
   if (tg.ptiles > 0) {
     const dim3 grid(tm.blocks() * (4 / GM_RENDER_FWD_WPW)), block(64 * GM_RENDER_FWD_WPW);
     if (g_render_trace)
-      hipLaunchKernelGGL((render_fwd_kernel<true, true>), grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
+      hipLaunchKernelGGL((render_fwd_kernel_v1<true, true>), grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
                          background, out_color, img.final_T, img.n_contrib, g_render_trace, g.counters, status_host, work_hint, img.epoch);
+    else if (fwd_v1 && image_only)
+      hipLaunchKernelGGL((render_fwd_kernel_v1<false, false>), grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
+                         background, out_color, img.final_T, img.n_contrib, nullptr, g.counters, status_host, work_hint, img.epoch);
+    else if (fwd_v1)
+      hipLaunchKernelGGL((render_fwd_kernel_v1<false, true>), grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
+                         background, out_color, img.final_T, img.n_contrib, nullptr, g.counters, status_host, work_hint, img.epoch);
     else if (image_only)
-      hipLaunchKernelGGL((render_fwd_kernel<false, false>), grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
-                         background, out_color, img.final_T, img.n_contrib, nullptr, g.counters, status_host, work_hint, img.epoch);
+      hipLaunchKernelGGL((render_fwd_kernel<false>), dim3(tm.blocks() * 4), dim3(64), 0, s, img.ranges, pairs, g.splat, W, H, tm,
+                         background, out_color, img.final_T, img.n_contrib, g.counters, status_host, work_hint, img.epoch);
     else
-      hipLaunchKernelGGL((render_fwd_kernel<false, true>), grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
-                         background, out_color, img.final_T, img.n_contrib, nullptr, g.counters, status_host, work_hint, img.epoch);
+      hipLaunchKernelGGL((render_fwd_kernel<true>), dim3(tm.blocks() * 4), dim3(64), 0, s, img.ranges, pairs, g.splat, W, H, tm,
+                         background, out_color, img.final_T, img.n_contrib, g.counters, status_host, work_hint, img.epoch);
   } else if (status_host) {
     GM_HIP(hipMemcpyAsync(status_host, g.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   }
@@ -514,7 +751,9 @@ __global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_kernel(cons
   int max_last = last;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) max_last = max(max_last, __shfl_xor(max_last, d));
-  const int start = max_last;           // number of list entries this wave has to visit (positions start-1 .. 0)
+  const int start = __builtin_amdgcn_readfirstlane(max_last);   // number of list entries this wave has to visit (positions start-1 .. 0);
+                                                                // readfirstlane: the compiler cannot see that the butterfly left a uniform value,
+                                                                // and everything the walk's loops carry would otherwise live in vector registers
   if (start == 0) return;
 
   const float rx0 = (float)(tx * GM_TILE + (wave & 1) * 8), ry0 = (float)(ty * GM_TILE + (wave >> 1) * 8);
@@ -534,6 +773,8 @@ __global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_kernel(cons
   const float rowy = ry0 + (float)r;
   const int cl = min(lane, 62), ce = cl / 9, ck = cl - 9 * ce;      // commit role of this lane: value ck of slot ce
   int m = 0;                                                          // slots in use (wave-uniform)
+  float2* mrow = &B.M[0][lane];
+  SlotB* mslot = &B.slot[0];
 
   auto phase2 = [&](const int cnt) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -640,24 +881,27 @@ __global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_kernel(cons
       for (int j = 0; j < ns; j++) {
         const float4 RA = B.st[j].a, RB = B.st[j].b, RC = B.st[j].c;
         v2f dd;
-        const float e = staged_exponent(RA, RB.x, pix, dd);             // power * log2(e), evaluated exactly as in the forward kernel
-        const float oG = RB.y * __builtin_amdgcn_exp2f(e);               // opacity * G (the unclamped alpha)
+        const float e = staged_exponent(RA, RB.x, pix, dd);             // power * log2(e), pixel-relative form (the forward kernel's polynomial
+                                                                         // agrees to ~1e-5; its decisions can differ on an entry in a few 10^5)
+        const float G = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(e), 0.0f, 1.0f);   // exponent clamped at 0, as in the forward kernel
+        const float oG = RB.y * G;                                       // opacity * G (the unclamped alpha)
         const int pos = (int)__float_as_uint(RC.y);
-        const float alpha = fminf(0.99f, oG);
-        const bool valid = (pos < last) && (e <= 0.0f) && (alpha >= 1.0f / 255.0f);
+        const bool valid = (pos < last) && (oG >= 1.0f / 255.0f);        // (alpha = min(0.99, oG) >= 1/255  <=>  oG >= 1/255)
         if (!__any(valid)) continue;
-        const float oGe = valid ? oG : 0.0f, al = valid ? alpha : 0.0f;   // a lane that skips the entry: alpha 0, every update the identity
+        const float oGe = valid ? oG : 0.0f;                             // a lane that skips the entry: alpha 0, every update the identity
+        const float al = __builtin_amdgcn_fmed3f(oGe, 0.0f, 0.99f);      // alpha = min(0.99, opacity G)
         const float inv = __builtin_amdgcn_rcpf(1.f - al);               // 1 / (1 - alpha)
         const float cd = __builtin_fmaf(RC.x, dpb, __builtin_fmaf(RB.w, dpg, RB.z * dpr));
         T = T * inv;                                                     // transmittance in front of the entry
         const float wv = al * T;
         const float dL_dalpha = T * cd - A * inv;
         A = __builtin_fmaf(wv, cd, A);
-        B.M[m][lane] = make_float2(wv, oGe * dL_dalpha);                 // w ; h = G dL/dG with dL/dG = opacity dL/dalpha
-        B.slot[m].xy = make_float2(RA.x, RA.y);                          // (uniform address, uniform value)
-        B.slot[m].id = __float_as_uint(RC.z);
-        m = __builtin_amdgcn_readfirstlane(m + 1);                       // (wave-uniform by construction; keeps it in a scalar register)
-        if (m == 7) { phase2(7); m = 0; }
+        *mrow = make_float2(wv, oGe * dL_dalpha);                        // M[m][lane]: w ; h = G dL/dG with dL/dG = opacity dL/dalpha
+        mslot->xy = make_float2(RA.x, RA.y);                             // slot[m] (uniform address, uniform value)
+        mslot->id = __float_as_uint(RC.z);
+        mrow += 65; mslot += 1;                                          // the two LDS addresses advance as vector registers of their own:
+        m += 1;                                                          // the slot count itself then lives in a scalar register
+        if (m == 7) { phase2(7); m = 0; mrow = &B.M[0][lane]; mslot = &B.slot[0]; }
       }
     }
     return true;
