@@ -83,7 +83,6 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
   const int tile_cull = mode != 0;
   constexpr int M = (1 << S) - 1;
   const int lane = threadIdx.x & 63;
-  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const uint32_t run = blockIdx.x;
   const uint32_t V = counters[GM_CNT_VISIBLE];
   constexpr uint32_t RUN = BN_PER_THREAD * BN_THREADS;                  // sorted positions of this workgroup: 1 or 2 entries of chunk_inst
@@ -215,7 +214,7 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
         }
         const unsigned long long bal = __ballot(pass);
         if (pass) {
-          const uint32_t pos = run + (uint32_t)__popcll(bal & lt_mask);
+          const uint32_t pos = run + lanes_below(bal);
           EMIT(pos, (pcy * (uint32_t)pgx + pcx) | (cm << GM_KEY_MASK_SHIFT), g);
         }
         run += (uint32_t)__popcll(bal);

@@ -382,7 +382,6 @@ __global__ __launch_bounds__(WAVES * 64, 4) void bk_scatter_kernel(const void* _
   __shared__ uint16_t dstart[ND];            // start of each digit's run inside the digit-sorted tile (< TILE <= 16384)
   __shared__ uint32_t wsum[WAVES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   if (zero_acc)
     for (uint32_t i = blockIdx.x * THREADS + threadIdx.x; i < zero_words; i += gridDim.x * THREADS) zero_acc[i] = 0u;
   uint32_t n = n_host;
@@ -431,7 +430,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void bk_scatter_kernel(const void* _
       const uint64_t bal = __ballot((d >> b) & 1u);
       peers &= ((d >> b) & 1u) ? bal : ~bal;
     }
-    const uint32_t before = __popcll(peers & lt_mask);
+    const uint32_t before = lanes_below(peers);
     const int leader = __ffsll((unsigned long long)peers) - 1;
     uint32_t old = 0;
     if (valid && lane == leader) {
@@ -532,7 +531,6 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t*
   __shared__ uint32_t lkey[BS_CAP];                                 // (key - first key) << 12 | position in the bucket: 16 KiB
   __shared__ uint32_t wsum[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const uint32_t nb = counters[GM_CNT_VISIBLE] ? counters[GM_CNT_NBUCKETS] : 0u;
   const uint32_t b = blockIdx.x;
   uint32_t start = 0, end = 0;
@@ -574,7 +572,7 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t*
             const uint64_t bal = __ballot((d >> bb) & 1u);
             peers &= ((d >> bb) & 1u) ? bal : ~bal;
           }
-          const uint32_t before = __popcll(peers & lt_mask);
+          const uint32_t before = lanes_below(peers);
           const int leader = __ffsll((unsigned long long)peers) - 1;
           uint32_t old = 0;
           if (valid && lane == leader) {
@@ -676,7 +674,7 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t*
             const uint64_t bal = __ballot((d >> bb) & 1u);
             peers &= ((d >> bb) & 1u) ? bal : ~bal;
           }
-          const uint32_t before = __popcll(peers & lt_mask);
+          const uint32_t before = lanes_below(peers);
           const int leader = __ffsll((unsigned long long)peers) - 1;
           uint32_t old = 0;
           if (valid && lane == leader) {

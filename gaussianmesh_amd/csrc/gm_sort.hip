@@ -98,7 +98,6 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const uint32_
   __shared__ uint32_t lkey[TILE_KEYS];       // locally sorted tile (32 KiB with lval at 4096 keys)
   __shared__ uint32_t lval[TILE_KEYS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
   for (int w = 0; w < RS_WAVES; w++) wcnt[w][threadIdx.x] = 0;
   {  // digit totals and the offset of this workgroup's chunk from the chunk totals, then the exclusive scan over digits
@@ -144,7 +143,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const uint32_
       const uint64_t bal = __ballot((d >> b) & 1u);
       peers &= ((d >> b) & 1u) ? bal : ~bal;
     }
-    const uint32_t before = __popcll(peers & lt_mask);
+    const uint32_t before = lanes_below(peers);
     const int leader = __ffsll((unsigned long long)peers) - 1;
     uint32_t old = 0;
     if (valid && lane == leader) {
