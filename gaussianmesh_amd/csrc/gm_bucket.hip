@@ -49,12 +49,12 @@ namespace gm {
 
 #define BK_THREADS 256
 #define BK_WAVES 4
-#define BK_ROUNDS 16
+#define BK_ROUNDS GM_BK_ROUNDS
 #define BK_CHUNK GM_BK_CHUNK
 #ifndef GM_TILE_PASS_WAVES
 #define GM_TILE_PASS_WAVES 8        // workgroup of the one-pass tile sort: 8 waves x 1024 keys
 #endif
-#define BS_CAP 4096                 // entries a bucket may have for the in-LDS sort (256 threads x 16)
+#define BS_CAP (256 * BK_ROUNDS)     // entries a bucket may have for the in-LDS sort (256 threads x BK_ROUNDS)
 
 struct DigitSpec { uint32_t sub, shift, mask; };       // digit(k) = ((k - sub) >> shift) & mask
 

@@ -70,7 +70,10 @@ static inline size_t sort_chunk_counters(size_t n) { return 256 * ((sort_blocks(
 
 // ordering of a forward (gm_bucket.hip)
 #define GM_BUCKET_BITS 11            // MSD partition of the depth keys into <= 2048 buckets; also the digit of the one-pass tile sort
-#define GM_BK_TILE 4096              // keys per workgroup of a partition / tile-sort pass
+#ifndef GM_BK_ROUNDS
+#define GM_BK_ROUNDS 16               // keys per thread of a partition / tile-sort pass and of the in-LDS bucket sort
+#endif
+#define GM_BK_TILE (4 * GM_BK_ROUNDS * 64)   // keys per (4-wave) workgroup of a partition / tile-sort pass
 #define GM_BK_CHUNK 32               // histogram rows per scan workgroup
 static inline size_t bk_blocks(size_t n) { return (n + GM_BK_TILE - 1) / GM_BK_TILE; }
 static inline size_t bk_chunks(size_t n) { return (bk_blocks(n) + GM_BK_CHUNK - 1) / GM_BK_CHUNK; }

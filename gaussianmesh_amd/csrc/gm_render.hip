@@ -7,24 +7,24 @@
 // CDNA4 mapping: the reference gives each 16x16 tile to a 256-thread block that stages
 // 256-entry batches in shared memory behind two block barriers and lets every pixel thread re-read the batch from LDS
 // (and the colour from global memory).  Here a 16x16 tile is four independent wave64s, each owning one 8x8 pixel
-// quadrant (one pixel per lane, lane = y * 8 + x):
-//   * the workgroup walks the list of its PARENT tile (gm_common.h: emission policies); a two-stage front end (see
-//     WaveLds below) turns it into dense batches of up to 64 candidate records: a scan of the contiguous (key, id)
-//     stream picks the entries whose key carries the tile's child bit, their records are gathered into registers two
-//     iterations ahead of their use;
+// quadrant (one pixel per lane, lane = y * 8 + x) and launched as a one-wave workgroup:
+//   * the wave walks the list of its PARENT tile (gm_common.h: emission policies); a two-stage front end (Gather, FwdLds /
+//     BwdLds below) turns it into dense batches of up to 64 candidate records: a scan of the contiguous (key, id) stream picks
+//     the entries whose key carries the tile's child bit, their records are gathered into registers two iterations ahead of
+//     their use;
 //   * while lane j holds candidate j it tests, once per batch and for all 64 in parallel, whether the entry can reach
 //     alpha >= 1/255 anywhere inside the bounding box of the quadrant's still-live pixels (exact minimum of the conic's
-//     quadratic form over the rectangle, with a rounding margin).  A 64-bit ballot of the survivors drives the inner loop
-//     (s_ff1 over set bits).  The cull is conservative: a culled entry would have been skipped by every live pixel
-//     (alpha < 1/255), so results and n_contrib are unchanged;
-//   * survivors are re-read as LDS broadcasts (conic pre-multiplied for the exp2 argument) and processed four at a time
-//     in the forward kernel; no s_barrier, no per-pixel global colour read;
-//   * "is every pixel done" is a ballot instead of __syncthreads_count; an entry that no pixel of the wave accepts
-//     is skipped with one __any.
-// Discrete semantics are the reference's: skip power>0, skip alpha<1/255, stop (without applying the
-// entry) when T(1-alpha)<1e-4, n_contrib = 1-based list position of the last accepted entry.
-// FMA contraction is allowed here and exp() is v_exp_f32 on power*log2(e); see DESIGN.md for the
-// tolerance argument.
+//     quadratic form over the rectangle, with a rounding margin).  The cull is conservative: a culled entry would have been
+//     skipped by every live pixel (alpha < 1/255), so results and n_contrib are unchanged;
+//   * forward: the survivors' exponents come from the matrix core, 16 survivors x 64 pixels per three chained
+//     v_mfma_f32_32x32x2_f32 (see render_fwd_kernel); the vector ALU keeps exp, the alpha decisions and the T / C recurrence;
+//   * backward: a scalar suffix recurrence per pixel, then (weight, h) per pixel through an LDS slot matrix into a row-parallel
+//     fold of the nine gradient sums and one atomic instruction per seven 36-byte records (see render_bwd_kernel);
+//   * no s_barrier; "is every pixel done" is a ballot instead of __syncthreads_count.
+// Discrete semantics are the reference's - skip alpha < 1/255, stop (without applying the entry) when T (1 - alpha) < 1e-4,
+// n_contrib = 1-based list position of the last accepted entry - except that "skip power > 0" is "power := min(power, 0)"
+// (see render_fwd_kernel: the two differ only where the reference's own rounding decides).
+// FMA contraction is allowed here and exp() is v_exp_f32 on power * log2(e); see DESIGN.md for the tolerance argument.
 #include "gm_common.h"
 #include "gm_cull.h"
 #include "gm_tile_order.h"
@@ -127,17 +127,6 @@ struct Gather {                  // lane j: record of candidate j
   float c;                       // b
   uint32_t id, pos;              // Gaussian id, list position
 };
-struct WaveLds {                 // 3.9 KiB per wave
-  uint2 qa[RQ_QA];               // candidate ring: (Gaussian id, list position)
-  // staged batch: the candidates that survive the cull, COMPACTED (entry k = k-th survivor in list order; 4 entries of
-  // padding with opacity 0 behind the last one), conic pre-multiplied for the exp2 argument.  Survivors are re-read from
-  // here as LDS broadcasts, consecutive entries at consecutive addresses: the loop over them needs no bit scanning.
-  float4 a[68];                  // x, y, conic.x', conic.z'
-  float4 b[68];                  // conic.y', opacity, r, g
-  float2 cp[68];                 // b, list position (as bits; +1 in the forward kernel)
-  uint32_t id[68];               // Gaussian id (backward kernel)
-};
-
 // exponent of one staged entry at one pixel, e = power * log2(e), on the packed-f32 pipe (v_pk_add / v_pk_mul operate on a
 // register PAIR in one issue slot): d = (x, y) - pix, q = (a', c') * d, q.x += b' d.y, e = q.x d.x + q.y d.y.
 // Staged record: RA = (x, y, a', c'), RB = (b', opacity, r, g) with a' = -log2e/2 conic.x, b' = -log2e conic.y, c' = -log2e/2 conic.z.
@@ -158,199 +147,6 @@ __device__ __forceinline__ Gather issue_gather(const float4* __restrict__ splat,
   g.id = cand.x; g.pos = cand.y;
   return g;
 }
-
-#ifndef GM_RENDER_FWD_WPW
-#define GM_RENDER_FWD_WPW 1      // waves per workgroup of the forward blend: 4 (one workgroup per 16-px tile) or 1 (one per 8x8 quadrant)
-#endif
-// STATE = false: image-only frame (GM_FWD_IMAGE_ONLY) - final_T / n_contrib, which only a backward pass reads, are neither
-// tracked nor written.
-template <bool TRACE, bool STATE>
-__global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel_v1(const uint2* __restrict__ ranges,
-                                                               const uint2* __restrict__ pairs,
-                                                               const float4* __restrict__ splat, int W, int H, TileMap tm,
-                                                               const float* __restrict__ bg, float* __restrict__ out_color,
-                                                               float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                               unsigned long long* __restrict__ trace,
-                                                               const uint32_t* __restrict__ counters, int* __restrict__ status_host,
-                                                               uint32_t* __restrict__ hint, const uint32_t* __restrict__ epoch) {
-  // The four quadrant waves of a tile are independent.  As one-wave workgroups they are placed and retired one by one: a
-  // tile whose quadrants differ in length does not hold four wave slots (one per SIMD) until its longest wave is done.
-  // Workgroup ids 8 apart still share an XCD: id = ((tile slot j) * 4 + quadrant) * 8 + xcd.
-  constexpr int WPW = GM_RENDER_FWD_WPW;
-  const int lane = threadIdx.x & 63;
-  const int wave = WPW == 4 ? (int)(threadIdx.x >> 6) : (int)((blockIdx.x >> 3) & 3);
-  const int tile_block = WPW == 4 ? (int)blockIdx.x : (int)(((blockIdx.x >> 5) << 3) | (blockIdx.x & 7));
-  const unsigned long long t_start = TRACE ? wall_clock64() : 0ull;      // tools/wave_trace.py: per-wave start / end / list length
-  if (status_host && blockIdx.x == 0 && threadIdx.x < 4)                 // the frame's status words {num_rendered, -, policy, refused}
-    __hip_atomic_store(status_host + threadIdx.x, (int)counters[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // straight into
-  int tx, ty, parent;                                                    // the caller's page-locked words: no copy launch behind the frame
-  uint32_t child_bit;
-  if (!tm.locate(tile_block, tx, ty, parent, child_bit)) return;
-  const uint2 range = ranges[parent];
-  const int n = (int)(range.y - range.x);
-  const uint2* list = pairs + range.x;           // (key, Gaussian id) per list entry
-
-  const int px = tx * GM_TILE + (wave & 1) * 8 + (lane & 7);
-  const int py = ty * GM_TILE + (wave >> 1) * 8 + (lane >> 3);
-  const float pixx = (float)px, pixy = (float)py;
-  const bool inside = px < W && py < H;
-  // T > 0: transmittance of a live pixel.  T < 0: the pixel has stopped (reference `done`) and |T| is its final transmittance - a
-  // stopped pixel then takes nothing with no extra state: T (1 - alpha) < 0 < 1e-4 is the stop test itself.
-  float T = inside ? 1.0f : -1.0f, Cb = 0.f;
-  v2f Crg = {0.f, 0.f};
-  const v2f pix = {pixx, pixy};
-  uint32_t last = 0;
-  int work = 0;                                                               // entries this wave evaluated (wave-uniform): the work hint
-  int tr_iters = 0, tr_cand = 0, tr_surv = 0, tr_useful = 0, tr_lanes = 0;    // (tools/wave_trace.py)
-  int tr_tb = 0, tr_lr = 0, tr_q4 = 0, tr_steps = 0;                           // sum over batches of max(list length) under 2-way / 4-way pixel splits
-  if (n > 0) {
-    // pixel-centre rectangle owned by this wave
-    const float rx0 = (float)(tx * GM_TILE + (wave & 1) * 8), ry0 = (float)(ty * GM_TILE + (wave >> 1) * 8);
-    __shared__ WaveLds l_w[WPW];
-    WaveLds& L = l_w[WPW == 4 ? wave : 0];
-    const int nlast = n - 1;
-    int kpos = 0;                                  // next list position to scan
-    uint32_t qa_head = 0, qa_cnt = 0;              // candidate ring (wave-uniform)
-    uint2 kv[RQ_K];
-    auto scan = [&]() {                            // stage A: the chunks in kv, in order, while the ring has room
-      bool go = true;
-#pragma unroll
-      for (int k = 0; k < RQ_K; k++) {
-        go = go && kpos < n && qa_cnt + 64u <= (uint32_t)RQ_QA;
-        if (go) {
-          const int p = kpos + lane;
-          const bool mine = p < n && (kv[k].x & child_bit) != 0u;
-          const unsigned long long bal = __ballot(mine);
-          if (mine) L.qa[(qa_head + qa_cnt + lanes_below(bal)) & (RQ_QA - 1)] = make_uint2(kv[k].y, (uint32_t)p);
-          qa_cnt += (uint32_t)__popcll(bal);
-          kpos += 64;
-        }
-      }
-    };
-    auto load_keys = [&]() {
-#pragma unroll
-      for (int k = 0; k < RQ_K; k++) kv[k] = list[min(kpos + k * 64 + lane, nlast)];
-    };
-    auto pop = [&](int& count) {                   // stage B: up to 64 candidates, lane j <- candidate j, record loads issued
-      count = (int)min(qa_cnt, 64u);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      const uint2 cand = lane < count ? L.qa[(qa_head + (uint32_t)lane) & (RQ_QA - 1)] : make_uint2(0u, 0u);
-      qa_head += (uint32_t)count; qa_cnt -= (uint32_t)count;
-      return issue_gather(splat, cand);
-    };
-    load_keys();
-    scan();                                        // (waits for the first keys)
-    load_keys();
-    // One iteration: `cur` (gather issued two iterations ago) is consumed while `nxt` is being issued.  The three register
-    // sets rotate by CALL SITE (the loop below is unrolled three times), never by register moves: a move out of a register
-    // that is still being loaded makes the compiler wait for the load, i.e. vmcnt(0) at the end of every iteration.
-    auto step = [&](Gather& cur, int& n0, const int n1, Gather& nxt, int& n2) -> bool {
-      tr_iters++;
-      const unsigned long long live = __ballot(T > 0.0f);
-      if (live == 0ull) return false;
-      if (n0 == 0 && n1 == 0 && qa_cnt == 0u && kpos >= n) return false;
-      // Entries are culled against the bounding box of the pixels that are still live, not the whole 8x8 quadrant (a
-      // quadrant kept alive by a few unsaturated pixels would otherwise evaluate every entry that touches any of its 64
-      // pixels).  Lane = y * 8 + x; scalar bit arithmetic.
-      uint32_t cols = (uint32_t)live | (uint32_t)(live >> 32);
-      cols |= cols >> 16; cols |= cols >> 8; cols &= 0xFFu;
-      const float cx0 = rx0 + (float)(__ffs((int)cols) - 1), cx1 = rx0 + (float)(31 - __clz((int)cols));
-      const float cy0 = ry0 + (float)((__ffsll(live) - 1) >> 3), cy1 = ry0 + (float)((63 - __clzll((long long)live)) >> 3);
-      __builtin_amdgcn_s_waitcnt(0x0F73);                                  // vmcnt(3): all but the gather issued last iteration
-      scan();
-      load_keys();
-      nxt = pop(n2);
-      if (n0 > 0) {
-        const bool keep = lane < n0 && may_touch(cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, cx0, cx1, cy0, cy1);
-        // staged record: the conic is stored pre-multiplied (lane-parallel, 3 multiplies per 64 entries) so that the
-        // per-survivor exponent is e = dx (a' dx + b' dy) + (c' dy) dy = power * log2(e): 5 instructions instead of 9
-        const unsigned long long kb = __ballot(keep);
-        const int ns = __popcll(kb);
-        tr_cand += n0; tr_surv += ns; work += ns;
-        if (lane < 4) {                             // padding behind the last survivor: opacity 0
-          L.a[ns + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-          L.b[ns + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-          L.cp[ns + lane] = make_float2(0.f, 0.f);
-        }
-        if (keep) {
-          const int slot = (int)lanes_below(kb);
-          L.a[slot] = make_float4(cur.a.x, cur.a.y, (-0.5f * LOG2E) * cur.a.z, (-0.5f * LOG2E) * cur.b.x);
-          L.b[slot] = make_float4((-LOG2E) * cur.a.w, cur.b.y, cur.b.z, cur.b.w);
-          L.cp[slot] = make_float2(cur.c, __uint_as_float(cur.pos + 1u));        // 1-based list position: n_contrib
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // Four survivors per step: the alpha evaluations (the long dependent chain: quadratic form, exp, min) are
-        // independent and interleave, only the short T / C recurrence is applied in list order.  Every decision of
-        // RAST/forward.cu:336-352 is a select on a value (VCC only), never a combination of lane masks: the scalar unit, which
-        // the four SIMDs of a CU share, was as busy as the vector units with the mask arithmetic of the first version
-        // (21 scalar instructions per survivor).  Padding / skipped entries carry alpha 0 and change nothing.
-        int b_t = 0, b_b = 0, b_l = 0, b_r = 0, b_q[4] = {0, 0, 0, 0};
-        for (int j = 0; j < ns; j += 4) {
-          float4 RA[4], RB[4]; float2 RC[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) { RA[u] = L.a[j + u]; RB[u] = L.b[j + u]; RC[u] = L.cp[j + u]; }
-          float al[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            v2f d;
-            const float e = staged_exponent(RA[u], RB[u].x, pix, d);                       // power * log2(e); same sign as power
-            const float alpha = fminf(0.99f, RB[u].y * __builtin_amdgcn_exp2f(e));
-            al[u] = (e <= 0.0f) ? alpha : 0.0f;                                           // skip power > 0
-          }
-#pragma unroll
-          for (int u = 0; u < 4; u++) {            // in list order
-            const float a = (al[u] >= 1.0f / 255.0f) ? al[u] : 0.0f;                      // skip alpha < 1/255
-            const float wa = a * T, t = T - wa;                                           // weight alpha T; T (1 - alpha) as T - alpha T
-            const bool stop = t < 0.0001f;                                                // (t == T >= 1e-4 when a == 0; t < 0 once stopped)
-            const float w = stop ? 0.0f : wa;
-            T = stop ? -__builtin_fabsf(T) : t;                                           // stop WITHOUT applying the entry
-            const v2f rg = {RB[u].z, RB[u].w}, ww = {w, w};
-            Crg = rg * ww + Crg; Cb += RC[u].x * w;
-            if (STATE) last = (w > 0.0f) ? __float_as_uint(RC[u].y) : last;
-            if (TRACE) {
-              const unsigned long long hit = __ballot(w > 0.0f); tr_useful += hit != 0ull; tr_lanes += __popcll(hit);
-              const unsigned long long LM = 0x0F0F0F0F0F0F0F0Full;
-              b_t += (hit & 0xFFFFFFFFull) != 0; b_b += (hit >> 32) != 0; b_l += (hit & LM) != 0; b_r += (hit & ~LM) != 0;
-              b_q[0] += (hit & LM & 0xFFFFFFFFull) != 0; b_q[1] += (hit & ~LM & 0xFFFFFFFFull) != 0;
-              b_q[2] += ((hit & LM) >> 32) != 0; b_q[3] += ((hit & ~LM) >> 32) != 0;
-            }
-          }
-          if (TRACE) tr_steps++;
-          if (!__any(T > 0.0f)) break;
-        }
-        if (TRACE) { tr_tb += max(b_t, b_b); tr_lr += max(b_l, b_r); tr_q4 += max(max(b_q[0], b_q[1]), max(b_q[2], b_q[3])); }
-      }
-      return true;
-    };
-    int n0, n1, n2 = 0;
-    Gather g0 = pop(n0), g1 = pop(n1), g2 = g1;
-    for (;;) {
-      if (!step(g0, n0, n1, g2, n2)) break;
-      if (!step(g1, n1, n2, g0, n0)) break;
-      if (!step(g2, n2, n0, g1, n1)) break;
-    }
-  }
-  if (hint && work > 0 && lane == 0)                                     // (gm_tile_order.h: the next frames' dispatch order)
-    atomicMax(&hint[1 + parent], (epoch[0] << 20) | min((uint32_t)work, GM_HINT_WORK_MASK));
-  if (inside) {
-    const size_t HW = (size_t)H * W, pid = (size_t)W * py + px;
-    T = __builtin_fabsf(T);
-    if (STATE) { final_T[pid] = T; n_contrib[pid] = last; }
-    out_color[pid] = Crg.x + T * bg[0];
-    out_color[HW + pid] = Crg.y + T * bg[1];
-    out_color[2 * HW + pid] = Cb + T * bg[2];
-  }
-  if (TRACE && lane == 0) {
-    unsigned long long* t = trace + 8 * ((size_t)tile_block * 4 + wave);
-    t[0] = t_start; t[1] = wall_clock64(); t[2] = (unsigned long long)n | ((unsigned long long)tr_useful << 24) | ((unsigned long long)tr_lanes << 44);
-    t[3] = (unsigned long long)tr_iters | ((unsigned long long)tr_cand << 16) | ((unsigned long long)tr_surv << 40);
-    t[4] = (unsigned long long)tr_tb | ((unsigned long long)tr_lr << 32);
-    t[5] = (unsigned long long)tr_q4 | ((unsigned long long)tr_steps << 32);
-  }
-}
-
 
 // ---------------------------------------------------------------------------------------------
 // Forward blend, round 3: the exponent of every (survivor, pixel) pair comes from the MATRIX core.
@@ -374,8 +170,8 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel_v1(c
 // rounding at the splat's own centre, where power = -0 +- 1e-7) becomes e := min(e, 0): skipping would drop a splat at its
 // brightest pixel whenever the polynomial came out at +1e-6.  The backward kernel clamps likewise.
 typedef float v16f __attribute__((ext_vector_type(16)));
-#ifndef GM_FWD_DB
-#define GM_FWD_DB 0
+#ifndef GM_FWD_SUB
+#define GM_FWD_SUB 4
 #endif
 struct FwdLds {                  // per wave: 5.25 KiB
   uint2 qa[RQ_QA];               // candidate ring: (Gaussian id, list position)
@@ -384,16 +180,18 @@ struct FwdLds {                  // per wave: 5.25 KiB
   uint32_t sp[68];               // list position + 1 per survivor (n_contrib; STATE only)
 };
 
-template <bool STATE>
-#ifdef GM_FWD_OCC
-__attribute__((amdgpu_waves_per_eu(GM_FWD_OCC, 8)))
-#endif
+// STATE = false: image-only frame (GM_FWD_IMAGE_ONLY) - final_T / n_contrib, which only a backward pass reads, are neither
+// tracked nor written.  TRACE: per-wave start / end / list length / iterations / candidates / survivors (tools/wave_trace.py).
+template <bool STATE, bool TRACE>
 __global__ __launch_bounds__(64) void render_fwd_kernel(const uint2* __restrict__ ranges, const uint2* __restrict__ pairs,
                                                         const float4* __restrict__ splat, int W, int H, TileMap tm,
                                                         const float* __restrict__ bg, float* __restrict__ out_color,
                                                         float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                                                        unsigned long long* __restrict__ trace,
                                                         const uint32_t* __restrict__ counters, int* __restrict__ status_host,
                                                         uint32_t* __restrict__ hint, const uint32_t* __restrict__ epoch) {
+  const unsigned long long t_start = TRACE ? wall_clock64() : 0ull;
+  int tr_iters = 0, tr_cand = 0;
   // One 8x8 pixel quadrant = one wave = one workgroup (placed and retired on its own); ids 8 apart share an XCD:
   // id = ((tile slot j) * 4 + quadrant) * 8 + xcd.
   const int lane = threadIdx.x & 63;
@@ -464,6 +262,7 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const uint2* __restrict_
     scan();                                        // (waits for the first keys)
     load_keys();
     auto step = [&](Gather& cur, int& n0, const int n1, Gather& nxt, int& n2) -> bool {      // register sets rotate by call site
+      if (TRACE) { tr_iters++; tr_cand += n0; }
       const unsigned long long live = __ballot(T > 0.0f);
       if (live == 0ull) return false;
       if (n0 == 0 && n1 == 0 && qa_cnt == 0u && kpos >= n) return false;
@@ -499,8 +298,8 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const uint2* __restrict_
         if (lane < 4) L.sb[ns + lane] = make_float4(0.f, 0.f, 0.f, 0.f);    // survivors are taken four at a time: opacity 0 behind the last
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // groups of 16 survivors; the three MFMA steps of the NEXT group are issued before the current group's exponents are
-        // consumed (two accumulator sets alternate by call site), so a wave that runs alone does not sit out the matrix latency
+        // groups of 16 survivors.  (Measured and dropped: issuing the NEXT group's three MFMA steps before the current group's
+        // exponents are consumed - two accumulator sets, 142 VGPRs, three waves per SIMD instead of four: 4430 vs 4700 frames/s.)
         auto exponents = [&](const int j) -> v16f {
           const float* ctg = &L.ct[12 * j + lane];                        // 192 (j / 16) + lane
           const float A0 = ctg[0], A1 = ctg[64], A2 = ctg[128];
@@ -511,26 +310,27 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const uint2* __restrict_
           return E;
         };
         auto blend16 = [&](const v16f& E, const int j) -> bool {          // false: every pixel of the wave has stopped
+          constexpr int SUB = GM_FWD_SUB;                                  // survivors per sub-block: their alpha evaluations interleave
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            if (q > 0 && j + 4 * q >= ns) break;
-            float4 S[4];
+          for (int q = 0; q < 16 / SUB; q++) {
+            if (q > 0 && j + SUB * q >= ns) break;
+            float4 S[SUB];
 #pragma unroll
-            for (int t = 0; t < 4; t++) S[t] = L.sb[j + 4 * q + t];
-            uint32_t SP[4];
+            for (int t = 0; t < SUB; t++) S[t] = L.sb[j + SUB * q + t];
+            uint32_t SP[SUB];
             if (STATE) {
 #pragma unroll
-              for (int t = 0; t < 4; t++) SP[t] = L.sp[j + 4 * q + t];
+              for (int t = 0; t < SUB; t++) SP[t] = L.sp[j + SUB * q + t];
             }
-            float al[4];
+            float al[SUB];
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-              const float G = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(E[4 * q + t]), 0.0f, 1.0f);   // G = min(2^e, 1): the exponent clamped
+            for (int t = 0; t < SUB; t++) {
+              const float G = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(E[SUB * q + t]), 0.0f, 1.0f);   // G = min(2^e, 1): the exponent clamped
               const float oG = S[t].w * G;                                                    // at 0 (see above) by v_exp_f32's clamp bit
               al[t] = (oG >= 1.0f / 255.0f) ? fminf(0.99f, oG) : 0.0f;                        // skip alpha < 1/255; alpha = min(0.99, .)
             }
 #pragma unroll
-            for (int t = 0; t < 4; t++) {            // in list order
+            for (int t = 0; t < SUB; t++) {          // in list order
               const float wa = al[t] * T, tt = T - wa;                                      // weight alpha T; T (1 - alpha) as T - alpha T
               const bool stop = tt < 0.0001f;                                               // (tt == T >= 1e-4 when alpha == 0; tt < 0 once stopped)
               const float w = stop ? 0.0f : wa;
@@ -543,21 +343,10 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const uint2* __restrict_
           }
           return true;
         };
-#if GM_FWD_DB
-        v16f Ea = exponents(0), Eb = Ea;
-        for (int j = 0; j < ns; j += 32) {
-          if (j + 16 < ns) Eb = exponents(j + 16);
-          if (!blend16(Ea, j)) break;
-          if (j + 16 >= ns) break;
-          if (j + 32 < ns) Ea = exponents(j + 32);
-          if (!blend16(Eb, j + 16)) break;
-        }
-#else
         for (int j = 0; j < ns; j += 16) {
           const v16f E = exponents(j);
           if (!blend16(E, j)) break;
         }
-#endif
       }
       return true;
     };
@@ -579,6 +368,12 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const uint2* __restrict_
     out_color[HW + pid] = Crg.y + T * bg[1];
     out_color[2 * HW + pid] = Cb + T * bg[2];
   }
+  if (TRACE && lane == 0) {
+    unsigned long long* t = trace + 8 * ((size_t)tile_block * 4 + wave);
+    t[0] = t_start; t[1] = wall_clock64(); t[2] = (unsigned long long)n;
+    t[3] = (unsigned long long)tr_iters | ((unsigned long long)tr_cand << 16) | ((unsigned long long)work << 40);
+    t[4] = 0; t[5] = 0;
+  }
 }
 
 static unsigned long long* g_render_trace = nullptr;      // debugging aid (tools/wave_trace.py), never set by the package
@@ -590,24 +385,17 @@ int launch_render_fwd(const GeomState& g, const uint2* pairs, ImageState& img, i
   StageScope sc(ST_RENDER, s);
   const TileGrid tg(W, H, mode);
   const TileMap tm{tg.gx, tg.gy, tg.pgx, tg.pgy, tg.s, img.tile_order};
-  static const bool fwd_v1 = getenv("GM_FWD_V1") != nullptr;
   if (tg.ptiles > 0) {
-    const dim3 grid(tm.blocks() * (4 / GM_RENDER_FWD_WPW)), block(64 * GM_RENDER_FWD_WPW);
+    const dim3 grid(tm.blocks() * 4), block(64);                           // one wave (8x8 quadrant) per workgroup
     if (g_render_trace)
-      hipLaunchKernelGGL((render_fwd_kernel_v1<true, true>), grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
+      hipLaunchKernelGGL((render_fwd_kernel<true, true>), grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
                          background, out_color, img.final_T, img.n_contrib, g_render_trace, g.counters, status_host, work_hint, img.epoch);
-    else if (fwd_v1 && image_only)
-      hipLaunchKernelGGL((render_fwd_kernel_v1<false, false>), grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
-                         background, out_color, img.final_T, img.n_contrib, nullptr, g.counters, status_host, work_hint, img.epoch);
-    else if (fwd_v1)
-      hipLaunchKernelGGL((render_fwd_kernel_v1<false, true>), grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
-                         background, out_color, img.final_T, img.n_contrib, nullptr, g.counters, status_host, work_hint, img.epoch);
     else if (image_only)
-      hipLaunchKernelGGL((render_fwd_kernel<false>), dim3(tm.blocks() * 4), dim3(64), 0, s, img.ranges, pairs, g.splat, W, H, tm,
-                         background, out_color, img.final_T, img.n_contrib, g.counters, status_host, work_hint, img.epoch);
+      hipLaunchKernelGGL((render_fwd_kernel<false, false>), grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
+                         background, out_color, img.final_T, img.n_contrib, nullptr, g.counters, status_host, work_hint, img.epoch);
     else
-      hipLaunchKernelGGL((render_fwd_kernel<true>), dim3(tm.blocks() * 4), dim3(64), 0, s, img.ranges, pairs, g.splat, W, H, tm,
-                         background, out_color, img.final_T, img.n_contrib, g.counters, status_host, work_hint, img.epoch);
+      hipLaunchKernelGGL((render_fwd_kernel<true, false>), grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
+                         background, out_color, img.final_T, img.n_contrib, nullptr, g.counters, status_host, work_hint, img.epoch);
   } else if (status_host) {
     GM_HIP(hipMemcpyAsync(status_host, g.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   }
@@ -617,66 +405,10 @@ int launch_render_fwd(const GeomState& g, const uint2* pairs, ImageState& img, i
 
 // ---------------------------------------------------------------------------------------------
 // Backward blend.
-//
-// Per (wave, surviving entry) every lane holds nine partial sums (its pixels' contributions to dL/dcolor rgb,
-// dL/dmean2D xy, dL/dconic x,y,w and dL/dopacity of that Gaussian).  The reference issues nine global atomics per
-// (pixel, entry); here the wave first reduces them, with the gfx950 lane-swap instructions doing a TRANSPOSED
-// reduction of eight values at once:
-//   v_permlane32_swap + add : (q0,q1) -> one register holding q0's 32-lane partials in lanes 0-31 and q1's in 32-63
-//   v_permlane16_swap + add : two such registers -> one register, one value per 16-lane row
-//   row_ror:8 add + select  : two such registers -> one register, one value per 8-lane group
-//   row_half_mirror, quad_perm[3,2,1,0], quad_perm[1,0,3,2] adds: finish inside the 8-lane groups
-// = 18 VALU instructions for eight totals (48 with a plain 6-step DPP tree each), and the eight totals sit in eight
-// different lanes, so ONE global_atomic_add_f32 instruction commits them.  The ninth value takes the plain DPP tree.
-// Accumulation goes to a packed per-Gaussian record grad_acc[P][12] (one cache line instead of four arrays);
-// preprocess_bwd_kernel unpacks it into the API's dL_dmean2D / dL_dconic / dL_dopacity / dL_dcolor.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v) {
-  const int sh = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
-  return v + __int_as_float(sh);
-}
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-  v = dpp_add<0x111, 0xf>(v);   // row_shr:1
-  v = dpp_add<0x112, 0xf>(v);   // row_shr:2
-  v = dpp_add<0x114, 0xf>(v);   // row_shr:4
-  v = dpp_add<0x118, 0xf>(v);   // row_shr:8
-  v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1,3
-  v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2,3
-  return v;
-}
-__device__ __forceinline__ float swap32_add(float a, float b) {   // lanes 0-31: a[l]+a[l+32]; lanes 32-63: b[l-32]+b[l]
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float swap16_add(float a, float b) {   // rows: a.r0+a.r1 | b.r0+b.r1 | a.r2+a.r3 | b.r2+b.r3
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-// totals of q0..q7; the total of q[slot] is returned in every lane of the 8-lane group with
-// slot == reduce8_slot(lane)
-__device__ __forceinline__ float reduce8(const float* q, int lane) {
-  const float s01 = swap32_add(q[0], q[1]), s23 = swap32_add(q[2], q[3]);
-  const float s45 = swap32_add(q[4], q[5]), s67 = swap32_add(q[6], q[7]);
-  const float ta = swap16_add(s01, s23);            // rows: q0 q2 q1 q3
-  const float tb = swap16_add(s45, s67);            // rows: q4 q6 q5 q7
-  const float x = dpp_add<0x128, 0xf>(ta);          // row_ror:8 -> 8-lane partials, duplicated in both halves
-  const float y = dpp_add<0x128, 0xf>(tb);
-  float u = (lane & 8) ? y : x;
-  u = dpp_add<0x141, 0xf>(u);                       // row_half_mirror
-  u = dpp_add<0x1B, 0xf>(u);                        // quad_perm [3,2,1,0]
-  u = dpp_add<0xB1, 0xf>(u);                        // quad_perm [1,0,3,2]
-  return u;
-}
-__device__ __forceinline__ int reduce8_slot(int lane) {
-  const int r = lane >> 4, h = (lane >> 3) & 1;
-  const int a_idx = (r == 0) ? 0 : (r == 1) ? 2 : (r == 2) ? 1 : 3;
-  return h ? a_idx + 4 : a_idx;                     // h = 1: q4 q6 q5 q7
-}
-
 #define GM_ACC_STRIDE 12   // floats per Gaussian in grad_acc: dcolor rgb (0-2), moments of h: 1, dx, dy, dx^2, dx dy, dy^2 (3-8)
 
 #ifndef GM_RENDER_BWD_WPW
-#define GM_RENDER_BWD_WPW 1      // waves per workgroup of the backward blend (as GM_RENDER_FWD_WPW)
+#define GM_RENDER_BWD_WPW 1      // waves per workgroup of the backward blend: 4 (one workgroup per 16-px tile) or 1 (one per 8x8 quadrant)
 #endif
 
 // Backward blend, two phases per wave (round 3).
@@ -697,13 +429,13 @@ __device__ __forceinline__ int reduce8_slot(int lane) {
 // Per entry: ~28 + ~9 vector instructions instead of ~44 + 28 for the per-entry cross-lane reduction of round 2
 // (v_permlane32/16_swap + DPP butterfly), which is gone.
 struct StagedB {                 // one survivor of the staged batch (one LDS address per entry in the walk)
-  float4 a;                      // x, y, conic.x', conic.z'   (as WaveLds::a)
+  float4 a;                      // x, y, conic.x', conic.z'   (conic pre-multiplied for the exp2 argument)
   float4 b;                      // conic.y', opacity, r, g
   float4 c;                      // b, list position (bits), Gaussian id (bits), -
 };
 struct SlotB { float2 xy; uint32_t id, pad; };   // splat centre and id of a phase-2 slot
 struct BwdLds {                  // per wave: 7.5 KiB
-  uint2 qa[RQ_QA];               // candidate ring (front end, as WaveLds::qa)
+  uint2 qa[RQ_QA];               // candidate ring of the front end: (Gaussian id, list position)
   StagedB st[64];                // staged batch
   union {
     float2 M[7][65];             // (w, h) per slot and pixel; row stride 65 keeps phase 2's row reads conflict-free
@@ -713,9 +445,6 @@ struct BwdLds {                  // per wave: 7.5 KiB
   SlotB slot[8];
 };
 
-#ifdef GM_BWD_OCC4
-__attribute__((amdgpu_waves_per_eu(4, 8)))
-#endif
 __global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_kernel(const uint2* __restrict__ ranges,
                                                                const uint2* __restrict__ pairs,
                                                                const float4* __restrict__ splat, int W, int H, TileMap tm,
@@ -916,188 +645,6 @@ __global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_kernel(cons
   if (m > 0) phase2(m);
 }
 
-// ---- round-2 form of the backward blend, kept only for A/B timing during round 3 (GM_BWD_V1=1)
-
-__global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_kernel_v1(const uint2* __restrict__ ranges,
-                                                               const uint2* __restrict__ pairs,
-                                                               const float4* __restrict__ splat, int W, int H, TileMap tm,
-                                                               const float* __restrict__ bg, const float* __restrict__ final_T,
-                                                               const uint32_t* __restrict__ n_contrib,
-                                                               const float* __restrict__ dL_dpix, float* __restrict__ grad_acc,
-                                                               const uint32_t* __restrict__ counters, int mode) {
-  constexpr int WPW = GM_RENDER_BWD_WPW;
-  const int lane = threadIdx.x & 63;
-  const int wave = WPW == 4 ? (int)(threadIdx.x >> 6) : (int)((blockIdx.x >> 3) & 3);
-  const int tile_block = WPW == 4 ? (int)blockIdx.x : (int)(((blockIdx.x >> 5) << 3) | (blockIdx.x & 7));
-  int tx, ty, parent;
-  uint32_t child_bit;
-  if ((int)counters[GM_CNT_POLICY] != mode || counters[GM_CNT_REFUSED] != 0u) return;   // lists were built under another emission policy: contribute nothing
-  if (!tm.locate(tile_block, tx, ty, parent, child_bit)) return;
-  const uint2 range = ranges[parent];
-  const int n = (int)(range.y - range.x);
-  if (n == 0) return;
-  const uint2* list = pairs + range.x;           // (key, Gaussian id) per list entry
-  const size_t HW = (size_t)H * W;
-  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-
-  const int px = tx * GM_TILE + (wave & 1) * 8 + (lane & 7);
-  const int py = ty * GM_TILE + (wave >> 1) * 8 + (lane >> 3);
-  const float pixx = (float)px, pixy = (float)py;
-  const bool inside = px < W && py < H;
-  const size_t pid = inside ? (size_t)W * py + px : 0;
-  const float T_final = inside ? final_T[pid] : 0.f;
-  float T = T_final;
-  const v2f pix = {pixx, pixy};
-  const int last = inside ? (int)n_contrib[pid] : 0;
-  const float dpr = inside ? dL_dpix[pid] : 0.f, dpg = inside ? dL_dpix[HW + pid] : 0.f, dpb = inside ? dL_dpix[2 * HW + pid] : 0.f;
-  const float bg_dot = bg0 * dpr + bg1 * dpg + bg2 * dpb;
-  float last_alpha = 0.f, lcb = 0.f, arb = 0.f;
-  v2f lc_rg = {0.f, 0.f}, ar_rg = {0.f, 0.f};                 // last colour / accum_rec, (r, g) as a register pair
-  const v2f dp_rg = {dpr, dpg};
-  const float tf_bg = T_final * bg_dot;
-  // entries at list positions >= max over the wave of n_contrib are never used: start there
-  int max_last = last;
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) max_last = max(max_last, __shfl_xor(max_last, d));
-  const int start = max_last;           // number of list entries this wave has to visit (positions start-1 .. 0)
-  if (start == 0) return;
-
-  const int my_slot = reduce8_slot(lane);
-  const bool committer = (lane & 7) == 0;
-  const float rx0 = (float)(tx * GM_TILE + (wave & 1) * 8), ry0 = (float)(ty * GM_TILE + (wave >> 1) * 8);
-  __shared__ WaveLds l_w[WPW];
-  WaveLds& L = l_w[WPW == 4 ? wave : 0];
-  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  // Same front end as render_fwd_kernel, walking the list back to front: chunk lane j <-> position start-1-kpos-j
-  // (positions below 0 re-read entry 0 and are not "mine"); candidates enter the ring in descending list position.
-  int kpos = 0;                                  // entries scanned so far (from the back)
-  uint32_t qa_head = 0, qa_cnt = 0;
-  uint2 kv[RQ_K];
-  auto scan = [&]() {
-    bool go = true;
-#pragma unroll
-    for (int k = 0; k < RQ_K; k++) {
-      go = go && kpos < start && qa_cnt + 64u <= (uint32_t)RQ_QA;
-      if (go) {
-        const int p = start - 1 - kpos - lane;
-        const bool mine = p >= 0 && (kv[k].x & child_bit) != 0u;
-        const unsigned long long bal = __ballot(mine);
-        if (mine) L.qa[(qa_head + qa_cnt + (uint32_t)__popcll(bal & lt_mask)) & (RQ_QA - 1)] = make_uint2(kv[k].y, (uint32_t)p);
-        qa_cnt += (uint32_t)__popcll(bal);
-        kpos += 64;
-      }
-    }
-  };
-  auto load_keys = [&]() {
-#pragma unroll
-    for (int k = 0; k < RQ_K; k++) kv[k] = list[max(start - 1 - kpos - k * 64 - lane, 0)];
-  };
-  auto pop = [&](int& count) {
-    count = (int)min(qa_cnt, 64u);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const uint2 cand = lane < count ? L.qa[(qa_head + (uint32_t)lane) & (RQ_QA - 1)] : make_uint2(0u, 0u);
-    qa_head += (uint32_t)count; qa_cnt -= (uint32_t)count;
-    return issue_gather(splat, cand);
-  };
-  load_keys();
-  scan();
-  load_keys();
-  auto step = [&](Gather& cur, int& n0, const int n1, Gather& nxt, int& n2) -> bool {      // see render_fwd_kernel
-    if (n0 == 0 && n1 == 0 && qa_cnt == 0u && kpos >= start) return false;
-    __builtin_amdgcn_s_waitcnt(0x0F73);                                  // vmcnt(3)
-    scan();
-    load_keys();
-    nxt = pop(n2);
-    if (n0 > 0) {
-      // A pixel takes part in this batch only if its last contributor lies above the batch's lowest position: cull against
-      // the bounding box of those pixels (at the deep end of the walk only the few pixels that reached far into the list
-      // are still in play).  Lane = y * 8 + x.
-      const int pos_lo = __builtin_amdgcn_readlane((int)cur.pos, n0 - 1);
-      const unsigned long long live = __ballot(last > pos_lo);
-      float cx0 = rx0, cx1 = rx0 + 7.0f, cy0 = ry0, cy1 = ry0 + 7.0f;
-      if (live != 0ull) {
-        uint32_t cols = (uint32_t)live | (uint32_t)(live >> 32);
-        cols |= cols >> 16; cols |= cols >> 8; cols &= 0xFFu;
-        cx0 = rx0 + (float)(__ffs((int)cols) - 1);
-        cx1 = rx0 + (float)(31 - __clz((int)cols));
-        cy0 = ry0 + (float)((__ffsll(live) - 1) >> 3);
-        cy1 = ry0 + (float)((63 - __clzll((long long)live)) >> 3);
-      }
-      const bool keep = live != 0ull && lane < n0 && may_touch(cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, cx0, cx1, cy0, cy1);
-      // compacted, conic pre-multiplied for the exp2 argument, as in render_fwd_kernel (the moments below only need dx, dy)
-      const unsigned long long kb = __ballot(keep);
-      const int ns = __popcll(kb);
-      if (keep) {
-        const int slot = __popcll(kb & lt_mask);
-        L.a[slot] = make_float4(cur.a.x, cur.a.y, (-0.5f * LOG2E) * cur.a.z, (-0.5f * LOG2E) * cur.b.x);
-        L.b[slot] = make_float4((-LOG2E) * cur.a.w, cur.b.y, cur.b.z, cur.b.w);
-        L.cp[slot] = make_float2(cur.c, __uint_as_float(cur.pos));      // 0-based list position == reference `contributor`
-        L.id[slot] = cur.id;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      for (int j = 0; j < ns; j++) {
-        const float4 RA = L.a[j], RB = L.b[j];
-        const float2 RC = L.cp[j];
-        const float op = RB.y;
-        v2f dd;
-        const float e = staged_exponent(RA, RB.x, pix, dd);             // power * log2(e), evaluated exactly as in the forward kernel
-        const float dy = dd.y;
-        const float G = __builtin_amdgcn_exp2f(e);
-        const float alpha = fminf(0.99f, op * G);
-        const int pos = (int)__float_as_uint(RC.y);
-        const bool valid = (pos < last) && (e <= 0.0f) && (alpha >= 1.0f / 255.0f);
-        if (!__any(valid)) continue;
-        const uint32_t gid = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.id[j]);
-        // The state of the walk (T, accum_rec, last colour / alpha: backward.cu:478-512) moves only on the lanes that take
-        // the entry; what leaves this block are the two per-lane factors every partial sum is a multiple of - the weight
-        // alpha T (dL/dcolour) and h = G dL/dG - both 0 on the other lanes, so the sums below need no masks.
-        float wv = 0.f, h = 0.f;
-        if (valid) {
-          const float inv = __builtin_amdgcn_rcpf(1.f - alpha);      // 1/(1-alpha): T recovery and the bg term
-          T = T * inv;
-          const v2f la2 = {last_alpha, last_alpha};
-          ar_rg = la2 * (lc_rg - ar_rg) + ar_rg;            // accum_rec = la*lc + (1-la)*accum_rec
-          arb += last_alpha * (lcb - arb);
-          const v2f rg = {RB.z, RB.w};
-          lc_rg = rg; lcb = RC.x;
-          const v2f t2 = (rg - ar_rg) * dp_rg;
-          float dL_dalpha = (t2.x + t2.y) + (RC.x - arb) * dpb;
-          last_alpha = alpha;
-          dL_dalpha = dL_dalpha * T - (tf_bg * inv);
-          wv = alpha * T;
-          h = (op * G) * dL_dalpha;                                  // G * dL/dG with dL/dG = opacity * dL/dalpha
-        }
-        // per-lane partial sums of: dL/dcolor rgb (q0-2) and the six moments of h over the wave's pixels
-        // (q3 = sum h, q4 = sum h dx, q5 = sum h dy, q6 = sum h dx^2, q7 = sum h dx dy, q8 = sum h dy^2).
-        // preprocess_bwd_kernel turns the moments into dL/dopacity, dL/dmean2D and dL/dconic (backward.cu:538-554):
-        //   dL/dopacity = q3 / opacity, dL/dmean2D = -(W/2)(cx q4 + cy q5), -(H/2)(cz q5 + cy q4), dL/dconic = -q6/2, -q7/2, -q8/2
-        const v2f wv2 = {wv, wv}, h2 = {h, h};
-        const v2f c01 = wv2 * dp_rg, hxy = h2 * dd, m2 = hxy * dd;
-        float q[8] = {c01.x, c01.y, wv * dpb, h, hxy.x, hxy.y, m2.x, hxy.x * dy};
-        float q8 = m2.y;
-        const float tot = reduce8(q, lane);
-        q8 = wave_sum_to_lane63(q8);
-        // eight totals sit in the lanes with (lane & 7) == 0, the ninth in lane 63: one atomic instruction commits all nine
-        // (measured and dropped: letting the ninth sum wait for the next entry's so that two share one tree - 13 % slower,
-        // the second code path costs more than the five DPP steps it saves)
-        const bool last_lane = lane == 63;
-        if (committer || last_lane)
-          atomicAdd(grad_acc + (size_t)gid * GM_ACC_STRIDE + (last_lane ? 8 : my_slot), last_lane ? q8 : tot);
-      }
-    }
-    return true;
-  };
-  int n0, n1, n2 = 0;
-  Gather g0 = pop(n0), g1 = pop(n1), g2 = g1;
-  for (;;) {
-    if (!step(g0, n0, n1, g2, n2)) break;
-    if (!step(g1, n1, n2, g0, n0)) break;
-    if (!step(g2, n2, n0, g1, n1)) break;
-  }
-}
-
 int launch_render_bwd(const GeomState& g, const uint2* pairs, ImageState& img, int W, int H, int mode,
                       const float* background, const float* dL_dpix, int debug, hipStream_t s) {
   StageScope sc(ST_RENDER_BWD, s);
@@ -1107,15 +654,9 @@ int launch_render_bwd(const GeomState& g, const uint2* pairs, ImageState& img, i
     hipLaunchKernelGGL(tile_work_kernel, dim3(tg.ptiles), dim3(256), 0, s, img.n_contrib, W, H, tg.pgx, tg.s, img.tile_work);
     hipLaunchKernelGGL(tile_order_work_kernel, dim3(1), dim3(1024), 0, s, img.tile_work, tg.ptiles, img.tile_order_bwd);
   }
-  static const bool v1 = getenv("GM_BWD_V1") != nullptr;
-  if (tg.ptiles > 0) {
-    if (v1)
-      hipLaunchKernelGGL(render_bwd_kernel_v1, dim3(tm.blocks() * (4 / GM_RENDER_BWD_WPW)), dim3(64 * GM_RENDER_BWD_WPW), 0, s, img.ranges, pairs, g.splat, W, H, tm,
-                         background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc, g.counters, mode);
-    else
-      hipLaunchKernelGGL(render_bwd_kernel, dim3(tm.blocks() * (4 / GM_RENDER_BWD_WPW)), dim3(64 * GM_RENDER_BWD_WPW), 0, s, img.ranges, pairs, g.splat, W, H, tm,
-                         background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc, g.counters, mode);
-  }
+  if (tg.ptiles > 0)
+    hipLaunchKernelGGL(render_bwd_kernel, dim3(tm.blocks() * (4 / GM_RENDER_BWD_WPW)), dim3(64 * GM_RENDER_BWD_WPW), 0, s, img.ranges, pairs, g.splat, W, H, tm,
+                       background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc, g.counters, mode);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }
