@@ -413,24 +413,29 @@ def main():
     # Three passes (~45 ms of device work) rather than one: a timed region that starts a few milliseconds after the device
     # leaves idle runs ~3 % slower than the same frames a little later (20-step regions, same cameras: 4010 frames/s after
     # one pass, 4130 after three, no further gain from eight).
+    # the cyclic garbage collector stays out of the timed regions (a generation-2 pass over the scene's objects is tens of
+    # milliseconds - 10 % of a 300-step region - whenever it happens to fall into one); reference counting still frees every
+    # frame.  Collected BEFORE the sizing passes: the device must not sit idle right in front of the timed region.
+    import gc
+    gc.collect()
+    gc.disable()
     for i in range(-3 * F, 0):
         step(i)
     for i in range(args.warmup):
         step(i)
     drain()
-    # the cyclic garbage collector stays out of the timed regions (a generation-2 pass over the scene's objects is tens of
-    # milliseconds - 10 % of a 300-step region - whenever it happens to fall into one); reference counting still frees every frame
-    import gc
-    gc.collect()
-    gc.disable()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    drain()                                      # the last frame of the timed region is completed inside it
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def timed_region(first):
+        """K steps bracketed by barrier + synchronize on both sides; seconds (this rank)."""
+        barrier()
+        t = time.perf_counter()
+        for i in range(args.steps):
+            step(first + i)
+        drain()                                  # the last frame of the timed region is completed inside it
+        torch.cuda.synchronize()
+        barrier()
+        return time.perf_counter() - t
+
+    elapsed = timed_region(args.warmup)
     elapsed = multiview.max_over_ranks(elapsed, dev)
     fps = world * args.steps / elapsed
     repeats = []
@@ -438,13 +443,7 @@ def main():
     if world == 1:
         nxt = args.warmup + args.steps
         for _ in range(max(0, args.repeats)):    # the same region again: run-to-run spread of the pipelined loop
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for i in range(args.steps):
-                step(nxt + i)
-            drain()
-            torch.cuda.synchronize()
-            repeats.append(args.steps / (time.perf_counter() - t1))
+            repeats.append(args.steps / timed_region(nxt))
             nxt += args.steps
         # latency of one frame: the same frames one after the other on one stream, each completed before the next begins
         nlat = min(args.steps, 100)
