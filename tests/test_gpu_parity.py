@@ -856,3 +856,40 @@ def test_work_hint_never_changes_an_image(W, H, policy):
         hv = hint.cpu().numpy().view(np.uint32)
         assert int(hv[0]) == k + 1 and (hv[1:] != 0).sum() > 0
         assert hv.size * 4 == lib.gm_work_hint_bytes(W, H)
+
+
+def test_splat_centred_on_a_pixel_is_not_dropped(oracle):
+    """Round 3's forward evaluates the exponent as a polynomial on the matrix core (|error| ~1e-5) and therefore clamps it at 0
+    where the reference skips `power > 0` (RAST/forward.cu:338-339: a guard against its own rounding at power = -0 +- 1e-7).
+    Splats whose centres fall EXACTLY on pixel centres - power == 0 there, the polynomial lands on either side of it - must still
+    be rendered at their brightest pixel: image and gradients against the oracle, which keeps power == 0."""
+    from gpu_utils import forward_state
+    from gaussianmesh_amd import scenes
+    W, H, D = 96, 64, 3
+    cam = scenes.orbit_camera(0, 8, W, H, radius=6.0)
+    sc = scenes.make_cloud(400, seed=21, scale_lo=0.02, scale_hi=0.15, D=D)
+    # move every Gaussian onto the ray through a pixel centre: project, round to the pixel grid, unproject at the same depth
+    view = cam["view"].astype(np.float64); proj = cam["proj"].astype(np.float64)
+    m = sc["means"].astype(np.float64)
+    hom = np.concatenate([m, np.ones((len(m), 1))], 1) @ proj
+    ndc = hom[:, :2] / hom[:, 3:4]
+    pix = ((ndc + 1.0) * np.array([W, H]) - 1.0) * 0.5
+    tgt = np.clip(np.round(pix), 2, [W - 3, H - 3])
+    ndc_t = (2.0 * tgt + 1.0) / np.array([W, H]) - 1.0
+    vz = (np.concatenate([m, np.ones((len(m), 1))], 1) @ view)[:, 2]
+    vx, vy = ndc_t[:, 0] * cam["tanx"] * vz, ndc_t[:, 1] * cam["tany"] * vz
+    back = np.concatenate([np.stack([vx, vy, vz], 1), np.ones((len(m), 1))], 1) @ np.linalg.inv(view)
+    sc["means"] = back[:, :3].astype(np.float32)
+    sc["opac"][:] = np.linspace(0.3, 0.95, len(m), dtype=np.float32).reshape(sc["opac"].shape)
+    bg = np.zeros(3, np.float32)
+    fw = oracle.forward_full(sc, cam, bg, D=D)
+    on_centre = np.abs(fw["geo"]["xy"] - np.round(fw["geo"]["xy"])).max(axis=1) < 2e-4
+    assert on_centre.sum() > 300                                          # (float32 projection: most land within 2e-4 px of a centre)
+    st = forward_state(sc, cam, bg, D=D)
+    assert np.array_equal(st["radii"], fw["geo"]["radii"])
+    assert_forward_gate(fw, st["color"], W, H, FWD_TOL, "centred splats")
+    dpix = np.random.default_rng(5).normal(size=(3, H, W)).astype(np.float32)
+    bw = oracle.backward_full(sc, cam, bg, fw, dpix, D=D)
+    _, _, g = _grads_gpu(sc, cam, bg, dpix, D, False, False)
+    _grad_gate(g["opac"].reshape(-1), bw["dopacity"], "opacity")
+    _grad_gate(g["means"], bw["dmean3D"], "means")
