@@ -14,6 +14,8 @@ from . import _lib
 
 
 def _f(t):
+    if t.dtype is torch.float32 and t.is_contiguous():
+        return t
     return t.detach().contiguous().float()
 
 
@@ -161,12 +163,14 @@ def mesh_rs_packed(rest_vertices, deformed_vertices, faces, adjacency, out=None)
         raise _lib.GmeshError("mesh_rs_packed needs tensors on a HIP (cuda) device; there is no CPU path")
     V0, V1 = _f(rest_vertices), _f(deformed_vertices)
     Vm = V0.shape[0]
-    faces = faces.detach().contiguous().to(torch.int32)
+    if faces.dtype is not torch.int32 or not faces.is_contiguous():
+        faces = faces.detach().contiguous().to(torch.int32)
     off, adj = adjacency
     packed = out if out is not None else torch.empty((Vm, 24), dtype=torch.float32, device=device)
-    with torch.cuda.device(device):
+    from .rasterizer import _on, _stream
+    with _on(device):
         _lib.check(lib.gm_mesh_rs_packed(Vm, faces.shape[0], V0.data_ptr(), V1.data_ptr(), faces.data_ptr(), off.data_ptr(), adj.data_ptr(),
-                                         packed.data_ptr(), torch.cuda.current_stream(device).cuda_stream))
+                                         packed.data_ptr(), _stream(device)))
     return packed
 
 

@@ -45,11 +45,45 @@ def _prep(t, device):
         return None
     if t.device != device:
         raise ValueError("rasterizer input on %s but means3D on %s" % (t.device, device))
+    if t.dtype is torch.float32 and t.is_contiguous():      # the usual case: nothing to convert (only the pointer is used; a render
+        return t                                            # loop issues a dozen of these per frame, each conversion a dispatcher trip)
     return t.detach().contiguous().float()
 
 
+class _on:
+    """`with torch.cuda.device(d)` for the usual case that d already is the current device: one C call instead of the context
+    manager's four (a pipelined render loop enters it three times per frame)."""
+    __slots__ = ("guard",)
+
+    def __init__(self, device):
+        self.guard = None if torch.cuda.current_device() == device.index else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self.guard is not None:
+            self.guard.__enter__()
+
+    def __exit__(self, *a):
+        if self.guard is not None:
+            return self.guard.__exit__(*a)
+
+
 def _stream(device):
-    return torch.cuda.current_stream(device).cuda_stream
+    return torch._C._cuda_getCurrentRawStream(device.index)
+
+
+_STREAM_OBJECTS = {}
+
+
+def _current_stream(device):
+    """torch.cuda.current_stream(device), with the Stream wrapper cached per raw handle (the torch call spends ~10 us in
+    device-index bookkeeping; a render loop asks three times per frame)."""
+    key = (device.index, torch._C._cuda_getCurrentRawStream(device.index))
+    st = _STREAM_OBJECTS.get(key)
+    if st is None:
+        st = torch.cuda.current_stream(device)
+        if len(_STREAM_OBJECTS) < 256:
+            _STREAM_OBJECTS[key] = st
+    return st
 
 
 # Instance emission policy (include/gmesh_hip.h): an argument of every call below (`emission_policy=`); None takes this
@@ -216,7 +250,20 @@ class PendingForward:
         a = self.args
         device = a["device"]
         ws = self.workspace
-        with torch.cuda.device(device), torch.cuda.stream(self.stream):
+        if sync_free and ws is not None and ws.capacity > 0 and a["P"] > 0 and self.status_event is None:
+            nbytes = lib.gm_binning_bytes(ws.capacity)
+            binning = ws._bufs.get("binning")
+            if binning is not None and binning.device == device and binning.numel() >= nbytes:
+                # steady state of a pipelined render loop: the buffer exists, nothing is allocated, so nothing here depends on
+                # torch's current stream - the launches take the frame's stream explicitly
+                with _on(device):
+                    self._geom(binning, -1, ws.capacity, ws.pinned_status())
+                    self.status_event = torch.cuda.Event()
+                    self.status_event.record(self.stream)
+                self.binning = binning
+                self.result = (-1, self.color, self.radii, self.geom, binning, self.img)
+                return self.result
+        with _on(device), torch.cuda.stream(self.stream):
             if sync_free and ws is None and capacity > 0 and a["P"] > 0 and self.status_event is None:
                 binning = torch.empty((lib.gm_binning_bytes(capacity),), dtype=torch.uint8, device=device)
                 self.status_host = _PINNED_STATUS.pop() if _PINNED_STATUS else torch.zeros((4,), dtype=torch.int32).pin_memory()
@@ -334,13 +381,13 @@ def rasterize_forward_begin(bg, means3D, colors, opacity, scales, rotations, sca
         M = sh.shape[1] if sh.dim() == 3 else sh.numel() // (3 * max(P, 1))
     if force_M is not None and sh is not None and M != force_M:
         raise ValueError("NewGaussianRasterizer expects shs of shape [P,%d,3]" % force_M)
-    stream = torch.cuda.current_stream(device)
+    stream = _current_stream(device)
     _note_stream(stream)
     h = PendingForward(policy=policy, workspace=workspace, stream=stream)
     if workspace is not None:
         workspace.acquire(h)
     try:
-        with torch.cuda.device(device):
+        with _on(device):
             color = torch.empty((3, H, W), dtype=torch.float32, device=device)
             radii = torch.empty((P,), dtype=torch.int32, device=device)
             geom, img, count_host = _scratch(workspace, P, W, H, device)
@@ -386,17 +433,18 @@ def forward_deformed_begin(bg, tri, weights, packed, cov, pos, shs, opacity, vie
         raise _lib.GmeshError("gaussianmesh_amd rasterizer needs tensors on a HIP (cuda) device; there is no CPU path")
     policy = _pol(emission_policy, image_width, image_height)
     P, M = pos.shape[0], shs.shape[1]
-    tri = tri.detach().contiguous().to(torch.int32)
+    if tri.dtype is not torch.int32 or not tri.is_contiguous():
+        tri = tri.detach().contiguous().to(torch.int32)
     weights, packed, cov, pos, shs, opacity = (_prep(t, device) for t in (weights, packed, cov, pos, shs, opacity))   # None when empty
     bg, viewmatrix, projmatrix, campos = (_prep(t, device) for t in (bg, viewmatrix, projmatrix, campos))
     H, W = int(image_height), int(image_width)
-    stream = torch.cuda.current_stream(device)
+    stream = _current_stream(device)
     _note_stream(stream)
     h = PendingForward(policy=policy, workspace=workspace, stream=stream)
     if workspace is not None:
         workspace.acquire(h)
     try:
-        with torch.cuda.device(device):
+        with _on(device):
             f = dict(dtype=torch.float32, device=device)
             color = torch.empty((3, H, W), **f)
             radii = torch.empty((P,), dtype=torch.int32, device=device)
@@ -442,7 +490,7 @@ def rasterize_backward(bg, means3D, radii, colors, scales, rotations, scale_modi
     dpix = _prep(dL_dout_color, device)
     H, W = dpix.shape[1], dpix.shape[2]
     M = sh.shape[1] if sh is not None else 0
-    with torch.cuda.device(device):
+    with _on(device):
         dmeans2D = torch.empty((P, 3), **f); dconic = torch.empty((P, 2, 2), **f); dopac = torch.empty((P, 1), **f)
         dcolors = torch.empty((P, 3), **f); dmeans3D = torch.empty((P, 3), **f); dcov3D = torch.empty((P, 6), **f)
         dsh = torch.empty((P, M, 3), **f) if sh is not None else None
@@ -465,7 +513,7 @@ def mark_visible(means3D, viewmatrix, projmatrix):
     P = 0 if means3D is None else means3D.shape[0]
     present = torch.zeros((P,), dtype=torch.uint8, device=device)
     if P:
-        with torch.cuda.device(device):
+        with _on(device):
             _lib.check(lib.gm_mark_visible(P, _ptr(means3D), _ptr(viewmatrix), _ptr(projmatrix), _ptr(present), _stream(device)))
     return present.bool()
 
