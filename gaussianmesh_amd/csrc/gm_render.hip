@@ -180,8 +180,11 @@ struct FwdLds {                  // per wave: 5.25 KiB
 
 // STATE = false: image-only frame (GM_FWD_IMAGE_ONLY) - final_T / n_contrib, which only a backward pass reads, are neither
 // tracked nor written.  TRACE: per-wave start / end / list length / iterations / candidates / survivors (tools/wave_trace.py).
+#ifndef GM_RENDER_FWD_WPW
+#define GM_RENDER_FWD_WPW 1      // waves per workgroup of the forward blend: 1 (one workgroup per 8x8 quadrant) or 4 (one per 16-px tile)
+#endif
 template <bool STATE, bool TRACE>
-__global__ __launch_bounds__(64) void render_fwd_kernel(const uint2* __restrict__ ranges, const uint2* __restrict__ pairs,
+__global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(const uint2* __restrict__ ranges, const uint2* __restrict__ pairs,
                                                         const float4* __restrict__ splat, int W, int H, TileMap tm,
                                                         const float* __restrict__ bg, float* __restrict__ out_color,
                                                         float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
@@ -192,9 +195,10 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const uint2* __restrict_
   int tr_iters = 0, tr_cand = 0;
   // One 8x8 pixel quadrant = one wave = one workgroup (placed and retired on its own); ids 8 apart share an XCD:
   // id = ((tile slot j) * 4 + quadrant) * 8 + xcd.
+  constexpr int WPW = GM_RENDER_FWD_WPW;
   const int lane = threadIdx.x & 63;
-  const int wave = (int)((blockIdx.x >> 3) & 3);
-  const int tile_block = (int)(((blockIdx.x >> 5) << 3) | (blockIdx.x & 7));
+  const int wave = WPW == 4 ? (int)(threadIdx.x >> 6) : (int)((blockIdx.x >> 3) & 3);
+  const int tile_block = WPW == 4 ? (int)blockIdx.x : (int)(((blockIdx.x >> 5) << 3) | (blockIdx.x & 7));
   if (status_host && blockIdx.x == 0 && threadIdx.x < 4)                 // the frame's status words {num_rendered, -, policy, refused}
     __hip_atomic_store(status_host + threadIdx.x, (int)counters[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // straight into
   int tx, ty, parent;                                                    // the caller's page-locked words: no copy launch behind the frame
@@ -215,7 +219,8 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const uint2* __restrict_
   int work = 0;                                                               // entries this wave evaluated (wave-uniform): the work hint
   if (n > 0) {
     const float rx0 = (float)(tx * GM_TILE + (wave & 1) * 8), ry0 = (float)(ty * GM_TILE + (wave >> 1) * 8);
-    __shared__ FwdLds L;
+    __shared__ FwdLds L_w[WPW];
+    FwdLds& L = L_w[WPW == 4 ? wave : 0];
     // B operand of the three MFMA steps: monomials (cx^2, cx cy) / (cy^2, cx) / (cy, 1) of this lane's pixel column; k = lane / 32
     const float ccx = (float)(lane & 7) - 3.5f, ccy = (float)((lane >> 3) & 3) - 1.5f;
     const bool khi = lane >= 32;
@@ -384,7 +389,7 @@ int launch_render_fwd(const GeomState& g, const uint2* pairs, ImageState& img, i
   const TileGrid tg(W, H, mode);
   const TileMap tm{tg.gx, tg.gy, tg.pgx, tg.pgy, tg.s, img.tile_order};
   if (tg.ptiles > 0) {
-    const dim3 grid(tm.blocks() * 4), block(64);                           // one wave (8x8 quadrant) per workgroup
+    const dim3 grid(tm.blocks() * (4 / GM_RENDER_FWD_WPW)), block(64 * GM_RENDER_FWD_WPW);     // one wave (8x8 quadrant) per workgroup
     if (g_render_trace)
       hipLaunchKernelGGL((render_fwd_kernel<true, true>), grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
                          background, out_color, img.final_T, img.n_contrib, g_render_trace, g.counters, status_host, work_hint, img.epoch);
