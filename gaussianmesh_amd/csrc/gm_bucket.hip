@@ -364,8 +364,9 @@ __global__ __launch_bounds__(WAVES * 64, 4) void bk_scatter_kernel(const void* _
                                                                  const uint2* __restrict__ ord_ranges, int ord_tiles,
                                                                  uint32_t* __restrict__ ord_out, const uint32_t* __restrict__ dmap,
                                                                  const uint32_t* __restrict__ counters, uint32_t* __restrict__ ord_hint,
-                                                                 uint32_t* __restrict__ ord_epoch) {
+                                                                 uint32_t* __restrict__ ord_epoch, unsigned long long* __restrict__ trace) {
   constexpr int ND = 1 << DB, THREADS = WAVES * 64, TILE = WAVES * BK_ROUNDS * 64;
+  const unsigned long long t_begin = trace ? wall_clock64() : 0ull;      // (tools/pipeline_trace.py: per-workgroup start / end)
   if (!MSD && ord_out && blockIdx.x == gridDim.x - 1) {      // the launch's extra workgroup: dispatch order of the blend kernels
     __shared__ uint32_t o_cnt[256];                          // from the ranges the scan kernel has just published
     __shared__ uint32_t o_wsum[WAVES];
@@ -501,6 +502,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void bk_scatter_kernel(const void* _
     const uint32_t d = digit(kv.x);
     out[gbase[d] + (i - dstart[d])] = kv;
   }
+  if (trace && threadIdx.x == 0) { trace[3 * blockIdx.x] = t_begin; trace[3 * blockIdx.x + 1] = wall_clock64(); trace[3 * blockIdx.x + 2] = tile_n; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -731,8 +733,11 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t*
   if (trace && threadIdx.x == 0) { trace[3 * b] = t_begin; trace[3 * b + 1] = wall_clock64(); trace[3 * b + 2] = n; }
 }
 
-static unsigned long long* g_bucket_trace = nullptr;      // debugging aid (tools/bucket_stats.py), never set by the package
+static unsigned long long* g_bucket_trace = nullptr;      // debugging aid (tools/bucket_stats.py, tools/pipeline_trace.py), never set by the package
 extern "C" void gm_debug_bucket_trace(void* buffer) { g_bucket_trace = reinterpret_cast<unsigned long long*>(buffer); }
+// bucket_sort_kernel's records are followed by those of the depth partition's scatter (from word 3 * 2048) and of the tile pass's
+// scatter (from word 3 * 4096); the buffer holds 3 * (2048 + 2048 + 4096) words
+static unsigned long long* scatter_trace(bool msd) { return g_bucket_trace ? g_bucket_trace + 3 * (msd ? 2048 : 4096) : nullptr; }
 
 // ---------------------------------------------------------------------------------------------
 // host side
@@ -756,7 +761,7 @@ int launch_depth_order(GeomState& g, int P, int debug, hipStream_t s, int* num_r
                      g.acc, g.bucket_start, g.counters, nullptr, 0u);
   GM_LAUNCH_CHECK(debug, s);
   hipLaunchKernelGGL((bk_scatter_kernel<true, DB, WAVES>), dim3(nblk), dim3(WAVES * 64), 0, s, g.depth_key, g.dpairs[1], (uint32_t)P, nullptr, ds,
-                     g.hist, nullptr, 0u, nullptr, 0, nullptr, g.dmap, g.counters, nullptr, nullptr);
+                     g.hist, nullptr, 0u, nullptr, 0, nullptr, g.dmap, g.counters, nullptr, nullptr, scatter_trace(true));
   GM_LAUNCH_CHECK(debug, s);
   hipLaunchKernelGGL(bucket_sort_kernel, dim3(1 << DB), dim3(BK_THREADS), 0, s, g.counters, g.bmap, g.bucket_start, g.dpairs[1], g.dpairs[0], g.order,
                      g.tiles_touched, g.bin, g.bin_sorted, g.chunk_inst, g_bucket_trace);
@@ -779,7 +784,7 @@ static int tile_pass(BinningState& b, GeomState& g, int from, uint32_t n, const 
   GM_LAUNCH_CHECK(debug, s);
   hipLaunchKernelGGL((bk_scatter_kernel<false, DB, WAVES>), dim3(nblk + (order_out ? 1u : 0u)), dim3(WAVES * 64), 0, s, b.pairs[from],
                      b.pairs[from ^ 1], n, n_dev, ds, b.hist, zero_acc_after ? b.acc : nullptr, (uint32_t)bk_acc_words(n), ranges,
-                     (int)nranges, order_out, nullptr, nullptr, hint, epoch);
+                     (int)nranges, order_out, nullptr, nullptr, hint, epoch, nblk <= 4096u ? scatter_trace(false) : nullptr);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }

@@ -318,7 +318,9 @@ int gm_profile_read(const char* stage, double* total_ms, int64_t* launches);
 
 /* Debugging aids of the repository's tools, never called by the package: while a device buffer is registered the forward
  * blend (tools/wave_trace.py: 8 x uint64 per wave - start / end clock, list length, entries evaluated ...) / the depth-bucket
- * sort (tools/bucket_stats.py) write per-wave / per-bucket records into it; NULL switches the tracing kernels off again.
+ * sort and the two scatter kernels of the ordering (tools/bucket_stats.py, tools/pipeline_trace.py: 3 x uint64 per workgroup -
+ * start / end clock, entries; 2048 records for the bucket sort, then 2048 for the depth partition's scatter, then 4096 for the tile
+ * pass's: 3 * 8192 words) write per-wave / per-workgroup records into it; NULL switches the tracing off again.
  * Process-wide, not thread-safe. */
 void gm_debug_render_trace(void* buffer);
 void gm_debug_bucket_trace(void* buffer);

@@ -19,7 +19,7 @@ ct = {n: torch.tensor(cam[n], device=dev) for n in ("view", "proj", "campos")}
 packed = pack_mesh_state(torch.tensor(host["mesh"][3], device=dev), g["verts"])
 lib0 = _lib.lib()
 fn = lib0.gm_debug_bucket_trace; fn.restype = None; fn.argtypes = [C.c_void_p]
-tbuf = torch.zeros((2048 * 3,), dtype=torch.int64, device=dev)
+tbuf = torch.zeros((8192 * 3,), dtype=torch.int64, device=dev)      # bucket sort | depth scatter | tile scatter records
 for _ in range(3):
     Rz.forward_deformed_begin(torch.ones(3, device=dev), g["tri"], g["weights"], packed, g["cov"], g["pos"], g["shs"],
                               g["opac"], ct["view"], ct["proj"], cam["tanx"], cam["tany"], H, W, 3, ct["campos"]).finish()
@@ -40,7 +40,7 @@ top = np.argsort(-sz)[:12]
 print("largest buckets (index: size):", [(int(i), int(sz[i])) for i in top], "first / last used bucket", int(np.nonzero(sz)[0][0]), int(np.nonzero(sz)[0][-1]))
 
 fn(None)
-tr = tbuf.cpu().numpy().reshape(-1, 3)
+tr = tbuf.cpu().numpy().reshape(-1, 3)[:2048]
 tr = tr[tr[:, 0] > 0]
 t0 = tr[:, 0].min()
 st, en, nn = (tr[:, 0] - t0) / 100.0, (tr[:, 1] - t0) / 100.0, tr[:, 2]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Where do the multi-wave ordering kernels lose their time inside the 4-stream frame loop?  Per-workgroup start / end
-timestamps of bucket_sort_kernel (gm_debug_bucket_trace: wall_clock64 at entry and exit of every workgroup), one trace buffer per
+timestamps of bucket_sort_kernel and of the two scatter kernels (gm_debug_bucket_trace: wall_clock64 at entry and exit of every workgroup), one trace buffer per
 frame, for the same frames issued (a) one at a time on one stream and (b) pipelined over four streams as bench.py does.
 rocprofv3 --pmc cannot answer this: it serialises the dispatches it counts (profiles/r03_4stream_pmc_serialized.txt).
 Prints, per mode: kernel span (first start to last end), how late workgroups START relative to the first one (placement), and
@@ -33,7 +33,7 @@ hint = Rz.new_work_hint(W, H, dev)
 def run(nstreams, nframes, traced):
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
     ws = [Rz.RasterWorkspace(growth=1.5) for _ in range(nstreams + 8)]
-    bufs = {i: torch.zeros((2048 * 3,), dtype=torch.int64, device=dev) for i in traced}
+    bufs = {i: torch.zeros((8192 * 3,), dtype=torch.int64, device=dev) for i in traced}
     pend = []
     for i in range(-2 * F, nframes):                       # two passes over the orbit size every workspace, untraced
         with torch.cuda.stream(streams[i % nstreams]):
@@ -50,19 +50,24 @@ def run(nstreams, nframes, traced):
     fn(None)
     for h in pend:
         h.check()
-    out = []
-    for i in traced:
-        tr = bufs[i].cpu().numpy().reshape(-1, 3)
-        tr = tr[tr[:, 0] > 0]
-        t0 = tr[:, 0].min()
-        st, en = (tr[:, 0] - t0) / 100.0, (tr[:, 1] - t0) / 100.0
-        out.append((en.max(), np.percentile(st, [50, 90, 100]), np.percentile(en - st, [50, 90, 100]), len(tr)))
+    out = {}
+    for name, lo, hi in (("bucket_sort_kernel", 0, 2048), ("bk_scatter<true> (depth partition)", 2048, 4096), ("bk_scatter<false> (tile pass)", 4096, 8192)):
+        rows = []
+        for i in traced:
+            tr = bufs[i].cpu().numpy().reshape(-1, 3)[lo:hi]
+            tr = tr[tr[:, 0] > 0]
+            t0 = tr[:, 0].min()
+            st, en = (tr[:, 0] - t0) / 100.0, (tr[:, 1] - t0) / 100.0
+            rows.append((en.max(), np.percentile(st, [50, 90, 100]), np.percentile(en - st, [50, 90, 100]), len(tr)))
+        out[name] = rows
     return out
 
 
 for label, ns in (("one stream", 1), ("four streams", 4)):
     res = run(ns, 40, list(range(20, 28)))
     print(label)
-    for span, st, du, n in res:
-        print("  span %6.1f us | start after the first workgroup: median %5.1f  p90 %5.1f  max %5.1f | run time: median %5.1f  p90 %5.1f  max %5.1f | %d workgroups"
-              % (span, st[0], st[1], st[2], du[0], du[1], du[2], n))
+    for name, rows in res.items():
+        print(" ", name)
+        for span, st, du, n in rows:
+            print("    span %6.1f us | start after the first workgroup: median %5.1f  p90 %5.1f  max %5.1f | run time: median %5.1f  p90 %5.1f  max %5.1f | %d workgroups"
+                  % (span, st[0], st[1], st[2], du[0], du[1], du[2], n))
