@@ -49,12 +49,13 @@ namespace gm {
 
 #define BK_THREADS 256
 #define BK_WAVES 4
-#define BK_ROUNDS GM_BK_ROUNDS
+#define BK_ROUNDS_MAX 16
 #define BK_CHUNK GM_BK_CHUNK
 #ifndef GM_TILE_PASS_WAVES
 #define GM_TILE_PASS_WAVES 8        // workgroup of the one-pass tile sort: 8 waves x 1024 keys
 #endif
-#define BS_CAP (256 * BK_ROUNDS)     // entries a bucket may have for the in-LDS sort (256 threads x BK_ROUNDS)
+#define BS_ROUNDS GM_BS_ROUNDS
+#define BS_CAP (256 * BS_ROUNDS)     // entries a bucket may have for the in-LDS sort (256 threads x BS_ROUNDS)
 
 struct DigitSpec { uint32_t sub, shift, mask; };       // digit(k) = ((k - sub) >> shift) & mask
 
@@ -233,14 +234,14 @@ __device__ __forceinline__ uint32_t load_key(const void* __restrict__ in, uint32
 // WAVES waves of 64 threads per workgroup, 1024 keys per wave: the depth partition (1 M keys) uses 4-wave workgroups so
 // that the launch covers the chip; the tile pass (millions of instances) 16-wave workgroups: 4x fewer histogram rows,
 // atomics and scan work per key.
-template <bool MSD, int DB, int WAVES>
+template <bool MSD, int DB, int WAVES, int ROUNDS>
 __global__ __launch_bounds__(WAVES * 64) void bk_hist_kernel(const void* __restrict__ in, uint32_t n_host,
                                                               const uint32_t* __restrict__ n_dev, DigitSpec ds,
                                                               const uint32_t* __restrict__ slots, uint32_t* __restrict__ hist,
                                                               uint32_t* __restrict__ acc, uint32_t* __restrict__ counters,
                                                               const uint32_t* __restrict__ coarse, uint32_t* __restrict__ dmap,
                                                               uint32_t* __restrict__ bmap) {
-  constexpr int ND = 1 << DB, THREADS = WAVES * 64, TILE = WAVES * BK_ROUNDS * 64;
+  constexpr int ND = 1 << DB, THREADS = WAVES * 64, TILE = WAVES * ROUNDS * 64;
   __shared__ uint32_t h[ND];
   __shared__ uint32_t s_tmp[4];
   __shared__ uint32_t s_w[4];
@@ -259,15 +260,15 @@ __global__ __launch_bounds__(WAVES * 64) void bk_hist_kernel(const void* __restr
   if (blockIdx.x >= nblk) return;
   for (int d = threadIdx.x; d < ND; d += THREADS) h[d] = 0;
   __syncthreads();
-  const uint32_t wbase = blockIdx.x * TILE + wave * (BK_ROUNDS * 64);
-  uint32_t k[BK_ROUNDS];
+  const uint32_t wbase = blockIdx.x * TILE + wave * (ROUNDS * 64);
+  uint32_t k[ROUNDS];
 #pragma unroll
-  for (int r = 0; r < BK_ROUNDS; r++) {
+  for (int r = 0; r < ROUNDS; r++) {
     const uint32_t idx = wbase + r * 64 + lane;
     k[r] = idx < n ? load_key<MSD>(in, idx) : 0xFFFFFFFFu;
   }
 #pragma unroll
-  for (int r = 0; r < BK_ROUNDS; r++) {
+  for (int r = 0; r < ROUNDS; r++) {
     const uint32_t idx = wbase + r * 64 + lane;
     const bool valid = idx < n && (!MSD || k[r] != 0xFFFFFFFFu);
     if (valid) atomicAdd(&h[digit(k[r])], 1u);
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(BK_THREADS) void bk_scan_kernel(uint32_t* __restric
 
 // ---------------------------------------------------------------------------------------------
 // zero_acc / zero_words: accumulators of the NEXT pass (two-pass tile sort), cleared here because no earlier launch can
-template <bool MSD, int DB, int WAVES>
+template <bool MSD, int DB, int WAVES, int ROUNDS>
 __global__ __launch_bounds__(WAVES * 64, 4) void bk_scatter_kernel(const void* __restrict__ in, uint2* __restrict__ out,
                                                                  uint32_t n_host, const uint32_t* __restrict__ n_dev, DigitSpec ds,
                                                                  const uint32_t* __restrict__ hist,
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void bk_scatter_kernel(const void* _
                                                                  uint32_t* __restrict__ ord_out, const uint32_t* __restrict__ dmap,
                                                                  const uint32_t* __restrict__ counters, uint32_t* __restrict__ ord_hint,
                                                                  uint32_t* __restrict__ ord_epoch, unsigned long long* __restrict__ trace) {
-  constexpr int ND = 1 << DB, THREADS = WAVES * 64, TILE = WAVES * BK_ROUNDS * 64;
+  constexpr int ND = 1 << DB, THREADS = WAVES * 64, TILE = WAVES * ROUNDS * 64;
   const unsigned long long t_begin = trace ? wall_clock64() : 0ull;      // (tools/pipeline_trace.py: per-workgroup start / end)
   if (!MSD && ord_out && blockIdx.x == gridDim.x - 1) {      // the launch's extra workgroup: dispatch order of the blend kernels
     __shared__ uint32_t o_cnt[256];                          // from the ranges the scan kernel has just published
@@ -405,10 +406,10 @@ __global__ __launch_bounds__(WAVES * 64, 4) void bk_scatter_kernel(const void* _
   }
   __syncthreads();
 
-  const uint32_t wbase = blockIdx.x * TILE + wave * (BK_ROUNDS * 64);
-  uint32_t key[BK_ROUNDS], val[BK_ROUNDS], rank[BK_ROUNDS];
+  const uint32_t wbase = blockIdx.x * TILE + wave * (ROUNDS * 64);
+  uint32_t key[ROUNDS], val[ROUNDS], rank[ROUNDS];
 #pragma unroll
-  for (int r = 0; r < BK_ROUNDS; r++) {
+  for (int r = 0; r < ROUNDS; r++) {
     const uint32_t idx = wbase + r * 64 + lane;
     if (MSD) {
       key[r] = idx < n ? reinterpret_cast<const uint32_t*>(in)[idx] : 0xFFFFFFFFu;
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void bk_scatter_kernel(const void* _
   }
   uint32_t vmask = 0;                          // bit r: this lane's key of round r takes part
 #pragma unroll
-  for (int r = 0; r < BK_ROUNDS; r++) {
+  for (int r = 0; r < ROUNDS; r++) {
     const uint32_t idx = wbase + r * 64 + lane;
     const bool valid = idx < n && (!MSD || key[r] != 0xFFFFFFFFu);
     vmask |= valid ? (1u << r) : 0u;
@@ -487,13 +488,13 @@ __global__ __launch_bounds__(WAVES * 64, 4) void bk_scatter_kernel(const void* _
   }
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < BK_ROUNDS; r++) {        // position of each key inside the digit-sorted tile
+  for (int r = 0; r < ROUNDS; r++) {        // position of each key inside the digit-sorted tile
     const uint32_t d = digit(key[r]);
     rank[r] += ((vmask >> r) & 1u) ? dstart[d] + wcnt[wave][d] : 0u;
   }
   __syncthreads();                             // wcnt is dead from here: its memory becomes the stage
 #pragma unroll
-  for (int r = 0; r < BK_ROUNDS; r++)
+  for (int r = 0; r < ROUNDS; r++)
     if ((vmask >> r) & 1u) stage[rank[r]] = make_uint2(key[r], val[r]);
   __syncthreads();
   // digit d's run goes to gbase[d] + (position in run): neighbouring lanes store neighbouring pairs
@@ -551,9 +552,9 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t*
     // What is sorted is ONE word per entry: the key relative to the bucket's first key (< 2^20: a bucket lies inside one coarse
     // bin) above the entry's position in the bucket (< 4096).  Half the LDS and half the traffic of (key, id) pairs; the id is
     // picked up from the bucket's own pair range at the end.  Equal keys keep their position order = ascending id.
-    uint32_t key[BK_ROUNDS], rank[BK_ROUNDS];
+    uint32_t key[BS_ROUNDS], rank[BS_ROUNDS];
 #pragma unroll
-    for (int r = 0; r < BK_ROUNDS; r++) {
+    for (int r = 0; r < BS_ROUNDS; r++) {
       const uint32_t p = (wave * rounds + r) * 64u + lane;
       const bool valid = (uint32_t)r < rounds && p < n;
       key[r] = valid ? ((p1[start + p].x - ds.sub) << 12) | p : 0u;
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t*
       wcnt[0][threadIdx.x] = 0; wcnt[1][threadIdx.x] = 0; wcnt[2][threadIdx.x] = 0; wcnt[3][threadIdx.x] = 0;
       __syncthreads();
 #pragma unroll
-      for (int r = 0; r < BK_ROUNDS; r++) {
+      for (int r = 0; r < BS_ROUNDS; r++) {
         if ((uint32_t)r < rounds) {                   // wave-uniform
           const uint32_t p = (wave * rounds + r) * 64u + lane;
           const bool valid = p < n;
@@ -600,7 +601,7 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t*
       }
       __syncthreads();
 #pragma unroll
-      for (int r = 0; r < BK_ROUNDS; r++) {
+      for (int r = 0; r < BS_ROUNDS; r++) {
         if ((uint32_t)r < rounds) {
           const uint32_t p = (wave * rounds + r) * 64u + lane;
           if (p < n) {
@@ -612,7 +613,7 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t*
       }
       __syncthreads();
 #pragma unroll
-      for (int r = 0; r < BK_ROUNDS; r++) {
+      for (int r = 0; r < BS_ROUNDS; r++) {
         if ((uint32_t)r < rounds) {
           const uint32_t p = (wave * rounds + r) * 64u + lane;
           if (p < n) key[r] = lkey[p];
@@ -621,7 +622,7 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t*
       __syncthreads();
     }
 #pragma unroll
-    for (int r = 0; r < BK_ROUNDS; r++) {
+    for (int r = 0; r < BS_ROUNDS; r++) {
       if ((uint32_t)r < rounds) {
         const uint32_t p = (wave * rounds + r) * 64u + lane;
         uint32_t inst = 0;
@@ -742,13 +743,13 @@ static unsigned long long* scatter_trace(bool msd) { return g_bucket_trace ? g_b
 // ---------------------------------------------------------------------------------------------
 // host side
 int launch_depth_order(GeomState& g, int P, int debug, hipStream_t s, int* num_rendered_host, hipEvent_t count_event) {
-  constexpr int DB = GM_BUCKET_BITS, WAVES = 4, TILE = WAVES * BK_ROUNDS * 64;
+  constexpr int DB = GM_BUCKET_BITS, WAVES = 4, ROUNDS = GM_DP_ROUNDS, TILE = WAVES * ROUNDS * 64;
   const uint32_t nblk = ((uint32_t)P + TILE - 1) / TILE;
   const uint32_t nchunks = (nblk + BK_CHUNK - 1) / BK_CHUNK;
   const DigitSpec ds{0u, 0u, 0xFFFFFFFFu};
   {
     StageScope sc(ST_DEPTH_SORT, s);
-    hipLaunchKernelGGL((bk_hist_kernel<true, DB, WAVES>), dim3(nblk + 1), dim3(WAVES * 64), 0, s, g.depth_key, (uint32_t)P, nullptr, ds, g.slots, g.hist,
+    hipLaunchKernelGGL((bk_hist_kernel<true, DB, WAVES, ROUNDS>), dim3(nblk + 1), dim3(WAVES * 64), 0, s, g.depth_key, (uint32_t)P, nullptr, ds, g.slots, g.hist,
                        g.acc, g.counters, g.coarse, g.dmap, g.bmap);
     GM_LAUNCH_CHECK(debug, s);
   }
@@ -760,7 +761,7 @@ int launch_depth_order(GeomState& g, int P, int debug, hipStream_t s, int* num_r
   hipLaunchKernelGGL((bk_scan_kernel<true, DB>), dim3(nchunks, (1 << DB) / 256), dim3(BK_THREADS), 0, s, g.hist, (uint32_t)TILE, (uint32_t)P, nullptr,
                      g.acc, g.bucket_start, g.counters, nullptr, 0u);
   GM_LAUNCH_CHECK(debug, s);
-  hipLaunchKernelGGL((bk_scatter_kernel<true, DB, WAVES>), dim3(nblk), dim3(WAVES * 64), 0, s, g.depth_key, g.dpairs[1], (uint32_t)P, nullptr, ds,
+  hipLaunchKernelGGL((bk_scatter_kernel<true, DB, WAVES, ROUNDS>), dim3(nblk), dim3(WAVES * 64), 0, s, g.depth_key, g.dpairs[1], (uint32_t)P, nullptr, ds,
                      g.hist, nullptr, 0u, nullptr, 0, nullptr, g.dmap, g.counters, nullptr, nullptr, scatter_trace(true));
   GM_LAUNCH_CHECK(debug, s);
   hipLaunchKernelGGL(bucket_sort_kernel, dim3(1 << DB), dim3(BK_THREADS), 0, s, g.counters, g.bmap, g.bucket_start, g.dpairs[1], g.dpairs[0], g.order,
@@ -773,16 +774,17 @@ int launch_depth_order(GeomState& g, int P, int debug, hipStream_t s, int* num_r
 template <int DB, int WAVES>
 static int tile_pass(BinningState& b, GeomState& g, int from, uint32_t n, const uint32_t* n_dev, DigitSpec ds, uint2* ranges, uint32_t nranges,
                      bool zero_acc_after, uint32_t* order_out, uint32_t* hint, uint32_t* epoch, int debug, hipStream_t s) {
-  constexpr uint32_t TILE = WAVES * BK_ROUNDS * 64;
+  constexpr int ROUNDS = GM_TP_ROUNDS;
+  constexpr uint32_t TILE = WAVES * ROUNDS * 64;
   const uint32_t nblk = (n + TILE - 1) / TILE;
   const uint32_t nchunks = (nblk + BK_CHUNK - 1) / BK_CHUNK;
-  hipLaunchKernelGGL((bk_hist_kernel<false, DB, WAVES>), dim3(nblk), dim3(WAVES * 64), 0, s, b.pairs[from], n, n_dev, ds, nullptr, b.hist, b.acc,
+  hipLaunchKernelGGL((bk_hist_kernel<false, DB, WAVES, ROUNDS>), dim3(nblk), dim3(WAVES * 64), 0, s, b.pairs[from], n, n_dev, ds, nullptr, b.hist, b.acc,
                      g.counters, nullptr, nullptr, nullptr);
   GM_LAUNCH_CHECK(debug, s);
   hipLaunchKernelGGL((bk_scan_kernel<false, DB>), dim3(nchunks ? nchunks : 1, (1 << DB) / 256), dim3(BK_THREADS), 0, s, b.hist, TILE, n, n_dev,
                      b.acc, nullptr, g.counters, ranges, nranges);
   GM_LAUNCH_CHECK(debug, s);
-  hipLaunchKernelGGL((bk_scatter_kernel<false, DB, WAVES>), dim3(nblk + (order_out ? 1u : 0u)), dim3(WAVES * 64), 0, s, b.pairs[from],
+  hipLaunchKernelGGL((bk_scatter_kernel<false, DB, WAVES, ROUNDS>), dim3(nblk + (order_out ? 1u : 0u)), dim3(WAVES * 64), 0, s, b.pairs[from],
                      b.pairs[from ^ 1], n, n_dev, ds, b.hist, zero_acc_after ? b.acc : nullptr, (uint32_t)bk_acc_words(n), ranges,
                      (int)nranges, order_out, nullptr, nullptr, hint, epoch, nblk <= 4096u ? scatter_trace(false) : nullptr);
   GM_LAUNCH_CHECK(debug, s);

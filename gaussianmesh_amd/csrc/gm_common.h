@@ -70,10 +70,20 @@ static inline size_t sort_chunk_counters(size_t n) { return 256 * ((sort_blocks(
 
 // ordering of a forward (gm_bucket.hip)
 #define GM_BUCKET_BITS 11            // MSD partition of the depth keys into <= 2048 buckets; also the digit of the one-pass tile sort
-#ifndef GM_BK_ROUNDS
-#define GM_BK_ROUNDS 16               // keys per thread of a partition / tile-sort pass and of the in-LDS bucket sort
+// keys per thread of the depth partition (DP), of the tile pass (TP) and of the in-LDS bucket sort (BS): 16 each.  Compile-time
+// knobs because register use follows them (8: 68-77 VGPRs instead of 117-133) and with it where a workgroup can be placed while
+// other frames' blend kernels fill the chip (measured, 16 stays)
+#ifndef GM_DP_ROUNDS
+#define GM_DP_ROUNDS 16
 #endif
-#define GM_BK_TILE (4 * GM_BK_ROUNDS * 64)   // keys per (4-wave) workgroup of a partition / tile-sort pass
+#ifndef GM_TP_ROUNDS
+#define GM_TP_ROUNDS 16
+#endif
+#ifndef GM_BS_ROUNDS
+#define GM_BS_ROUNDS 16
+#endif
+#define GM_BK_ROUNDS_MIN (GM_DP_ROUNDS < GM_TP_ROUNDS ? GM_DP_ROUNDS : GM_TP_ROUNDS)
+#define GM_BK_TILE (4 * GM_BK_ROUNDS_MIN * 64)   // fewest keys a workgroup of a partition / tile-sort pass takes (sizes the histogram rows)
 #define GM_BK_CHUNK 32               // histogram rows per scan workgroup
 static inline size_t bk_blocks(size_t n) { return (n + GM_BK_TILE - 1) / GM_BK_TILE; }
 static inline size_t bk_chunks(size_t n) { return (bk_blocks(n) + GM_BK_CHUNK - 1) / GM_BK_CHUNK; }
