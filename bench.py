@@ -7,14 +7,17 @@ Workload (BASELINE.json configs[2] = "C3", the configuration the metric is quote
     deform + view-dependent colour (gm_deform_shade, one fused pass: mesh state (V1,R,S) of frame t -> x', Sigma',
     rotated view direction, SH degree 3 -> colors_precomp)
   + rasterize forward (gm_forward_0/1 with colors_precomp + cov3D_precomp) at 1920x1080.
-All inputs are resident in HBM before the timed region.  With --gpus N every rank renders its own camera of
-the 64-camera orbit (views shard); rank 0 owns the mesh animation and broadcasts the per-frame
-mesh state (0.63 MB) over RCCL, the static cloud is broadcast once before timing.  value = frames of all ranks
-per second (weak scaling).
+All inputs are resident in HBM before the timed region.  With --gpus N every rank renders its own camera of the 64-camera orbit
+(views shard); rank 0 owns the mesh animation and broadcasts the deformed VERTEX POSITIONS of eight loop steps at a
+time (90 KB per step) over RCCL, one batch ahead of their use, every rank derives the per-vertex (R, S) itself (gm_mesh_rs); the
+static cloud is broadcast once before timing.  value = frames of all ranks per second (weak scaling).
 
-One JSON line on stdout (rank 0).  Extra objects: "roofline" (dominant kernel, HIP-event timing from
-gm_profile_*), "cpu_baseline" (oracle port on the host cores, N=1 only), "fwd_bwd" (ms/iter of forward +
-backward on the same cloud through the autograd operator, N=1 only).
+One JSON line on stdout (rank 0).  Extra objects: "roofline" (dominant kernel of the frame, HIP-event timing from gm_profile_*),
+"frame_roofline" (whole frame), "cpu_baseline" (oracle port on the host cores, N=1 only), "fwd_bwd" (ms/iter of forward + backward
+on the same cloud through the autograd operator, with its stage times, "roofline" of the backward blend and "iteration_roofline";
+also the iteration with the L1 + SSIM loss, a whole training iteration and BASELINE config C2; N=1 only), "c5" (a bounded leg of
+BASELINE config C5: --c5-iters iterations of the 3 M-Gaussian 4K training loop; `--config c5` runs its 1000 iterations as a line
+of its own), "repeats" (the timed region four more times) and "single_stream" (latency of one frame).
 """
 import argparse
 import json
