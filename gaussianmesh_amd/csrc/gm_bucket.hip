@@ -16,10 +16,12 @@
 //       to the keys a coarse bin holds, so the partition stays balanced when a background or a floater stretches the depth
 //       range): bk_hist -> bk_scan -> bk_scatter (stable, visible keys only);
 //    2. bucket_sort_kernel: one workgroup per bucket sorts its few hundred to few thousand entries by the key bits inside
-//       the bucket entirely in LDS (stable LSD passes of <= 8 bits on registers + one LDS copy; one word per entry), writes
-//       the final order and the emission records in that order and adds the instance counts to the per-run totals the
-//       emission reads.  A bucket that does not fit (a pile-up of equal depths) takes a slow, still exact, path through
-//       global memory.
+//       the bucket entirely in LDS, one word per entry ((key - first key of the bucket) << 12 | position: unique, so no
+//       pass has to be stable): a counting split on the top <= 10 bits of the bucket's range with LDS atomics, then every
+//       entry counts the smaller words of its own bin (a handful); bins above 48 entries (piles of equal depths) fall back
+//       to stable LSD passes of <= 8 bits (ballot matching on registers + one LDS copy).  It writes the final order and the
+//       emission records in that order and adds the instance counts to the per-run totals the emission reads.  A bucket
+//       that does not fit the LDS (> 4096 entries) takes a slow, still exact, path through global memory.
 //    Four launches and two passes over 8 B/Gaussian instead of twelve launches and four passes.
 // B. Instances (emitted by duplicate_kernel in that order, keyed by list tile id | child mask << 16):
 //    list tiles <= 2048 (1080p with 32-px parents: 2040; 4K with 64-px parents: 2040): ONE stable pass on an 11-bit digit,
@@ -56,6 +58,9 @@ namespace gm {
 #endif
 #define BS_ROUNDS GM_BS_ROUNDS
 #define BS_CAP (256 * BS_ROUNDS)     // entries a bucket may have for the in-LDS sort (256 threads x BS_ROUNDS)
+#define BS_BINS 1024                 // bins of the in-LDS sort's counting split (= the words of wcnt)
+static_assert(BS_BINS == BK_WAVES * 256, "the counting split's bins live in wcnt");
+#define BS_BIN_MAX 48u               // largest bin the counting split accepts before the stable radix passes take over
 
 struct DigitSpec { uint32_t sub, shift, mask; };       // digit(k) = ((k - sub) >> shift) & mask
 
@@ -559,7 +564,84 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t*
       const bool valid = (uint32_t)r < rounds && p < n;
       key[r] = valid ? ((p1[start + p].x - ds.sub) << 12) | p : 0u;
     }
-    for (uint32_t pass = 0; pass < npass; pass++) {
+    // Fast path: the words are UNIQUE (position in the low bits), so any correct sort of them is THE order and no pass has to be
+    // stable.  One counting split on the top <= 10 bits of the bucket's key range with LDS atomics (a key's slot inside its bin is
+    // whatever the atomic returned), then every key counts the smaller words of its own bin - a bucket's keys are spread over its
+    // range (the bucket map divides coarse bins linearly), so a bin holds a handful.  ~50 vector instructions per round of 64 keys
+    // instead of ~220 per 8-bit ballot-matching pass.  Bins above BS_BIN_MAX entries (piles of equal depths): the stable passes below.
+    bool done = false;
+    {
+      uint32_t* __restrict__ hist = &wcnt[0][0];                      // BS_BINS bins, then their first positions
+      const uint32_t hb = min(low_bits, 10u), hs = 12u + low_bits - hb;
+#pragma unroll
+      for (int j = 0; j < BS_BINS / BK_THREADS; j++) hist[threadIdx.x + BK_THREADS * j] = 0u;
+      if (threadIdx.x == 0) dstart[0] = 0u;
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < BS_ROUNDS; r++) {
+        if ((uint32_t)r < rounds) {                   // wave-uniform
+          const uint32_t p = (wave * rounds + r) * 64u + lane;
+          if (p < n) rank[r] = atomicAdd(&hist[min(key[r] >> hs, (uint32_t)BS_BINS - 1u)], 1u);
+        }
+      }
+      __syncthreads();
+      {
+        constexpr int PER = BS_BINS / BK_THREADS;
+        uint32_t c[PER], sum = 0, mx = 0;
+#pragma unroll
+        for (int j = 0; j < PER; j++) { c[j] = hist[threadIdx.x * PER + j]; sum += c[j]; mx = max(mx, c[j]); }
+        uint32_t tot;
+        uint32_t excl = block_exclusive_scan_256(sum, wsum, tot);
+#pragma unroll
+        for (int j = 0; j < PER; j++) { hist[threadIdx.x * PER + j] = excl; excl += c[j]; }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d));
+        if (lane == 0) atomicMax(&dstart[0], mx);
+      }
+      __syncthreads();
+      if (dstart[0] <= BS_BIN_MAX) {                   // workgroup-uniform
+#pragma unroll
+        for (int r = 0; r < BS_ROUNDS; r++) {
+          if ((uint32_t)r < rounds) {
+            const uint32_t p = (wave * rounds + r) * 64u + lane;
+            if (p < n) lkey[hist[min(key[r] >> hs, (uint32_t)BS_BINS - 1u)] + rank[r]] = key[r];
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < BS_ROUNDS; r++) {
+          if ((uint32_t)r < rounds) {
+            const uint32_t p = (wave * rounds + r) * 64u + lane;
+            if (p < n) {
+              const uint32_t d = min(key[r] >> hs, (uint32_t)BS_BINS - 1u);
+              const uint32_t lo = hist[d], hi = d + 1u < (uint32_t)BS_BINS ? hist[d + 1u] : n;
+              uint32_t below = 0;
+              for (uint32_t j = lo; j < hi; j++) below += lkey[j] < key[r] ? 1u : 0u;
+              rank[r] = lo + below;
+            }
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < BS_ROUNDS; r++) {
+          if ((uint32_t)r < rounds) {
+            const uint32_t p = (wave * rounds + r) * 64u + lane;
+            if (p < n) lkey[rank[r]] = key[r];
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < BS_ROUNDS; r++) {
+          if ((uint32_t)r < rounds) {
+            const uint32_t p = (wave * rounds + r) * 64u + lane;
+            if (p < n) key[r] = lkey[p];
+          }
+        }
+        done = true;
+      }
+      __syncthreads();
+    }
+    for (uint32_t pass = 0; !done && pass < npass; pass++) {
       const uint32_t lo = pass * pb, pmask = (1u << min(pb, low_bits - lo)) - 1u;
       wcnt[0][threadIdx.x] = 0; wcnt[1][threadIdx.x] = 0; wcnt[2][threadIdx.x] = 0; wcnt[3][threadIdx.x] = 0;
       __syncthreads();
