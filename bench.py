@@ -398,7 +398,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if rank == 0 and not args.unfused:
+    if rank == 0 and not args.unfused and not os.environ.get("GM_DEBUG_STOP_AFTER"):   # (tools/stage_marginal.sh: truncated frames)
         # the timed path (fused deform + colour + preprocess, async halves) must render what the unfused chain
         # (gm_deform_shade_packed -> gm_forward_0/1) renders for the same frame: bit-identical image and radii
         c = cam_t[multiview.view_for_step(0, F, rank, world)]

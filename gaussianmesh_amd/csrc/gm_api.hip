@@ -130,8 +130,20 @@ static int check_policy(int p) {
   a.cam_pos = cam_pos; a.scale_modifier = scale_modifier; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;        \
   a.prefiltered = prefiltered; a.debug = debug; a.tile_cull = (POLICY); a.stream = reinterpret_cast<hipStream_t>(stream);
 
+// Measurement aid (tools/stage_marginal.sh): GM_DEBUG_STOP_AFTER = deform | depth | dup | tile in the environment makes every forward
+// stop launching after that stage - the frames are garbage, the loop's rate tells what the remaining stages cost the pipeline.
+static int debug_stop_after() {
+  static const int v = [] {
+    const char* e = getenv("GM_DEBUG_STOP_AFTER");
+    if (!e) return 0;
+    return !strcmp(e, "deform") ? 1 : !strcmp(e, "depth") ? 2 : !strcmp(e, "dup") ? 3 : !strcmp(e, "tile") ? 4 : 0;
+  }();
+  return v;
+}
+
 // first half of a forward after the per-Gaussian kernel: order the visible Gaussians, hand the instance count to the host
 static int order_and_count(GeomState& g, int P, int debug, hipStream_t st, int* num_rendered_host, void* count_event) {
+  if (debug_stop_after() == 1) return GM_OK;
   return launch_depth_order(g, P, debug, st, num_rendered_host, reinterpret_cast<hipEvent_t>(count_event));
 }
 
@@ -197,6 +209,10 @@ int gm_forward_1_geom(int emission_policy, void* geom_buffer, void* binning_buff
   BinningState b = BinningState::from(binning_buffer, (size_t)cap);
   const int slot = sort_final_slot(tiles);
   bool order_done = false;
+  if (const int stop = debug_stop_after()) {
+    if (stop <= 2) return GM_OK;
+    if (stop == 3) return launch_duplicate(g, b, P, width, height, mode, (size_t)cap, debug, st);
+  }
   if (P > 0 && cap > 0) {
     if (int rc = launch_duplicate(g, b, P, width, height, mode, (size_t)cap, debug, st)) return rc;
     if (int rc = launch_tile_sort(g, b, img, (size_t)cap, device_count ? g.counters + GM_CNT_RENDERED : nullptr, tiles, &order_done, work_hint, debug, st)) return rc;
@@ -211,6 +227,7 @@ int gm_forward_1_geom(int emission_policy, void* geom_buffer, void* binning_buff
     status_host[0] = 0; status_host[1] = 0; status_host[2] = mode; status_host[3] = 0;
     status_host = nullptr;
   }
+  if (debug_stop_after() == 4) return GM_OK;
   return launch_render_fwd(g, b.pairs[slot], img, width, height, mode, background, out_color, status_host, (flags & GM_FWD_IMAGE_ONLY) != 0,
                            work_hint, debug, st);
 }

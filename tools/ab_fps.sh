@@ -7,7 +7,7 @@ cp gaussianmesh_amd/csrc/$f /tmp/orig_$f
 for rep in 1 2 3; do
   for v in "$@"; do
     cp tools/variants/$v gaussianmesh_amd/csrc/$f
-    (cd gaussianmesh_amd/csrc && make >/dev/null 2>&1)
+    (cd gaussianmesh_amd/csrc && make -B -j12 >/dev/null 2>&1)
     python bench.py --steps 300 --warmup 20 --repeats 3 --no-cpu-baseline --no-fwd-bwd --no-c5 > gpurun_out/abf_$v.json 2> gpurun_out/abf_$v.err || tail -3 gpurun_out/abf_$v.err
     python - <<PY
 import json
@@ -17,4 +17,4 @@ PY
   done
 done
 cp /tmp/orig_$f gaussianmesh_amd/csrc/$f
-(cd gaussianmesh_amd/csrc && make >/dev/null 2>&1)
+(cd gaussianmesh_amd/csrc && make -B -j12 >/dev/null 2>&1)
