@@ -41,6 +41,20 @@ __global__ __launch_bounds__(TH) void preprocess_fwd_kernel(const PreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds_pre[];
   constexpr int LROW = DMA ? 12 : 13;
   const int idx = blockIdx.x * TH + threadIdx.x;
+  // DMA path: every per-Gaussian input is requested BEFORE the SH rows are waited for - one memory round per wave instead of
+  // rows -> mean -> rotation / scale -> opacity one after the other (the kernel is bound by latency, not by bytes)
+  float in_p[3] = {0.f, 0.f, 0.f}, in_s[3] = {0.f, 0.f, 0.f}, in_op = 0.f;
+  float4 in_q = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (DMA && idx < a.P) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) in_p[k] = a.means[3 * (size_t)idx + k];
+    in_op = a.opac[idx];
+    if (!a.cov3D_pre) {
+      in_q = reinterpret_cast<const float4*>(a.rots)[idx];
+#pragma unroll
+      for (int k = 0; k < 3; k++) in_s[k] = a.scales[3 * (size_t)idx + k];
+    }
+  }
   if (STAGE_SH) {
     const size_t row0 = (size_t)blockIdx.x * TH;
     const int nrows = min(TH, a.P - (int)row0);
@@ -65,9 +79,9 @@ __global__ __launch_bounds__(TH) void preprocess_fwd_kernel(const PreArgs a) {
   uint32_t tiles = 0, dkey = 0xFFFFFFFFu;
   uint4 bin = make_uint4(0u, 0u, 0u, 0u);
   if (idx < a.P) do {
-    const V3 p = {a.means[3 * (size_t)idx], a.means[3 * (size_t)idx + 1], a.means[3 * (size_t)idx + 2]};
+    const V3 p = DMA ? V3{in_p[0], in_p[1], in_p[2]} : V3{a.means[3 * (size_t)idx], a.means[3 * (size_t)idx + 1], a.means[3 * (size_t)idx + 2]};
     const PreCam cam = {a.W, a.H, a.gx, a.gy, a.tile_cull, a.view, a.proj, a.tanx, a.tany, a.fx, a.fy};
-    {                                               // in_frustum first (auxiliary.h:153): culled Gaussians read nothing else
+    {                                               // in_frustum first (auxiliary.h:153): culled Gaussians read nothing else (non-DMA path)
       const float vz = a.view[2] * p.x + a.view[6] * p.y + a.view[10] * p.z + a.view[14];
       if (vz <= 0.2f) {
         // the reference prints "Point is filtered although prefiltered is set" and traps the kernel (auxiliary.h:155-159);
@@ -81,11 +95,11 @@ __global__ __launch_bounds__(TH) void preprocess_fwd_kernel(const PreArgs a) {
 #pragma unroll
       for (int k = 0; k < 6; k++) c3[k] = a.cov3D_pre[6 * (size_t)idx + k];
     } else {                                        // computeCov3D, forward.cu:118-152
-      const float4 q = reinterpret_cast<const float4*>(a.rots)[idx];
+      const float4 q = DMA ? in_q : reinterpret_cast<const float4*>(a.rots)[idx];
       float Rg[9], Mc[9];
       quat_cols(q.x, q.y, q.z, q.w, Rg);
-      const float s[3] = {a.mod * a.scales[3 * (size_t)idx], a.mod * a.scales[3 * (size_t)idx + 1],
-                          a.mod * a.scales[3 * (size_t)idx + 2]};
+      const float s[3] = {a.mod * (DMA ? in_s[0] : a.scales[3 * (size_t)idx]), a.mod * (DMA ? in_s[1] : a.scales[3 * (size_t)idx + 1]),
+                          a.mod * (DMA ? in_s[2] : a.scales[3 * (size_t)idx + 2])};
 #pragma unroll
       for (int c = 0; c < 3; c++)
 #pragma unroll
@@ -125,7 +139,7 @@ __global__ __launch_bounds__(TH) void preprocess_fwd_kernel(const PreArgs a) {
       }
     }
     a.clamped[idx] = clampbits;
-    const float opac = a.opac[idx];
+    const float opac = DMA ? in_op : a.opac[idx];
     a.splat[3 * (size_t)idx + 0] = make_float4(pix, piy, pg.conx, pg.cony);
     a.splat[3 * (size_t)idx + 1] = make_float4(pg.conz, opac, col[0], col[1]);
     a.splat[3 * (size_t)idx + 2] = make_float4(col[2], pg.depth, 0.f, 0.f);

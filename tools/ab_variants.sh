@@ -6,7 +6,7 @@ f=$1; shift
 cp gaussianmesh_amd/csrc/$f /tmp/orig_$f
 for v in "$@" "$@"; do
   cp tools/variants/$v gaussianmesh_amd/csrc/$f
-  (cd gaussianmesh_amd/csrc && make -B -j12 >/dev/null 2>&1)
+  (cd gaussianmesh_amd/csrc && make >/dev/null 2>&1)
   tools/fwd_bwd_once.sh $v | tail -1
 done
 cp /tmp/orig_$f gaussianmesh_amd/csrc/$f
