@@ -144,6 +144,16 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
           EMIT(pos, tile0 + row * (uint32_t)gx + (k - row * w), gid[i]);
           pos++;
         }
+      } else if (S == 1 && quad_rect(x0, y0, w, h)) {
+        // quadrant-level record (gm_cull.h): the mask IS the four parents' 16-bit quadrant masks, in parent-row-major order
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+          const uint32_t cm = (uint32_t)(m >> (16 * k)) & 0xFFFFu;
+          if (cm) {
+            EMIT(pos, (((y0 >> 1) + (k >> 1)) * (uint32_t)pgx + (x0 >> 1) + (k & 1u)) | (cm << GM_KEY_MASK_SHIFT), gid[i]);
+            pos++;
+          }
+        }
       } else {
         const unsigned long long rowmask = (1ull << w) - 1ull;
         const int a = (int)(x0 & M);
@@ -162,6 +172,7 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
             uint32_t cm = 0;
 #pragma unroll
             for (int j = 0; j <= M; j++) cm |= (uint32_t)((rows[j] >> b) & (unsigned long long)((1 << (1 << S)) - 1)) << (j << S);
+            if (S == 1) cm = tile_to_quad_mask(cm);       // policy 2 keys carry quadrant bits
             EMIT(pos, (pr * (uint32_t)pgx + (x0 >> S) + (uint32_t)(b >> S)) | (cm << GM_KEY_MASK_SHIFT), gid[i]);
             pos++;
           }
@@ -215,6 +226,7 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
         const unsigned long long bal = __ballot(pass);
         if (pass) {
           const uint32_t pos = run + lanes_below(bal);
+          if (S == 1) cm = tile_to_quad_mask(cm);
           EMIT(pos, (pcy * (uint32_t)pgx + pcx) | (cm << GM_KEY_MASK_SHIFT), g);
         }
         run += (uint32_t)__popcll(bal);

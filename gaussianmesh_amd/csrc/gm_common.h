@@ -246,8 +246,9 @@ static inline int sort_final_slot(int tiles) { return tiles <= (1 << GM_BUCKET_B
 // Emission policy (gm_set_tile_culling): 0 = the reference's lists (every tile of the rectangle, 16-px tiles);
 // 1 = exact culling, lists per 16-px tile; 2 / 3 = exact culling, lists per 32- / 64-px PARENT tile (the instance
 // stream shrinks ~2x / ~3x): an instance is one (Gaussian, parent tile) pair whose key carries, above bit 16, the
-// mask of the parent's 16-px child tiles the Gaussian reaches.  The blend kernels still run one workgroup per 16-px
-// tile; it walks its parent's list and takes the entries whose mask has its bit.
+// mask of the parent's children the Gaussian reaches: policy 3 one bit per 16-px child tile (4 x 4), policy 2 one bit per
+// 8x8-pixel QUADRANT of the 32-px parent (4 x 4: bit 4 qy + qx; gm_cull.h quad_rect).  The blend kernels run one wave per
+// quadrant; it walks its parent's list and takes the entries whose mask has its tile's / its quadrant's bit.
 #define GM_KEY_MASK_SHIFT 16
 #define GM_KEY_TILE_MASK 0xFFFFu
 static inline int tile_shift_of(int mode) { return mode >= 2 ? mode - 1 : 0; }

@@ -152,6 +152,20 @@ __device__ __forceinline__ void row_tiles_pair(const TileCull& t, float sx, floa
 }
 
 // ---------------------------------------------------------------------------------------------
+// Policy 2 (2 x 2-tile parents = 4 x 4 quadrants of 8 x 8 pixels, one blend wave per quadrant) records the reach of a Gaussian per
+// QUADRANT when its rectangle (x0, y0, w, h in tiles) meets at most 2 x 2 parents - every rectangle of up to 3 x 3 tiles, i.e.
+// nearly every Gaussian of an object seen from outside: the emission record's 64-bit mask then holds the four parents' 16-bit
+// quadrant masks, parent (x0 / 2 + pi, y0 / 2 + pj) in bits [16 (2 pj + pi), +16), quadrant (qx, qy) of a parent in bit 4 qy + qx
+// (gm_pre_body.h pre_emit builds them, duplicate_kernel<1> turns each non-empty one into an instance).
+__device__ __forceinline__ bool quad_rect(uint32_t x0, uint32_t y0, uint32_t w, uint32_t h) {
+  return ((x0 + w - 1u) >> 1) - (x0 >> 1) <= 1u && ((y0 + h - 1u) >> 1) - (y0 >> 1) <= 1u;
+}
+// the 2 x 2 quadrant block of every set tile bit of a 2 x 2-tile parent (tile bit cy * 2 + cx -> quadrant bits (2 cy + {0,1}) * 4 + 2 cx + {0,1})
+__device__ __forceinline__ uint32_t tile_to_quad_mask(uint32_t cm) {
+  return ((cm & 1u) ? 0x0033u : 0u) | ((cm & 2u) ? 0x00CCu : 0u) | ((cm & 4u) ? 0x3300u : 0u) | ((cm & 8u) ? 0xCC00u : 0u);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Parent tiles (2^s x 2^s tiles, s = 1 or 2).  `bits`: bit c = tile column x0 + c of one parent ROW is reached
 // (union over the row's child rows; at most 60 columns).  Returns the number of parent columns with a reached child.
 __device__ __forceinline__ unsigned long long fold_parent_bits(unsigned long long bits, int x0, int s) {

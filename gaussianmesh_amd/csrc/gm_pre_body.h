@@ -146,6 +146,18 @@ __device__ __forceinline__ void pre_emit(const PreCam& a, const PreGeom& g, floa
       //   small rectangles  parents with a reached child = |PA u PB| = |PA| + |PB| - |PA n PB|  (PA, PB: the rows' spans in parent columns)
       //   others            the hull of the two spans
       // (an empty span is (GM_ROW_EMPTY_LO, -1): every length below comes out <= 0 and clamps to 0).
+      // Rectangles inside 2 x 2 parents (quad_rect, gm_cull.h) record their reach per 8x8 QUADRANT instead of per tile - the blend
+      // kernels run one wave per quadrant: the quadrants of the reached tiles that the bounding box of the alpha >= 1/255 ellipse
+      // (tile_cull_setup's xext x dymax) touches.  A parent none of whose quadrants passes is not emitted.
+      const bool quad = quad_rect((uint32_t)x0, (uint32_t)y0, (uint32_t)rw, (uint32_t)rh);
+      const int px0 = x0 >> 1, py0 = y0 >> 1;
+      int bqx0 = 0, bqx1 = 7, bqy0 = 0, bqy1 = 7;                       // the box in quadrant columns / rows relative to parent (px0, py0)
+      if (quad && tc.mode == 1) {
+        const float ex = tc.xext + 2e-3f, ey = tc.dymax + 2e-3f;         // quadrant q covers pixel centres [8 q, 8 q + 7]
+        bqx0 = (int)fmaxf(ceilf((g.pix - ex - 7.f) * 0.125f), -1e9f) - 4 * px0; bqx1 = (int)fminf(floorf((g.pix + ex) * 0.125f), 1e9f) - 4 * px0;
+        bqy0 = (int)fmaxf(ceilf((g.piy - ey - 7.f) * 0.125f), -1e9f) - 4 * py0; bqy1 = (int)fminf(floorf((g.piy + ey) * 0.125f), 1e9f) - 4 * py0;
+      }
+      uint32_t qw[2] = {0u, 0u};                                        // qw[pj]: quadrant masks of parents (px0, py0 + pj) | (px0 + 1, py0 + pj) << 16
       const int pr_last = tc.mode != 0 ? (y1 - 1) >> 1 : (y0 >> 1) - 1;
       for (int pr = y0 >> 1; pr <= pr_last; pr++) {
         const int ty = 2 * pr;
@@ -163,8 +175,27 @@ __device__ __forceinline__ void pre_emit(const PreCam& a, const PreGeom& g, floa
           const unsigned long long run = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
           mask |= run << (((ty + r - y0) * rw + (ta[r] - x0)) & 63);
         }
+        if (quad) {
+          uint32_t word = 0;
+#pragma unroll
+          for (int r = 0; r < 2; r++) {
+            const int qa = max(2 * ta[r] - 4 * px0, bqx0), qb = min(2 * tb[r] + 1 - 4 * px0, bqx1);     // quadrant columns 0..7 of the two parents
+            const uint32_t r8 = qa <= qb ? ((1u << (qb - qa + 1)) - 1u) << qa : 0u;
+            const uint32_t two = (r8 & 0xFu) | ((r8 >> 4) << 16);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              const int ql = 2 * r + h, qrow = 4 * (pr - py0) + ql;                                     // quadrant row in the parent / relative to parent row py0
+              if (qrow >= bqy0 && qrow <= bqy1) word |= two << (4 * ql);
+            }
+          }
+          if (pr == py0) qw[0] = word; else qw[1] = word;
+        }
       }
       if (ncand > 64) mask = 0ull;
+      if (quad) {
+        mask = (unsigned long long)qw[0] | ((unsigned long long)qw[1] << 32);
+        cnt = ((qw[0] & 0xFFFFu) ? 1u : 0u) + ((qw[0] >> 16) ? 1u : 0u) + ((qw[1] & 0xFFFFu) ? 1u : 0u) + ((qw[1] >> 16) ? 1u : 0u);
+      }
     } else {
     int cur_pr = -1, hull_lo = 0x7fffffff, hull_hi = -1;           // hull empty while hull_hi < 0
     unsigned long long prow = 0ull;

@@ -60,6 +60,12 @@ struct TileMap {
   int blocks() const { return ((pgx * pgy + 7) / 8) * 8 << (2 * s); }
 };
 
+// Policy 2 (32-px parents): the key's mask has one bit per 8x8 QUADRANT of the parent, bit qy * 4 + qx; quadrant (wave & 1, wave >> 1)
+// of tile (tx, ty) is quadrant (2 (tx & 1) + (wave & 1), 2 (ty & 1) + (wave >> 1)) of its parent.
+__device__ __forceinline__ uint32_t quadrant_bit(int tx, int ty, int wave) {
+  return 1u << (GM_KEY_MASK_SHIFT + (2 * (ty & 1) + (wave >> 1)) * 4 + 2 * (tx & 1) + (wave & 1));
+}
+
 // Dispatch order of the blend kernels (gm_tile_order.h) as a launch of its own: only when the tile pass did not produce it.
 __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restrict__ ranges, int tiles, uint32_t* __restrict__ order,
                                                           uint32_t* __restrict__ hint, uint32_t* __restrict__ epoch) {
@@ -204,6 +210,7 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
   int tx, ty, parent;                                                    // the caller's page-locked words: no copy launch behind the frame
   uint32_t child_bit;
   if (!tm.locate(tile_block, tx, ty, parent, child_bit)) return;
+  if (tm.s == 1) child_bit = quadrant_bit(tx, ty, wave);                 // policy 2: the keys carry one bit per 8x8 quadrant of the parent
   const uint2 range = ranges[parent];
   const int n = (int)(range.y - range.x);
   const uint2* list = pairs + range.x;           // (key, Gaussian id) per list entry
@@ -463,6 +470,7 @@ __global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_kernel(cons
   uint32_t child_bit;
   if ((int)counters[GM_CNT_POLICY] != mode || counters[GM_CNT_REFUSED] != 0u) return;   // lists were built under another emission policy: contribute nothing
   if (!tm.locate(tile_block, tx, ty, parent, child_bit)) return;
+  if (tm.s == 1) child_bit = quadrant_bit(tx, ty, wave);
   const uint2 range = ranges[parent];
   const int n = (int)(range.y - range.x);
   if (n == 0) return;

@@ -142,7 +142,9 @@ int gm_mark_visible(int P, const float* means3D, const float* viewmatrix, const 
  *            in (depth, id) order; V = "bucket_start"[2048]), "bucket_start" uint32[2049]
  *   image:   "final_T" float[H*W], "n_contrib" uint32[H*W], "ranges" uint32[T][2]
  *   binning: "pairs" uint32[R][2] = (list tile id | child mask << 16, Gaussian id) per instance, sorted by tile then
- *            (depth, id): column 1 is the reference's point_list, column 0 its sorted tile keys */
+ *            (depth, id): column 1 is the reference's point_list, column 0 its sorted tile keys (child mask: policy 0/1
+ *            = 1; policy 2 = the 4 x 4 8-pixel quadrants of the 32-px list tile, bit 4 qy + qx; policy 3 = the 4 x 4
+ *            16-px tiles of the 64-px list tile, bit 4 ty + tx) */
 void* gm_geom_field(void* geom_buffer, int P, const char* name);
 void* gm_image_field(void* image_buffer, int W, int H, const char* name);
 void* gm_binning_field(void* binning_buffer, int64_t R, int W, int H, int emission_policy, const char* name);

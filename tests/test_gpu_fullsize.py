@@ -58,7 +58,8 @@ def _check_list_invariants(st, cam, mode=0):
     x, y, rad = st["splat"][g, 0], st["splat"][g, 1], st["radii"][g]
     tx, ty = keys % gx, keys // gx
     assert ((tx * ts <= x + rad + 15) & (tx * ts + ts - 1 >= x - rad - 15) & (ty * ts <= y + rad + 15) & (ty * ts + ts - 1 >= y - rad - 15)).all()
-    assert (st["child_mask"] < (1 << (1 << (2 * shift)))).all()
+    # mask bits: policy 2 (32-px parents) carries one bit per 8x8 quadrant of the parent (16), policy 3 one per 16-px child (16)
+    assert (st["child_mask"] < (1 << (16 if mode >= 2 else 1))).all()
 
 
 def test_c1_plumbing_case(oracle):

@@ -184,8 +184,8 @@ def test_backward_medium(oracle):
 @pytest.mark.parametrize("case", ["small", "medium", "huge_splats"])
 def test_tile_culling_is_exact(oracle, case, mode):
     """Culled emission policies vs the reference policy: per 16-px tile the entries the blend kernel takes (the
-    parent tile's list filtered by the tile's bit in the child mask) are the reference list minus instances no pixel
-    of the tile accepts; images are bit-identical."""
+    parent tile's list filtered by the tile's bit(s) in the child mask: one per tile, under policy 2 one per 8x8
+    quadrant) are the reference list minus instances no pixel of the tile accepts; images are bit-identical."""
     from gpu_utils import forward_state
     from gaussianmesh_amd import scenes
     if case == "small":
@@ -221,7 +221,12 @@ def test_tile_culling_is_exact(oracle, case, mode):
         p = (ty >> sh) * pgx + (tx >> sh); c = ((ty & m) << sh) | (tx & m)
         a0, a1 = ex["ranges"][t]; b0, b1 = cu["ranges"][p]
         ref = ex["point_list"][a0:a1]
-        sub = cu["point_list"][b0:b1][((cu["child_mask"][b0:b1] >> c) & 1) == 1]
+        if mode == 2:                            # policy 2: one bit per 8x8 quadrant of the parent, qy * 4 + qx; the tile's four quadrants
+            cx, cy = tx & 1, ty & 1
+            tbits = 0x33 << (8 * cy + 2 * cx)
+        else:
+            tbits = 1 << c
+        sub = cu["point_list"][b0:b1][(cu["child_mask"][b0:b1] & tbits) != 0]
         j = 0
         for g in sub:                            # two-pointer subsequence check (ids are unique within a tile)
             while j < len(ref) and ref[j] != g:
