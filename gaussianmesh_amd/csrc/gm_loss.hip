@@ -22,6 +22,7 @@ namespace gm {
 #define LS_THREADS 256
 
 struct LossWindow { float w[11]; };
+typedef float lv2f __attribute__((ext_vector_type(2)));
 
 static LossWindow make_window() {
   // loss_utils.py:23-25: exp(-(x - 5)^2 / (2 sigma^2)) in Python doubles -> float32 array -> divided by its float32 sum
@@ -47,8 +48,12 @@ __global__ __launch_bounds__(LS_THREADS) void ssim_fwd_kernel(const float* __res
                                                               int H, int W, LossWindow win, float* __restrict__ d_mu1,
                                                               float* __restrict__ d_e11, float* __restrict__ d_e12,
                                                               float* __restrict__ partial) {
-  __shared__ float sx[LS_SPAN][LS_SPAN + 1], sy[LS_SPAN][LS_SPAN + 1];
-  __shared__ float hb[5][LS_SPAN][LS_TILE + 1];
+  // Quantities travel in PAIRS - (x, y), (xx, yy), then xy alone - so that the 11-tap sums run on the packed-f32 pipe (v_pk_fma_f32:
+  // two of them per issue slot): three instructions per tap and output instead of five, and one 8-byte LDS access per pair.  Every sum
+  // keeps its own order of additions: results are bit-identical to the one-quantity-at-a-time form.
+  __shared__ float2 sxy[LS_SPAN][LS_SPAN + 1];                    // staged (image, target) with the halo
+  __shared__ float2 hb01[LS_SPAN][LS_TILE + 1], hb23[LS_SPAN][LS_TILE + 1];   // horizontal sums of (x, y) and (xx, yy)
+  __shared__ float hb4[LS_SPAN][LS_TILE + 1];                     // ... and of xy
   __shared__ float red[4];
   const int tid = threadIdx.x;
   const int ox = blockIdx.x * LS_TILE, oy = blockIdx.y * LS_TILE;
@@ -58,29 +63,33 @@ __global__ __launch_bounds__(LS_THREADS) void ssim_fwd_kernel(const float* __res
     const int gx = ox + c - LS_HALO, gy = oy + r - LS_HALO;
     const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;          // zero padding (conv2d padding = 5)
     const size_t p = plane + (size_t)(in ? gy : 0) * W + (in ? gx : 0);
-    sx[r][c] = in ? img1[p] : 0.f;
-    sy[r][c] = in ? img2[p] : 0.f;
+    sxy[r][c] = make_float2(in ? img1[p] : 0.f, in ? img2[p] : 0.f);
   }
   __syncthreads();
   // horizontal taps: one work item = 4 adjacent output columns of one row (14 staged values feed 4 x 11 taps);
-  // consecutive lanes take consecutive rows (row stride 43 words: conflict-free)
+  // consecutive lanes take consecutive rows (row stride 43 pairs: conflict-free)
   for (int i = tid; i < LS_SPAN * (LS_TILE / 4); i += LS_THREADS) {
     const int r = i % LS_SPAN, c0 = (i / LS_SPAN) * 4;
-    float xv[14], yv[14], xx[14], yy[14], xy[14];
+    lv2f p0[14], p1[14];
+    float xy[14];
 #pragma unroll
     for (int k = 0; k < 14; k++) {
-      xv[k] = sx[r][c0 + k]; yv[k] = sy[r][c0 + k];
-      xx[k] = xv[k] * xv[k]; yy[k] = yv[k] * yv[k]; xy[k] = xv[k] * yv[k];
+      const float2 v = sxy[r][c0 + k];
+      p0[k] = lv2f{v.x, v.y};
+      p1[k] = p0[k] * p0[k];
+      xy[k] = v.x * v.y;
     }
 #pragma unroll
     for (int o = 0; o < 4; o++) {
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+      lv2f a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+      float a4 = 0.f;
 #pragma unroll
       for (int k = 0; k < 11; k++) {
         const float w = win.w[k];
-        a0 += w * xv[o + k]; a1 += w * yv[o + k]; a2 += w * xx[o + k]; a3 += w * yy[o + k]; a4 += w * xy[o + k];
+        const lv2f ww = {w, w};
+        a01 = ww * p0[o + k] + a01; a23 = ww * p1[o + k] + a23; a4 += w * xy[o + k];
       }
-      hb[0][r][c0 + o] = a0; hb[1][r][c0 + o] = a1; hb[2][r][c0 + o] = a2; hb[3][r][c0 + o] = a3; hb[4][r][c0 + o] = a4;
+      hb01[r][c0 + o] = make_float2(a01.x, a01.y); hb23[r][c0 + o] = make_float2(a23.x, a23.y); hb4[r][c0 + o] = a4;
     }
   }
   __syncthreads();
@@ -89,17 +98,25 @@ __global__ __launch_bounds__(LS_THREADS) void ssim_fwd_kernel(const float* __res
   float s_sum = 0.f, l1_sum = 0.f;
   // vertical taps: a thread owns 4 adjacent rows of one column (14 values per quantity feed 4 x 11 taps)
   float vq[5][4];
+  {
+    lv2f c01[14], c23[14];
+    float c4[14];
 #pragma unroll
-  for (int q = 0; q < 5; q++) {
-    float col[14];
-#pragma unroll
-    for (int k = 0; k < 14; k++) col[k] = hb[q][(tid >> 5) * 4 + k][c];
+    for (int k = 0; k < 14; k++) {
+      const float2 u = hb01[(tid >> 5) * 4 + k][c], v = hb23[(tid >> 5) * 4 + k][c];
+      c01[k] = lv2f{u.x, u.y}; c23[k] = lv2f{v.x, v.y}; c4[k] = hb4[(tid >> 5) * 4 + k][c];
+    }
 #pragma unroll
     for (int o = 0; o < 4; o++) {
-      float acc = 0.f;
+      lv2f a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+      float a4 = 0.f;
 #pragma unroll
-      for (int k = 0; k < 11; k++) acc += win.w[k] * col[o + k];
-      vq[q][o] = acc;
+      for (int k = 0; k < 11; k++) {
+        const float w = win.w[k];
+        const lv2f ww = {w, w};
+        a01 = ww * c01[o + k] + a01; a23 = ww * c23[o + k] + a23; a4 += w * c4[o + k];
+      }
+      vq[0][o] = a01.x; vq[1][o] = a01.y; vq[2][o] = a23.x; vq[3][o] = a23.y; vq[4][o] = a4;
     }
   }
 #pragma unroll
@@ -114,7 +131,7 @@ __global__ __launch_bounds__(LS_THREADS) void ssim_fwd_kernel(const float* __res
       const float inv_b1 = 1.0f / B1, inv_b2 = 1.0f / B2;
       const float S = (A1 * A2) * (inv_b1 * inv_b2);
       s_sum += S;
-      l1_sum += fabsf(sx[r + LS_HALO][c + LS_HALO] - sy[r + LS_HALO][c + LS_HALO]);
+      { const float2 v = sxy[r + LS_HALO][c + LS_HALO]; l1_sum += fabsf(v.x - v.y); }
       if (WRITE_MAPS) {
         const size_t p = plane + (size_t)gy * W + gx;
         // S as a function of (mu1, E[xx], E[xy]) with sigma1^2 = E[xx] - mu1^2, sigma12 = E[xy] - mu1 mu2
@@ -141,8 +158,11 @@ __global__ __launch_bounds__(LS_THREADS) void ssim_bwd_kernel(const float* __res
                                                               const float* __restrict__ g_ssim /*[planes]*/,
                                                               const float* __restrict__ g_l1 /*[1] or null*/,
                                                               float* __restrict__ dL_dimg1) {
-  __shared__ float sm[3][LS_SPAN][LS_SPAN + 1];
-  __shared__ float hb[3][LS_SPAN][LS_TILE + 1];
+  // (dS/dmu1, dS/dE[xx]) travel as a pair, dS/dE[xy] alone: packed-f32 sums as in ssim_fwd_kernel
+  __shared__ float2 sm01[LS_SPAN][LS_SPAN + 1];
+  __shared__ float sm2[LS_SPAN][LS_SPAN + 1];
+  __shared__ float2 hb01[LS_SPAN][LS_TILE + 1];
+  __shared__ float hb2[LS_SPAN][LS_TILE + 1];
   const int tid = threadIdx.x;
   const int ox = blockIdx.x * LS_TILE, oy = blockIdx.y * LS_TILE;
   const size_t plane = (size_t)blockIdx.z * H * W;
@@ -151,22 +171,27 @@ __global__ __launch_bounds__(LS_THREADS) void ssim_bwd_kernel(const float* __res
     const int gx = ox + c - LS_HALO, gy = oy + r - LS_HALO;
     const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;          // no ssim-map pixel outside the image
     const size_t p = plane + (size_t)(in ? gy : 0) * W + (in ? gx : 0);
-    sm[0][r][c] = in ? d_mu1[p] : 0.f;
-    sm[1][r][c] = in ? d_e11[p] : 0.f;
-    sm[2][r][c] = in ? d_e12[p] : 0.f;
+    sm01[r][c] = make_float2(in ? d_mu1[p] : 0.f, in ? d_e11[p] : 0.f);
+    sm2[r][c] = in ? d_e12[p] : 0.f;
   }
   __syncthreads();
-  for (int i = tid; i < 3 * LS_SPAN * (LS_TILE / 4); i += LS_THREADS) {      // see ssim_fwd_kernel
-    const int r = i % LS_SPAN, rest = i / LS_SPAN, c0 = (rest & 7) * 4, q = rest >> 3;
-    float v[14];
+  for (int i = tid; i < LS_SPAN * (LS_TILE / 4); i += LS_THREADS) {      // see ssim_fwd_kernel
+    const int r = i % LS_SPAN, c0 = (i / LS_SPAN) * 4;
+    lv2f v01[14];
+    float v2[14];
 #pragma unroll
-    for (int k = 0; k < 14; k++) v[k] = sm[q][r][c0 + k];
+    for (int k = 0; k < 14; k++) { const float2 u = sm01[r][c0 + k]; v01[k] = lv2f{u.x, u.y}; v2[k] = sm2[r][c0 + k]; }
 #pragma unroll
     for (int o = 0; o < 4; o++) {
-      float acc = 0.f;
+      lv2f a01 = {0.f, 0.f};
+      float a2 = 0.f;
 #pragma unroll
-      for (int k = 0; k < 11; k++) acc += win.w[k] * v[o + k];
-      hb[q][r][c0 + o] = acc;
+      for (int k = 0; k < 11; k++) {
+        const float w = win.w[k];
+        const lv2f ww = {w, w};
+        a01 = ww * v01[o + k] + a01; a2 += w * v2[o + k];
+      }
+      hb01[r][c0 + o] = make_float2(a01.x, a01.y); hb2[r][c0 + o] = a2;
     }
   }
   __syncthreads();
@@ -174,17 +199,22 @@ __global__ __launch_bounds__(LS_THREADS) void ssim_bwd_kernel(const float* __res
   const float gl = g_l1 ? g_l1[0] : 0.f;
   const int c = tid & 31;
   float vq[3][4];
+  {
+    lv2f c01[14];
+    float c2[14];
 #pragma unroll
-  for (int q = 0; q < 3; q++) {
-    float col[14];
-#pragma unroll
-    for (int k = 0; k < 14; k++) col[k] = hb[q][(tid >> 5) * 4 + k][c];
+    for (int k = 0; k < 14; k++) { const float2 u = hb01[(tid >> 5) * 4 + k][c]; c01[k] = lv2f{u.x, u.y}; c2[k] = hb2[(tid >> 5) * 4 + k][c]; }
 #pragma unroll
     for (int o = 0; o < 4; o++) {
-      float acc = 0.f;
+      lv2f a01 = {0.f, 0.f};
+      float a2 = 0.f;
 #pragma unroll
-      for (int k = 0; k < 11; k++) acc += win.w[k] * col[o + k];
-      vq[q][o] = acc;
+      for (int k = 0; k < 11; k++) {
+        const float w = win.w[k];
+        const lv2f ww = {w, w};
+        a01 = ww * c01[o + k] + a01; a2 += w * c2[o + k];
+      }
+      vq[0][o] = a01.x; vq[1][o] = a01.y; vq[2][o] = a2;
     }
   }
 #pragma unroll

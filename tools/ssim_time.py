@@ -11,7 +11,7 @@ for (W, H) in ((3840, 2160), (1920, 1080)):
         photometric_loss(img, gt, 0.2).backward()
     for _ in range(5): it()
     torch.cuda.synchronize(); t = time.perf_counter()
-    n = 50
+    n = 300
     for _ in range(n): it()
     torch.cuda.synchronize()
     print("%dx%d: %.4f ms per forward+backward of the loss" % (W, H, 1e3 * (time.perf_counter() - t) / n))
