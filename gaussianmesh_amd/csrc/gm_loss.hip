@@ -51,9 +51,13 @@ __global__ __launch_bounds__(LS_THREADS) void ssim_fwd_kernel(const float* __res
   // Quantities travel in PAIRS - (x, y), (xx, yy), then xy alone - so that the 11-tap sums run on the packed-f32 pipe (v_pk_fma_f32:
   // two of them per issue slot): three instructions per tap and output instead of five, and one 8-byte LDS access per pair.  Every sum
   // keeps its own order of additions: results are bit-identical to the one-quantity-at-a-time form.
-  __shared__ float2 sxy[LS_SPAN][LS_SPAN + 1];                    // staged (image, target) with the halo
-  __shared__ float2 hb01[LS_SPAN][LS_TILE + 1], hb23[LS_SPAN][LS_TILE + 1];   // horizontal sums of (x, y) and (xx, yy)
-  __shared__ float hb4[LS_SPAN][LS_TILE + 1];                     // ... and of xy
+  // LDS: the staged inputs and the horizontal sums share their memory (27.1 KiB per workgroup, five workgroups per CU instead of the
+  // three that 41 KiB allowed): the horizontal pass keeps its results in registers until every thread has read its inputs.
+  struct Horiz { float2 hb01[LS_SPAN][LS_TILE + 1], hb23[LS_SPAN][LS_TILE + 1]; float hb4[LS_SPAN][LS_TILE + 1]; };
+  __shared__ __attribute__((aligned(16))) char lds_raw[sizeof(Horiz)];
+  static_assert(sizeof(float2) * LS_SPAN * (LS_SPAN + 1) <= sizeof(Horiz), "the staged inputs fit the horizontal sums' memory");
+  float2 (*sxy)[LS_SPAN + 1] = reinterpret_cast<float2 (*)[LS_SPAN + 1]>(lds_raw);          // staged (image, target) with the halo
+  Horiz& hz = *reinterpret_cast<Horiz*>(lds_raw);                  // horizontal sums of (x, y), (xx, yy) and xy
   __shared__ float red[4];
   const int tid = threadIdx.x;
   const int ox = blockIdx.x * LS_TILE, oy = blockIdx.y * LS_TILE;
@@ -68,28 +72,52 @@ __global__ __launch_bounds__(LS_THREADS) void ssim_fwd_kernel(const float* __res
   __syncthreads();
   // horizontal taps: one work item = 4 adjacent output columns of one row (14 staged values feed 4 x 11 taps);
   // consecutive lanes take consecutive rows (row stride 43 pairs: conflict-free)
-  for (int i = tid; i < LS_SPAN * (LS_TILE / 4); i += LS_THREADS) {
-    const int r = i % LS_SPAN, c0 = (i / LS_SPAN) * 4;
-    lv2f p0[14], p1[14];
-    float xy[14];
+  constexpr int HITEMS = LS_SPAN * (LS_TILE / 4), HPASS = (HITEMS + LS_THREADS - 1) / LS_THREADS;     // 336 items, 2 passes
+  lv2f h01[HPASS][4], h23[HPASS][4];
+  float h4[HPASS][4];
 #pragma unroll
-    for (int k = 0; k < 14; k++) {
-      const float2 v = sxy[r][c0 + k];
-      p0[k] = lv2f{v.x, v.y};
-      p1[k] = p0[k] * p0[k];
-      xy[k] = v.x * v.y;
-    }
+  for (int ps = 0; ps < HPASS; ps++) {
+    const int i = tid + ps * LS_THREADS;
+    if (i < HITEMS) {
+      const int r = i % LS_SPAN, c0 = (i / LS_SPAN) * 4;
+      lv2f p0[14], p1[14];
+      float xy[14];
 #pragma unroll
-    for (int o = 0; o < 4; o++) {
-      lv2f a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
-      float a4 = 0.f;
-#pragma unroll
-      for (int k = 0; k < 11; k++) {
-        const float w = win.w[k];
-        const lv2f ww = {w, w};
-        a01 = ww * p0[o + k] + a01; a23 = ww * p1[o + k] + a23; a4 += w * xy[o + k];
+      for (int k = 0; k < 14; k++) {
+        const float2 v = sxy[r][c0 + k];
+        p0[k] = lv2f{v.x, v.y};
+        p1[k] = p0[k] * p0[k];
+        xy[k] = v.x * v.y;
       }
-      hb01[r][c0 + o] = make_float2(a01.x, a01.y); hb23[r][c0 + o] = make_float2(a23.x, a23.y); hb4[r][c0 + o] = a4;
+#pragma unroll
+      for (int o = 0; o < 4; o++) {
+        lv2f a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+        float a4 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+          const float w = win.w[k];
+          const lv2f ww = {w, w};
+          a01 = ww * p0[o + k] + a01; a23 = ww * p1[o + k] + a23; a4 += w * xy[o + k];
+        }
+        h01[ps][o] = a01; h23[ps][o] = a23; h4[ps][o] = a4;
+      }
+    }
+  }
+  // the thread's own four pixels (L1 term) before the staged inputs are overwritten
+  float2 own[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) own[j] = sxy[(tid >> 5) * 4 + j + LS_HALO][(tid & 31) + LS_HALO];
+  __syncthreads();
+#pragma unroll
+  for (int ps = 0; ps < HPASS; ps++) {
+    const int i = tid + ps * LS_THREADS;
+    if (i < HITEMS) {
+      const int r = i % LS_SPAN, c0 = (i / LS_SPAN) * 4;
+#pragma unroll
+      for (int o = 0; o < 4; o++) {
+        hz.hb01[r][c0 + o] = make_float2(h01[ps][o].x, h01[ps][o].y); hz.hb23[r][c0 + o] = make_float2(h23[ps][o].x, h23[ps][o].y);
+        hz.hb4[r][c0 + o] = h4[ps][o];
+      }
     }
   }
   __syncthreads();
@@ -103,8 +131,8 @@ __global__ __launch_bounds__(LS_THREADS) void ssim_fwd_kernel(const float* __res
     float c4[14];
 #pragma unroll
     for (int k = 0; k < 14; k++) {
-      const float2 u = hb01[(tid >> 5) * 4 + k][c], v = hb23[(tid >> 5) * 4 + k][c];
-      c01[k] = lv2f{u.x, u.y}; c23[k] = lv2f{v.x, v.y}; c4[k] = hb4[(tid >> 5) * 4 + k][c];
+      const float2 u = hz.hb01[(tid >> 5) * 4 + k][c], v = hz.hb23[(tid >> 5) * 4 + k][c];
+      c01[k] = lv2f{u.x, u.y}; c23[k] = lv2f{v.x, v.y}; c4[k] = hz.hb4[(tid >> 5) * 4 + k][c];
     }
 #pragma unroll
     for (int o = 0; o < 4; o++) {
@@ -131,7 +159,7 @@ __global__ __launch_bounds__(LS_THREADS) void ssim_fwd_kernel(const float* __res
       const float inv_b1 = 1.0f / B1, inv_b2 = 1.0f / B2;
       const float S = (A1 * A2) * (inv_b1 * inv_b2);
       s_sum += S;
-      { const float2 v = sxy[r + LS_HALO][c + LS_HALO]; l1_sum += fabsf(v.x - v.y); }
+      l1_sum += fabsf(own[j].x - own[j].y);
       if (WRITE_MAPS) {
         const size_t p = plane + (size_t)gy * W + gx;
         // S as a function of (mu1, E[xx], E[xy]) with sigma1^2 = E[xx] - mu1^2, sigma12 = E[xy] - mu1 mu2

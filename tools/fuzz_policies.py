@@ -5,7 +5,7 @@ import numpy as np, torch
 from gaussianmesh_amd import scenes, _lib
 from gpu_utils import forward_state
 bad = 0
-for seed in range(40):
+for seed in range(int(os.environ.get("FUZZ_SEEDS", "40"))):
     rng = np.random.default_rng(seed)
     P = int(rng.integers(200, 30000))
     lo = float(10 ** rng.uniform(-3, -1)); hi = lo * float(10 ** rng.uniform(0.3, 2.2))
