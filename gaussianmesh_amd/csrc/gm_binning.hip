@@ -194,42 +194,53 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
       const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)gid[i], j);
       const uint32_t x0 = rx & 0xFFFu, y0 = (rx >> 16) & 0xFFFu, w = ry & 0xFFFu, h = (ry >> 16) & 0xFFFu;
       const uint32_t px0 = x0 >> S, py0 = y0 >> S, pw = ((x0 + w - 1) >> S) - px0 + 1, ph = ((y0 + h - 1) >> S) - py0 + 1;
-      const uint32_t ncand = pw * ph;
       const float inv_w = 1.0f / (float)pw;
       const float4 s0 = splat[3 * (size_t)g], s1 = splat[3 * (size_t)g + 1];
       const TileCull tc = tile_cull_setup(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, (float)(x0 * GM_TILE), (float)((x0 + w) * GM_TILE - 1),
                                           (float)(y0 * GM_TILE), (float)((y0 + h) * GM_TILE - 1));
       uint32_t run = o;
-      for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
-        const uint32_t k = c0 + lane;
-        const uint32_t row = (uint32_t)(((float)k + 0.5f) * inv_w), col = k - row * pw;
-        const uint32_t pcx = px0 + col, pcy = py0 + row;
-        bool pass = false;
-        uint32_t cm = 0;
-        if (k < ncand) {
-          int lo = 0x7fffffff, hi = -1;              // hull over the child rows, as preprocess counted
+      // The row spans are computed ONCE per tile row (lane = tile row; 64 tile rows = 64 >> S parent rows per chunk) and handed to the
+      // parents' lanes by cross-lane reads - every lane of a parent row walking the same 2^S rows again cost ~4x the instructions for
+      // the rectangles of near Gaussians (C5's emission: 204 us).  Parents are taken in row-major order, 64 per step, as before.
+      constexpr uint32_t PR_CHUNK = 64u >> S;
+      for (uint32_t pr0 = 0; pr0 < ph; pr0 += PR_CHUNK) {
+        int ta = GM_ROW_EMPTY_LO, tb = -1;                        // span of tile row ((py0 + pr0) << S) + lane
+        {
+          const int ty = (int)((py0 + pr0) << S) + lane;
+          if (ty >= (int)y0 && ty < (int)(y0 + h)) {
+            int ra = (int)x0, rb = (int)(x0 + w) - 1;
+            if (!tile_cull || row_tiles(tc, s0.x, s0.y, ty, (int)x0, (int)(x0 + w), ra, rb)) { ta = ra; tb = rb; }
+          }
+        }
+        const uint32_t nrows = min(PR_CHUNK, ph - pr0), nchunk = nrows * pw;
+        for (uint32_t c0 = 0; c0 < nchunk; c0 += 64) {
+          const uint32_t k = c0 + lane;
+          const uint32_t row = min((uint32_t)(((float)k + 0.5f) * inv_w), nrows - 1u), col = k - row * pw;
+          const uint32_t pcx = px0 + col, pcy = py0 + pr0 + row;
+          uint32_t cm = 0;
+          int lo = 0x7fffffff, hi = -1;                           // hull over the child rows, as preprocess counted
 #pragma unroll
           for (int jr = 0; jr <= M; jr++) {
-            const int ty = (int)(pcy << S) + jr;
-            if (ty < (int)y0 || ty >= (int)(y0 + h)) continue;
-            int ta = (int)x0, tb = (int)(x0 + w) - 1;
-            if (tile_cull && !row_tiles(tc, s0.x, s0.y, ty, (int)x0, (int)(x0 + w), ta, tb)) continue;
-            lo = min(lo, ta); hi = max(hi, tb);
+            const int src = (int)(row << S) + jr;                 // the lane that holds that tile row (< 64)
+            const int ra = __shfl(ta, src), rb = __shfl(tb, src);
+            if (rb >= ra) {
+              lo = min(lo, ra); hi = max(hi, rb);
 #pragma unroll
-            for (int jc = 0; jc <= M; jc++) {
-              const int tx = (int)(pcx << S) + jc;
-              if (tx >= ta && tx <= tb) cm |= 1u << ((jr << S) + jc);
+              for (int jc = 0; jc <= M; jc++) {
+                const int tx = (int)(pcx << S) + jc;
+                if (tx >= ra && tx <= rb) cm |= 1u << ((jr << S) + jc);
+              }
             }
           }
-          pass = hi >= 0 && (int)pcx >= (lo >> S) && (int)pcx <= (hi >> S);
+          const bool pass = k < nchunk && hi >= 0 && (int)pcx >= (lo >> S) && (int)pcx <= (hi >> S);
+          const unsigned long long bal = __ballot(pass);
+          if (pass) {
+            const uint32_t pos = run + lanes_below(bal);
+            if (S == 1) cm = tile_to_quad_mask(cm);
+            EMIT(pos, (pcy * (uint32_t)pgx + pcx) | (cm << GM_KEY_MASK_SHIFT), g);
+          }
+          run += (uint32_t)__popcll(bal);
         }
-        const unsigned long long bal = __ballot(pass);
-        if (pass) {
-          const uint32_t pos = run + lanes_below(bal);
-          if (S == 1) cm = tile_to_quad_mask(cm);
-          EMIT(pos, (pcy * (uint32_t)pgx + pcx) | (cm << GM_KEY_MASK_SHIFT), g);
-        }
-        run += (uint32_t)__popcll(bal);
       }
     }
   }
