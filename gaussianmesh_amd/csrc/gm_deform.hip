@@ -342,8 +342,9 @@ int launch_deform_shade_pre(const RasterArgs& r, GeomState& g, int* radii, int d
   fp.opac = r.opacities;
   fp.splat = g.splat; fp.radii_int = g.radii; fp.radii_out = radii; fp.tiles = g.tiles_touched; fp.bin = g.bin; fp.counters = g.counters; fp.slots = g.slots; fp.coarse = g.coarse;
   fp.clamped = g.clamped; fp.depth_key = g.depth_key;
-  static const size_t lds_extra = [] { const char* e = getenv("GM_DEBUG_DEFORM_LDS"); return e ? (size_t)atoi(e) : (size_t)0; }();
-  const size_t lds_bytes = sizeof(float) * 64 * 48 + lds_extra;
+  // (measured: fewer resident workgroups per CU - 8 / 6 / 5 instead of 12, by padding this allocation - make the kernel 10 / 24 / 52 %
+  // slower and the four-stream loop 6 / 13 / 21 %: it needs every wave it can get to keep enough bytes in flight)
+  const size_t lds_bytes = sizeof(float) * 64 * 48;
   hipLaunchKernelGGL((deform_shade_kernel<true, true>), dim3((N + 63) / 64), dim3(64), lds_bytes, r.stream, N, deg, tri, w, packed, nullptr,
                      nullptr, cov, pos, shs, r.cam_pos, pos_out, cov6_out, rgb_out, nullptr, nullptr, fp);
   GM_LAUNCH_CHECK(r.debug, r.stream);

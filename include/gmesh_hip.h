@@ -323,7 +323,10 @@ int gm_profile_read(const char* stage, double* total_ms, int64_t* launches);
  * sort and the two scatter kernels of the ordering (tools/bucket_stats.py, tools/pipeline_trace.py: 3 x uint64 per workgroup -
  * start / end clock, entries; 2048 records for the bucket sort, then 2048 for the depth partition's scatter, then 4096 for the tile
  * pass's: 3 * 8192 words) write per-wave / per-workgroup records into it; NULL switches the tracing off again.
- * Process-wide, not thread-safe. */
+ * Process-wide, not thread-safe.
+ * One more measurement aid, read once from the environment: GM_DEBUG_STOP_AFTER = deform | depth | dup | tile makes every forward
+ * stop launching after that stage (tools/stage_marginal.sh times the pipelined loop with it: what the remaining stages cost);
+ * the frames are then garbage.  Unset in any real use. */
 void gm_debug_render_trace(void* buffer);
 void gm_debug_bucket_trace(void* buffer);
 
