@@ -154,7 +154,7 @@ struct GeomState {              // per-Gaussian state (P-sized)
   uint32_t* coarse;             // [GM_COARSE_COPIES][GM_COARSE_BINS] coarse histogram of the visible depth keys
   uint32_t* counters;           // [GM_CNT_COUNT] device scalars
   uint32_t* acc;                // [bk_acc_words(P)] accumulators of the partition pass
-  float* grad_acc;              // [P][12] backward accumulators (gm_render.hip GM_ACC_STRIDE): dcolor rgb | sum h | conic-weighted first moments (2) | second moments (3) | pad
+  float* grad_acc;              // [P][12] backward accumulators: dcolor rgb | dmean2D xy | dconic x,y,w | dopacity | pad
   static GeomState from(void* buf, size_t P) {
     char* p = reinterpret_cast<char*>(buf);
     GeomState g;

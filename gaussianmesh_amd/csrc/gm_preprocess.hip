@@ -256,7 +256,7 @@ __device__ __forceinline__ void preprocess_bwd_body(const PreBwdArgs& a, const i
   float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const bool visible = a.radii[idx] > 0;
   // unpack the blend-stage accumulators (all zero for Gaussians no tile ever touched)
-  // grad_acc = dL/dcolor rgb + sum h, the two conic-weighted first moments and the second moments (dx^2, dx dy, dy^2) of h = G dL/dG over all pixels; combine them
+  // grad_acc = dL/dcolor rgb + the moments (1, dx, dy, dx^2, dx dy, dy^2) of h = G dL/dG over all pixels; combine them
   // with this Gaussian's conic / opacity into the reference's accumulators (backward.cu:538-554)
   const float4 acc0 = reinterpret_cast<const float4*>(a.grad_acc)[3 * (size_t)idx];
   const float4 acc1 = reinterpret_cast<const float4*>(a.grad_acc)[3 * (size_t)idx + 1];
@@ -264,13 +264,11 @@ __device__ __forceinline__ void preprocess_bwd_body(const PreBwdArgs& a, const i
   const float dcol[3] = {acc0.x, acc0.y, acc0.z};
   float g2dx = 0.f, g2dy = 0.f, gop = 0.f;
   if (visible) {
-    const float op = a.splat[3 * (size_t)idx + 1].y;
-    // acc1.x / .y: sum h (2a' dx + b' dy), sum h (b' dx + 2c' dy) with (a', b', c') = (-log2e/2 conic.x, -log2e conic.y, -log2e/2 conic.z),
-    // i.e. -log2e times the reference's sum h (conic d) (render_bwd_kernel combines the moments with the conic per pixel row)
-    const float m0 = acc0.w;
-    constexpr float INV_LOG2E = 0.6931471805599453f;
-    g2dx = (0.5f * a.W * INV_LOG2E) * acc1.x;
-    g2dy = (0.5f * a.H * INV_LOG2E) * acc1.y;
+    const float4 s0 = a.splat[3 * (size_t)idx], s1 = a.splat[3 * (size_t)idx + 1];
+    const float cx = s0.z, cy = s0.w, cz = s1.x, op = s1.y;
+    const float m0 = acc0.w, m1x = acc1.x, m1y = acc1.y;
+    g2dx = -(0.5f * a.W) * (cx * m1x + cy * m1y);
+    g2dy = -(0.5f * a.H) * (cz * m1y + cy * m1x);
     gop = (m0 != 0.f) ? m0 / op : 0.f;
   }
   const float gcx = -0.5f * acc1.z, gcy = -0.5f * acc1.w, gcw = -0.5f * m2yy;

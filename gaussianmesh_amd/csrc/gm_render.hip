@@ -415,8 +415,7 @@ int launch_render_fwd(const GeomState& g, const uint2* pairs, ImageState& img, i
 
 // ---------------------------------------------------------------------------------------------
 // Backward blend.
-#define GM_ACC_STRIDE 12   // floats per Gaussian in grad_acc: dcolor rgb (0-2), sum h (3), the conic-weighted first moments
-                           // sum h (2a' dx + b' dy), sum h (b' dx + 2c' dy) (4-5; a', b', c': the exp2-scaled conic), sums h dx^2, h dx dy, h dy^2 (6-8)
+#define GM_ACC_STRIDE 12   // floats per Gaussian in grad_acc: dcolor rgb (0-2), moments of h: 1, dx, dy, dx^2, dx dy, dy^2 (3-8)
 
 #ifndef GM_RENDER_BWD_WPW
 #define GM_RENDER_BWD_WPW 1      // waves per workgroup of the backward blend: 4 (one workgroup per 16-px tile) or 1 (one per 8x8 quadrant)
@@ -444,7 +443,7 @@ struct StagedB {                 // one survivor of the staged batch (one LDS ad
   float4 b;                      // conic.y', opacity, r, g
   float4 c;                      // b, list position (bits), Gaussian id (bits), -
 };
-struct SlotB { float2 xy; uint32_t id; float a, b, c; };   // splat centre, id and exp2-scaled conic (a', b', c') of a phase-2 slot
+struct SlotB { float2 xy; uint32_t id, pad; };   // splat centre and id of a phase-2 slot
 struct BwdLds {                  // per wave: 7.5 KiB
   uint2 qa[RQ_QA];               // candidate ring of the front end: (Gaussian id, list position)
   StagedB st[64];                // staged batch
@@ -534,19 +533,12 @@ __global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_kernel(cons
       s01 = ww * drg + s01;
       s2 = __builtin_fmaf(v.x, dqb[i], s2);
     }
-    const float s5 = dy * s3, s7 = dy * s4, s8 = dy * s5;
-    // first moments leave the row already combined with the conic (dL/dmean2D = -(W/2) sum h (conic d), backward.cu:545-546): for a
-    // needle-shaped splat the two raw moments sum h dx, sum h dy are large and cancel in that product - combined per ROW of eight
-    // pixels the cancellation happens here, at the magnitude of the terms, as in the reference's per-pixel accumulation, instead of
-    // after the float atomics have rounded sums over the whole splat.  (The SECOND moments are the reference's own dL/dconic
-    // accumulators and as order-sensitive as there: a 177-px needle's dL/dcov takes one of three values 3e-4 apart from run to run.)
-    const SlotB sl = B.slot[esc];
-    const float gxp = __builtin_fmaf(2.0f * sl.a, s4, sl.b * s5), gyp = __builtin_fmaf(sl.b, s4, 2.0f * sl.c * s5);
-    const v2f s34 = {s3, gxp};
+    const v2f s34 = {s3, s4};
+    const float s5 = dy * s34.x, s7 = dy * s34.y, s8 = dy * s5;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // every lane has read M before `part` (same storage) is written
     __builtin_amdgcn_wave_barrier();
     float* prow = &B.part[r][es * 9];
-    prow[0] = s01.x; prow[1] = s01.y; prow[2] = s2; prow[3] = s34.x; prow[4] = s34.y; prow[5] = gyp; prow[6] = s6; prow[7] = s7; prow[8] = s8;
+    prow[0] = s01.x; prow[1] = s01.y; prow[2] = s2; prow[3] = s34.x; prow[4] = s34.y; prow[5] = s5; prow[6] = s6; prow[7] = s7; prow[8] = s8;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     float tot = 0.f;
@@ -647,7 +639,6 @@ __global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_kernel(cons
         *mrow = make_float2(wv, oGe * dL_dalpha);                        // M[m][lane]: w ; h = G dL/dG with dL/dG = opacity dL/dalpha
         mslot->xy = make_float2(RA.x, RA.y);                             // slot[m] (uniform address, uniform value)
         mslot->id = __float_as_uint(RC.z);
-        mslot->a = RA.z; mslot->b = RB.x; mslot->c = RA.w;
         mrow += 65; mslot += 1;                                          // the two LDS addresses advance as vector registers of their own:
         m += 1;                                                          // the slot count itself then lives in a scalar register
         if (m == 7) { phase2(7); m = 0; mrow = &B.M[0][lane]; mslot = &B.slot[0]; }
