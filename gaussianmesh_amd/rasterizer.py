@@ -140,6 +140,7 @@ class RasterWorkspace:
         self._bufs = {}
         self._pinned = None
         self._status = None
+        self._event = None
         self.in_flight = None
         self.capacity = 0            # instances the binning buffer holds (sync-free mode)
 
@@ -153,6 +154,13 @@ class RasterWorkspace:
         if self._status is None:
             self._status = torch.zeros((4,), dtype=torch.int32).pin_memory()
         return self._status
+
+    def status_event(self):
+        """the event recorded behind a sync-free frame's status words: one per workspace (a workspace carries one frame at a
+        time, and its event is only recorded again after that frame has been checked and released it)"""
+        if self._event is None:
+            self._event = torch.cuda.Event()
+        return self._event
 
     def get(self, name, nbytes, device):
         b = self._bufs.get(name)
@@ -242,9 +250,14 @@ class PendingForward:
         dispatch order then follows what tiles cost in recent frames.  Never changes an image."""
         self.image_only = bool(image_only)
         if work_hint is not None:
-            need = _lib.lib().gm_work_hint_bytes(self.args["W"], self.args["H"])
-            if work_hint.dtype != torch.int32 or not work_hint.is_contiguous() or work_hint.numel() * 4 < need or work_hint.device != self.args["device"]:
-                raise _lib.GmeshError("work_hint: contiguous int32 tensor of gm_work_hint_bytes(W, H) bytes on the frame's device expected")
+            key = (work_hint.data_ptr(), work_hint.numel(), self.args["W"], self.args["H"], self.args["device"])
+            if key not in _CHECKED_HINTS:                     # (a render loop hands the same buffer over every frame)
+                need = _lib.lib().gm_work_hint_bytes(self.args["W"], self.args["H"])
+                if work_hint.dtype != torch.int32 or not work_hint.is_contiguous() or work_hint.numel() * 4 < need or work_hint.device != self.args["device"]:
+                    raise _lib.GmeshError("work_hint: contiguous int32 tensor of gm_work_hint_bytes(W, H) bytes on the frame's device expected")
+                if len(_CHECKED_HINTS) > 64:
+                    _CHECKED_HINTS.clear()
+                _CHECKED_HINTS.add(key)
         self.work_hint = work_hint
         lib = _lib.lib()
         a = self.args
@@ -258,7 +271,7 @@ class PendingForward:
                 # torch's current stream - the launches take the frame's stream explicitly
                 with _on(device):
                     self._geom(binning, -1, ws.capacity, ws.pinned_status())
-                    self.status_event = torch.cuda.Event()
+                    self.status_event = ws.status_event()
                     self.status_event.record(self.stream)
                 self.binning = binning
                 self.result = (-1, self.color, self.radii, self.geom, binning, self.img)
@@ -339,6 +352,7 @@ class PendingForward:
 
 
 _PREFILTER_MESSAGE = "Point is filtered although prefiltered is set. This shouldn't happen!"      # auxiliary.h:157
+_CHECKED_HINTS = set()     # (pointer, size, W, H, device) of work-hint buffers already validated
 _PINNED_POOL = []          # page-locked int32[1] counters of workspace-less forwards (allocating one per call costs ~0.1 ms)
 _PINNED_STATUS = []        # page-locked int32[4] status words of sync-free forwards without a workspace
 
