@@ -59,6 +59,7 @@ SIGNATURES = {
     "gm_ssim_partials": (i64, [i32, i32, i32]),
     "gm_ssim_fwd": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     "gm_ssim_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
+    "gm_loss_combine": (i32, [vp, i64, f64, f64, f64, vp, vp]),
     "gm_profile_enable": (None, [i32]),
     "gm_profile_reset": (None, []),
     "gm_profile_read": (i32, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]),

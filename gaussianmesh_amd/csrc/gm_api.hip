@@ -456,6 +456,12 @@ int gm_ssim_bwd(const float* img1, const float* img2, const float* dS_dmu1, cons
   return launch_ssim_bwd(img1, img2, dS_dmu1, dS_dE11, dS_dE12, planes, H, W, g_ssim, g_l1, dL_dimg1, reinterpret_cast<hipStream_t>(stream));
 }
 
+int gm_loss_combine(const float* partial, int64_t n_partials, double c_ssim, double c_l1, double offset, float* out, void* stream) {
+  if (n_partials < 0) { set_error("gm_loss_combine: negative count"); return GM_ERR_INVALID_ARG; }
+  if (!out || (n_partials > 0 && !partial)) { set_error("gm_loss_combine: null partial / out"); return GM_ERR_INVALID_ARG; }
+  return launch_loss_combine(partial, (long long)n_partials, c_ssim, c_l1, offset, out, reinterpret_cast<hipStream_t>(stream));
+}
+
 static int fill_act(ActArgs& a, int N, float alpha, const float* bc, const float* dist, const float* scaling, const float* rotation,
                     const float* opacity, const float* v1, const float* v2, const float* v3, const float* normal, const float* r) {
   if (N < 0) { set_error("gm_mesh_activate: negative N"); return GM_ERR_INVALID_ARG; }

@@ -321,6 +321,7 @@ int launch_mesh_rs(int Vm, const float* V0, const float* V1, const int* faces, c
                    float* S, float* state, float* packed, hipStream_t s);
 int launch_ssim_fwd(const float* img1, const float* img2, int planes, int H, int W, float* d_mu1, float* d_e11, float* d_e12,
                     float* partial, hipStream_t s);
+int launch_loss_combine(const float* partial, long long n, double c_ssim, double c_l1, double offset, float* out, hipStream_t s);
 int launch_ssim_bwd(const float* img1, const float* img2, const float* d_mu1, const float* d_e11, const float* d_e12, int planes,
                     int H, int W, const float* g_ssim, const float* g_l1, float* dL_dimg1, hipStream_t s);
 struct ActArgs {                 // mesh-bound parameter -> rasterizer-input map (gm_train.hip)

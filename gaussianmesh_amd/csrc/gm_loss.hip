@@ -259,6 +259,31 @@ __global__ __launch_bounds__(LS_THREADS) void ssim_bwd_kernel(const float* __res
   }
 }
 
+// value = offset + c_ssim * sum partial[.][0] + c_l1 * sum partial[.][1], summed in double by one workgroup: the fused loss's scalar
+// without the four small launches (reduce, dot, add, cast) the tensor library spends on it
+__global__ __launch_bounds__(1024) void loss_combine_kernel(const float* __restrict__ partial, long long n, double c_ssim, double c_l1,
+                                                            double offset, float* __restrict__ out) {
+  __shared__ double red[2][16];
+  double a = 0.0, b = 0.0;
+  for (long long i = threadIdx.x; i < n; i += 1024) { a += (double)partial[2 * i]; b += (double)partial[2 * i + 1]; }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d); b += __shfl_xor(b, d); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sa = 0.0, sb = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { sa += red[0][w]; sb += red[1][w]; }
+    out[0] = (float)(offset + c_ssim * sa + c_l1 * sb);
+  }
+}
+
+int launch_loss_combine(const float* partial, long long n, double c_ssim, double c_l1, double offset, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(1024), 0, s, partial, n, c_ssim, c_l1, offset, out);
+  GM_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_ssim_fwd(const float* img1, const float* img2, int planes, int H, int W, float* d_mu1, float* d_e11, float* d_e12,
                     float* partial, hipStream_t s) {
   StageScope sc(ST_LOSS, s);

@@ -121,12 +121,16 @@ class _Photometric(torch.autograd.Function):
         a, b, maps, partial = _fwd(image, gt, ctx.needs_input_grad[0])
         lam, n = float(lambda_dssim), a.numel()
         planes, _ = _planes(a)
-        val, grad = _coefs(lam, n, planes, a.device)
-        total = partial.view(-1, 2).sum(dim=0, dtype=torch.float64)            # {sum ssim, sum |a-b|}
+        _, grad = _coefs(lam, n, planes, a.device)
         ctx.shape, ctx.planes = image.shape, planes
         if maps is not None:
             ctx.save_for_backward(a, b, maps, grad)
-        return (torch.dot(total, val) + lam).float()
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        flat = partial.reshape(-1, 2)
+        with torch.cuda.device(a.device):                                      # lam + <(-lam/n, (1-lam)/n), (sum ssim, sum |a-b|)>, one launch
+            _lib.check(_lib.lib().gm_loss_combine(flat.data_ptr(), flat.shape[0], -lam / n, (1.0 - lam) / n, lam, out.data_ptr(),
+                                                  torch.cuda.current_stream(a.device).cuda_stream))
+        return out
 
     @staticmethod
     def backward(ctx, g):

@@ -264,12 +264,16 @@ int gm_cov_to_scale_rot(int N, const float* cov, float* scales, float* rots, voi
  * all NULL) receive the per-pixel partial derivatives gm_ssim_bwd needs.
  * gm_ssim_bwd: dL_dimg1 = g_ssim[plane] * d(sum of ssim map)/d img1 + g_l1[0] * sign(img1 - img2); g_ssim (device float
  * [planes]) and g_l1 (device float [1], may be NULL) carry the upstream gradient times 1/count, so no host
- * synchronisation is needed between forward and backward. */
+ * synchronisation is needed between forward and backward.
+ * gm_loss_combine: out[0] = offset + c_ssim * sum_i partial[i][0] + c_l1 * sum_i partial[i][1] (sums in double, one launch):
+ * with c_ssim = -lambda/count, c_l1 = (1 - lambda)/count, offset = lambda this is the training loss
+ * (1 - lambda) * l1_loss + lambda * (1 - ssim) of train_mesh_gaussian.py:92-94 as a device scalar. */
 int64_t gm_ssim_partials(int planes, int H, int W);
 int gm_ssim_fwd(const float* img1, const float* img2, int planes, int H, int W, float* dS_dmu1, float* dS_dE11, float* dS_dE12,
                 float* partial, void* stream);
 int gm_ssim_bwd(const float* img1, const float* img2, const float* dS_dmu1, const float* dS_dE11, const float* dS_dE12, int planes,
                 int H, int W, const float* g_ssim, const float* g_l1, float* dL_dimg1, void* stream);
+int gm_loss_combine(const float* partial, int64_t n_partials, double c_ssim, double c_l1, double offset, float* out, void* stream);
 
 /* Training-loop fusions around the rasterizer ("MeshBasedGaussianModel.get_xyz ... fused into the op").
  * gm_mesh_activate_fwd: raw parameters -> rasterizer inputs in one pass, replacing the Jittor elementwise chains of
