@@ -202,6 +202,10 @@ def main():
     ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams the frame loop alternates over (frame i runs on stream i %% streams): consecutive frames are "
                          "independent, so frame i+1's per-Gaussian stages overlap the low-occupancy tail of frame i's blend")
+    ap.add_argument("--begin-ahead", type=int, default=2, help="frames whose first half (deformation .. depth order) is issued before the "
+                    "oldest of them is completed (emission .. blend): 2 fills the four streams sooner after the barrier that opens a timed "
+                    "region than 1 (20-step regions, three runs each: 4389-4504 / 4540-4554 / 4039-4518 frames/s with 1 / 2 / 3; no "
+                    "difference in steady state)")
     ap.add_argument("--status-lag", type=int, default=6, help="sync-free loop: the host reads a frame's status words this many frames "
                     "after completing it (how far the host may run ahead of the GPU).  With four frames in flight a lag of 3 still "
                     "makes the host wait for a frame that is running (4470 frames/s); 6 or more never does (4550-4570)")
@@ -288,7 +292,8 @@ def main():
     nstreams = max(1, args.streams)
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
     lag = max(1, args.status_lag)
-    nws = nstreams + 1 + lag                    # frame i+1 is begun before frame i is completed, and frame i's status is read `lag` frames later
+    ahead = max(1, args.begin_ahead)
+    nws = nstreams + ahead + lag                # frames i+1 .. i+ahead are begun before frame i is completed, and frame i's status is read `lag` frames later
     workspaces = [Rz.RasterWorkspace(growth=1.5) for _ in range(nws)]
     torch.cuda.synchronize()
 
@@ -301,12 +306,13 @@ def main():
 
     def step(i):
         """Issue frame i's first half (deform + colour + preprocess + depth order) on stream i % nstreams, THEN complete frame
-        i-1.  Default: sync-free completion - the instance count stays on the device (binning buffer at the workspace's
-        capacity, learned during warm-up), the host only reads frame i-2's status words, which landed long ago.
-        --exact-count: the host waits for frame i-1's count (one 4-byte read-back, hidden behind frame i's first half)."""
+        i - ahead (--begin-ahead, default 2).  Default: sync-free completion - the instance count stays on the device (binning
+        buffer at the workspace's capacity, learned during warm-up), the host only reads the status words of frames completed
+        `lag` steps ago, which landed long before.
+        --exact-count: the host waits for the completed frame's count (one 4-byte read-back, hidden behind frame i's first half)."""
         torch.cuda.set_stream(streams[i % nstreams])     # (not `with torch.cuda.stream(...)`: entering and leaving the context costs the
         pending[i] = step_on_stream(i, workspaces[i % nws], begin_only=True)   # host ~20 us per frame; drain() restores the default stream)
-        prev = pending.pop(i - 1, None)
+        prev = pending.pop(i - ahead, None)
         return finish(prev) if prev is not None else None
 
     def verify(h):
