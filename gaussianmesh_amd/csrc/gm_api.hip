@@ -345,6 +345,7 @@ void* gm_image_field(void* image_buffer, int W, int H, const char* name) {
   if (!strcmp(name, "final_T")) return s.final_T;
   if (!strcmp(name, "n_contrib")) return s.n_contrib;
   if (!strcmp(name, "ranges")) return s.ranges;
+  if (!strcmp(name, "tile_order")) return s.tile_order;
   return nullptr;
 }
 void* gm_binning_field(void* binning_buffer, int64_t R, int W, int H, int emission_policy, const char* name) {

@@ -370,13 +370,14 @@ __global__ __launch_bounds__(WAVES * 64, 4) void bk_scatter_kernel(const void* _
                                                                  const uint2* __restrict__ ord_ranges, int ord_tiles,
                                                                  uint32_t* __restrict__ ord_out, const uint32_t* __restrict__ dmap,
                                                                  const uint32_t* __restrict__ counters, uint32_t* __restrict__ ord_hint,
-                                                                 uint32_t* __restrict__ ord_epoch, unsigned long long* __restrict__ trace) {
+                                                                 uint32_t* __restrict__ ord_epoch, unsigned long long* __restrict__ trace,
+                                                                 uint32_t* __restrict__ ord_scratch) {
   constexpr int ND = 1 << DB, THREADS = WAVES * 64, TILE = WAVES * ROUNDS * 64;
   const unsigned long long t_begin = trace ? wall_clock64() : 0ull;      // (tools/pipeline_trace.py: per-workgroup start / end)
   if (!MSD && ord_out && blockIdx.x == gridDim.x - 1) {      // the launch's extra workgroup: dispatch order of the blend kernels
     __shared__ uint32_t o_cnt[256];                          // from the ranges the scan kernel has just published
     __shared__ uint32_t o_wsum[WAVES];
-    tile_order_block<THREADS>(ord_ranges, ord_tiles, ord_out, o_cnt, o_wsum, ord_hint, ord_epoch);
+    tile_order_block<THREADS>(ord_ranges, ord_tiles, ord_out, o_cnt, o_wsum, ord_hint, ord_epoch, ord_scratch);
     return;
   }
   // wcnt: per-wave running digit counts (<= 1024) -> per-wave exclusive offsets (< TILE <= 16384); once every key knows its
@@ -844,7 +845,7 @@ int launch_depth_order(GeomState& g, int P, int debug, hipStream_t s, int* num_r
                      g.acc, g.bucket_start, g.counters, nullptr, 0u);
   GM_LAUNCH_CHECK(debug, s);
   hipLaunchKernelGGL((bk_scatter_kernel<true, DB, WAVES, ROUNDS>), dim3(nblk), dim3(WAVES * 64), 0, s, g.depth_key, g.dpairs[1], (uint32_t)P, nullptr, ds,
-                     g.hist, nullptr, 0u, nullptr, 0, nullptr, g.dmap, g.counters, nullptr, nullptr, scatter_trace(true));
+                     g.hist, nullptr, 0u, nullptr, 0, nullptr, g.dmap, g.counters, nullptr, nullptr, scatter_trace(true), nullptr);
   GM_LAUNCH_CHECK(debug, s);
   hipLaunchKernelGGL(bucket_sort_kernel, dim3(1 << DB), dim3(BK_THREADS), 0, s, g.counters, g.bmap, g.bucket_start, g.dpairs[1], g.dpairs[0], g.order,
                      g.tiles_touched, g.bin, g.bin_sorted, g.chunk_inst, g_bucket_trace);
@@ -855,7 +856,7 @@ int launch_depth_order(GeomState& g, int P, int debug, hipStream_t s, int* num_r
 // One stable pass over the pair stream b.pairs[from] -> b.pairs[from ^ 1].  b.acc must be zero on entry.
 template <int DB, int WAVES>
 static int tile_pass(BinningState& b, GeomState& g, int from, uint32_t n, const uint32_t* n_dev, DigitSpec ds, uint2* ranges, uint32_t nranges,
-                     bool zero_acc_after, uint32_t* order_out, uint32_t* hint, uint32_t* epoch, int debug, hipStream_t s) {
+                     bool zero_acc_after, uint32_t* order_out, uint32_t* hint, uint32_t* epoch, uint32_t* order_scratch, int debug, hipStream_t s) {
   constexpr int ROUNDS = GM_TP_ROUNDS;
   constexpr uint32_t TILE = WAVES * ROUNDS * 64;
   const uint32_t nblk = (n + TILE - 1) / TILE;
@@ -868,7 +869,7 @@ static int tile_pass(BinningState& b, GeomState& g, int from, uint32_t n, const 
   GM_LAUNCH_CHECK(debug, s);
   hipLaunchKernelGGL((bk_scatter_kernel<false, DB, WAVES, ROUNDS>), dim3(nblk + (order_out ? 1u : 0u)), dim3(WAVES * 64), 0, s, b.pairs[from],
                      b.pairs[from ^ 1], n, n_dev, ds, b.hist, zero_acc_after ? b.acc : nullptr, (uint32_t)bk_acc_words(n), ranges,
-                     (int)nranges, order_out, nullptr, nullptr, hint, epoch, nblk <= 4096u ? scatter_trace(false) : nullptr);
+                     (int)nranges, order_out, nullptr, nullptr, hint, epoch, nblk <= 4096u ? scatter_trace(false) : nullptr, order_scratch);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }
@@ -890,12 +891,12 @@ int launch_tile_sort(GeomState& g, BinningState& b, ImageState& img, size_t n, c
     *order_done = true;                 // the scatter launch carries the dispatch-order workgroup
     if (n <= (size_t(1) << 19))
       return tile_pass<GM_BUCKET_BITS, 4>(b, g, 0, (uint32_t)n, n_dev, DigitSpec{0u, 0u, (1u << GM_BUCKET_BITS) - 1u}, img.ranges, (uint32_t)tiles,
-                                          false, img.tile_order, work_hint, img.epoch, debug, s);
+                                          false, img.tile_order, work_hint, img.epoch, img.tile_work, debug, s);
     return tile_pass<GM_BUCKET_BITS, GM_TILE_PASS_WAVES>(b, g, 0, (uint32_t)n, n_dev, DigitSpec{0u, 0u, (1u << GM_BUCKET_BITS) - 1u}, img.ranges, (uint32_t)tiles,
-                                         false, img.tile_order, work_hint, img.epoch, debug, s);
+                                         false, img.tile_order, work_hint, img.epoch, img.tile_work, debug, s);
   }
-  if (int rc = tile_pass<8, 4>(b, g, 0, (uint32_t)n, n_dev, DigitSpec{0u, 0u, 0xFFu}, nullptr, 0u, true, nullptr, nullptr, nullptr, debug, s)) return rc;
-  return tile_pass<8, 4>(b, g, 1, (uint32_t)n, n_dev, DigitSpec{0u, 8u, 0xFFu}, nullptr, 0u, false, nullptr, nullptr, nullptr, debug, s);
+  if (int rc = tile_pass<8, 4>(b, g, 0, (uint32_t)n, n_dev, DigitSpec{0u, 0u, 0xFFu}, nullptr, 0u, true, nullptr, nullptr, nullptr, nullptr, debug, s)) return rc;
+  return tile_pass<8, 4>(b, g, 1, (uint32_t)n, n_dev, DigitSpec{0u, 8u, 0xFFu}, nullptr, 0u, false, nullptr, nullptr, nullptr, nullptr, debug, s);
 }
 
 }  // namespace gm

@@ -194,7 +194,8 @@ struct ImageState {             // per-pixel / per-tile state
   uint32_t* n_contrib;          // [H*W]
   uint2* ranges;                // [tiles]
   uint32_t* tile_order;         // [tiles] list tiles by descending list length (the forward blend's dispatch order)
-  uint32_t* tile_work;          // [tiles] deepest contributor (max n_contrib) among the pixels of a list tile's area
+  uint32_t* tile_work;          // [tiles] deepest contributor (max n_contrib) among the pixels of a list tile's area (backward); during a forward: scratch of
+                                //         the dispatch-order sort (gm_tile_order.h)
   uint32_t* tile_order_bwd;     // [tiles] list tiles by descending tile_work (the backward blend's dispatch order)
   uint32_t* epoch;              // [1] frame number of the work hint this frame's blend tags its entries with (gm_tile_order.h)
   static ImageState from(void* buf, int W, int H) {

@@ -68,10 +68,11 @@ __device__ __forceinline__ uint32_t quadrant_bit(int tx, int ty, int wave) {
 
 // Dispatch order of the blend kernels (gm_tile_order.h) as a launch of its own: only when the tile pass did not produce it.
 __global__ __launch_bounds__(1024) void tile_order_kernel(const uint2* __restrict__ ranges, int tiles, uint32_t* __restrict__ order,
-                                                          uint32_t* __restrict__ hint, uint32_t* __restrict__ epoch) {
+                                                          uint32_t* __restrict__ hint, uint32_t* __restrict__ epoch,
+                                                          uint32_t* __restrict__ scratch) {
   __shared__ uint32_t cnt[256];
   __shared__ uint32_t wsum[16];
-  tile_order_block<1024>(ranges, tiles, order, cnt, wsum, hint, epoch);
+  tile_order_block<1024>(ranges, tiles, order, cnt, wsum, hint, epoch, scratch);
 }
 
 // Dispatch order of the BACKWARD blend.  What a quadrant's wave has to walk is known exactly after the forward: the list
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(1024) void tile_order_work_kernel(const uint32_t* _
 
 int launch_tile_order(ImageState& img, int tiles, uint32_t* work_hint, int debug, hipStream_t s) {
   StageScope sc(ST_RANGES, s);
-  hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, img.ranges, tiles, img.tile_order, work_hint, img.epoch);
+  hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, img.ranges, tiles, img.tile_order, work_hint, img.epoch, img.tile_work);   // tile_work: scratch here, the backward fills it anew
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }

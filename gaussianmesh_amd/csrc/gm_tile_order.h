@@ -8,16 +8,25 @@
 
 namespace gm {
 
-// key(t): work measure of list tile t (list length for the forward, the deepest contributor of its pixels for the backward)
+// key(t): work measure of list tile t (list length for the forward, the deepest contributor of its pixels for the backward).
+// scratch [tiles] (may be null ONLY when key(t) cannot change while this runs): a tile's bucket and its rank inside the bucket are
+// taken ONCE and parked there between the counting and the placement pass.  With the work hint the key is read from memory that
+// the blend kernels of other frames update concurrently; evaluated twice, the two passes could disagree, and a counting sort whose
+// passes disagree is no permutation - list tiles dispatched twice and others never (found by the two-rank bench test once the loop
+// ran two first halves ahead: a frame in ~10 came back with a few tiles unrendered).
 template <int THREADS, class Key>
 __device__ __forceinline__ void tile_order_by(Key key, int tiles, uint32_t* __restrict__ order,
-                                              uint32_t* cnt /*[256] shared*/, uint32_t* wsum /*[THREADS / 64] shared*/) {
+                                              uint32_t* cnt /*[256] shared*/, uint32_t* wsum /*[THREADS / 64] shared*/,
+                                              uint32_t* __restrict__ scratch = nullptr) {
   static_assert(THREADS >= 256 && THREADS % 64 == 0, "tile_order_block: 256 or more threads");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x < 256) cnt[threadIdx.x] = 0;
   __syncthreads();
   auto bucket = [&](int t) { return 255u - min(key(t) >> 5, 255u); };   // bucket 0 = most work
-  for (int t = threadIdx.x; t < tiles; t += THREADS) atomicAdd(&cnt[bucket(t)], 1u);
+  for (int t = threadIdx.x; t < tiles; t += THREADS) {
+    const uint32_t b = bucket(t), r = atomicAdd(&cnt[b], 1u);
+    if (scratch) scratch[t] = b | (r << 8);                             // (tiles <= 65536: the rank fits 24 bits)
+  }
   __syncthreads();
   uint32_t v = threadIdx.x < 256 ? cnt[threadIdx.x] : 0u, incl = v;
 #pragma unroll
@@ -32,7 +41,11 @@ __device__ __forceinline__ void tile_order_by(Key key, int tiles, uint32_t* __re
   __syncthreads();
   if (threadIdx.x < 256) cnt[threadIdx.x] = woff + incl - v;          // exclusive start of each bucket
   __syncthreads();
-  for (int t = threadIdx.x; t < tiles; t += THREADS) order[atomicAdd(&cnt[bucket(t)], 1u)] = (uint32_t)t;
+  if (scratch) {                                                        // same thread, same t as in the counting pass: its own words
+    for (int t = threadIdx.x; t < tiles; t += THREADS) { const uint32_t p = scratch[t]; order[cnt[p & 255u] + (p >> 8)] = (uint32_t)t; }
+  } else {
+    for (int t = threadIdx.x; t < tiles; t += THREADS) order[atomicAdd(&cnt[bucket(t)], 1u)] = (uint32_t)t;
+  }
 }
 
 // Work hint (optional, gm_forward_1_geom's work_hint): list length is a poor predictor of a tile's blend time - a 12 k-entry
@@ -41,13 +54,14 @@ __device__ __forceinline__ void tile_order_by(Key key, int tiles, uint32_t* __re
 // good one.  hint[0] counts frames; hint[1 + t] = (frame & 0xFFF) << 20 | work of list tile t, written by the forward blend
 // with atomicMax (work = entries evaluated by the busiest of the tile's waves).  Entries older than GM_HINT_MAX_AGE frames are
 // ignored and cleared.  Frames in flight on other streams read and write the same buffer concurrently: whatever they see only
-// moves work in time.
+// moves work in time - as long as every tile's key is read ONCE (tile_order_by's scratch).
 #define GM_HINT_MAX_AGE 64u
 #define GM_HINT_WORK_MASK 0xFFFFFu
 template <int THREADS>
 __device__ __forceinline__ void tile_order_block(const uint2* __restrict__ ranges, int tiles, uint32_t* __restrict__ order,
                                                  uint32_t* cnt /*[256] shared*/, uint32_t* wsum /*[THREADS / 64] shared*/,
-                                                 uint32_t* __restrict__ hint = nullptr, uint32_t* __restrict__ epoch_out = nullptr) {
+                                                 uint32_t* __restrict__ hint = nullptr, uint32_t* __restrict__ epoch_out = nullptr,
+                                                 uint32_t* __restrict__ scratch = nullptr /*[tiles], required with a hint*/) {
   if (!hint) {
     tile_order_by<THREADS>([&](int t) { const uint2 r = ranges[t]; return r.y - r.x; }, tiles, order, cnt, wsum);
     return;
@@ -69,7 +83,7 @@ __device__ __forceinline__ void tile_order_block(const uint2* __restrict__ range
     const uint32_t len = r.y - r.x, v = hint[1 + t];
     if (len == 0u) return 0u;
     return v != 0u ? min(((v & GM_HINT_WORK_MASK) + 1u) << 3, 8191u) : min(len, 2040u);
-  }, tiles, order, cnt, wsum);
+  }, tiles, order, cnt, wsum, scratch);
 }
 
 }  // namespace gm

@@ -140,7 +140,8 @@ int gm_mark_visible(int P, const float* means3D, const float* viewmatrix, const 
  *            "radii" int32[P] (internal copy), "tiles_touched" uint32[P], "cov3D" float[P][6],
  *            "clamped" uint8[P] (bit ch set = channel ch clamped), "order" uint32[V] (ids of the V visible Gaussians
  *            in (depth, id) order; V = "bucket_start"[2048]), "bucket_start" uint32[2049]
- *   image:   "final_T" float[H*W], "n_contrib" uint32[H*W], "ranges" uint32[T][2]
+ *   image:   "final_T" float[H*W], "n_contrib" uint32[H*W], "ranges" uint32[T][2], "tile_order" uint32[T] (the forward blend's
+ *            dispatch order: a permutation of the list tiles)
  *   binning: "pairs" uint32[R][2] = (list tile id | child mask << 16, Gaussian id) per instance, sorted by tile then
  *            (depth, id): column 1 is the reference's point_list, column 0 its sorted tile keys (child mask: policy 0/1
  *            = 1; policy 2 = the 4 x 4 8-pixel quadrants of the 32-px list tile, bit 4 qy + qx; policy 3 = the 4 x 4

@@ -863,6 +863,42 @@ def test_work_hint_never_changes_an_image(W, H, policy):
         assert hv.size * 4 == lib.gm_work_hint_bytes(W, H)
 
 
+def test_dispatch_order_is_a_permutation_while_the_work_hint_changes_under_it():
+    """The work hint is shared by the frames in flight of a view stream: other frames' blend kernels update it while a frame's
+    dispatch order is sorted from it.  Here a second stream rewrites the hint's entries with random costs for as long as the
+    frames run; every frame's dispatch order must be a permutation of the list tiles and its image that of a frame without hint.
+    (The sort used to read a tile's key in both of its passes; when the two reads disagreed, tiles were dispatched twice and
+    others never - found by the two-rank bench test, a frame in ~10.)"""
+    from gpu_utils import T
+    from gaussianmesh_amd import rasterizer as Rz, scenes
+    lib = Rz._lib.lib()
+    for (W, H, policy) in ((640, 400, 2), (1600, 1000, 0)):         # one-pass tile sort (order from the scatter launch) / tile_order_kernel
+        sc = scenes.make_cloud(6000, seed=8, scale_lo=0.01, scale_hi=0.2)
+        bg = T(np.array([0.2, 0.3, 0.4], np.float32))
+        cam = scenes.orbit_camera(1, 9, W, H, radius=7.0)
+        args = (bg, T(sc["means"]), None, T(sc["opac"]), T(sc["scales"]), T(sc["rots"]), 1.0, None, T(cam["view"]), T(cam["proj"]), cam["tanx"],
+                cam["tany"], H, W, T(sc["shs"]), 3, T(cam["campos"]), False, False)
+        _, ref, *_ = Rz.rasterize_forward_begin(*args, emission_policy=policy).finish()
+        hint = Rz.new_work_hint(W, H, bg.device)
+        tiles = hint.numel() - 1 if policy == 0 else ((W + 31) // 32) * ((H + 31) // 32)
+        side = torch.cuda.Stream()
+        noise = [torch.randint(0, 1 << 20, (hint.numel() - 1,), dtype=torch.int32, device=bg.device) for _ in range(8)]
+        bad_perm = bad_img = 0
+        for k in range(8):
+            noise[k] |= 1 << 20                                     # (a plausible frame tag, so that no entry is discarded as stale)
+        for it in range(60):
+            nr, color, _, _, _, img = Rz.rasterize_forward_begin(*args, emission_policy=policy).finish(work_hint=hint)
+            with torch.cuda.stream(side):                           # rewrites of the costs racing with the frame's second half, which the
+                for k in range(24):                                 # host has just enqueued (emission, tile pass + dispatch order, blend)
+                    hint[1:].copy_(noise[(it + k) % 8])
+            torch.cuda.synchronize()
+            off = lib.gm_image_field(img.data_ptr(), W, H, b"tile_order") - img.data_ptr()
+            order = img[off:off + 4 * tiles].view(torch.int32).cpu().numpy()
+            bad_perm += int(not np.array_equal(np.sort(order), np.arange(tiles)))
+            bad_img += int(not torch.equal(color, ref))
+        assert bad_perm == 0 and bad_img == 0, (W, H, policy, bad_perm, bad_img)
+
+
 def test_splat_centred_on_a_pixel_is_not_dropped(oracle):
     """Round 3's forward evaluates the exponent as a polynomial on the matrix core (|error| ~1e-5) and therefore clamps it at 0
     where the reference skips `power > 0` (RAST/forward.cu:338-339: a guard against its own rounding at power = -0 +- 1e-7).
