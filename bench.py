@@ -526,8 +526,15 @@ def main():
                            "traffic_source": "static: profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this "
                                              "workload; counters cannot be read inside the timed run)",
                            "algorithmic_bytes": ab, "avg_ms": per[dom],
-                           "note": "the blend kernel is bound by vector-ALU issue, not by HBM (DESIGN.md section 4); the HBM figure is "
-                                   "reported because the contract asks for it"}
+                           "note": ("the blend kernel is bound by vector-ALU issue, not by HBM (DESIGN.md section 4); the HBM figure is "
+                                    "reported because the contract asks for it") if dom == "render" else
+                                   ("stage = the per-vertex (R, S) kernel + the fused deformation / SH colour / preprocess kernel, a streaming "
+                                    "kernel bound by HBM (rocprof: 77 us of the stage for 346 MB); since the blend dropped below 0.09 ms it "
+                                    "is the longest stage of a frame; the blend's own figure is under stage_roofline") if dom == "deform" else
+                                   "longest stage of the frame"}
+        # the other stages, same definition (algorithmic bytes of the stage / its time): the blend is the vector-ALU-bound one
+        out["stage_roofline"] = {st: round(algorithmic_bytes(bytes_key(st), P, V, Rn, W, H, Vm, list_tiles=list_tiles) / (per[st] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                 for st in per if st in ("deform", "depth_sort", "duplicate", "tile_sort", "render")}
         out["stage_ms"] = {k: round(v, 4) for k, v in per.items()}
         out["scene"] = {"P": P, "V": V, "R": Rn}
         tot_bytes = sum(algorithmic_bytes(bytes_key(s), P, V, Rn, W, H, Vm, list_tiles=list_tiles) for s in per)
