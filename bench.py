@@ -358,12 +358,12 @@ def main():
     if world > 1 or batch > 0:
         if args.analytic_rs:
             pipe = multiview.MeshStatePipe(lambda i, out: frame_table(i % F, out), (Vm, 24), max(1, batch), dev, src=0,
-                                           frames_in_flight=nstreams + lag + 1)
+                                           frames_in_flight=nws)
         else:
             def produce_positions(b, buf):           # one gather launch per batch on the pipe's stream (rank 0 only)
                 idx = (torch.arange(buf.shape[0], device=dev) + b * buf.shape[0]) % F
                 torch.index_select(v1_frames, 0, idx, out=buf)
-            pipe = multiview.MeshStatePipe(None, (Vm, 3), max(1, batch), dev, src=0, frames_in_flight=nstreams + lag + 1,
+            pipe = multiview.MeshStatePipe(None, (Vm, 3), max(1, batch), dev, src=0, frames_in_flight=nws,
                                            produce_batch=produce_positions)
     exchange_bytes = Vm * (96 if args.analytic_rs else 12)
 
