@@ -899,6 +899,73 @@ def test_dispatch_order_is_a_permutation_while_the_work_hint_changes_under_it():
         assert bad_perm == 0 and bad_img == 0, (W, H, policy, bad_perm, bad_img)
 
 
+def test_pipelined_deformed_loop_renders_every_frame_exactly():
+    """bench.py's frame loop in small: mesh-driven frames pipelined over four streams, sync-free, image-only, one work hint shared by
+    all of them, the first halves of two frames issued ahead of the oldest frame's completion - and EVERY frame compared, bit for
+    bit, with the image the synchronous operator renders for its (mesh frame, camera)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from gpu_utils import T
+    from gaussianmesh_amd import rasterizer as Rz, scenes
+    from gaussianmesh_amd.deform import mesh_rs_packed, vertex_face_adjacency
+    P, W, H, F, nstreams, ahead, lag, frames = 20000, 320, 200, 8, 4, 2, 3, 640
+    host = bench.build_scene(P, W, H, F)
+    g = {k: T(host[k]) for k in ("weights", "pos", "cov", "opac", "shs", "verts")}
+    g["tri"] = T(host["tri"], dtype=torch.int32)
+    faces = T(host["faces"], dtype=torch.int32)
+    off, adj = vertex_face_adjacency(host["faces"], host["verts"].shape[0])
+    adjacency = (torch.tensor(off, device="cuda"), torch.tensor(adj, device="cuda"))
+    v1 = [T(np.ascontiguousarray(host["mesh"][t][:, 0:3])) for t in range(F)]
+    bg = torch.zeros(3, device="cuda")
+    cams = []
+    for k in range(F):
+        cam = scenes.orbit_camera(k, F, W, H)
+        cams.append((T(cam["view"]), T(cam["proj"]), cam["tanx"], cam["tany"], T(cam["campos"])))
+
+    def begin(i, ws=None):
+        t, c = i % F, cams[(3 * i) % F]                    # mesh frame and camera move at different rates: 8 x 8 combinations
+        packed = mesh_rs_packed(g["verts"], v1[t], faces, adjacency)
+        return Rz.forward_deformed_begin(bg, g["tri"], g["weights"], packed, g["cov"], g["pos"], g["shs"], g["opac"], c[0], c[1], c[2], c[3],
+                                         H, W, 3, c[4], False, workspace=ws, want_count=ws is None)
+    ref = {}
+    for i in range(F * F):
+        ref[(i % F, (3 * i) % F)] = begin(i).finish()[1].clone()
+    hint = Rz.new_work_hint(W, H, bg.device)
+    streams = [torch.cuda.Stream() for _ in range(nstreams)]
+    nws = nstreams + ahead + lag
+    ws = [Rz.RasterWorkspace() for _ in range(nws)]
+    for k, w in enumerate(ws):                              # size the binning buffers: every combination once through the exact path
+        for i in range(F * F):
+            h = begin(i, w)
+            h.finish(work_hint=hint)
+    torch.cuda.synchronize()
+    pending, done, bad = {}, [], []
+
+    def complete(j):
+        h = pending.pop(j)
+        done.append((j, h, h.finish(sync_free=True, image_only=True, work_hint=hint)[1]))
+
+    def verify():
+        j, h, img = done.pop(0)
+        ok, _ = h.check()
+        assert ok, "frame %d outgrew a buffer sized for the heaviest frame" % j
+        if not torch.equal(img, ref[(j % F, (3 * j) % F)]):
+            bad.append(j)
+    for i in range(frames):
+        with torch.cuda.stream(streams[i % nstreams]):
+            pending[i] = begin(i, ws[i % nws])
+        if i - ahead in pending:
+            complete(i - ahead)
+        while len(done) > lag:
+            verify()
+    for j in sorted(pending):
+        complete(j)
+    while done:
+        verify()
+    assert not bad, "%d of %d pipelined frames differ from the synchronous render: %s" % (len(bad), frames, bad[:8])
+
+
 def test_splat_centred_on_a_pixel_is_not_dropped(oracle):
     """Round 3's forward evaluates the exponent as a polynomial on the matrix core (|error| ~1e-5) and therefore clamps it at 0
     where the reference skips `power > 0` (RAST/forward.cu:338-339: a guard against its own rounding at power = -0 +- 1e-7).
