@@ -218,6 +218,7 @@ class PendingForward:
     def __init__(self, **kw):
         self.__dict__.update(kw)
         self.status_event = None
+        self.checked = None              # (fitted, num_rendered) once check() has consumed the status
         self.result = None
         self.known_count = None
         self.image_only = False
@@ -263,7 +264,7 @@ class PendingForward:
         a = self.args
         device = a["device"]
         ws = self.workspace
-        if sync_free and ws is not None and ws.capacity > 0 and a["P"] > 0 and self.status_event is None:
+        if sync_free and ws is not None and ws.capacity > 0 and a["P"] > 0 and self.status_event is None and self.checked is None:
             nbytes = lib.gm_binning_bytes(ws.capacity)
             binning = ws._bufs.get("binning")
             if binning is not None and binning.device == device and binning.numel() >= nbytes:
@@ -277,7 +278,7 @@ class PendingForward:
                 self.result = (-1, self.color, self.radii, self.geom, binning, self.img)
                 return self.result
         with _on(device), torch.cuda.stream(self.stream):
-            if sync_free and ws is None and capacity > 0 and a["P"] > 0 and self.status_event is None:
+            if sync_free and ws is None and capacity > 0 and a["P"] > 0 and self.status_event is None and self.checked is None:
                 binning = torch.empty((lib.gm_binning_bytes(capacity),), dtype=torch.uint8, device=device)
                 self.status_host = _PINNED_STATUS.pop() if _PINNED_STATUS else torch.zeros((4,), dtype=torch.int32).pin_memory()
                 self._geom(binning, -1, capacity, self.status_host)      # the blend kernel writes the status words itself
@@ -286,7 +287,7 @@ class PendingForward:
                 self.capacity = capacity
                 self.result = (-1, self.color, self.radii, self.geom, binning, self.img)
                 return self.result
-            if sync_free and ws is not None and ws.capacity > 0 and a["P"] > 0 and self.status_event is None:
+            if sync_free and ws is not None and ws.capacity > 0 and a["P"] > 0 and self.status_event is None and self.checked is None:
                 binning = ws.get("binning", lib.gm_binning_bytes(ws.capacity), device)
                 self._geom(binning, -1, ws.capacity, ws.pinned_status())
                 self.status_event = torch.cuda.Event()
@@ -326,29 +327,42 @@ class PendingForward:
 
     def check(self):
         """After finish(sync_free=True): wait for the frame's status and return (fitted, num_rendered).  When the instance
-        count exceeded the workspace's capacity the image is the background; finish() renders the frame again, exactly."""
+        count exceeded the workspace's capacity the image is the background; finish() renders the frame again, exactly.
+        The status is consumed by the first call: a workspace carries ONE event and ONE pinned status block for the frames that
+        pass through it, so a second look through an old handle must not read what a later frame left there - it returns the
+        answer the first call recorded."""
         if self.status_event is None:
+            if self.checked is not None:
+                return self.checked
             return True, (self.result[0] if self.result else 0)
+        ws = self.workspace
+        if ws is not None and ws.in_flight is not self:
+            raise _lib.GmeshError("PendingForward.check(): the workspace of this frame has been released and reacquired; its status "
+                                  "words now belong to a later frame")
         self.status_event.synchronize()
-        if self.workspace is None:
+        self.status_event = None
+        if ws is None:
             st = self.status_host
             nr, refused, violated = int(st[0]), int(st[3]), int(st[1])
             self.known_count = nr
             if len(_PINNED_STATUS) < 64:
                 _PINNED_STATUS.append(st)
+            self.status_host = None
+            self.checked = ((not refused), nr)
             if violated and self.args.get("prefiltered"):
                 raise _lib.GmeshError(_PREFILTER_MESSAGE)
-            return (not refused), nr
-        st = self.workspace.pinned_status()
+            return self.checked
+        st = ws.pinned_status()
         nr, refused = int(st[0]), int(st[3])
         self.known_count = nr
+        self.checked = ((not refused), nr)
         if int(st[1]) and self.args.get("prefiltered"):
-            self.workspace.release(self)
+            ws.release(self)
             raise _lib.GmeshError(_PREFILTER_MESSAGE)
-        if refused:
-            return False, nr
-        self.workspace.release(self)
-        return True, nr
+        if refused:                      # still holds the workspace: finish() renders the frame again on the exact path
+            return self.checked
+        ws.release(self)
+        return self.checked
 
 
 _PREFILTER_MESSAGE = "Point is filtered although prefiltered is set. This shouldn't happen!"      # auxiliary.h:157
@@ -558,33 +572,79 @@ def _shared_workspace(device):
     return ws
 
 
-# Sync-free training forward (off by default): the autograd operator never waits for the instance count.  The binning
-# buffer of an iteration is sized from the largest count seen so far (x growth); the forward's status words are checked by
-# verify_sync_free() - typically after backward() has been enqueued, so the host never idles the GPU - and an iteration
-# whose count outgrew its buffer (image = background, gradients = 0) is reported so the caller can redo it.
-_sync_free = {"on": False, "capacity": {}, "unchecked": [], "growth": 1.3}
+# Sync-free training forward: the autograd operator never waits for the instance count.  The binning buffer of an iteration
+# is sized from the largest count seen so far (x growth); the forward's status words are checked by SyncFreeState.verify() -
+# typically after backward() has been enqueued, so the host never idles the GPU - and an iteration whose count outgrew its
+# buffer (image = background, gradients = 0) is reported so the caller can redo it.
+#
+# The state (capacity per device, the forwards not yet verified) belongs to its OWNER - a train.Trainer holds one - and the
+# operator sees it only while the owner has made it current for the calling THREAD (`with state:`): two trainers in one
+# process, or two threads, do not share a capacity guess or an unverified list.  Nothing here is module-global.
 _SYNC_FREE_MAX_UNCHECKED = 64      # unverified sync-free forwards (each pins its geometry / binning / image buffers)
 
 
-def set_sync_free_training(on, growth=1.3):
-    _sync_free["on"] = bool(on)
-    _sync_free["growth"] = float(growth)
-    if not on:
-        _sync_free["unchecked"].clear()
+class SyncFreeState:
+    """Per-owner state of the sync-free training forward.
+
+        state = SyncFreeState()
+        with state:                      # forwards that need a gradient, issued by this thread inside the block, are sync-free
+            loss = f(render(...)); loss.backward()
+            ok = state.verify()          # False: the instance count outgrew the buffer; redo the iteration (capacity was raised)
+
+    capacity[device]: instances the next binning buffer holds (0 / absent: the next forward takes the exact-count path and
+    seeds the guess).  `enabled = False` keeps the block on the exact path (and keeps learning the capacity)."""
+
+    def __init__(self, growth=1.3, enabled=True):
+        self.growth = float(growth)
+        self.enabled = bool(enabled)
+        self.capacity = {}
+        self.unchecked = []
+
+    def __enter__(self):
+        stack = getattr(_sync_free_tls, "stack", None)
+        if stack is None:
+            stack = _sync_free_tls.stack = []
+        stack.append(self)
+        return self
+
+    def __exit__(self, *exc):
+        stack = _sync_free_tls.stack
+        if not stack or stack[-1] is not self:
+            raise _lib.GmeshError("SyncFreeState: blocks must be exited in the order they were entered")
+        stack.pop()
+        self.unchecked.clear()           # handles left unverified (an exception inside the block) must not pin their buffers
+        return False
+
+    def note_count(self, device, num_rendered):
+        self.capacity[device] = max(self.capacity.get(device, 0), int(num_rendered * self.growth) + 4096)
+
+    def scale_capacity(self, factor, extra=4096):
+        """the cloud grew by `factor` rows (a topology change): scale the guesses with it"""
+        for k in list(self.capacity):
+            self.capacity[k] = int(self.capacity[k] * factor) + extra
+
+    def verify(self):
+        """Wait for the status of every sync-free forward issued under this state since the last call (the status words were
+        written by the forwards' own blend kernels, long before this is normally called).  Returns True when all of them fitted
+        their binning buffers; on False the capacity guess has been raised and the caller should repeat the iteration (its image
+        was the background)."""
+        ok = True
+        for h in self.unchecked:
+            fitted, nr = h.check()
+            self.note_count(h.args["device"], nr)
+            ok = ok and fitted
+        self.unchecked.clear()
+        return ok
 
 
-def verify_sync_free():
-    """Wait for the status of every sync-free forward issued since the last call (the copies were enqueued right behind the
-    forwards, long before this is normally called).  Returns True when all of them fitted their binning buffers; on False the
-    capacity estimate has been raised and the caller should repeat the iteration (its image was the background)."""
-    ok = True
-    for h in _sync_free["unchecked"]:
-        fitted, nr = h.check()
-        key = h.args["device"]
-        _sync_free["capacity"][key] = max(_sync_free["capacity"].get(key, 0), int(nr * _sync_free["growth"]) + 4096)
-        ok = ok and fitted
-    _sync_free["unchecked"].clear()
-    return ok
+import threading as _threading
+_sync_free_tls = _threading.local()
+
+
+def current_sync_free():
+    """The SyncFreeState the calling thread is inside of, or None."""
+    stack = getattr(_sync_free_tls, "stack", None)
+    return stack[-1] if stack else None
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -597,7 +657,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         needs_grad = any(ctx.needs_input_grad)
         ws = None if needs_grad else _shared_workspace(means3D.device)   # inference: reuse scratch
         policy = get_default_emission_policy(rs.image_width, rs.image_height)
-        cap = _sync_free["capacity"].get(means3D.device, 0) if (_sync_free["on"] and needs_grad) else 0
+        sf = current_sync_free() if needs_grad else None
+        cap = sf.capacity.get(means3D.device, 0) if (sf is not None and sf.enabled) else 0
         try:
             h = rasterize_forward_begin(rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                                         rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
@@ -606,16 +667,15 @@ class _RasterizeGaussians(torch.autograd.Function):
             if cap > 0:
                 num_rendered, color, radii, geom, binning, img = h.finish(sync_free=True, capacity=cap, work_hint=rs.work_hint)
                 num_rendered = cap                        # the binning layout is that of the capacity
-                if len(_sync_free["unchecked"]) >= _SYNC_FREE_MAX_UNCHECKED:
-                    raise _lib.GmeshError("sync-free training: %d forwards were issued without verify_sync_free(); every unverified "
-                                          "forward keeps its scratch buffers alive - call verify_sync_free() once per iteration"
+                if len(sf.unchecked) >= _SYNC_FREE_MAX_UNCHECKED:
+                    raise _lib.GmeshError("sync-free training: %d forwards were issued without SyncFreeState.verify(); every "
+                                          "unverified forward keeps its scratch buffers alive - call verify() once per iteration"
                                           % _SYNC_FREE_MAX_UNCHECKED)
-                _sync_free["unchecked"].append(h)
+                sf.unchecked.append(h)
             else:
                 num_rendered, color, radii, geom, binning, img = h.finish(image_only=not needs_grad, work_hint=rs.work_hint)   # image_only: no backward will follow
-                if _sync_free["on"] and needs_grad:
-                    key = means3D.device
-                    _sync_free["capacity"][key] = max(_sync_free["capacity"].get(key, 0), int(num_rendered * _sync_free["growth"]) + 4096)
+                if sf is not None:
+                    sf.note_count(means3D.device, num_rendered)
         except Exception:
             if rs.debug:       # the reference's debugging aid (diff_gaussian_rasterizater/__init__.py:61-67): keep the failing call's inputs
                 _snapshot("snapshot_fw.dump", dict(bg=rs.bg, means3D=means3D, colors_precomp=colors_precomp, opacities=opacities, scales=scales,

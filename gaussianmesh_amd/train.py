@@ -64,8 +64,9 @@ class FrozenGaussians:
 class Trainer:
     """densify_stats: keep the densification bookkeeping of train_mesh_gaussian.py:119-126 (max_radii2D, accumulated
     view-space gradient norm, visit count) up to date every iteration (one fused kernel).
-    sync_free: the rasterizer never waits for the instance count (rasterizer.set_sync_free_training); the status of the
-    forward is checked after backward() has been enqueued and an iteration that overflowed its binning buffer is redone.
+    sync_free: the rasterizer never waits for the instance count; the status of the forward is checked after backward() has
+    been enqueued and an iteration that overflowed its binning buffer is redone.  The capacity guess and the list of unverified
+    forwards live in `self.sync_state` (a rasterizer.SyncFreeState owned by THIS trainer and current only inside its step()).
     bg_gaussian: a FrozenGaussians cloud composited behind the trainable one."""
 
     def __init__(self, gaussians, spatial_lr_scale=1.0, densify_stats=False, sync_free=False, bg_gaussian=None, **opt):
@@ -95,6 +96,10 @@ class Trainer:
                                     mesh_restrict_weight=(o["alpha_mrloss"] or None))
         self.iteration = 0
         self.sync_free = bool(sync_free)
+        from .rasterizer import SyncFreeState
+        self.sync_state = SyncFreeState(enabled=self.sync_free)
+        self.keep_grads = False
+        self.last_grads = None
         self.redone = 0                          # iterations repeated because the instance count outgrew the binning buffer
         self.resizes = 0                         # topology changes applied (resize and everything built on it)
         self.densify_stats = bool(densify_stats)
@@ -119,7 +124,6 @@ class Trainer:
         (:452-455) and reset to zero when rows are (:503-505 followed by the prune of the split originals); the SH parameter
         goes back into the storage it shares with the frozen background; screenspace_points is re-made; the sync-free binning
         capacity is scaled with the row count (a too small guess only costs one redone iteration).  Returns the new row count."""
-        from . import rasterizer
         g = self.g
         n_old = g._bc.shape[0]
         if keep_mask is not None and keep_mask.shape[0] != n_old:
@@ -164,10 +168,8 @@ class Trainer:
                 self.max_radii2D = self.max_radii2D.index_select(0, idx)
                 self.bc_gradient_accum = self.bc_gradient_accum.index_select(0, idx)
                 self.denom = self.denom.index_select(0, idx)
-        cap = rasterizer._sync_free["capacity"]
         if n_old and n > n_old:
-            for k in list(cap):
-                cap[k] = int(cap[k] * n / n_old) + 4096
+            self.sync_state.scale_capacity(n / n_old)
         self.resizes += 1
         return n
 
@@ -264,30 +266,44 @@ class Trainer:
     def step(self, camera, gt_image, background):
         """One iteration; returns (loss tensor, render package).  Host synchronisation: the rasterizer's instance-count
         read-back, or with sync_free only the (long completed) status words of the forward."""
-        from . import rasterizer
         self.iteration += 1
         self.update_learning_rate()
-        rasterizer.set_sync_free_training(self.sync_free)
-        try:
+        st = self.sync_state
+        st.enabled = self.sync_free
+        with st:
             loss, pkg = self._forward_backward(camera, gt_image, background)
             attempts = 0
-            while self.sync_free and not rasterizer.verify_sync_free():
+            while self.sync_free and not st.verify():
                 # the image was the background and the render gradients zero: the same iteration again, with the buffer
-                # verify_sync_free() just enlarged; the third attempt takes the exact-count path, which cannot overflow
+                # verify() just enlarged; the third attempt takes the exact-count path, which cannot overflow
                 attempts += 1
                 self.redone += 1
                 if attempts >= 2:
-                    rasterizer.set_sync_free_training(False)
+                    st.enabled = False
                 self.optimizer.zero_grad(set_to_none=True)
                 loss, pkg = self._forward_backward(camera, gt_image, background)
                 if attempts >= 2:
                     break
-        finally:
-            rasterizer.set_sync_free_training(False)
         if self.densify_stats:
             from .model_ops import densify_stats
             N = self.max_radii2D.shape[0]
             densify_stats(pkg["radii"][:N], self.g.screenspace_points.grad, self.max_radii2D, self.bc_gradient_accum, self.denom)
+        if self.keep_grads:                      # diagnostics / tests: the gradients this step consumed, by group name
+            self.last_grads = {gr["name"]: gr["params"][0].grad for gr in self.optimizer.param_groups}
+            self.last_grads["viewspace"] = self.g.screenspace_points.grad
         self.optimizer.step()
         self.optimizer.zero_grad(set_to_none=True)
         return loss.detach(), pkg
+
+    def copy_state_from(self, other):
+        """Make this trainer's optimisation state equal to `other`'s (same row count): parameter values (in place - views and
+        shared storage stay), both Adam moments, step counters, densification statistics.  For tests and A/B runs that compare
+        two configurations of one iteration from the SAME state."""
+        with torch.no_grad():
+            for ga, gb in zip(self.optimizer.param_groups, other.optimizer.param_groups):
+                ga["params"][0].copy_(gb["params"][0]); ga["m"][0].copy_(gb["m"][0]); ga["values"][0].copy_(gb["values"][0])
+                ga["lr"] = gb["lr"]
+            if self.densify_stats and other.densify_stats:
+                self.max_radii2D.copy_(other.max_radii2D); self.bc_gradient_accum.copy_(other.bc_gradient_accum); self.denom.copy_(other.denom)
+        self.optimizer.n_step = other.optimizer.n_step
+        self.iteration = other.iteration

@@ -56,16 +56,13 @@ def test_training_iterations_reduce_the_loss():
     assert tr.optimizer.param_groups[0]["lr"] < tr.opt.position_lr_init          # schedule is applied
 
 
-def test_trainer_sync_free_densify_stats_and_background_cloud():
-    """Trainer(sync_free=True, densify_stats=True, bg_gaussian=...): the same parameter trajectory as the exact-count
-    trainer (bit-identical images and losses: the instance count only sizes a buffer), the densification statistics of
-    train_mesh_gaussian.py:119-126 against their torch statement, and an overflowing iteration is redone, not lost."""
+def _bg_scene(N=4000):
+    """two builders of ONE mesh-bound model (same seed), a frozen background shell and five cameras"""
     from gpu_utils import T
-    from gaussianmesh_amd import rasterizer as Rz, scenes
+    from gaussianmesh_amd import scenes
     from gaussianmesh_amd.renderer import Camera, MeshBoundGaussians
-    from gaussianmesh_amd.train import FrozenGaussians, Trainer
+    from gaussianmesh_amd.train import FrozenGaussians
     verts, faces = scenes.torus_mesh(24, 16)
-    N = 4000
 
     def build():
         cl = scenes.bind_cloud_to_mesh(N, verts, faces, seed=2)
@@ -80,31 +77,133 @@ def test_trainer_sync_free_densify_stats_and_background_cloud():
     nb = np.linalg.norm(b["means"], axis=1, keepdims=True) + 1e-6
     bg = FrozenGaussians(T(b["means"] / nb * (4 + nb)), T(b["scales"]), torch.nn.functional.normalize(T(b["rots"])), T(b["opac"]).reshape(-1, 1), T(b["shs"]))
     cams = [Camera(scenes.orbit_camera(k, 5, 160, 96, radius=6.5), "cuda") for k in range(5)]
+    return build, bg, cams
+
+
+def _group_lr(gr):
+    return max(float(gr["lr"]), float(gr.get("lr_rest", 0.0)))
+
+
+# What two runs of ONE iteration from ONE state may differ by: the backward pass adds its per-pixel terms with float atomics
+# (as the reference does, backward.cu:523-554), so a gradient entry is reproducible to a few 1e-7 of the TENSOR's largest entry,
+# not of itself.  Adam (eps = 1e-15, as the reference sets it) divides by sqrt(v): an entry whose gradient is rounding noise still
+# moves by about +-lr, in a direction that noise decides.  What is true every time, and asserted below:
+#   gradients        |ga - gb| <= GRAD_NOISE * max|ga|                                             (all entries)
+#   moments          the same bound through m = b1 m0 + (1-b1) g and v = b2 v0 + (1-b2) g^2
+#   parameter step   entries with |g| >= SOLID * max|g| move alike to STEP_TOL * lr;  every entry moves by at most lr, so two
+#                    runs differ by at most 2 lr on the rest.
+GRAD_NOISE, SOLID, STEP_TOL = 1e-5, 1e-3, 0.05
+
+
+def _assert_same_step(ta, tb, before, where):
+    """ta and tb have just stepped once from the same state `before` {name: tensor}."""
+    assert ta.optimizer.n_step == tb.optimizer.n_step, where
+    b1, b2 = ta.optimizer.betas
+    for ga, gb in zip(ta.optimizer.param_groups, tb.optimizer.param_groups):
+        name = ga["name"]
+        g_a, g_b = ta.last_grads[name], tb.last_grads[name]
+        gmax = float(g_a.abs().max())
+        assert gmax > 0 and torch.isfinite(g_a).all() and torch.isfinite(g_b).all(), (where, name)
+        dg = float((g_a - g_b).abs().max())
+        assert dg <= GRAD_NOISE * gmax, (where, name, "gradient", dg / gmax)
+        dm = float((ga["m"][0] - gb["m"][0]).abs().max())
+        assert dm <= (1 - b1) * GRAD_NOISE * gmax * 1.01 + 1e-30, (where, name, "first moment", dm, gmax)
+        dv = float((ga["values"][0] - gb["values"][0]).abs().max())
+        assert dv <= (1 - b2) * 2.02 * GRAD_NOISE * gmax * gmax + 1e-30, (where, name, "second moment", dv, gmax)
+        lr = _group_lr(ga)
+        da, db = ga["params"][0].detach() - before[name], gb["params"][0].detach() - before[name]
+        assert float(da.abs().max()) <= 1.001 * lr + 1e-7 and float(db.abs().max()) <= 1.001 * lr + 1e-7, (where, name, "step larger than lr")
+        solid = (g_a.abs() >= SOLID * gmax) & (g_b.abs() >= SOLID * gmax)
+        assert int(solid.sum()) > 0, (where, name)
+        d_solid = float((da - db)[solid].abs().max())
+        assert d_solid <= STEP_TOL * lr + 1e-7, (where, name, "step of entries with a solid gradient", d_solid / lr)
+
+
+def test_trainer_sync_free_step_equals_exact_step_from_equal_state():
+    """Trainer(sync_free=True) against Trainer(sync_free=False), both with densification statistics and a frozen background
+    cloud, stepped SIX times FROM THE SAME STATE each time (the sync-free trainer's state is set to the exact trainer's before
+    every iteration): images and losses are bit-identical every iteration - the instance count only sizes a buffer -, the
+    gradients, both Adam moments and the parameter step agree to what float-atomic summation order allows (see _assert_same_step),
+    the densification statistics agree exactly, and the iteration whose binning buffer is far too small is REDONE: it leaves the
+    step counter, moments and parameters as an iteration that fitted would."""
+    build, bg, cams = _bg_scene()
+    from gaussianmesh_amd.train import Trainer
+    N = 4000
     gt = torch.rand((3, 96, 160), device="cuda")
     zero = torch.zeros(3, device="cuda")
     ta = Trainer(build(), densify_stats=True, sync_free=False, bg_gaussian=bg)
     tb = Trainer(build(), densify_stats=True, sync_free=True, bg_gaussian=bg)
-    max_r = torch.zeros(N, device="cuda"); acc = torch.zeros((N, 1), device="cuda"); den = torch.zeros((N, 1), device="cuda")
+    ta.keep_grads = tb.keep_grads = True
+    max_r = torch.zeros(N, device="cuda")
+    dev = torch.device("cuda", torch.cuda.current_device())
     for i in range(6):
+        tb.copy_state_from(ta)
+        before = {gr["name"]: gr["params"][0].detach().clone() for gr in ta.optimizer.param_groups}
         if i == 4:
-            Rz._sync_free["capacity"][torch.device("cuda", 0)] = 64          # far too small: iteration 4 of tb must be redone
+            assert tb.sync_state.capacity[dev] > 64
+            tb.sync_state.capacity[dev] = 64                   # far too small: iteration 4 of tb must be redone
         la, pa = ta.step(cams[i % 5], gt, zero)
-        vs_grad = ta.g.screenspace_points.grad                                # cleared at the start of the next step only
         lb, pb = tb.step(cams[i % 5], gt, zero)
-        if i == 0:                      # same parameters: bit-identical image (the instance count only sizes a buffer) ...
-            assert torch.equal(pa["render"], pb["render"]) and torch.equal(la, lb)
-        else:                           # ... afterwards the two runs differ by the float-atomic summation order of their backward passes
-            assert (pa["render"] - pb["render"]).abs().max() <= 2e-2 and abs(float(la) - float(lb)) <= 1e-3 * abs(float(la)), i
+        assert torch.equal(pa["render"], pb["render"]) and torch.equal(la, lb) and torch.equal(pa["radii"], pb["radii"]), i
+        assert tb.redone == (1 if i >= 4 else 0) and ta.redone == 0
+        _assert_same_step(ta, tb, before, "iteration %d" % i)
         vis = pa["radii"][:N] > 0
         max_r[vis] = torch.maximum(max_r[vis], pa["radii"][:N][vis].float())
-    assert tb.redone == 1 and ta.redone == 0
-    for p, q in zip(ta.g.parameters(), tb.g.parameters()):
-        assert (p - q).abs().max() <= 5e-3 * max(float(p.abs().max()), 1.0)
-    assert torch.equal(ta.max_radii2D, max_r)
-    assert (ta.max_radii2D - tb.max_radii2D).abs().max() <= 1 and (ta.denom - tb.denom).abs().max() <= 1      # radii may flip by one
+        assert torch.equal(ta.max_radii2D, max_r) and torch.equal(tb.max_radii2D, max_r) and torch.equal(ta.denom, tb.denom)
+        acc = float(ta.bc_gradient_accum.abs().max())
+        assert float((ta.bc_gradient_accum - tb.bc_gradient_accum).abs().max()) <= 1e-5 * acc
+    assert ta.optimizer.n_step == 6 and tb.optimizer.n_step == 6 and tb.iteration == 6
     assert ta.denom.max() <= 6 and ta.denom.sum() > 0
     assert torch.isfinite(ta.bc_gradient_accum).all() and (ta.bc_gradient_accum[ta.denom > 0] >= 0).all()
     assert pa["radii"].shape[0] == N + 500 and pa["scale"].shape[0] == N
+    assert not tb.sync_state.unchecked and ta.sync_state is not tb.sync_state        # per-trainer state, nothing left pinned
+
+
+def test_trainer_sync_free_free_running_trajectory_stays_inside_the_adam_bound():
+    """The two trainers left to themselves for six iterations (no state copy): what separates them is bounded by the number of
+    steps times 2 lr on ANY entry (noise-level gradients, see above), and the bulk of the entries - the median - stays together
+    to 1e-4 of the tensor's size; losses agree to 1e-3.  (This is the round-3 test with the assertion it can actually keep.)"""
+    build, bg, cams = _bg_scene()
+    from gaussianmesh_amd.train import Trainer
+    gt = torch.rand((3, 96, 160), device="cuda")
+    zero = torch.zeros(3, device="cuda")
+    ta = Trainer(build(), densify_stats=True, sync_free=False, bg_gaussian=bg)
+    tb = Trainer(build(), densify_stats=True, sync_free=True, bg_gaussian=bg)
+    steps = 6
+    lr_max = {gr["name"]: 0.0 for gr in ta.optimizer.param_groups}
+    for i in range(steps):
+        la, pa = ta.step(cams[i % 5], gt, zero)
+        lb, pb = tb.step(cams[i % 5], gt, zero)
+        for gr in ta.optimizer.param_groups:
+            lr_max[gr["name"]] = max(lr_max[gr["name"]], _group_lr(gr))
+        assert abs(float(la) - float(lb)) <= 1e-3 * abs(float(la)), i
+    for ga, gb in zip(ta.optimizer.param_groups, tb.optimizer.param_groups):
+        p, q = ga["params"][0].detach(), gb["params"][0].detach()
+        d = (p - q).abs()
+        assert float(d.max()) <= steps * 2.0 * lr_max[ga["name"]] * 1.001 + 1e-7, (ga["name"], float(d.max()))
+        assert float(d.median()) <= 1e-4 * max(float(p.abs().max()), 1.0), (ga["name"], float(d.median()))
+    assert (ta.max_radii2D - tb.max_radii2D).abs().max() <= 1 and (ta.denom - tb.denom).abs().max() <= 1      # radii may flip by one
+
+
+def test_two_trainers_do_not_share_sync_free_state():
+    """rasterizer.SyncFreeState is per owner and current per thread: a trainer's capacity guess and unverified forwards are
+    invisible to another trainer, to code outside step(), and to another thread."""
+    import threading
+    from gaussianmesh_amd import rasterizer as Rz
+    assert Rz.current_sync_free() is None
+    a, b = Rz.SyncFreeState(), Rz.SyncFreeState()
+    seen = []
+    with a:
+        assert Rz.current_sync_free() is a
+        t = threading.Thread(target=lambda: seen.append(Rz.current_sync_free()))
+        t.start(); t.join()
+        with b:
+            assert Rz.current_sync_free() is b
+        assert Rz.current_sync_free() is a
+    assert Rz.current_sync_free() is None and seen == [None]
+    a.note_count("dev", 1000)
+    assert b.capacity == {} and a.capacity["dev"] == int(1000 * a.growth) + 4096
+    assert not hasattr(Rz, "_sync_free")
 
 
 def test_densify_stats_kernel_matches_the_reference_statements():
