@@ -39,6 +39,11 @@ STAGES = ["deform", "sh_colors", "preprocess", "depth_sort", "duplicate", "tile_
 # that share a queue serialise against each other (4 streams on 4 queues: 3460 frames/s, on 8 queues: 4300).  Must be set
 # before the HIP runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# N > 1: RCCL sets up its xGMI peer buffers through HIP IPC handles, and the host driver of these nodes supports only the dmabuf
+# flavour: with the legacy mode left on, the first collective fails with `hipIpcGetMemHandle: invalid argument`.  The image
+# exports it; set here as well (before HIP starts) so that a launch from a clean environment - the driver's torch.distributed.run,
+# a test's subprocess - runs in the same mode.  Harmless at N = 1.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
 def build_scene(P, W, H, frames, seed=0):
@@ -243,6 +248,11 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    # one block of host cores per rank (before the HIP runtime and RCCL start their threads); GM_RANK_AFFINITY=0 leaves it to the OS
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    pinned = multiview.pin_rank_to_cores(local_rank, local_world)
+    if pinned is not None:
+        torch.set_num_threads(max(1, min(4, len(pinned))))
     image_only = not args.backward_state
     # GM_BENCH_SHARE_DEVICE=1 + GM_BENCH_BACKEND=gloo: functional smoke test of the N>1 path on a one-GPU box
     # (RCCL refuses two ranks on one device); never used for measurements.
@@ -448,6 +458,7 @@ def main():
         return time.perf_counter() - t
 
     elapsed = timed_region(args.warmup)
+    per_rank_s = multiview.gather_over_ranks(elapsed, dev)       # every rank's own clock around the same barriers
     elapsed = multiview.max_over_ranks(elapsed, dev)
     fps = world * args.steps / elapsed
     repeats = []
@@ -484,7 +495,11 @@ def main():
                    "gaussians": P, "width": W, "height": H, "sh_degree": 3, "views_per_step_per_gpu": 1,
                    "vertex_rs": "analytic tables" if args.analytic_rs else "gm_mesh_rs per frame", "hip_streams": nstreams,
                    "exchange": None if pipe is None else {"steps_per_broadcast": pipe.batch, "bytes_per_step": exchange_bytes, "broadcasts": pipe.broadcasts,
-                                                          "payload": "per-vertex (R, S) tables" if args.analytic_rs else "deformed vertex positions; (R, S) by gm_mesh_rs on every rank"},
+                                                          "payload": "per-vertex (R, S) tables" if args.analytic_rs else "deformed vertex positions; (R, S) by gm_mesh_rs on every rank",
+                                                          # a slow rank is visible here: each rank's own time for the region / steps
+                                                          "ms_per_step_by_rank": [round(1e3 * t / args.steps, 4) for t in per_rank_s],
+                                                          "slowest_over_fastest_rank": round(max(per_rank_s) / max(min(per_rank_s), 1e-12), 4),
+                                                          "cores_per_rank": None if pinned is None else len(pinned)},
                    "emission_policy": Rz.get_default_emission_policy(W, H), "image_only": image_only, "work_hint": hint is not None,
                    "frames_redone": stats["overflows"],          # sync-free frames that outgrew their binning buffer (rendered again, exactly)
                    "parallelism": "views x%d" % world},

@@ -8,8 +8,9 @@
                               #   utils.loss_utils l1_loss / ssim              -> gaussianmesh_amd.loss  (opt-in, see install)
     compat.install(edit_tool=True)   # additionally, for edit.py: `from edittool import ObjectVisualTool, SceneVisualTool`
                               # resolves to gaussianmesh_amd.edittool (the reference's package needs igl, plyfile and
-                              # the pyACAP binary), and `from render_origin import save_image` (a module missing from the
-                              # reference tree) to gaussianmesh_amd.io.save_image
+                              # the pyACAP binary), `from render_origin import save_image` (a module missing from the
+                              # reference tree) to gaussianmesh_amd.io.save_image, and - when libigl is not installed -
+                              # `import igl` (edit.py:7) to compat/igl_subset.py: the four calls the reference makes
 
 Only the ~60 symbols the in-scope reference python uses are provided; anything else raises
 AttributeError naming the symbol.  A real Jittor installation is never shadowed unless install(force=True).
@@ -53,6 +54,10 @@ def install(force=False, operators=True, edit_tool=False):
             ro.save_image = gio.save_image
             ro.__gaussianmesh_compat__ = True
             sys.modules["render_origin"] = ro
+        have_igl = "igl" in sys.modules or importlib.util.find_spec("igl") is not None
+        if force or not have_igl:
+            from . import igl_subset
+            sys.modules["igl"] = igl_subset
     return sys.modules["jittor"]
 
 
@@ -64,7 +69,7 @@ def uninstall():
         j._unpatch_tensor()
         for k in [k for k in sys.modules if k == "jittor" or k.startswith("jittor.")]:
             del sys.modules[k]
-    for k in ("gaussian_renderer.diff_gaussian_rasterizater", "scene.simple_knn", "edittool", "render_origin"):
+    for k in ("gaussian_renderer.diff_gaussian_rasterizater", "scene.simple_knn", "edittool", "render_origin", "igl"):
         m = sys.modules.get(k)
         if m is not None and (getattr(m, "__name__", "").startswith("gaussianmesh_amd") or getattr(m, "__gaussianmesh_compat__", False)):
             del sys.modules[k]            # only what install() put there

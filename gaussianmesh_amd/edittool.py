@@ -34,15 +34,15 @@ def _covariance(scaling_raw, rotation_raw):
     return L @ L.transpose(1, 2)
 
 
-def closest_triangles(points, vertex, triangles, chunk=4096):
-    """Index of the closest triangle to each point (igl.point_mesh_squared_distance's second output,
-    edittool/__init__.py:82), exact, brute force in chunks: closest point on each triangle by the region test of
-    Ericson, "Real-Time Collision Detection" 5.1.5.  Host side (numpy), used once per object and only when the Gaussian
-    file carries no face ids."""
-    P = np.asarray(points, np.float64); V = np.asarray(vertex, np.float64); F = np.asarray(triangles, np.int64)
+def point_mesh_squared_distance(points, vertex, triangles, chunk=4096):
+    """igl.point_mesh_squared_distance(P, V, F) -> (sqrD [n], I [n], C [n,3]) (edittool/__init__.py:80): squared distance to,
+    index of, and closest point on the closest triangle, exact, brute force in chunks: closest point on each triangle by the
+    region test of Ericson, "Real-Time Collision Detection" 5.1.5 (ties go to the lowest face index).  Host side (numpy, float64),
+    used once per object and only when the Gaussian file carries no face ids."""
+    P = np.asarray(points, np.float64).reshape(-1, 3); V = np.asarray(vertex, np.float64); F = np.asarray(triangles, np.int64)
     a, b, c = V[F[:, 0]][None], V[F[:, 1]][None], V[F[:, 2]][None]
     ab, ac = b - a, c - a
-    out = np.zeros(len(P), np.int64)
+    idx = np.zeros(len(P), np.int64); sqr = np.zeros(len(P), np.float64); close = np.zeros((len(P), 3), np.float64)
     for s0 in range(0, len(P), chunk):
         p = P[s0:s0 + chunk][:, None, :]
         ap = p - a
@@ -63,8 +63,16 @@ def closest_triangles(points, vertex, triangles, chunk=4096):
         m = (d6 >= 0) & (d5 <= d6); q = np.where(m[..., None], c, q)
         m = (d3 >= 0) & (d4 <= d3); q = np.where(m[..., None], b, q)
         m = (d1 <= 0) & (d2 <= 0); q = np.where(m[..., None], a, q)
-        out[s0:s0 + chunk] = np.argmin(((p - q) ** 2).sum(-1), axis=1)
-    return out
+        d2all = ((p - q) ** 2).sum(-1)
+        k = np.argmin(d2all, axis=1)
+        rows = np.arange(len(k))
+        idx[s0:s0 + chunk] = k; sqr[s0:s0 + chunk] = d2all[rows, k]; close[s0:s0 + chunk] = q[rows, k]
+    return sqr, idx, close
+
+
+def closest_triangles(points, vertex, triangles, chunk=4096):
+    """Index of the closest triangle to each point (point_mesh_squared_distance's second output, edittool/__init__.py:82)."""
+    return point_mesh_squared_distance(points, vertex, triangles, chunk)[1]
 
 
 class SingleObjectDeform(_TensorObject):

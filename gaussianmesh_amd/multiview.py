@@ -159,6 +159,47 @@ def max_over_ranks(value, device):
     return float(t.item())
 
 
+def gather_over_ranks(value, device):
+    """Every rank's python float, as a list indexed by rank (timing diagnostics: a slow rank shows in the bench line)."""
+    rank, ws = world()
+    if ws == 1:
+        return [float(value)]
+    dev = "cpu" if dist.get_backend() == "gloo" else device
+    mine = torch.tensor([value], dtype=torch.float64, device=dev)
+    got = [torch.empty_like(mine) for _ in range(ws)]
+    dist.all_gather(got, mine)
+    return [float(t.item()) for t in got]
+
+
+def rank_core_set(local_rank, local_world, allowed):
+    """The cores rank `local_rank` of `local_world` ranks on one node gets out of the sorted list `allowed`: a contiguous block of
+    len(allowed) // local_world (at least one core; blocks wrap when there are more ranks than cores)."""
+    allowed = sorted(allowed)
+    n = len(allowed)
+    if local_world <= 1 or n == 0:
+        return set(allowed)
+    per = max(1, n // local_world)
+    start = (local_rank * per) % n
+    return {allowed[(start + k) % n] for k in range(per)}
+
+
+def pin_rank_to_cores(local_rank, local_world):
+    """One process per GPU, eight on a node: each rank's frame loop needs ~0.08 ms of ONE host core per 0.2-ms frame, plus the
+    runtime's helper threads.  Left to the scheduler, eight Python ranks migrate and now and then share a core, and the slowest
+    rank sets a max-over-ranks timing.  Give every rank its own block of the cores this process may use (os.sched_setaffinity:
+    inherited by the threads HIP and RCCL start afterwards, so call it before the runtime initialises).  Returns the sorted core
+    list, or None where the platform has no affinity call or GM_RANK_AFFINITY=0 asks for none."""
+    import os
+    if os.environ.get("GM_RANK_AFFINITY", "1") == "0" or not hasattr(os, "sched_setaffinity") or local_world <= 1:
+        return None
+    try:
+        cores = rank_core_set(local_rank, local_world, os.sched_getaffinity(0))
+        os.sched_setaffinity(0, cores)
+        return sorted(cores)
+    except OSError:
+        return None
+
+
 def render_trajectory(n_views, n_frames, mesh_state_of, deform_and_render, state_buffer, src=0):
     """Reference driver of the sharded loop (used by the gloo test and mirrored by bench.py):
     for every deformation frame t, rank `src` produces the mesh state, all ranks receive it and render their views.

@@ -265,3 +265,68 @@ def test_uninstall_restores_torch_tensor():
     with pytest.raises(RuntimeError):
         t.numpy()                                                                          # torch's own behaviour is back
     compat.install(force=True)                                                             # (other tests expect the shim)
+
+
+def test_igl_subset_and_edit_py_import_block(tmp_path):
+    """compat.install(edit_tool=True): `import igl` (edit.py:7; libigl is not installed in this image) resolves to the subset with
+    the four calls the in-scope reference code makes, next to `from edittool import ...` and `from render_origin import ...`; where the
+    reference tree is mounted, every import statement at the top of its edit.py is executed as it stands."""
+    import ast
+    import importlib.util
+    placeholder = sys.modules.get("igl")                         # (ref_env above parks an empty module under this name)
+    if placeholder is not None and getattr(placeholder, "__file__", None) is None:
+        del sys.modules["igl"]
+    real_igl = "igl" not in sys.modules and importlib.util.find_spec("igl") is not None
+    compat.install(edit_tool=True)
+    try:
+        _check_igl_and_imports(tmp_path, real_igl)
+    finally:
+        if placeholder is not None and getattr(placeholder, "__file__", None) is None:
+            sys.modules["igl"] = placeholder
+
+
+def _check_igl_and_imports(tmp_path, real_igl):
+    import ast
+    ns = {}
+    exec("import igl\nfrom edittool import ObjectVisualTool, SceneVisualTool\nfrom render_origin import save_image", ns)
+    igl = ns["igl"]
+    assert callable(ns["save_image"]) and ns["ObjectVisualTool"].__module__.startswith("gaussianmesh_amd")
+    if os.path.isfile(os.path.join(REF, "edit.py")):
+        tree = ast.parse(open(os.path.join(REF, "edit.py")).read())
+        imports = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
+        assert any(isinstance(n, ast.Import) and n.names[0].name == "igl" for n in imports)
+        exec(compile(ast.Module(body=imports, type_ignores=[]), "edit.py imports", "exec"), {})
+    if real_igl:
+        return                                                   # a real libigl answers; nothing of ours to check
+    assert getattr(igl, "__gaussianmesh_compat__", False)
+    # unit square of two triangles in z = 0, one degenerate face
+    V = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], np.float64)
+    F = np.array([[0, 1, 2], [0, 2, 3], [1, 1, 2]], np.int32)
+    n = igl.per_face_normals(V, F, np.array([1.0, 0.0, 0.0]))
+    assert np.allclose(n, [[0, 0, 1], [0, 0, 1], [1, 0, 0]])      # the fallback row for the degenerate face (mesh_based_gaussian_model.py:193)
+    P = np.array([[0.75, 0.25, 2.0], [0.25, 0.75, -1.0], [2.0, 0.5, 0.0], [-1.0, -1.0, 0.0], [0.5, 0.5, 0.5]])
+    sqr, idx, close = igl.point_mesh_squared_distance(P, V, F[:2])
+    assert np.allclose(sqr, [4.0, 1.0, 1.0, 2.0, 0.25]) and idx.tolist()[:2] == [0, 1]
+    assert np.allclose(close, [[0.75, 0.25, 0], [0.25, 0.75, 0], [1, 0.5, 0], [0, 0, 0], [0.5, 0.5, 0]])
+    # brute force over a dense sampling of a random mesh
+    rng = np.random.default_rng(0)
+    Vr = rng.normal(size=(12, 3)); Fr = rng.integers(0, 12, size=(20, 3)).astype(np.int32)
+    Fr = Fr[(Fr[:, 0] != Fr[:, 1]) & (Fr[:, 1] != Fr[:, 2]) & (Fr[:, 0] != Fr[:, 2])]
+    Pr = rng.normal(size=(40, 3))
+    sqr, idx, close = igl.point_mesh_squared_distance(Pr, Vr, Fr)
+    u = np.linspace(0, 1, 60); uu, vv = np.meshgrid(u, u); keep = uu + vv <= 1
+    bary = np.stack([1 - uu[keep] - vv[keep], uu[keep], vv[keep]], 1)                      # [S,3]
+    samples = np.einsum("sk,fkc->fsc", bary, Vr[Fr])                                      # [F,S,3]
+    d2 = ((Pr[:, None, None, :] - samples[None]) ** 2).sum(-1).min(axis=2)                 # [P,F]
+    assert (sqr <= d2.min(axis=1) + 1e-12).all() and np.allclose(sqr, d2.min(axis=1), atol=5e-2)
+    assert np.allclose(((Pr - close) ** 2).sum(1), sqr)
+    # files: OBJ and OFF round trips, polygon fan triangulation
+    for ext in (".obj", ".off"):
+        path = str(tmp_path / ("m" + ext))
+        assert igl.write_triangle_mesh(path, Vr, Fr)
+        v2, f2 = igl.read_triangle_mesh(path)
+        assert v2.dtype == np.float64 and np.array_equal(v2, Vr) and np.array_equal(f2, Fr)
+    with pytest.raises(AttributeError):
+        igl.cotmatrix
+    with pytest.raises(ValueError):
+        igl.read_triangle_mesh(str(tmp_path / "m.stl"))

@@ -66,6 +66,8 @@ def _two_ranks(tmp_path, batch, env_extra):
     ex = out["config"]["exchange"]                                      # vertex positions: `batch` loop steps per broadcast, one batch ahead
     assert ex["steps_per_broadcast"] == batch and ex["broadcasts"] >= (3 * F + warm + steps) // batch and ex["bytes_per_step"] == 7500 * 12
     assert abs(out["value"] - 2 * steps / (out["ms_per_step"] * 1e-3 * steps)) < 1e-6 * out["value"]        # frames of both ranks / max time
+    by_rank = ex["ms_per_step_by_rank"]                                 # every rank's own clock; the line's time is the slowest rank's
+    assert len(by_rank) == 2 and abs(max(by_rank) - out["ms_per_step"]) <= 1e-3 and ex["slowest_over_fastest_rank"] >= 1.0
     # single-process render of the same frame for each rank's view
     sys.path.insert(0, ROOT)
     import bench

@@ -11,4 +11,6 @@ pytestmark = [pytest.mark.gpu, pytest.mark.skipif(torch.cuda.device_count() < 2,
 @pytest.mark.parametrize("batch", [None, 1])
 def test_bench_two_ranks_on_rccl(tmp_path, batch):
     from test_gpu_bench_multirank import _two_ranks
-    _two_ranks(tmp_path, batch, dict(GM_BENCH_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    # no IPC variable here: bench.py itself selects the dmabuf IPC mode RCCL needs on these hosts (HSA_ENABLE_IPC_MODE_LEGACY=0, set
+    # before HIP starts), so this runs in the environment the driver's `bench.py --gpus N` runs in
+    _two_ranks(tmp_path, batch, dict(GM_BENCH_BACKEND="nccl"))

@@ -91,8 +91,13 @@ def _group_lr(gr):
 #   gradients        |ga - gb| <= GRAD_NOISE * max|ga|                                             (all entries)
 #   moments          the same bound through m = b1 m0 + (1-b1) g and v = b2 v0 + (1-b2) g^2
 #   parameter step   entries with |g| >= SOLID * max|g| move alike to STEP_TOL * lr;  every entry moves by at most lr, so two
-#                    runs differ by at most 2 lr on the rest.
-GRAD_NOISE, SOLID, STEP_TOL = 1e-5, 1e-3, 0.05
+#                    runs differ by at most 2 lr on the rest.  (+ one rounding of the parameter itself: log-barycentrics reach 14,
+#                    their ulp is 1e-6 = 0.6 % of the position learning rate.)
+# Measured over 60 x 6 iterations of this scene (tools/stress_trainer.py, profiles/r04_stress_trainer.txt): worst |ga - gb| / max|ga|
+# 1.1e-5 (rotation), 9.4e-6 (scaling), 3.6e-6 (distance), 1.9e-6 (bc), 4e-7 (opacity, SH); worst step difference of entries with a
+# solid gradient 1.5e-3 lr.
+GRAD_NOISE, SOLID, STEP_TOL = 5e-5, 1e-2, 0.05
+ULP = 2.0 ** -23
 
 
 def _assert_same_step(ta, tb, before, where):
@@ -112,11 +117,12 @@ def _assert_same_step(ta, tb, before, where):
         assert dv <= (1 - b2) * 2.02 * GRAD_NOISE * gmax * gmax + 1e-30, (where, name, "second moment", dv, gmax)
         lr = _group_lr(ga)
         da, db = ga["params"][0].detach() - before[name], gb["params"][0].detach() - before[name]
-        assert float(da.abs().max()) <= 1.001 * lr + 1e-7 and float(db.abs().max()) <= 1.001 * lr + 1e-7, (where, name, "step larger than lr")
+        rnd = ULP * float(before[name].abs().max()) + 1e-9
+        assert float(da.abs().max()) <= 1.001 * lr + rnd and float(db.abs().max()) <= 1.001 * lr + rnd, (where, name, "step larger than lr")
         solid = (g_a.abs() >= SOLID * gmax) & (g_b.abs() >= SOLID * gmax)
         assert int(solid.sum()) > 0, (where, name)
         d_solid = float((da - db)[solid].abs().max())
-        assert d_solid <= STEP_TOL * lr + 1e-7, (where, name, "step of entries with a solid gradient", d_solid / lr)
+        assert d_solid <= STEP_TOL * lr + 2 * rnd, (where, name, "step of entries with a solid gradient", d_solid / lr)
 
 
 def test_trainer_sync_free_step_equals_exact_step_from_equal_state():
@@ -180,7 +186,7 @@ def test_trainer_sync_free_free_running_trajectory_stays_inside_the_adam_bound()
     for ga, gb in zip(ta.optimizer.param_groups, tb.optimizer.param_groups):
         p, q = ga["params"][0].detach(), gb["params"][0].detach()
         d = (p - q).abs()
-        assert float(d.max()) <= steps * 2.0 * lr_max[ga["name"]] * 1.001 + 1e-7, (ga["name"], float(d.max()))
+        assert float(d.max()) <= steps * (2.0 * lr_max[ga["name"]] * 1.001 + 2 * ULP * float(p.abs().max())), (ga["name"], float(d.max()))
         assert float(d.median()) <= 1e-4 * max(float(p.abs().max()), 1.0), (ga["name"], float(d.median()))
     assert (ta.max_radii2D - tb.max_radii2D).abs().max() <= 1 and (ta.denom - tb.denom).abs().max() <= 1      # radii may flip by one
 

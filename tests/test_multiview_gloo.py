@@ -21,6 +21,20 @@ def test_shard_views_partition():
     assert [view_for_step(s, 64, 1, 8) for s in range(10)] == [8, 9, 10, 11, 12, 13, 14, 15, 8, 9]
 
 
+def test_rank_core_blocks_are_disjoint_and_cover():
+    """multiview.rank_core_set: the block of host cores each of the node's ranks is pinned to (bench.py, before HIP starts)"""
+    from gaussianmesh_amd import multiview
+    allowed = list(range(4, 132))                                # e.g. a cgroup that starts at core 4
+    blocks = [multiview.rank_core_set(r, 8, allowed) for r in range(8)]
+    assert all(len(b) == 16 for b in blocks) and set().union(*blocks) == set(allowed)
+    assert all(blocks[i].isdisjoint(blocks[j]) for i in range(8) for j in range(i))
+    assert blocks[0] == set(range(4, 20)) and blocks[7] == set(range(116, 132))
+    assert multiview.rank_core_set(0, 1, allowed) == set(allowed)
+    three = [multiview.rank_core_set(r, 8, [0, 1, 2]) for r in range(8)]          # more ranks than cores: one core each, wrapping
+    assert all(len(b) == 1 for b in three) and set().union(*three) == {0, 1, 2}
+    assert multiview.pin_rank_to_cores(0, 1) is None             # single rank: nothing is pinned
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
     return p
@@ -66,7 +80,8 @@ def _worker(rank, world, port, out_dir):
     state = torch.zeros((Vm, 21), dtype=torch.float32)
     out = multiview.render_trajectory(views, frames, mesh_state_of, deform_and_render, state, src=0)
     t = multiview.max_over_ranks(float(rank + 1), torch.device("cpu"))
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), tmax=t, **{"%d_%d" % k: v for k, v in out.items()})
+    every = multiview.gather_over_ranks(float(rank + 1), torch.device("cpu"))
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), tmax=t, tall=np.array(every), **{"%d_%d" % k: v for k, v in out.items()})
     dist.barrier()
     dist.destroy_process_group()
 
@@ -78,12 +93,13 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     r0 = dict(np.load(tmp_path / "rank0.npz")); r1 = dict(np.load(tmp_path / "rank1.npz"))
     assert float(r0.pop("tmax")) == 2.0 and float(r1.pop("tmax")) == 2.0      # MAX all-reduce over ranks
+    assert r0.pop("tall").tolist() == [1.0, 2.0] and r1.pop("tall").tolist() == [1.0, 2.0]      # every rank's own value, by rank
     assert sorted(r0) == ["0_0", "0_1", "1_0", "1_1"] and sorted(r1) == ["0_2", "0_3", "1_2", "1_3"]
     # single-process reference of the same trajectory
     port2 = _free_port()
     single = tmp_path / "single"; single.mkdir()
     mp.spawn(_worker, args=(1, port2, str(single)), nprocs=1, join=True)
-    s = dict(np.load(single / "rank0.npz")); s.pop("tmax")
+    s = dict(np.load(single / "rank0.npz")); s.pop("tmax"); assert s.pop("tall").tolist() == [1.0]
     both = {**r0, **r1}
     assert sorted(both) == sorted(s)
     for k in s:

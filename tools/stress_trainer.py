@@ -15,6 +15,7 @@ from test_gpu_train import _bg_scene, _group_lr
 from gaussianmesh_amd.train import Trainer
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+FREE_ONLY = len(sys.argv) > 2 and sys.argv[2] == "free"      # only part (1), for long hunts
 build, bg, cams = _bg_scene()
 zero = torch.zeros(3, device="cuda")
 dev = torch.device("cuda", torch.cuda.current_device())
@@ -58,6 +59,10 @@ for rep in range(R):
                       % (i, float(A[0].reshape(-1)[flat]), float(B[0].reshape(-1)[flat]), gmax, abs(float(A[0].reshape(-1)[flat])) / gmax,
                          float(A[1].reshape(-1)[flat]), float(B[1].reshape(-1)[flat]), float(A[2].reshape(-1)[flat]), float(B[2].reshape(-1)[flat]),
                          float(A[3].reshape(-1)[flat]), float(B[3].reshape(-1)[flat])))
+    if FREE_ONLY:
+        if rep % 100 == 99:
+            print("rep", rep, "done", flush=True)
+        continue
     # ---- (2) one iteration from equal state, every iteration
     ta = Trainer(build(), densify_stats=True, sync_free=False, bg_gaussian=bg)
     tb = Trainer(build(), densify_stats=True, sync_free=True, bg_gaussian=bg)
