@@ -202,7 +202,7 @@ def test_render_with_background_cloud_vs_oracle(oracle, cov_py, sh_py, shared):
     assert (radii[:N] > 0).sum() > N // 4 and (radii[N:] > 0).sum() > NB // 8        # both clouds are in the picture
     if not cov_py:                  # inputs of the op are the model's own float32 activations: bit-identical geometry
         assert np.array_equal(radii, fw["geo"]["radii"]), what
-        assert out["scale"].shape == (N, 3) and float((out["scale"].double() - act["scales"]).abs().max()) <= 2e-6 * float(act["scales"].abs().max())
+        assert out["scale"].shape == (N, 3) and float((out["scale"].detach().double() - act["scales"].detach()).abs().max()) <= 2e-6 * float(act["scales"].detach().abs().max())
     else:                           # float32 torch covariance vs the float64 one rounded once: a radius may sit on a rounding edge
         assert (radii != fw["geo"]["radii"]).sum() <= 2 and np.abs(radii - fw["geo"]["radii"]).max() <= 1, what
         assert out["scale"] is None                                                   # :143 returns the (unset) scales

@@ -90,14 +90,27 @@ def _group_lr(gr):
 # moves by about +-lr, in a direction that noise decides.  What is true every time, and asserted below:
 #   gradients        |ga - gb| <= GRAD_NOISE * max|ga|                                             (all entries)
 #   moments          the same bound through m = b1 m0 + (1-b1) g and v = b2 v0 + (1-b2) g^2
-#   parameter step   entries with |g| >= SOLID * max|g| move alike to STEP_TOL * lr;  every entry moves by at most lr, so two
-#                    runs differ by at most 2 lr on the rest.  (+ one rounding of the parameter itself: log-barycentrics reach 14,
-#                    their ulp is 1e-6 = 0.6 % of the position learning rate.)
+#   parameter step   entries with |g| >= SOLID * max|g| move alike to STEP_TOL * lr;  every entry moves by at most about lr
+#                    (_adam_step_bound: 1.0 .. 1.016 lr over the first six steps), so two runs differ by at most twice that on
+#                    the rest.  (+ one rounding of the parameter itself: log-barycentrics reach 14, their ulp is 1e-6 = 0.6 % of
+#                    the position learning rate.)
 # Measured over 60 x 6 iterations of this scene (tools/stress_trainer.py, profiles/r04_stress_trainer.txt): worst |ga - gb| / max|ga|
 # 1.1e-5 (rotation), 9.4e-6 (scaling), 3.6e-6 (distance), 1.9e-6 (bc), 4e-7 (opacity, SH); worst step difference of entries with a
 # solid gradient 1.5e-3 lr.
 GRAD_NOISE, SOLID, STEP_TOL = 5e-5, 1e-2, 0.05
 ULP = 2.0 ** -23
+# The rare event behind round 3's red run, caught by tools/stress_trainer.py (profiles/r04_stress_trainer_free.txt: 3 of 4000
+# repetitions of the old free-running comparison over the old gate, all three on _opacity): an entry whose gradient is 1e-9 .. 1e-5 of
+# the tensor's largest (|g| ~ 1e-11 .. 1e-8) comes out of the two backward passes with another sign or size (-6.3e-12 | +2.2e-11), and
+# Adam moves it by +0.6 lr in one run and -0.2 lr in the other.
+
+
+def _adam_step_bound(t, b1=0.9, b2=0.999):
+    """Largest |step| / lr Adam's t-th update can make whatever the gradient history: |m| / sqrt(v) <= sqrt(sum a_k^2 / b_k) by
+    Cauchy-Schwarz with m = sum a_k g_k, v = sum b_k g_k^2, a_k = (1-b1) b1^k, b_k = (1-b2) b2^k, times the bias corrections.
+    1.000 at t = 1, 1.0014 at t = 2, 1.016 at t = 6 (and 7.3 for t -> infinity: not a bound to use on long runs)."""
+    s = sum(((1 - b1) * b1 ** k) ** 2 / ((1 - b2) * b2 ** k) for k in range(t))
+    return (1 - b2 ** t) ** 0.5 / (1 - b1 ** t) * s ** 0.5
 
 
 def _assert_same_step(ta, tb, before, where):
@@ -118,7 +131,8 @@ def _assert_same_step(ta, tb, before, where):
         lr = _group_lr(ga)
         da, db = ga["params"][0].detach() - before[name], gb["params"][0].detach() - before[name]
         rnd = ULP * float(before[name].abs().max()) + 1e-9
-        assert float(da.abs().max()) <= 1.001 * lr + rnd and float(db.abs().max()) <= 1.001 * lr + rnd, (where, name, "step larger than lr")
+        cap = 1.001 * _adam_step_bound(ta.optimizer.n_step) * lr + rnd
+        assert float(da.abs().max()) <= cap and float(db.abs().max()) <= cap, (where, name, "step larger than Adam's bound")
         solid = (g_a.abs() >= SOLID * gmax) & (g_b.abs() >= SOLID * gmax)
         assert int(solid.sum()) > 0, (where, name)
         d_solid = float((da - db)[solid].abs().max())
@@ -166,8 +180,8 @@ def test_trainer_sync_free_step_equals_exact_step_from_equal_state():
 
 
 def test_trainer_sync_free_free_running_trajectory_stays_inside_the_adam_bound():
-    """The two trainers left to themselves for six iterations (no state copy): what separates them is bounded by the number of
-    steps times 2 lr on ANY entry (noise-level gradients, see above), and the bulk of the entries - the median - stays together
+    """The two trainers left to themselves for six iterations (no state copy): what separates them is bounded by twice the sum of
+    Adam's step bounds on ANY entry (noise-level gradients, see above), and the bulk of the entries - the median - stays together
     to 1e-4 of the tensor's size; losses agree to 1e-3.  (This is the round-3 test with the assertion it can actually keep.)"""
     build, bg, cams = _bg_scene()
     from gaussianmesh_amd.train import Trainer
@@ -176,17 +190,17 @@ def test_trainer_sync_free_free_running_trajectory_stays_inside_the_adam_bound()
     ta = Trainer(build(), densify_stats=True, sync_free=False, bg_gaussian=bg)
     tb = Trainer(build(), densify_stats=True, sync_free=True, bg_gaussian=bg)
     steps = 6
-    lr_max = {gr["name"]: 0.0 for gr in ta.optimizer.param_groups}
+    reach = {gr["name"]: 0.0 for gr in ta.optimizer.param_groups}        # how far one run can have moved an entry: sum of step bounds
     for i in range(steps):
         la, pa = ta.step(cams[i % 5], gt, zero)
         lb, pb = tb.step(cams[i % 5], gt, zero)
         for gr in ta.optimizer.param_groups:
-            lr_max[gr["name"]] = max(lr_max[gr["name"]], _group_lr(gr))
+            reach[gr["name"]] += 1.001 * _adam_step_bound(i + 1) * _group_lr(gr)
         assert abs(float(la) - float(lb)) <= 1e-3 * abs(float(la)), i
     for ga, gb in zip(ta.optimizer.param_groups, tb.optimizer.param_groups):
         p, q = ga["params"][0].detach(), gb["params"][0].detach()
         d = (p - q).abs()
-        assert float(d.max()) <= steps * (2.0 * lr_max[ga["name"]] * 1.001 + 2 * ULP * float(p.abs().max())), (ga["name"], float(d.max()))
+        assert float(d.max()) <= 2.0 * reach[ga["name"]] + steps * 2 * ULP * float(p.abs().max()), (ga["name"], float(d.max()))
         assert float(d.median()) <= 1e-4 * max(float(p.abs().max()), 1.0), (ga["name"], float(d.median()))
     assert (ta.max_radii2D - tb.max_radii2D).abs().max() <= 1 and (ta.denom - tb.denom).abs().max() <= 1      # radii may flip by one
 
