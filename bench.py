@@ -32,7 +32,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s measured achievable
 
-STAGES = ["deform", "sh_colors", "preprocess", "depth_sort", "duplicate", "tile_sort", "ranges", "render"]
+STAGES = ["mesh_rs", "deform", "sh_colors", "preprocess", "depth_sort", "duplicate", "tile_sort", "ranges", "render"]
+# stages that are ONE kernel launch per frame (gm_profile_* brackets it alone): the candidates for `roofline`, the dominant KERNEL
+KERNEL_OF_STAGE = {"mesh_rs": "gm::mesh_rs_kernel", "deform": "gm::deform_shade_kernel<true,true>", "duplicate": "gm::duplicate_kernel",
+                   "render": "gm::render_fwd_kernel", "sh_colors": "gm::sh_colors_kernel", "preprocess": "gm::preprocess_fwd_kernel"}
 
 
 # The frame loop rotates over four HIP streams; the runtime multiplexes streams onto 4 hardware queues by default, and streams
@@ -75,7 +78,9 @@ def algorithmic_bytes(stage, P, V, R, W, H, Vm, M=16, list_tiles=2040):
         "deform": P * (12 + 12 + 36 + 12 + 12 * M) + P * (12 + 24 + 12) + Vm * 84,     # fused deform + colour
         # deform + colour + forward preprocess in one kernel: the 48 B/Gaussian of intermediates disappear, the
         # preprocess outputs (splat 48 B per visible Gaussian; radius, count, bin, depth key 28 B) and opacity appear
-        "deform_pre": P * (12 + 12 + 36 + 12 + 12 * M + 4) + Vm * (24 + 96 + 96) + V * 48 + P * 28,
+        "deform_pre": P * (12 + 12 + 36 + 12 + 12 * M + 4) + Vm * 96 + V * 48 + P * 28,
+        # per-vertex (R, S) from the deformed mesh: rest + deformed positions, one-ring face ids (~6 faces x (4 + 12)), the 96-byte table row
+        "mesh_rs": Vm * (24 + 96 + 96),
         "sh_colors": P * (12 + 36 + 12 * M) + P * 12,
         "preprocess": P * (12 + 24 + 4 + 12) + V * 48,
         # bucket partition (key read twice, (key, id) written once) + in-LDS bucket sort ((key, id) in; id, count out; count gather)
@@ -103,14 +108,21 @@ def measured_traffic(stage, P, W, H):
     return int(1024 * (2 * e["fetch_kib"] + e["write_kib"]))
 
 
-def build_c5(Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, dev=None, sync_free=True, ncams=32, seed=0):
+def build_c5(Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, dev=None, sync_free=True, ncams=32, seed=0, teacher=False):
     """BASELINE config C5 on this package's training harness: Nfg Gaussians bound to the 15 k-face torus + Nbg free, frozen
     "background" Gaussians in a shell of radius 6-12 that contains the cameras, W x H, a Trainer with FusedAdam on the six
-    parameter groups, densification statistics, sync-free forward, and `ncams` orbit cameras with one fixed random target
-    (SURVEY.md 8d).  Returns (trainer, cameras, target, background colour).  Also used by tests/test_gpu_fullsize.py."""
+    parameter groups, densification statistics, sync-free forward, and `ncams` orbit cameras.
+    teacher=False: one fixed random target; returns (trainer, cameras, target, background colour) - also used by
+    tests/test_gpu_fullsize.py.
+    teacher=True: the cloud as generated is the TEACHER; every camera's target is its render at SH degree 3, kept as (colour over a
+    black background, final transmittance) so that the loop can composite it over that iteration's random background exactly as
+    train_mesh_gaussian.py:92-93 does with the dataset's mask; the STUDENT the trainer gets starts grey (all SH coefficients 0)
+    and half transparent at SH degree 0, on the teacher's geometry.  Returns (trainer, cameras, (colour [ncams,3,H,W],
+    transmittance [ncams,1,H,W]), None)."""
     import torch
+    from types import SimpleNamespace
     from gaussianmesh_amd import scenes
-    from gaussianmesh_amd.renderer import Camera, MeshBoundGaussians
+    from gaussianmesh_amd.renderer import Camera, MeshBoundGaussians, render
     from gaussianmesh_amd.train import FrozenGaussians, Trainer
     dev = dev or torch.device("cuda", 0)
     t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)
@@ -131,13 +143,35 @@ def build_c5(Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, dev=None, sync_free=T
     bg = FrozenGaussians(t(b["means"] / nb * (6 + 6 * nb)), t(b["scales"]), torch.nn.functional.normalize(t(b["rots"])), t(b["opac"]).reshape(-1, 1),
                          t(b["shs"]))
     cams = [Camera(scenes.orbit_camera(k, ncams, W, H), dev) for k in range(ncams)]
-    target = torch.rand((3, H, W), device=dev, generator=torch.Generator(device=dev).manual_seed(seed))
+    if not teacher:
+        target = torch.rand((3, H, W), device=dev, generator=torch.Generator(device=dev).manual_seed(seed))
+        tr = Trainer(model, densify_stats=True, sync_free=sync_free, bg_gaussian=bg)
+        return tr, cams, target, torch.zeros(3, device=dev)
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
+    colour = torch.empty((ncams, 3, H, W), device=dev); trans = torch.empty((ncams, 1, H, W), device=dev)
+    zero, one = torch.zeros(3, device=dev), torch.ones(3, device=dev)
+    with torch.no_grad():
+        for k, c in enumerate(cams):
+            colour[k] = render(c, model, pipe, zero, bg_gaussian=bg)["render"]
+            trans[k] = (render(c, model, pipe, one, bg_gaussian=bg)["render"][:1] - colour[k][:1]).clamp(0.0, 1.0)   # C + T.1 - C
+        model._features.zero_()                                      # the student: grey ...
+        model._opacity.fill_(-1.0)                                   # ... half transparent ...
+    model.active_sh_degree = 0                                       # ... and at SH degree 0, where the reference's model starts
     tr = Trainer(model, densify_stats=True, sync_free=sync_free, bg_gaussian=bg)
-    return tr, cams, target, torch.zeros(3, device=dev)
+    return tr, cams, (colour, trans), None
 
 
-def c5_leg(steps, warm, Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, sync_free=True, policy=None, work_hint=True, dev=None):
-    """Times `steps` Trainer.step iterations of the C5 workload (after `warm` untimed ones); returns the "c5" object of the bench line."""
+def c5_leg(steps, warm, Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, sync_free=True, policy=None, work_hint=True, dev=None, as_reference=False,
+           ncams=32):
+    """The "c5" object of the bench line.
+    as_reference=False (the leg rounds 1-3 reported, kept for comparison): `steps` Trainer.step iterations after `warm` untimed ones at
+    a fixed topology, SH degree 3, a zero background and one fixed random target.
+    as_reference=True: iterations 1 .. `steps` of train_mesh_gaussian.py AS IT RUNS THEM (Trainer.train_iteration): SH degree 0
+    (one up at iteration 1000, :70-71), a camera popped at random without replacement (:74-76), a random background per iteration
+    because a background cloud exists (:85), the target composited over it (:92-93), densification statistics every iteration,
+    densify_and_prune(0.0002, 0.005, extent, None, 5) at iterations 600 / 800 / 1000 with the optimizer step of those iterations
+    skipped (:126-139) - all inside the timed region, no warm-up (the first iteration IS iteration 1)."""
+    import random
     import torch
     from gaussianmesh_amd import rasterizer as Rz
     from gaussianmesh_amd.renderer import set_work_hints
@@ -145,47 +179,92 @@ def c5_leg(steps, warm, Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, sync_free=
     dev = dev or torch.device("cuda", 0)
     if policy is not None:
         Rz.set_default_emission_policy(policy)
-    tr, cams, target, zero_bg = build_c5(Nfg, Nbg, W, H, dev, sync_free)
+    tr, cams, target, zero_bg = build_c5(Nfg, Nbg, W, H, dev, sync_free, ncams=ncams, teacher=as_reference)
     nc = len(cams)
     losses = []
-    for i in range(warm):
-        losses.append(tr.step(cams[i % nc], target, zero_bg)[0])
+    if not as_reference:
+        for i in range(warm):
+            losses.append(tr.step(cams[i % nc], target, zero_bg)[0])
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats(dev)
+        redone0 = tr.redone
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loss, pkg = tr.step(cams[(warm + i) % nc], target, zero_bg)
+            if i % 50 == 0 or i == steps - 1:
+                losses.append(loss)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        out = {"ms_per_iter": 1e3 * el / steps, "iters": steps, "warmup": warm, "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
+               "iterations_redone": tr.redone - redone0, "gaussians": Nfg + Nbg, "trainable": Nfg, "width": W, "height": H,
+               "visible": int((pkg["radii"] > 0).sum().item()), "emission_policy": Rz.get_default_emission_policy(W, H), "sync_free": bool(sync_free),
+               "loss_first": float(losses[0]), "loss_last": float(losses[-1]), "sh_degree": 3,
+               "workload": "C5 (fixed topology): %d mesh-bound + %d frozen free Gaussians, %dx%d, render + L1/SSIM/mesh-restrict loss + backward + FusedAdam + "
+                           "densification statistics, %d orbit cameras, SH degree 3, zero background, fixed random target" % (Nfg, Nbg, W, H, nc)}
+        del tr, cams, target, pkg
+        torch.cuda.empty_cache()
+        return out
+    colour, trans = target
+    rng = random.Random(0)
+    stack = []
     torch.cuda.synchronize()
     torch.cuda.reset_peak_memory_stats(dev)
-    redone0 = tr.redone
+    densify_ms, rows_after, marks = [], [], {}
     t0 = time.perf_counter()
-    for i in range(steps):
-        loss, pkg = tr.step(cams[(warm + i) % nc], target, zero_bg)
-        if i % 50 == 0 or i == steps - 1:
+    for it in range(1, steps + 1):
+        if not stack:
+            stack = list(range(nc))
+        k = stack.pop(rng.randint(0, len(stack) - 1))                    # :74-76
+        bgc = torch.rand(3, device=dev)                                  # :85 (device generator: no host round trip)
+        gt = torch.addcmul(colour[k], trans[k], bgc.view(3, 1, 1))       # :92-93 gt * mask + bg * (1 - mask), with the teacher's transmittance
+        plan = tr.schedule(it)
+        if plan["densify"]:                                              # bracket the three topology changes (three extra host syncs in 1000 iterations)
+            torch.cuda.synchronize(); td = time.perf_counter()
+        loss, pkg, plan = tr.train_iteration(cams[k], gt, bgc)
+        if plan["densify"]:
+            torch.cuda.synchronize()
+            densify_ms.append(1e3 * (time.perf_counter() - td)); rows_after.append(plan["rows"])
+        if it in (1, 599, 600):
+            torch.cuda.synchronize(); marks[it] = time.perf_counter()
+        if it <= 20 or it > steps - 20:
             losses.append(loss)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    out = {"ms_per_iter": 1e3 * el / steps, "iters": steps, "warmup": warm, "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
-           "iterations_redone": tr.redone - redone0, "gaussians": Nfg + Nbg, "trainable": Nfg, "width": W, "height": H,
+    lf = float(torch.stack(losses[:20]).mean()); ll = float(torch.stack(losses[-20:]).mean())
+    out = {"ms_per_iter": 1e3 * el / steps, "iters": steps, "warmup": 0, "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
+           "iterations_redone": tr.redone, "gaussians": Nfg + Nbg, "trainable": Nfg, "trainable_at_end": int(tr.g._bc.shape[0]), "width": W, "height": H,
            "visible": int((pkg["radii"] > 0).sum().item()), "emission_policy": Rz.get_default_emission_policy(W, H), "sync_free": bool(sync_free),
-           "loss_first": float(losses[0]), "loss_last": float(losses[-1]),
-           "workload": "C5: %d mesh-bound + %d frozen free Gaussians, %dx%d, render + L1/SSIM/mesh-restrict loss + backward + FusedAdam + "
-                       "densification statistics, %d orbit cameras, fixed random target" % (Nfg, Nbg, W, H, nc)}
-    del tr, cams, target, pkg
+           "loss_first": lf, "loss_last": ll, "loss_ratio": ll / lf, "sh_degree": "0, 1 from iteration 1000",
+           # iterations 2 .. 599: before the first topology change (iteration 1 carries the first allocations and the capacity seed)
+           "ms_per_iter_before_first_densify": (1e3 * (marks[599] - marks[1]) / 598) if 599 in marks and 1 in marks else None,
+           "densify_iterations_ms": [round(x, 3) for x in densify_ms],       # the WHOLE iteration that ends in densify_and_prune (no Adam step)
+           "rows_after_densify": rows_after, "topology_changes": tr.resizes,
+           "workload": "C5 as train_mesh_gaussian.py runs its first %d iterations: %d mesh-bound + %d frozen free Gaussians, %dx%d, SH degree 0 "
+                       "(1 at iteration 1000), random camera / random background per iteration, teacher-rendered targets composited over the "
+                       "background, L1/SSIM/mesh-restrict loss, backward, FusedAdam, densification statistics, densify_and_prune(0.0002, N=5) at "
+                       "600 / 800 / 1000 (optimizer step skipped there), %d orbit cameras" % (steps, Nfg, Nbg, W, H, nc)}
+    del tr, cams, target, colour, trans, pkg
     torch.cuda.empty_cache()
     return out
 
 
 def run_c5(args):
-    """`bench.py --config c5`: the C5 training loop as the headline of its own JSON line (ms per iteration)."""
+    """`bench.py --config c5`: the C5 training loop as the headline of its own JSON line (ms per iteration): the reference's first
+    1000 iterations with their schedule (c5_leg(as_reference=True)); `--c5-fixed` times the fixed-topology SH-3 leg instead."""
     import torch
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(0)
     W, H = args.width if args.width != 1920 else 3840, args.height if args.height != 1080 else 2160
     Nfg, Nbg = ((2 * args.gaussians) // 3, args.gaussians // 3) if args.gaussians != 1_000_000 else (2_000_000, 1_000_000)
     steps = args.steps if args.steps != 300 else 1000
-    c5 = c5_leg(steps, max(args.warmup, 5), Nfg, Nbg, W, H, sync_free=not args.exact_count, policy=args.policy, work_hint=not args.no_work_hint)
+    c5 = c5_leg(steps, max(args.warmup, 5), Nfg, Nbg, W, H, sync_free=not args.exact_count, policy=args.policy, work_hint=not args.no_work_hint,
+                as_reference=not args.c5_fixed, ncams=min(args.cameras, 32))
     out = {"metric": "ms/iter (fwd+bwd+optimizer), 3M Gaussians @4K training loop", "value": c5["ms_per_iter"], "unit": "ms/iter", "n_gpus": 1,
            "steps": steps, "warmup": c5["warmup"], "ms_per_step": c5["ms_per_iter"], "higher_is_better": False, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": c5["workload"], "gaussians": Nfg + Nbg, "trainable": Nfg, "width": W, "height": H, "sh_degree": 3,
+           "config": {"workload": c5["workload"], "gaussians": Nfg + Nbg, "trainable": Nfg, "width": W, "height": H, "sh_degree": c5["sh_degree"],
                       "emission_policy": c5["emission_policy"], "sync_free": c5["sync_free"], "iterations_redone": c5["iterations_redone"]},
-           "peak_memory_gb": c5["peak_memory_gb"], "visible": c5["visible"], "loss_first": c5["loss_first"], "loss_last": c5["loss_last"]}
+           "c5": c5}
     print(json.dumps(out))
 
 
@@ -230,8 +309,11 @@ def main():
                     "with GM_FWD_IMAGE_ONLY by default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fwd-bwd", action="store_true")
-    ap.add_argument("--no-c5", action="store_true", help="leave out the bounded C5 leg (200 iterations of the 3 M-Gaussian 4K training loop)")
+    ap.add_argument("--no-c5", action="store_true", help="leave out the C5 legs (the 3 M-Gaussian 4K training loop: the reference's first 1000 "
+                    "iterations with their schedule, and --c5-iters iterations at a fixed topology)")
     ap.add_argument("--c5-iters", type=int, default=200)
+    ap.add_argument("--c5-fixed", action="store_true", help="--config c5: time the fixed-topology SH-degree-3 leg of rounds 1-3 instead of the "
+                    "reference's first 1000 iterations with their schedule")
     args = ap.parse_args()
     if args.config == "c5":
         return run_c5(args)
@@ -533,26 +615,28 @@ def main():
             if n.value:
                 per[s] = ms.value / nprof               # ms per frame (a stage may be several launches)
         bytes_key = lambda st: "deform_pre" if (st == "deform" and not args.unfused) else st
-        dom = max(per, key=per.get)
-        ab = algorithmic_bytes(bytes_key(dom), P, V, Rn, W, H, Vm, list_tiles=list_tiles)
+        stage_bytes = lambda st: algorithmic_bytes(bytes_key(st), P, V, Rn, W, H, Vm, list_tiles=list_tiles)
+        # `roofline` = the dominant KERNEL of the frame: the longest of the stages that are one launch each (the ordering stages are
+        # 4 + 3 launches of at most 30 us each; they are under stage_roofline)
+        dom = max((st for st in per if st in KERNEL_OF_STAGE), key=per.get)
+        ab = stage_bytes(dom)
         ach = ab / (per[dom] * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "kernel_name": KERNEL_OF_STAGE[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic(dom, P, W, H),
                            "traffic_source": "static: profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this "
                                              "workload; counters cannot be read inside the timed run)",
                            "algorithmic_bytes": ab, "avg_ms": per[dom],
-                           "note": ("the blend kernel is bound by vector-ALU issue, not by HBM (DESIGN.md section 4); the HBM figure is "
-                                    "reported because the contract asks for it") if dom == "render" else
-                                   ("stage = the per-vertex (R, S) kernel + the fused deformation / SH colour / preprocess kernel, a streaming "
-                                    "kernel bound by HBM (rocprof: 77 us of the stage for 346 MB); since the blend dropped below 0.09 ms it "
-                                    "is the longest stage of a frame; the blend's own figure is under stage_roofline") if dom == "deform" else
-                                   "longest stage of the frame"}
-        # the other stages, same definition (algorithmic bytes of the stage / its time): the blend is the vector-ALU-bound one
-        out["stage_roofline"] = {st: round(algorithmic_bytes(bytes_key(st), P, V, Rn, W, H, Vm, list_tiles=list_tiles) / (per[st] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                                 for st in per if st in ("deform", "depth_sort", "duplicate", "tile_sort", "render")}
+                           "note": ("the forward blend: bound by vector-ALU issue, not by HBM (DESIGN.md section 4: ~3.6e7 vector instructions "
+                                    "per launch = 59 us of the chip's issue slots); the HBM figure is reported because the contract asks for it")
+                                   if dom == "render" else
+                                   ("the fused deformation / SH colour / preprocess kernel: a streaming kernel bound by HBM") if dom == "deform" else
+                                   "longest single kernel of the frame"}
+        # every stage, same definition (algorithmic bytes of the stage / its HIP-event time); "deform" is the fused kernel alone
+        out["stage_roofline"] = {st: round(stage_bytes(st) / (per[st] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                 for st in per if st in ("mesh_rs", "deform", "depth_sort", "duplicate", "tile_sort", "render")}
         out["stage_ms"] = {k: round(v, 4) for k, v in per.items()}
         out["scene"] = {"P": P, "V": V, "R": Rn}
-        tot_bytes = sum(algorithmic_bytes(bytes_key(s), P, V, Rn, W, H, Vm, list_tiles=list_tiles) for s in per)
+        tot_bytes = sum(stage_bytes(s) for s in per)
         out["frame_roofline"] = {"algorithmic_bytes": tot_bytes, "achieved": tot_bytes / (elapsed / args.steps) / 1e9,
                                  "frac": tot_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s",
                                  "single_stream_ms_per_frame": sum(per.values())}
@@ -699,7 +783,10 @@ def main():
         g.clear(); workspaces.clear(); pending.clear()
         del lv, m2, rast2, rs2, wgt, gt, rast, rs, v1_frames, hint, adjacency, stats      # C3 / C2 state: not part of C5's peak memory
         torch.cuda.empty_cache()
-        out["c5"] = c5_leg(max(1, args.c5_iters), 10, policy=args.policy, work_hint=not args.no_work_hint, dev=dev)
+        # "c5": the reference's first 1000 iterations with their schedule (SH ramp, random background, densify_and_prune at 600 / 800 /
+        # 1000); "c5_fixed": the fixed-topology SH-3 leg rounds 1-3 reported (--c5-iters iterations), for comparison across rounds
+        out["c5"] = c5_leg(1000, 0, policy=args.policy, work_hint=not args.no_work_hint, dev=dev, as_reference=True)
+        out["c5_fixed"] = c5_leg(max(1, args.c5_iters), 10, policy=args.policy, work_hint=not args.no_work_hint, dev=dev)
     else:
         host_keep = mesh_keep = None
 

@@ -55,6 +55,7 @@ SIGNATURES = {
     "gm_mesh_activate_fwd": (i32, [i32, f32] + [vp] * 10 + [vp] * 4 + [f32, vp] + [vp]),
     "gm_mesh_activate_bwd": (i32, [i32, f32] + [vp] * 10 + [vp] * 4 + [vp] * 5 + [f32, vp] + [vp]),
     "gm_adam_step": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, f64, f64, f64, i32, vp]),
+    "gm_adam_step_active": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f64, f64, f64, i32, vp]),
     "gm_densify_stats": (i32, [i32, vp, vp, vp, vp, vp, vp]),
     "gm_ssim_partials": (i64, [i32, i32, i32]),
     "gm_ssim_fwd": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),

@@ -29,7 +29,7 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
 
 // ---- per-stage profiling -------------------------------------------------------------------
 static const char* kStageNames[ST_COUNT] = {"preprocess", "depth_sort", "scan", "duplicate", "tile_sort", "ranges",
-                                            "render", "render_bwd", "preprocess_bwd", "deform", "sh_colors", "loss", "loss_bwd"};
+                                            "render", "render_bwd", "preprocess_bwd", "deform", "sh_colors", "loss", "loss_bwd", "mesh_rs"};
 struct EvPair { hipEvent_t a, b; int st; };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
@@ -503,6 +503,12 @@ int gm_mesh_activate_bwd(int N, float alpha, const float* bc, const float* dist,
 int gm_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                  const uint64_t* sizes, const float* lr, const float* lr_rest, const uint32_t* period, const uint32_t* split,
                  double beta1, double beta2, double eps, int step, void* stream) {
+  return gm_adam_step_active(count, params, grads, exp_avg, exp_avg_sq, sizes, lr, lr_rest, period, split, nullptr, beta1, beta2, eps, step, stream);
+}
+
+int gm_adam_step_active(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                        const uint64_t* sizes, const float* lr, const float* lr_rest, const uint32_t* period, const uint32_t* split,
+                        const uint32_t* active, double beta1, double beta2, double eps, int step, void* stream) {
   if (count < 0 || count > 8 || step < 1) { set_error("gm_adam_step: 0..8 tensors per call, step >= 1"); return GM_ERR_INVALID_ARG; }
   if (count > 0 && (!params || !grads || !exp_avg || !exp_avg_sq || !sizes || !lr)) { set_error("gm_adam_step: null table"); return GM_ERR_INVALID_ARG; }
   AdamTable tab;
@@ -519,6 +525,8 @@ int gm_adam_step(int count, float* const* params, const float* const* grads, flo
     t.step_lo = (float)(lr[i] * corr);
     t.period = period ? period[i] : 0u; t.split = split ? split[i] : 0u;
     if (t.period & 3u) { set_error("gm_adam_step: period must be a multiple of 4"); return GM_ERR_INVALID_ARG; }
+    t.active = (active && active[i] && t.period && active[i] < t.period) ? active[i] : 0u;
+    if (t.active && (t.n % t.period) != 0) { set_error("gm_adam_step_active: tensor %d is not a whole number of periods", i); return GM_ERR_INVALID_ARG; }
     t.step_hi = (float)((lr_rest && t.period) ? lr_rest[i] * corr : lr[i] * corr);
   }
   return launch_adam(tab, reinterpret_cast<hipStream_t>(stream));

@@ -34,7 +34,7 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 // per-stage timing (gm_profile_*)
 enum Stage {
   ST_PREPROCESS = 0, ST_DEPTH_SORT, ST_SCAN, ST_DUPLICATE, ST_TILE_SORT, ST_RANGES, ST_RENDER,
-  ST_RENDER_BWD, ST_PREPROCESS_BWD, ST_DEFORM, ST_SH_COLORS, ST_LOSS, ST_LOSS_BWD, ST_COUNT
+  ST_RENDER_BWD, ST_PREPROCESS_BWD, ST_DEFORM, ST_SH_COLORS, ST_LOSS, ST_LOSS_BWD, ST_MESH_RS, ST_COUNT
 };
 struct StageScope {            // records start/stop events on `s` if profiling is enabled
   StageScope(Stage st, hipStream_t s);
@@ -335,6 +335,7 @@ struct AdamTensor {
   unsigned long long n;
   float step_lo, step_hi;      // lr * sqrt(1-b2^t)/(1-b1^t) for elements with (index % period) < split / the others
   unsigned period, split;      // period == 0: one rate (step_lo) for the whole tensor
+  unsigned active;             // 0: every element; else only elements with (index % period) < active (rounded up to a 16-byte granule) are touched
 };
 struct AdamTable { AdamTensor t[8]; int count; float b1, b2, eps, omb1, omb2; };   // omb = (float)(1 - beta), formed in double
 int launch_mesh_activate_fwd(const ActArgs& a, float* xyz, float* scales, float* rots, float* opac, float mr_weight, float* mr_partial,

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(GM_MESH_THREADS) void mesh_rs_kernel(int Vm, const 
 int launch_mesh_rs(int Vm, const float* V0, const float* V1, const int* faces, const int* adj_offsets, const int* adj_faces, float* R,
                    float* S, float* state, float* packed, hipStream_t s) {
   if (Vm <= 0) return 0;
-  StageScope sc(ST_DEFORM, s);
+  StageScope sc(ST_MESH_RS, s);          // a stage of its own: bench.py's `roofline` names single kernels
   hipLaunchKernelGGL(mesh_rs_kernel, dim3((Vm + GM_MESH_THREADS - 1) / GM_MESH_THREADS), dim3(GM_MESH_THREADS), 0, s, Vm, V0, V1, faces, adj_offsets, adj_faces, R, S, state,
                      reinterpret_cast<float4*>(packed));
   GM_HIP(hipGetLastError());

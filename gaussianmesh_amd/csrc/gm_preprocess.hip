@@ -62,8 +62,18 @@ __global__ __launch_bounds__(TH) void preprocess_fwd_kernel(const PreArgs a) {
       float4* l4 = reinterpret_cast<float4*>(lds_pre);
       if (nrows == TH) {
         const char* gsh = reinterpret_cast<const char*>(a.shs + row0 * 48) + threadIdx.x * 16;
+        if (a.D >= 3) {
 #pragma unroll
-        for (int q = 0; q < 12; q++) dma16(gsh + q * (TH * 16), reinterpret_cast<char*>(l4) + q * (TH * 16));
+          for (int q = 0; q < 12; q++) dma16(gsh + q * (TH * 16), reinterpret_cast<char*>(l4) + q * (TH * 16));
+        } else {
+          // below the full degree only the leading (D+1)^2 coefficients of a row are read (forward.cu:20-71 touches no others): the
+          // lanes whose 16-byte granule lies behind them sit the copy out - at degree 0 (the first 1000 training iterations,
+          // train_mesh_gaussian.py:70-71) one granule of twelve; the rest of the LDS row is never looked at
+          const int nq = (3 * (a.D + 1) * (a.D + 1) + 3) >> 2;
+#pragma unroll
+          for (int q = 0; q < 12; q++)
+            if ((int)((q * TH + threadIdx.x) % 12u) < nq) dma16(gsh + q * (TH * 16), reinterpret_cast<char*>(l4) + q * (TH * 16));
+        }
         __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
       } else if ((int)threadIdx.x < nrows) {
 #pragma unroll
@@ -225,8 +235,15 @@ __global__ __launch_bounds__(TH) void preprocess_bwd_kernel(const PreBwdArgs a) 
     if (DMA) {
       if (nrows == TH) {
         const char* gsh = reinterpret_cast<const char*>(a.shs + row0 * 48) + threadIdx.x * 16;
+        if (a.D >= 3) {
 #pragma unroll
-        for (int q = 0; q < 12; q++) dma16(gsh + q * (TH * 16), reinterpret_cast<char*>(l4) + q * (TH * 16));
+          for (int q = 0; q < 12; q++) dma16(gsh + q * (TH * 16), reinterpret_cast<char*>(l4) + q * (TH * 16));
+        } else {                                     // only the granules that hold the active degree's coefficients (see preprocess_fwd_kernel)
+          const int nq = (3 * (a.D + 1) * (a.D + 1) + 3) >> 2;
+#pragma unroll
+          for (int q = 0; q < 12; q++)
+            if ((int)((q * TH + threadIdx.x) % 12u) < nq) dma16(gsh + q * (TH * 16), reinterpret_cast<char*>(l4) + q * (TH * 16));
+        }
         __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
       } else if ((int)threadIdx.x < nrows) {
 #pragma unroll

@@ -190,7 +190,11 @@ struct FwdLds {                  // per wave: 5.25 KiB
 #ifndef GM_RENDER_FWD_WPW
 #define GM_RENDER_FWD_WPW 1      // waves per workgroup of the forward blend: 1 (one workgroup per 8x8 quadrant) or 4 (one per 16-px tile)
 #endif
-template <bool STATE, bool TRACE>
+// EXACT (verification build, gm_debug_forward_exact_exponent; never on the product path): the exponents of a group come from the
+// pixel-relative form of round 2 / of the backward kernel (staged_exponent: |e - e_exact| ~ 5e-7) instead of the matrix core's
+// polynomial (~1e-5).  Everything else - lists, cull, decisions, recurrence - is the same code, so the two builds may differ only
+// where an entry's alpha or a pixel's T sits within the polynomial's error of a threshold (tests/test_gpu_parity.py).
+template <bool STATE, bool TRACE, bool EXACT = false>
 __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(const uint2* __restrict__ ranges, const uint2* __restrict__ pairs,
                                                         const float4* __restrict__ splat, int W, int H, TileMap tm,
                                                         const float* __restrict__ bg, float* __restrict__ out_color,
@@ -229,6 +233,9 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
     const float rx0 = (float)(tx * GM_TILE + (wave & 1) * 8), ry0 = (float)(ty * GM_TILE + (wave >> 1) * 8);
     __shared__ FwdLds L_w[WPW];
     FwdLds& L = L_w[WPW == 4 ? wave : 0];
+    __shared__ float4 x_ra[EXACT ? 68 * WPW : 1];                               // EXACT: (x, y, a', c') and b' per survivor
+    __shared__ float x_bq[EXACT ? 68 * WPW : 1];
+    const v2f pixf = {(float)px, (float)py};
     // B operand of the three MFMA steps: monomials (cx^2, cx cy) / (cy^2, cx) / (cy, 1) of this lane's pixel column; k = lane / 32
     const float ccx = (float)(lane & 7) - 3.5f, ccy = (float)((lane >> 3) & 3) - 1.5f;
     const bool khi = lane >= 32;
@@ -304,6 +311,7 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
           row[128] = -bu - 2.0f * c * v0; row[132] = -bu - 2.0f * c * v1;
           row[160] = u * (au + b * v0) + c * v0 * v0; row[164] = u * (au + b * v1) + c * v1 * v1;
           L.sb[slot] = make_float4(cur.b.z, cur.b.w, cur.c, cur.b.y);
+          if (EXACT) { x_ra[68 * (WPW == 4 ? wave : 0) + slot] = make_float4(cur.a.x, cur.a.y, a, c); x_bq[68 * (WPW == 4 ? wave : 0) + slot] = b; }
           if (STATE) L.sp[slot] = cur.pos + 1u;                           // 1-based list position: n_contrib
         }
         if (lane < 4) L.sb[ns + lane] = make_float4(0.f, 0.f, 0.f, 0.f);    // survivors are taken four at a time: opacity 0 behind the last
@@ -312,6 +320,16 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
         // groups of 16 survivors.  (Measured and dropped: issuing the NEXT group's three MFMA steps before the current group's
         // exponents are consumed - two accumulator sets, 142 VGPRs, three waves per SIMD instead of four: 4430 vs 4700 frames/s.)
         auto exponents = [&](const int j) -> v16f {
+          if (EXACT) {                                                    // slots behind the last survivor: opacity 0, any exponent will do
+            v16f E;
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+              const int sl = 68 * (WPW == 4 ? wave : 0) + min(j + t, 67);
+              v2f dd;
+              E[t] = staged_exponent(x_ra[sl], x_bq[sl], pixf, dd);
+            }
+            return E;
+          }
           const float* ctg = &L.ct[12 * j + lane];                        // 192 (j / 16) + lane
           const float A0 = ctg[0], A1 = ctg[64], A2 = ctg[128];
           v16f E = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -389,6 +407,8 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
 
 static unsigned long long* g_render_trace = nullptr;      // debugging aid (tools/wave_trace.py), never set by the package
 extern "C" void gm_debug_render_trace(void* buffer) { g_render_trace = reinterpret_cast<unsigned long long*>(buffer); }
+static bool g_fwd_exact = false;                          // verification aid (tests only): the EXACT build of the forward blend
+extern "C" void gm_debug_forward_exact_exponent(int on) { g_fwd_exact = on != 0; }
 
 int launch_render_fwd(const GeomState& g, const uint2* pairs, ImageState& img, int W, int H, int mode,
                       const float* background, float* out_color, int* status_host, bool image_only, uint32_t* work_hint, int debug,
@@ -398,7 +418,10 @@ int launch_render_fwd(const GeomState& g, const uint2* pairs, ImageState& img, i
   const TileMap tm{tg.gx, tg.gy, tg.pgx, tg.pgy, tg.s, img.tile_order};
   if (tg.ptiles > 0) {
     const dim3 grid(tm.blocks() * (4 / GM_RENDER_FWD_WPW)), block(64 * GM_RENDER_FWD_WPW);     // one wave (8x8 quadrant) per workgroup
-    if (g_render_trace)
+    if (g_fwd_exact)
+      hipLaunchKernelGGL((render_fwd_kernel<true, false, true>), grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
+                         background, out_color, img.final_T, img.n_contrib, nullptr, g.counters, status_host, work_hint, img.epoch);
+    else if (g_render_trace)
       hipLaunchKernelGGL((render_fwd_kernel<true, true>), grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
                          background, out_color, img.final_T, img.n_contrib, g_render_trace, g.counters, status_host, work_hint, img.epoch);
     else if (image_only)

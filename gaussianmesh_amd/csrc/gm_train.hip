@@ -11,6 +11,10 @@
 //     the rest "f_rest" - so no concatenation / split of the 192-byte SH rows is needed per iteration):
 //       m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr sqrt(1-b2^t)/(1-b1^t) m / (sqrt(v) + eps)
 //     (scene/mesh_based_gaussian_model.py:242-263 training_setup; jittor/optim.py Adam.step).
+//     `active` (gm_adam_step_active): while the model's active SH degree D is below 3 (train_mesh_gaussian.py:70-71: one degree per
+//     1000 iterations, starting at 0) the coefficients >= (D+1)^2 of every row have never had a non-zero gradient: g = m = v = 0,
+//     and the rule above leaves p, m and v exactly as they are.  The kernel then does not touch them at all - at D = 0 that is
+//     45 of the 60 parameters of a Gaussian, 28 bytes each.
 #include "gm_common.h"
 
 namespace gm {
@@ -137,6 +141,28 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable tab) {
   const AdamTensor t = tab.t[blockIdx.y];
   const float b1 = tab.b1, b2 = tab.b2, eps = tab.eps, c1 = tab.omb1, c2 = tab.omb2;
   const unsigned long long n4 = t.n >> 2;
+  if (t.active) {
+    // only the first ga granules of every period: thread <-> (period index, live granule)
+    const unsigned gp = t.period >> 2, ga = (t.active + 3u) >> 2;
+    const unsigned long long rows = n4 / gp, live = rows * ga;
+    for (unsigned long long w = (unsigned long long)blockIdx.x * 256 + threadIdx.x; w < live; w += (unsigned long long)gridDim.x * 256) {
+      const unsigned long long row = w / ga;
+      const unsigned k = (unsigned)(w - row * ga);
+      const unsigned long long q = row * gp + k;
+      const float4 g = reinterpret_cast<const float4*>(t.g)[q];
+      float4 p = reinterpret_cast<float4*>(t.p)[q], m = reinterpret_cast<float4*>(t.m)[q], v = reinterpret_cast<float4*>(t.v)[q];
+      float* pp = &p.x; float* mm = &m.x; float* vv = &v.x; const float* gg = &g.x;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const float st = (4u * k + c >= t.split) ? t.step_hi : t.step_lo;
+        mm[c] = b1 * mm[c] + c1 * gg[c];
+        vv[c] = b2 * vv[c] + c2 * gg[c] * gg[c];
+        pp[c] -= st * mm[c] / (sqrtf(vv[c]) + eps);
+      }
+      reinterpret_cast<float4*>(t.p)[q] = p; reinterpret_cast<float4*>(t.m)[q] = m; reinterpret_cast<float4*>(t.v)[q] = v;
+    }
+    return;                                        // (API: n is a multiple of the period when `active` is given)
+  }
   for (unsigned long long q = (unsigned long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (unsigned long long)gridDim.x * 256) {
     const float4 g = reinterpret_cast<const float4*>(t.g)[q];
     float4 p = reinterpret_cast<float4*>(t.p)[q], m = reinterpret_cast<float4*>(t.m)[q], v = reinterpret_cast<float4*>(t.v)[q];

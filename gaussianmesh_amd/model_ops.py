@@ -187,9 +187,12 @@ class FusedAdam:
         LR2 = arr(C.c_float, [float(g.get("lr_rest", g["lr"])) for g in live])
         PER = arr(C.c_uint32, [int(g.get("period", 0)) for g in live])
         SPL = arr(C.c_uint32, [int(g.get("split", 0)) for g in live])
+        # "active" (optional, with "period"): only the first `active` elements of every period have ever had a gradient - the SH
+        # coefficients of the degrees the model has switched on so far (Trainer keeps it at 3 (D+1)^2); the rest is left alone
+        ACT = arr(C.c_uint32, [int(g.get("active", 0)) for g in live])
         with torch.cuda.device(dev), torch.no_grad():
-            _lib.check(lib.gm_adam_step(n, P, G, M, V, S, LR, LR2, PER, SPL, float(self.betas[0]), float(self.betas[1]), float(self.eps),
-                                        int(self.n_step), torch.cuda.current_stream(dev).cuda_stream))
+            _lib.check(lib.gm_adam_step_active(n, P, G, M, V, S, LR, LR2, PER, SPL, ACT, float(self.betas[0]), float(self.betas[1]),
+                                               float(self.eps), int(self.n_step), torch.cuda.current_stream(dev).cuda_stream))
 
 
 def densify_stats(radii, viewspace_grad, max_radii2D, grad_accum, denom):

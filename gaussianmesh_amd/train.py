@@ -41,8 +41,10 @@ def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, ma
 
 
 # arguments/__init__.py:70-93 OptimizationParams (pinned by tests/golden/schedule.npz)
-DEFAULT_OPT = dict(position_lr_init=0.00016, position_lr_final=0.0000016, position_lr_delay_mult=0.01, position_lr_max_steps=30000,
-                   feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001, lambda_dssim=0.2, alpha_mrloss=6.0)
+DEFAULT_OPT = dict(iterations=30000, position_lr_init=0.00016, position_lr_final=0.0000016, position_lr_delay_mult=0.01, position_lr_max_steps=30000,
+                   feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001, lambda_dssim=0.2, alpha_mrloss=6.0,
+                   densification_interval=200, opacity_reset_interval=3000, densify_from_iter=500, densify_until_iter=15000,
+                   densify_grad_threshold=0.0002)
 
 
 class FrozenGaussians:
@@ -100,6 +102,7 @@ class Trainer:
         self.sync_state = SyncFreeState(enabled=self.sync_free)
         self.keep_grads = False
         self.last_grads = None
+        self._sh_degree_seen = int(getattr(gaussians, "active_sh_degree", 3))     # highest SH degree a gradient has been taken at
         self.redone = 0                          # iterations repeated because the instance count outgrew the binning buffer
         self.resizes = 0                         # topology changes applied (resize and everything built on it)
         self.densify_stats = bool(densify_stats)
@@ -263,9 +266,44 @@ class Trainer:
         loss.backward()
         return loss, pkg
 
-    def step(self, camera, gt_image, background):
+    def schedule(self, iteration, white_background=False):
+        """What train_mesh_gaussian.py:66-148 does besides render / loss / backward at `iteration` (1-based), from the
+        OptimizationParams in self.opt (arguments/__init__.py:70-93): {"oneup": raise the SH degree before rendering (:70-71),
+        "stats": keep the densification statistics (:119-124), "densify": densify_and_prune(densify_grad_threshold, 0.005, extent,
+        size_threshold, 5) after the statistics - and NO optimizer step in that iteration (:126-128, update_flag :139),
+        "size_threshold", "reset_opacity" (:129-130), "optimizer_step" (:137-139)}."""
+        o = self.opt
+        before_until = iteration < o.densify_until_iter
+        densify = before_until and iteration > o.densify_from_iter and iteration % o.densification_interval == 0
+        return {"oneup": iteration % 1000 == 0, "stats": before_until, "densify": densify,
+                "size_threshold": 20 if iteration > o.opacity_reset_interval else None,
+                "reset_opacity": before_until and (iteration % o.opacity_reset_interval == 0 or
+                                                   (white_background and iteration == o.densify_from_iter)),
+                "optimizer_step": iteration < o.iterations and not densify}
+
+    def train_iteration(self, camera, gt_image, background, white_background=False, extent=None):
+        """One iteration of the reference's loop INCLUDING its schedule (self.schedule): SH degree ramp, densification statistics,
+        densify_and_prune every densification_interval iterations past densify_from_iter (N = 5, the optimizer step of that
+        iteration skipped, as the reference's update_flag does), opacity reset.  Returns (loss, render package, plan) with
+        plan["rows"] = the row count after the iteration."""
+        plan = self.schedule(self.iteration + 1, white_background)
+        if plan["oneup"] and hasattr(self.g, "oneupSHdegree"):
+            self.g.oneupSHdegree()
+        loss, pkg = self.step(camera, gt_image, background, stats=plan["stats"],
+                              densify=(self.opt.densify_grad_threshold, 0.005, extent, plan["size_threshold"], 5) if plan["densify"] else None,
+                              optimizer_step=plan["optimizer_step"])
+        if plan["reset_opacity"]:
+            self.reset_opacity()
+        plan["rows"] = self.g._bc.shape[0]
+        return loss, pkg, plan
+
+    def step(self, camera, gt_image, background, stats=True, densify=None, optimizer_step=True):
         """One iteration; returns (loss tensor, render package).  Host synchronisation: the rasterizer's instance-count
-        read-back, or with sync_free only the (long completed) status words of the forward."""
+        read-back, or with sync_free only the (long completed) status words of the forward.
+        stats=False: leave the densification statistics alone (iterations past densify_until_iter).
+        densify: None, or the argument tuple of densify_and_prune, applied after this iteration's statistics.
+        optimizer_step=False: gradients are taken (and dropped) without an Adam step - what the reference does in an iteration
+        that changed the topology."""
         self.iteration += 1
         self.update_learning_rate()
         st = self.sync_state
@@ -284,14 +322,23 @@ class Trainer:
                 loss, pkg = self._forward_backward(camera, gt_image, background)
                 if attempts >= 2:
                     break
-        if self.densify_stats:
+        if self.densify_stats and stats:
             from .model_ops import densify_stats
             N = self.max_radii2D.shape[0]
             densify_stats(pkg["radii"][:N], self.g.screenspace_points.grad, self.max_radii2D, self.bc_gradient_accum, self.denom)
         if self.keep_grads:                      # diagnostics / tests: the gradients this step consumed, by group name
             self.last_grads = {gr["name"]: gr["params"][0].grad for gr in self.optimizer.param_groups}
             self.last_grads["viewspace"] = self.g.screenspace_points.grad
-        self.optimizer.step()
+        self._sh_degree_seen = max(self._sh_degree_seen, int(getattr(self.g, "active_sh_degree", 3)))
+        if densify is not None:
+            self.densify_and_prune(*densify)
+        if optimizer_step and densify is None:
+            # SH coefficients above the highest degree a gradient was ever taken at have g = m = v = 0: Adam leaves them as they are,
+            # FusedAdam does not even read them ("active", gm_adam_step_active) - 45 of a Gaussian's 60 parameters at degree 0
+            for gr in self.optimizer.param_groups:
+                if gr.get("period") == 48:
+                    gr["active"] = 3 * (self._sh_degree_seen + 1) ** 2 if self._sh_degree_seen < 3 else 0
+            self.optimizer.step()
         self.optimizer.zero_grad(set_to_none=True)
         return loss.detach(), pkg
 

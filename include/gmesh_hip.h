@@ -307,6 +307,15 @@ int gm_mesh_activate_bwd(int N, float alpha, const float* bc, const float* dist,
 int gm_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                  const uint64_t* sizes, const float* lr, const float* lr_rest, const uint32_t* period, const uint32_t* split,
                  double beta1, double beta2, double eps, int step, void* stream);
+/* The same with `active` (host array, may be NULL; 0 = the whole tensor): of every period of tensor i only the elements with
+ * (index % period) < active[i] - rounded up to a 16-byte granule - are read and written.  For the SH tensor while the model's
+ * active degree D is below its maximum (train_mesh_gaussian.py:70-71 raises it every 1000 iterations): active = 3 (D+1)^2.
+ * Coefficients above the active degree have g = m = v = 0, the update rule leaves them unchanged, so skipping them gives the
+ * result of gm_adam_step bit for bit (the caller guarantees their gradients are zero: the rasterizer's backward writes zeros
+ * there).  Needs sizes[i] % period[i] == 0. */
+int gm_adam_step_active(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                        const uint64_t* sizes, const float* lr, const float* lr_rest, const uint32_t* period, const uint32_t* split,
+                        const uint32_t* active, double beta1, double beta2, double eps, int step, void* stream);
 
 /* Densification statistics of a training iteration in one pass (train_mesh_gaussian.py:119-126 and
  * scene/mesh_based_gaussian_model.py:587-589): for every Gaussian with radii[i] > 0 (render()'s visibility_filter)

@@ -19,7 +19,7 @@ def small_scene(P=300, W=48, H=40, seed=0, D=3, scale_lo=0.05, scale_hi=0.6, cam
     return sc, cam
 
 
-def account_outlier_pixels(fw, color, W, H, tol=1e-4):
+def account_outlier_pixels(fw, color, W, H, tol=1e-4, mask=None):
     """Flip accounting for the forward gate (north_star: <= 1e-4 max-abs per pixel).
 
     `fw` is the oracle's forward (oracle.forward_full), `color` the image under test.  Two correct float evaluations of
@@ -28,10 +28,12 @@ def account_outlier_pixels(fw, color, W, H, tol=1e-4):
     entries the pixel visits.  For every pixel whose colour differs from the oracle's by more than `tol`, the pixel's
     list is re-walked in float64 and such an entry must exist; the rounding distance of an entry is derived from its own
     cancellation (the quadratic form's terms), not from a blanket tolerance.  Returns
-    (n_outliers, n_unexplained, worst_error_among_explained)."""
+    (n_outliers, n_unexplained, worst_error_among_explained).
+    mask ([H, W] bool, optional): examine THESE pixels instead of the ones whose colour is off by more than tol - e.g. the pixels whose
+    contributor count differs from the oracle's: a different last contributor is a flipped decision too."""
     geo, bins = fw["geo"], fw["bins"]
     err = np.abs(np.asarray(color, np.float64) - fw["color"]).max(axis=0)           # [H, W]
-    ys, xs = np.nonzero(err > tol)
+    ys, xs = np.nonzero(err > tol if mask is None else np.asarray(mask, bool).reshape(H, W))
     gx = (W + 15) // 16
     eps = 2.0 ** -23
     xy = geo["xy"].astype(np.float64); co = geo["conic_op"].astype(np.float64)
@@ -93,13 +95,32 @@ def assert_grads_elementwise(got, ref, what="", floor=1e-3, rtol=1e-2, straggler
     return n, bad, worst
 
 
-def assert_forward_gate(fw, color, W, H, tol=1e-4, what=""):
+def assert_contributor_counts(fw, n_contrib, color, W, H, what=""):
+    """n_contrib (forward.cu:370: list position of the last contributor; what the backward pass starts from) against the oracle's:
+    equal, except on pixels where re-walking the oracle's list finds an entry at a decision threshold - every differing pixel is
+    accounted for, none is waved through.  Returns the number of differing pixels."""
+    diff = np.asarray(n_contrib).reshape(H, W) != np.asarray(fw["n_contrib"]).reshape(H, W)
+    n, n_bad, _ = account_outlier_pixels(fw, color, W, H, mask=diff)
+    print("contributor counts %-20s %dx%d: %d pixel(s) differ, %d unexplained" % (what, W, H, n, n_bad))
+    assert n_bad == 0, "%s: %d of %d pixels with another last contributor have no entry at a decision threshold" % (what, n_bad, n)
+    assert n <= max(2, 1e-3 * W * H), "%s: %d pixels with another last contributor" % (what, n)
+    return n
+
+
+def assert_forward_gate(fw, color, W, H, tol=1e-4, what="", plain_tol=None):
     """The strict forward gate: every pixel within `tol` of the oracle, except pixels with a provable threshold flip
-    (account_outlier_pixels), which are bounded by one flipped entry's weight: alpha * T * |colour| <= 2 / 255."""
+    (account_outlier_pixels), which are bounded by one flipped entry's weight: alpha * T * |colour| <= 2 / 255.
+    The largest error among the pixels that are NOT outliers - how much of the 1e-4 budget plain rounding uses - is printed every
+    time and, with `plain_tol`, asserted (the full-size configurations pass 5e-5: half the budget)."""
     n_out, n_bad, worst = account_outlier_pixels(fw, color, W, H, tol)
-    GATE_LOG.append((what, W, H, n_out, n_bad, worst))
-    print("forward gate %-22s %dx%d: %d pixel(s) above %g, %d unexplained, worst explained %.3g" % (what, W, H, n_out, tol, n_bad, worst))
+    err = np.abs(np.asarray(color, np.float64) - fw["color"]).max(axis=0)
+    plain = float(err[err <= tol].max()) if (err <= tol).any() else 0.0
+    GATE_LOG.append((what, W, H, n_out, n_bad, worst, plain))
+    print("forward gate %-22s %dx%d: %d pixel(s) above %g, %d unexplained, worst explained %.3g; largest error of the other pixels %.3g"
+          % (what, W, H, n_out, tol, n_bad, worst, plain))
     assert n_bad == 0, "%s: %d of %d outlier pixels (> %g) have no entry at a decision threshold" % (what, n_bad, n_out, tol)
     assert n_out <= max(2, 1e-4 * W * H), "%s: %d outlier pixels" % (what, n_out)
     assert worst <= 2.0 / 255.0 + 1e-3, "%s: explained outlier of %g" % (what, worst)
+    if plain_tol is not None:
+        assert plain <= plain_tol, "%s: a pixel without a threshold flip is %.3g off (limit %g)" % (what, plain, plain_tol)
     return n_out

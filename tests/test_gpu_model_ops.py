@@ -88,3 +88,36 @@ def test_fused_adam_matches_torch_adam_and_two_rate_tensor():
     assert all(p.grad is None for p in ps)
     ps[0].grad = None
     opt.step()                                             # nothing to do: no gradients
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2])
+def test_fused_adam_active_coefficients_only(deg):
+    """gm_adam_step_active: while only the coefficients of SH degrees <= deg have ever had a gradient, an optimizer that skips the
+    rest gives, bit for bit, what the full update gives on zero gradients - parameters, both moments - also across the step at
+    which the degree goes up."""
+    from gaussianmesh_amd.model_ops import FusedAdam
+    g = torch.Generator(device="cuda").manual_seed(deg)
+    N = 1537
+    p0 = torch.randn((N, 16, 3), device="cuda", generator=g)
+    other0 = torch.randn((N, 3), device="cuda", generator=g)
+
+    def make():
+        p, o = p0.clone().requires_grad_(True), other0.clone().requires_grad_(True)
+        return p, o, FusedAdam([{"params": [p], "lr": 0.0025, "lr_rest": 0.0025 / 20, "period": 48, "split": 3, "name": "f"},
+                                {"params": [o], "lr": 0.01, "name": "o"}], eps=1e-15)
+    pa, oa, full = make()
+    pb, ob, lim = make()
+    for it in range(7):
+        d = deg if it < 4 else deg + 1                                   # the degree goes up before the fifth step
+        nc = (d + 1) ** 2
+        grad = torch.zeros((N, 16, 3), device="cuda")
+        grad[:, :nc] = torch.randn((N, nc, 3), device="cuda", generator=g)
+        go = torch.randn((N, 3), device="cuda", generator=g)
+        pa.grad, oa.grad, pb.grad, ob.grad = grad.clone(), go.clone(), grad.clone(), go.clone()
+        lim.param_groups[0]["active"] = 3 * nc if d < 3 else 0
+        full.step(); lim.step()
+        assert torch.equal(pa, pb) and torch.equal(oa, ob), it
+        for k in ("m", "values"):
+            assert torch.equal(full.param_groups[0][k][0], lim.param_groups[0][k][0]), (it, k)
+    assert torch.equal(pa.detach()[:, (deg + 2) ** 2:], p0[:, (deg + 2) ** 2:]) or deg == 2       # never-active coefficients never moved
+    assert not torch.equal(pa.detach()[:, :1], p0[:, :1])

@@ -274,3 +274,16 @@ def test_shared_feature_storage_equals_concatenation():
     ia = render(cam, ma, pipe, zero, bg_gaussian=bg)["render"]
     ib = render(cam, mb, pipe, zero, bg_gaussian=bg)["render"]
     assert torch.equal(ia, ib) and not torch.equal(ia.detach(), outs[0][0])
+
+
+def test_reference_schedule_loop_small():
+    """bench.c5_leg(as_reference=True) in small: the reference's first 620 iterations as train_mesh_gaussian.py runs them - SH degree
+    0, random camera and background, teacher targets composited over the background, densification statistics, densify_and_prune
+    at iteration 600 with that iteration's optimizer step skipped - on the HIP path: the loss goes down by more than 30 %, the
+    topology change happened inside the loop and the loop went on with the new row count."""
+    import bench
+    out = bench.c5_leg(620, 0, Nfg=20000, Nbg=6000, W=320, H=200, as_reference=True, ncams=8)
+    assert out["iters"] == 620 and out["topology_changes"] == 1 and len(out["densify_iterations_ms"]) == 1
+    assert out["rows_after_densify"][0] >= 20000 and out["trainable_at_end"] == out["rows_after_densify"][0]
+    assert np.isfinite(out["loss_first"]) and out["loss_ratio"] < 0.7, out
+    assert out["iterations_redone"] <= 3 and out["ms_per_iter_before_first_densify"] > 0

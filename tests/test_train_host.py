@@ -24,3 +24,24 @@ def test_schedule_and_defaults_match_values_computed_by_the_reference():
     ref_opt = dict(zip([str(k) for k in f["opt_names"]], f["opt_values"]))
     for k, v in DEFAULT_OPT.items():
         assert float(v) == ref_opt[k], (k, v, ref_opt[k])
+
+
+def test_iteration_schedule_is_the_reference_loops():
+    """Trainer.schedule: which iterations of train_mesh_gaussian.py:66-148 raise the SH degree (:70-71), keep the densification
+    statistics (:119-124), run densify_and_prune (:126-128), skip the optimizer step (:137-139 update_flag), reset the opacity
+    (:129-130) - with the defaults of arguments/__init__.py:70-93 (pinned by tests/golden/schedule.npz above)."""
+    from types import SimpleNamespace
+    from gaussianmesh_amd.train import DEFAULT_OPT, Trainer
+    tr = Trainer.__new__(Trainer)                                 # schedule() reads self.opt only
+    tr.opt = SimpleNamespace(**DEFAULT_OPT)
+    plans = {it: tr.schedule(it) for it in range(1, 30001)}
+    assert [it for it, p in plans.items() if p["oneup"]] == list(range(1000, 30001, 1000))
+    assert [it for it, p in plans.items() if p["densify"]] == list(range(600, 15000, 200))        # > 500, every 200, < 15000
+    assert all(p["stats"] == (it < 15000) for it, p in plans.items())
+    assert [it for it, p in plans.items() if p["reset_opacity"]] == [3000, 6000, 9000, 12000]
+    assert [it for it, p in plans.items() if not p["optimizer_step"]] == list(range(600, 15000, 200)) + [30000]
+    assert plans[600]["size_threshold"] is None and plans[3000]["size_threshold"] is None and plans[3200]["size_threshold"] == 20
+    white = [it for it in range(1, 3001) if tr.schedule(it, white_background=True)["reset_opacity"]]
+    assert white == [500, 3000]
+    # the first 1000 iterations (BASELINE config C5): densify at 600, 800 - and 1000, where the degree goes from 0 to 1 first
+    assert [it for it in range(1, 1001) if plans[it]["densify"]] == [600, 800, 1000] and plans[1000]["oneup"]

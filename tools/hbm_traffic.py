@@ -8,7 +8,8 @@ import re
 import sys
 
 STAGES = [  # stage, (kernel name fragment, launches per frame)
-    ("deform", [("mesh_rs_kernel", 1), ("deform_shade_kernel<true, true>", 1)]),
+    ("mesh_rs", [("mesh_rs_kernel", 1)]),
+    ("deform", [("deform_shade_kernel<true, true>", 1)]),
     ("depth_sort", [("bk_hist_kernel<true, 11, 4,", 1), ("bk_scan_kernel<true, 11>", 1), ("bk_scatter_kernel<true, 11, 4,", 1), ("bucket_sort_kernel", 1)]),
     ("duplicate", [("duplicate_kernel<1, 2>", 1)]),
     ("tile_sort", [("bk_hist_kernel<false, 11, 8,", 1), ("bk_scan_kernel<false, 11>", 1), ("bk_scatter_kernel<false, 11, 8,", 1)]),
