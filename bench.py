@@ -21,6 +21,7 @@ of its own), "repeats" (the timed region four more times) and "single_stream" (l
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -154,9 +155,16 @@ def build_c5(Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, dev=None, sync_free=T
         for k, c in enumerate(cams):
             colour[k] = render(c, model, pipe, zero, bg_gaussian=bg)["render"]
             trans[k] = (render(c, model, pipe, one, bg_gaussian=bg)["render"][:1] - colour[k][:1]).clamp(0.0, 1.0)   # C + T.1 - C
-        model._features.zero_()                                      # the student: grey ...
-        model._opacity.fill_(-1.0)                                   # ... half transparent ...
-    model.active_sh_degree = 0                                       # ... and at SH degree 0, where the reference's model starts
+        # the student: the teacher's cloud dimmed (a quarter of its base colour, no view dependence), a quarter opaque, shrunk by a
+        # fifth and pushed around inside its faces - so that colour, opacity, scale AND position have something to learn and the
+        # view-space gradients that drive densify_and_prune are not identically zero - at SH degree 0, where the reference starts
+        g = torch.Generator(device=dev).manual_seed(seed + 7)
+        model._features[:, 0] *= 0.25
+        model._features[:, 1:] = 0.0
+        model._opacity.fill_(-1.0)
+        model._scaling += math.log(0.8)
+        model._bc += 0.5 * torch.randn(model._bc.shape, device=dev, generator=g)
+    model.active_sh_degree = 0
     tr = Trainer(model, densify_stats=True, sync_free=sync_free, bg_gaussian=bg)
     return tr, cams, (colour, trans), None
 
@@ -205,6 +213,14 @@ def c5_leg(steps, warm, Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, sync_free=
         torch.cuda.empty_cache()
         return out
     colour, trans = target
+    # the one-time costs of the FIRST topology change (the runtime loads the code objects of a dozen torch kernels: 60 ms) are paid
+    # here, on a 256-Gaussian model, not inside iteration 600 of the timed loop
+    tiny = build_c5(256, 64, 64, 48, dev, sync_free, ncams=2, teacher=True)
+    for _ in range(2):
+        tiny[0].step(tiny[1][0], torch.addcmul(tiny[2][0][0], tiny[2][1][0], torch.rand(3, device=dev).view(3, 1, 1)), torch.rand(3, device=dev))
+    tiny[0].densify_and_split(torch.arange(256, device=dev) % 2 == 0, 5)
+    tiny[0].step(tiny[1][1], tiny[2][0][1], torch.zeros(3, device=dev))
+    del tiny
     rng = random.Random(0)
     stack = []
     torch.cuda.synchronize()

@@ -75,7 +75,7 @@ def test_c1_plumbing_case(oracle):
         # C1: at most a pixel or two go through the flip exemption (round 2's pixel-relative exponent: none; the matrix-core
         # polynomial of round 3 carries ~1e-5 of absolute error in the exponent and lands on the other side of a threshold that
         # lies within the entry's own rounding distance slightly more often)
-        assert assert_forward_gate(fw, st["color"], 256, 256, 1e-4, "C1") <= 2
+        assert assert_forward_gate(fw, st["color"], 256, 256, 1e-4, "C1", plain_tol=5e-5) <= 2
 
 
 def test_mid_size_oracle_parity(oracle):
@@ -89,7 +89,7 @@ def test_mid_size_oracle_parity(oracle):
     st = _forward(sc, cam, bg)
     assert np.array_equal(st["radii"], fw["geo"]["radii"]) and st["R"] == fw["bins"]["R"]
     assert np.array_equal(st["point_list"], fw["bins"]["point_list"]) and np.array_equal(st["ranges"], fw["bins"]["ranges"])
-    assert_forward_gate(fw, st["color"], 640, 360, 1e-4, "100k")
+    assert_forward_gate(fw, st["color"], 640, 360, 1e-4, "100k", plain_tol=5e-5)
     dpix = np.random.default_rng(1).normal(size=(3, 360, 640)).astype(np.float32)
     bw = oracle.backward_full(sc, cam, bg, fw, dpix, D=3)
     _, _, g = _grads_gpu(sc, cam, bg, dpix, 3, False, False)
@@ -207,7 +207,7 @@ def test_c2_full_size_gradients_vs_oracle(oracle):
     color, radii, g = _grads_gpu(sc, cam, bg, dpix, 3, False, False)          # the product's default emission policy
     assert np.array_equal(radii, fw["geo"]["radii"])
     assert np.array_equal(color, ex["color"])                                # policies agree bit for bit
-    assert_forward_gate(fw, color, W, H, 1e-4, "C2")
+    assert_forward_gate(fw, color, W, H, 1e-4, "C2", plain_tol=5e-5)
     _check_all_grads(g, bw, 1e-3)
 
 
@@ -266,4 +266,4 @@ def test_c3_bench_path_full_size_vs_oracle(oracle):
         fw = oracle.forward_full(sc, cam, bg, D=3, use_precomp_cov=True, use_precomp_color=True)
         assert np.array_equal(out[0][2], fw["geo"]["radii"])
         assert out[0][0] == fw["bins"]["R"] and np.array_equal(plist, fw["bins"]["point_list"])
-        assert_forward_gate(fw, out[2][1], W, H, 1e-4, "C3 frame %d" % t)
+        assert_forward_gate(fw, out[2][1], W, H, 1e-4, "C3 frame %d" % t, plain_tol=5e-5)
