@@ -109,6 +109,18 @@ def measured_traffic(stage, P, W, H):
     return int(1024 * (2 * e["fetch_kib"] + e["write_kib"]))
 
 
+def measured_valu(stage, P, W, H):
+    """Vector instructions per launch of a stage from the committed PMC pass (profiles/inst_mix.json), or None."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "inst_mix.json")))
+    except OSError:
+        return None
+    w = t["workload"]
+    if (w["gaussians"], w["width"], w["height"]) != (P, W, H) or stage not in t["stages"]:
+        return None
+    return t["stages"][stage].get("valu")
+
+
 def build_c5(Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, dev=None, sync_free=True, ncams=32, seed=0, teacher=False):
     """BASELINE config C5 on this package's training harness: Nfg Gaussians bound to the 15 k-face torus + Nbg free, frozen
     "background" Gaussians in a shell of radius 6-12 that contains the cameras, W x H, a Trainer with FusedAdam on the six
@@ -164,6 +176,13 @@ def build_c5(Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, dev=None, sync_free=T
         model._opacity.fill_(-1.0)
         model._scaling += math.log(0.8)
         model._bc += 0.5 * torch.randn(model._bc.shape, device=dev, generator=g)
+        # ... and one Gaussian in fifty stands for an under-reconstructed region: four times too large and of the wrong colour.  With
+        # 2 M small Gaussians on a 4K image nothing else reaches densify_grad_threshold = 0.0002 (the view-space gradient of a
+        # Gaussian scales with the fraction of the image it covers), and the topology changes of iterations 600 / 800 / 1000 would
+        # select no row at all
+        big = torch.rand(model._bc.shape[0], device=dev, generator=g) < 0.02
+        model._scaling[big] += math.log(4.0)
+        model._features[big, 0] = 1.5 * torch.randn((int(big.sum()), 3), device=dev, generator=g)
     model.active_sh_degree = 0
     tr = Trainer(model, densify_stats=True, sync_free=sync_free, bg_gaussian=bg)
     return tr, cams, (colour, trans), None
@@ -218,14 +237,15 @@ def c5_leg(steps, warm, Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, sync_free=
     tiny = build_c5(256, 64, 64, 48, dev, sync_free, ncams=2, teacher=True)
     for _ in range(2):
         tiny[0].step(tiny[1][0], torch.addcmul(tiny[2][0][0], tiny[2][1][0], torch.rand(3, device=dev).view(3, 1, 1)), torch.rand(3, device=dev))
-    tiny[0].densify_and_split(torch.arange(256, device=dev) % 2 == 0, 5)
+    tiny[0].bc_gradient_accum[::2] = 1.0                             # every other row over the threshold: 128 x 5 new rows, 128 pruned
+    tiny[0].densify_and_prune(0.0002, 0.005, None, None, 5)
     tiny[0].step(tiny[1][1], tiny[2][0][1], torch.zeros(3, device=dev))
     del tiny
     rng = random.Random(0)
     stack = []
     torch.cuda.synchronize()
     torch.cuda.reset_peak_memory_stats(dev)
-    densify_ms, rows_after, marks = [], [], {}
+    densify_ms, rows_after, marks, curve = [], [], {}, {}
     t0 = time.perf_counter()
     for it in range(1, steps + 1):
         if not stack:
@@ -242,15 +262,18 @@ def c5_leg(steps, warm, Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, sync_free=
             densify_ms.append(1e3 * (time.perf_counter() - td)); rows_after.append(plan["rows"])
         if it in (1, 599, 600):
             torch.cuda.synchronize(); marks[it] = time.perf_counter()
-        if it <= 20 or it > steps - 20:
+        if it <= 5 or it > steps - 20:
             losses.append(loss)
+        if it in (1, 2, 5, 10, 20, 50, 100, 200, 400, 599, 601, 700, 799, 801, 900, 999, steps):
+            curve[it] = loss
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    lf = float(torch.stack(losses[:20]).mean()); ll = float(torch.stack(losses[-20:]).mean())
+    lf = float(torch.stack(losses[:5]).mean()); ll = float(torch.stack(losses[-20:]).mean())
     out = {"ms_per_iter": 1e3 * el / steps, "iters": steps, "warmup": 0, "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
            "iterations_redone": tr.redone, "gaussians": Nfg + Nbg, "trainable": Nfg, "trainable_at_end": int(tr.g._bc.shape[0]), "width": W, "height": H,
            "visible": int((pkg["radii"] > 0).sum().item()), "emission_policy": Rz.get_default_emission_policy(W, H), "sync_free": bool(sync_free),
            "loss_first": lf, "loss_last": ll, "loss_ratio": ll / lf, "sh_degree": "0, 1 from iteration 1000",
+           "loss_first_note": "mean of iterations 1-5 / of the last 20 (a random camera each)", "loss_curve": {str(k): round(float(v), 5) for k, v in curve.items()},
            # iterations 2 .. 599: before the first topology change (iteration 1 carries the first allocations and the capacity seed)
            "ms_per_iter_before_first_densify": (1e3 * (marks[599] - marks[1]) / 598) if 599 in marks and 1 in marks else None,
            "densify_iterations_ms": [round(x, 3) for x in densify_ms],       # the WHOLE iteration that ends in densify_and_prune (no Adam step)
@@ -647,15 +670,27 @@ def main():
                                    if dom == "render" else
                                    ("the fused deformation / SH colour / preprocess kernel: a streaming kernel bound by HBM") if dom == "deform" else
                                    "longest single kernel of the frame"}
+        # the ceiling the dominant kernel actually runs against when it is the blend: vector-instruction ISSUE.  A wave64 vector
+        # instruction occupies its SIMD for 4 cycles; the chip has 1024 SIMDs at 2.4 GHz.  Instruction counts: static, from the PMC
+        # pass of the same workload (profiles/inst_mix.json), like `traffic`
+        nv = measured_valu(dom, P, W, H)
+        if nv:
+            issue_ms = nv * 4.0 / (1024 * 2.4e9) * 1e3
+            out["roofline"]["valu_issue"] = {"vector_instructions": nv, "issue_ms_at_full_rate": issue_ms, "frac_of_issue_ceiling": issue_ms / per[dom],
+                                             "source": "static: profiles/inst_mix.json (rocprofv3 --pmc SQ_INSTS_VALU)"}
         # every stage, same definition (algorithmic bytes of the stage / its HIP-event time); "deform" is the fused kernel alone
         out["stage_roofline"] = {st: round(stage_bytes(st) / (per[st] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                                  for st in per if st in ("mesh_rs", "deform", "depth_sort", "duplicate", "tile_sort", "render")}
         out["stage_ms"] = {k: round(v, 4) for k, v in per.items()}
         out["scene"] = {"P": P, "V": V, "R": Rn}
+        frame_valu = [measured_valu(s, P, W, H) for s in per]
         tot_bytes = sum(stage_bytes(s) for s in per)
         out["frame_roofline"] = {"algorithmic_bytes": tot_bytes, "achieved": tot_bytes / (elapsed / args.steps) / 1e9,
                                  "frac": tot_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s",
                                  "single_stream_ms_per_frame": sum(per.values())}
+        if all(frame_valu):                      # the frame's other ceiling: time to issue its vector instructions on all 1024 SIMDs
+            out["frame_roofline"]["valu_issue_ms"] = sum(frame_valu) * 4.0 / (1024 * 2.4e9) * 1e3
+            out["frame_roofline"]["valu_issue_frac"] = out["frame_roofline"]["valu_issue_ms"] / (1e3 * elapsed / args.steps)
 
     if rank == 0 and world == 1 and not args.no_fwd_bwd:
         # ---- forward + backward through the autograd operator (train-time input mode: SH + scale/rot)
