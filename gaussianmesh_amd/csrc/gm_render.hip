@@ -730,12 +730,11 @@ __global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_exact_kerne
 //     five LDS reads: 16 instead of 24 vector instructions for an entry a pixel uses, 4 instead of 10 for one nobody uses.
 // A group's sixteen entries are sixteen copies of the entry body with a static accumulator index; the phase-2 flush, which can
 // fall due after any of them, is ONE copy behind a re-entrant switch (the group is left at entry k and re-entered at k + 1).
-struct BwdLds {                  // per wave: 9.4 KiB
+struct StagedB { float4 c; float2 xy; uint32_t pos, pad; };   // (r, g, b, Gaussian id bits), splat centre, list position
+struct BwdLds {                  // per wave: 9.7 KiB
   uint2 qa[RQ_QA];               // candidate ring of the front end: (Gaussian id, list position)
   float ct[4 * 6 * 32];          // coefficient table of the staged batch (stage_poly)
-  float4 sc[64];                 // staged batch: (r, g, b, Gaussian id bits)
-  float2 sxy[64];                //               splat centre
-  uint32_t spos[64];             //               list position
+  StagedB st[64];                // staged batch (ONE record per entry: one LDS base address per group of 16, immediate offsets from it)
   union {
     float2 M[7][65];             // (w, h) per slot and pixel; row stride 65 keeps phase 2's row reads conflict-free
     float part[8][72];           // phase 2: row partials [row][slot * 9 + value] (columns 63.. belong to the idle lanes)
@@ -879,11 +878,11 @@ __global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_kernel(cons
   // one staged entry at one pixel: e = e' of the entry at this lane's pixel, j = its index in the staged batch (wave-uniform)
   auto entry = [&](const float e, const int j) {
     const float oG = __builtin_amdgcn_exp2f(e);                        // opacity * G: the number the forward compared with 1/255
-    const int pos = (int)B.spos[j];
+    const int pos = (int)B.st[j].pos;
     const bool valid = (pos < last) && (oG >= 1.0f / 255.0f);
     if (!__any(valid)) return;
-    const float4 C = B.sc[j];
-    const float2 xy = B.sxy[j];
+    const float4 C = B.st[j].c;
+    const float2 xy = B.st[j].xy;
     const float oGe = valid ? oG : 0.0f;                             // a lane that skips the entry: alpha 0, every update the identity
     const float al = __builtin_amdgcn_fmed3f(oGe, 0.0f, 0.99f);      // alpha = min(0.99, opacity G)
     const float inv = __builtin_amdgcn_rcpf(1.f - al);               // 1 / (1 - alpha)
@@ -927,26 +926,27 @@ __global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_kernel(cons
       if (keep) {                                                        // compacted, in walk order
         const int slot = (int)lanes_below(kb);
         stage_poly(B.ct, slot, cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, ucx, vcy);
-        B.sc[slot] = make_float4(cur.b.z, cur.b.w, cur.c, __uint_as_float(cur.id));
-        B.sxy[slot] = make_float2(cur.a.x, cur.a.y);
-        B.spos[slot] = cur.pos;                                          // 0-based list position == reference `contributor`
+        StagedB& o = B.st[slot];
+        o.c = make_float4(cur.b.z, cur.b.w, cur.c, __uint_as_float(cur.id));
+        o.xy = make_float2(cur.a.x, cur.a.y);
+        o.pos = cur.pos;                                                 // 0-based list position == reference `contributor`
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       for (int j0 = 0; j0 < ns; j0 += 16) {
         const v16f E = poly_exponents(B.ct, j0, lane, B0, B1, B2);
-        const int cnt = min(16, ns - j0);
-        int t = 0;                                                       // next entry of the group (wave-uniform)
-        while (t < cnt) {
+        int rem = min(16, ns - j0);                                      // entries of the group still to do (wave-uniform)
+        int t = 0;                                                       // next entry of the group
+        do {
           switch (t) {
-#define GM_BWD_ENTRY(k) case k: entry(E[k], j0 + k); t = k + 1; if (m == 7 || k + 1 >= cnt) break; [[fallthrough]];
+#define GM_BWD_ENTRY(k) case k: entry(E[k], j0 + k); t = k + 1; rem -= 1; if (m == 7 || rem == 0) break; [[fallthrough]];
             GM_BWD_ENTRY(0) GM_BWD_ENTRY(1) GM_BWD_ENTRY(2) GM_BWD_ENTRY(3) GM_BWD_ENTRY(4) GM_BWD_ENTRY(5) GM_BWD_ENTRY(6) GM_BWD_ENTRY(7)
             GM_BWD_ENTRY(8) GM_BWD_ENTRY(9) GM_BWD_ENTRY(10) GM_BWD_ENTRY(11) GM_BWD_ENTRY(12) GM_BWD_ENTRY(13) GM_BWD_ENTRY(14)
 #undef GM_BWD_ENTRY
-            default: entry(E[15], j0 + 15); t = 16; break;
+            default: entry(E[15], j0 + 15); t = 16; rem = 0; break;
           }
           if (m == 7) { phase2(7); m = 0; mrow = &B.M[0][lane]; mslot = &B.slot[0]; }
-        }
+        } while (rem > 0);
       }
     }
     return true;
