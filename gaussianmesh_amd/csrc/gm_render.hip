@@ -339,12 +339,14 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
         if (keep) {
           const int slot = (int)lanes_below(kb);
           stage_poly(L.ct, slot, cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, ucx, vcy);
-          L.sb[slot] = make_float4(cur.b.z, cur.b.w, cur.c, cur.b.y);
+          // (r, g, b, w): w = the opacity in the EXACT build, otherwise (the opacity lives in the polynomial) the 1-based list position
+          // the backward state wants - one broadcast read per survivor for colour AND n_contrib
+          L.sb[slot] = make_float4(cur.b.z, cur.b.w, cur.c, EXACT ? cur.b.y : __uint_as_float(cur.pos + 1u));
           if (EXACT) {
             x_ra[68 * (WPW == 4 ? wave : 0) + slot] = make_float4(cur.a.x, cur.a.y, (-0.5f * LOG2E) * cur.a.z, (-0.5f * LOG2E) * cur.b.x);
             x_bq[68 * (WPW == 4 ? wave : 0) + slot] = (-LOG2E) * cur.a.w;
           }
-          if (STATE) L.sp[slot] = cur.pos + 1u;                           // 1-based list position: n_contrib
+          if (STATE && EXACT) L.sp[slot] = cur.pos + 1u;                  // 1-based list position: n_contrib
         }
         // survivors are taken four at a time: the up to three slots behind the last must come out as alpha = 0
         if (lane < 4 && ns + lane < 64) pad_poly(L.ct, ns + lane);
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
             uint32_t SP[SUB];
             if (STATE) {
 #pragma unroll
-              for (int t = 0; t < SUB; t++) SP[t] = L.sp[j + SUB * q + t];
+              for (int t = 0; t < SUB; t++) SP[t] = EXACT ? L.sp[j + SUB * q + t] : __float_as_uint(S[t].w);
             }
             float al[SUB];
 #pragma unroll
