@@ -192,7 +192,9 @@ __device__ __forceinline__ void stage_poly(float* __restrict__ ct, int slot, flo
   const int g = slot >> 4, sg = slot & 15;
   const float a = (-0.5f * LOG2E) * conx, b = (-LOG2E) * cony, c = (-0.5f * LOG2E) * conz;
   const float u = x - ucx, v0 = y - vcy, v1 = v0 - 4.0f;
-  const float au = a * u, bu = b * u, lo = __builtin_amdgcn_logf(opacity);        // v_log_f32: log2
+  // log2(opacity) (v_log_f32); a conic that is not positive (an overflowing or rounded-away determinant in the preprocess) has
+  // power > 0 wherever the reference evaluates it and is skipped there (forward.cu:336): the row is padded out
+  const float au = a * u, bu = b * u, lo = (conx > 0.f && conz > 0.f) ? __builtin_amdgcn_logf(opacity) : GM_POLY_PAD;
   float* row = &ct[192 * g + 8 * (sg >> 2) + (sg & 3)];                           // row of (half 0, survivor sg); half 1: + 4
   row[0] = a; row[4] = a; row[32] = b; row[36] = b; row[64] = c; row[68] = c;
   row[96] = -2.0f * au - b * v0;  row[100] = -2.0f * au - b * v1;
