@@ -252,10 +252,12 @@ __global__ __launch_bounds__(64) void deform_shade_kernel(int N, int deg, const 
       pre_emit(fp.cam, pg, opac, tiles, bin);
       dkey = __float_as_uint(pg.depth);
     }
-    fp.clamped[i] = 0;
-    fp.radii_int[i] = radius_i;
-    if (fp.radii_out) fp.radii_out[i] = radius_i;
-    fp.tiles[i] = tiles;
+    // Written once, where it is read: the radius goes to the caller's array (the internal copy exists for callers that pass none);
+    // the clamp flags and the per-Gaussian instance count are read by the backward pass and by the emission of a rectangle with
+    // 65535 instances or more only - a frame of this path has no backward, and the count rides in the emission record otherwise
+    // (9 of 349 bytes per Gaussian in a kernel that runs at the HBM's pace)
+    if (fp.radii_out) fp.radii_out[i] = radius_i; else fp.radii_int[i] = radius_i;
+    if (tiles >= GM_BIN_COUNT_SAT) fp.tiles[i] = tiles;
     fp.bin[i] = bin;
     fp.depth_key[i] = dkey;
     if (i == 0) fp.counters[GM_CNT_POLICY] = (uint32_t)fp.cam.tile_cull;

@@ -158,8 +158,7 @@ __global__ __launch_bounds__(TH) void preprocess_fwd_kernel(const PreArgs a) {
     dkey = __float_as_uint(pg.depth);
   } while (0);
   if (idx < a.P) {
-    a.radii_int[idx] = radius_i;
-    if (a.radii_out) a.radii_out[idx] = radius_i;
+    if (a.radii_out) a.radii_out[idx] = radius_i; else a.radii_int[idx] = radius_i;     // (the internal copy: for callers that pass no radii array)
     a.tiles[idx] = tiles;
     a.bin[idx] = bin;
     a.depth_key[idx] = dkey;

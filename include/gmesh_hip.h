@@ -137,7 +137,9 @@ int gm_mark_visible(int P, const float* means3D, const float* viewmatrix, const 
  * same data as the GeometryState/ImageState/BinningState structs, RAST/rasterizer_impl.h:29-65).
  * Each returns a device pointer inside the given buffer, or NULL for an unknown name.
  *   geom:    "splat" float[P][12] = {x,y,conic.x,conic.y | conic.z,opacity,r,g | b,depth,0,0},
- *            "radii" int32[P] (internal copy), "tiles_touched" uint32[P], "cov3D" float[P][6],
+ *            "radii" int32[P] (internal copy: filled only by a forward that was given NO radii array; gm_backward reads it when it
+ *            is given none either - pass the forward's array otherwise), "tiles_touched" uint32[P] (gm_forward_0_deformed_async
+ *            fills it only for rectangles of 65535 instances or more: the count rides in the emission record), "cov3D" float[P][6],
  *            "clamped" uint8[P] (bit ch set = channel ch clamped), "order" uint32[V] (ids of the V visible Gaussians
  *            in (depth, id) order; V = "bucket_start"[2048]), "bucket_start" uint32[2049]
  *   image:   "final_T" float[H*W], "n_contrib" uint32[H*W], "ranges" uint32[T][2], "tile_order" uint32[T] (the forward blend's
