@@ -150,6 +150,10 @@ __device__ __forceinline__ void pre_emit(const PreCam& a, const PreGeom& g, floa
       // kernels run one wave per quadrant: the quadrants of the reached tiles that the bounding box of the alpha >= 1/255 ellipse
       // (tile_cull_setup's xext x dymax) touches.  A parent none of whose quadrants passes is not emitted.
       const bool quad = quad_rect((uint32_t)x0, (uint32_t)y0, (uint32_t)rw, (uint32_t)rh);
+      // a wave whose Gaussians ALL have such a rectangle (the usual case: neighbours in memory are neighbours on the mesh and of
+      // one size) takes count and mask from the quadrant words alone: the per-tile count and column mask of the general rule, which
+      // every lane would otherwise compute and a quad lane then throws away, are skipped by a wave-uniform branch
+      const bool all_quad = __all(quad);
       const int px0 = x0 >> 1, py0 = y0 >> 1;
       int bqx0 = 0, bqx1 = 7, bqy0 = 0, bqy1 = 7;                       // the box in quadrant columns / rows relative to parent (px0, py0)
       if (quad && tc.mode == 1) {
@@ -165,15 +169,17 @@ __device__ __forceinline__ void pre_emit(const PreCam& a, const PreGeom& g, floa
         row_tiles_pair(tc, g.pix, g.piy, ty, x0, x1, ta, tb);
         if (ty < y0) { ta[0] = GM_ROW_EMPTY_LO; tb[0] = -1; }            // rows of the parent outside the rectangle
         if (ty + 1 >= y1) { ta[1] = GM_ROW_EMPTY_LO; tb[1] = -1; }
-        const int la = ta[0] >> 1, ha = tb[0] >> 1, lb = ta[1] >> 1, hb = tb[1] >> 1;
-        const int uni = max(ha - la + 1, 0) + max(hb - lb + 1, 0) - max(min(ha, hb) - max(la, lb) + 1, 0);
-        const int hull = max((max(tb[0], tb[1]) >> 1) - (min(ta[0], ta[1]) >> 1) + 1, 0);
-        cnt += (uint32_t)(small ? uni : hull);
+        if (!all_quad) {                                                   // (wave-uniform: see above)
+          const int la = ta[0] >> 1, ha = tb[0] >> 1, lb = ta[1] >> 1, hb = tb[1] >> 1;
+          const int uni = max(ha - la + 1, 0) + max(hb - lb + 1, 0) - max(min(ha, hb) - max(la, lb) + 1, 0);
+          const int hull = max((max(tb[0], tb[1]) >> 1) - (min(ta[0], ta[1]) >> 1) + 1, 0);
+          cnt += (uint32_t)(small ? uni : hull);
 #pragma unroll
-        for (int r = 0; r < 2; r++) {                                      // child mask of a rectangle of <= 64 tiles
-          const int len = max(tb[r] - ta[r] + 1, 0);
-          const unsigned long long run = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
-          mask |= run << (((ty + r - y0) * rw + (ta[r] - x0)) & 63);
+          for (int r = 0; r < 2; r++) {                                    // child mask of a rectangle of <= 64 tiles
+            const int len = max(tb[r] - ta[r] + 1, 0);
+            const unsigned long long run = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
+            mask |= run << (((ty + r - y0) * rw + (ta[r] - x0)) & 63);
+          }
         }
         if (quad) {
           uint32_t word = 0;
