@@ -245,7 +245,7 @@ def c5_leg(steps, warm, Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, sync_free=
     stack = []
     torch.cuda.synchronize()
     torch.cuda.reset_peak_memory_stats(dev)
-    densify_ms, rows_after, marks, curve = [], [], {}, {}
+    densify_ms, rows_after, marks, curve, quant = [], [], {}, {}, []
     t0 = time.perf_counter()
     for it in range(1, steps + 1):
         if not stack:
@@ -255,7 +255,15 @@ def c5_leg(steps, warm, Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, sync_free=
         gt = torch.addcmul(colour[k], trans[k], bgc.view(3, 1, 1))       # :92-93 gt * mask + bg * (1 - mask), with the teacher's transmittance
         plan = tr.schedule(it)
         if plan["densify"]:                                              # bracket the three topology changes (three extra host syncs in 1000 iterations)
-            torch.cuda.synchronize(); td = time.perf_counter()
+            torch.cuda.synchronize()
+            if not quant:                                                # what densify_and_prune will see the first time (diagnostic, outside the bracket)
+                gq = (tr.bc_gradient_accum / tr.denom.clamp_min(1)).reshape(-1)
+                ks = [int(f * (gq.numel() - 1)) for f in (0.5, 0.9, 0.99, 0.999)]
+                srt = torch.sort(gq).values
+                quant.extend([float(srt[k]) for k in ks] + [float(srt[-1]), float((gq >= tr.opt.densify_grad_threshold).float().mean())])
+                del gq, srt
+                torch.cuda.synchronize()
+            td = time.perf_counter()
         loss, pkg, plan = tr.train_iteration(cams[k], gt, bgc)
         if plan["densify"]:
             torch.cuda.synchronize()
@@ -278,6 +286,7 @@ def c5_leg(steps, warm, Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, sync_free=
            "ms_per_iter_before_first_densify": (1e3 * (marks[599] - marks[1]) / 598) if 599 in marks and 1 in marks else None,
            "densify_iterations_ms": [round(x, 3) for x in densify_ms],       # the WHOLE iteration that ends in densify_and_prune (no Adam step)
            "rows_after_densify": rows_after, "topology_changes": tr.resizes,
+           "viewspace_grad_at_first_densify": dict(zip(("q50", "q90", "q99", "q999", "max", "fraction_over_threshold"), quant)),
            "workload": "C5 as train_mesh_gaussian.py runs its first %d iterations: %d mesh-bound + %d frozen free Gaussians, %dx%d, SH degree 0 "
                        "(1 at iteration 1000), random camera / random background per iteration, teacher-rendered targets composited over the "
                        "background, L1/SSIM/mesh-restrict loss, backward, FusedAdam, densification statistics, densify_and_prune(0.0002, N=5) at "
