@@ -276,6 +276,30 @@ def c5_leg(steps, warm, Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, sync_free=
             curve[it] = loss
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    # What one topology change costs at this size, whatever the reference's threshold selected above (on this synthetic cloud - 2 M
+    # small Gaussians on a 4K image - no row's mean view-space gradient reaches 0.0002, see viewspace_grad_at_first_densify): split
+    # the 2 % of the rows with the largest statistic (N = 5, originals pruned: +8 % rows), timed on its own, then 20 more
+    # iterations of the same loop at the new row count.  Outside the 1000 iterations that define ms_per_iter.
+    forced = None
+    if steps >= 600:
+        gq = (tr.bc_gradient_accum / tr.denom.clamp_min(1)).reshape(-1)
+        thr = float(torch.sort(gq).values[int(0.98 * (gq.numel() - 1))])
+        del gq
+        rows0 = int(tr.g._bc.shape[0])
+        torch.cuda.synchronize(); td = time.perf_counter()
+        tr.densify_and_prune(max(thr, 1e-30), 0.005, None, None, 5)
+        torch.cuda.synchronize(); t_split = 1e3 * (time.perf_counter() - td)
+        td = time.perf_counter()
+        for it in range(20):
+            if not stack:
+                stack = list(range(nc))
+            k = stack.pop(rng.randint(0, len(stack) - 1))
+            bgc = torch.rand(3, device=dev)
+            loss, pkg = tr.step(cams[k], torch.addcmul(colour[k], trans[k], bgc.view(3, 1, 1)), bgc)
+        torch.cuda.synchronize()
+        forced = {"rows_before": rows0, "rows_after": int(tr.g._bc.shape[0]), "densify_and_prune_ms": round(t_split, 3),
+                  "ms_per_iter_after": 1e3 * (time.perf_counter() - td) / 20, "iterations_redone_after": tr.redone,
+                  "selection": "rows whose mean view-space gradient is in the top 2 % (threshold %.3g)" % thr}
     lf = float(torch.stack(losses[:5]).mean()); ll = float(torch.stack(losses[-20:]).mean())
     out = {"ms_per_iter": 1e3 * el / steps, "iters": steps, "warmup": 0, "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
            "iterations_redone": tr.redone, "gaussians": Nfg + Nbg, "trainable": Nfg, "trainable_at_end": int(tr.g._bc.shape[0]), "width": W, "height": H,
@@ -286,6 +310,7 @@ def c5_leg(steps, warm, Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, sync_free=
            "ms_per_iter_before_first_densify": (1e3 * (marks[599] - marks[1]) / 598) if 599 in marks and 1 in marks else None,
            "densify_iterations_ms": [round(x, 3) for x in densify_ms],       # the WHOLE iteration that ends in densify_and_prune (no Adam step)
            "rows_after_densify": rows_after, "topology_changes": tr.resizes,
+           "forced_densify": forced,
            "viewspace_grad_at_first_densify": dict(zip(("q50", "q90", "q99", "q999", "max", "fraction_over_threshold"), quant)),
            "workload": "C5 as train_mesh_gaussian.py runs its first %d iterations: %d mesh-bound + %d frozen free Gaussians, %dx%d, SH degree 0 "
                        "(1 at iteration 1000), random camera / random background per iteration, teacher-rendered targets composited over the "
