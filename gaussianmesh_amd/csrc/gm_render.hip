@@ -479,11 +479,11 @@ int launch_render_fwd(const GeomState& g, const uint2* pairs, ImageState& img, i
 #define GM_RENDER_BWD_WPW 1      // waves per workgroup of the backward blend: 4 (one workgroup per 16-px tile) or 1 (one per 8x8 quadrant)
 #endif
 
-// VERIFICATION BUILD of the backward blend (gm_debug_backward_exact_exponent; never on the product path): round 3's kernel, which
-// evaluates every entry's exponent per pixel in the pixel-relative form (staged_exponent, |e - e_exact| ~ 5e-7) and multiplies the
-// opacity in afterwards.  The product kernel (render_bwd_kernel, below) takes the exponents from the matrix core exactly as the
-// forward does; tests compare the two builds' gradients.
-// Two phases per wave (round 3).
+// Backward blend, two phases per wave (round 3).  The exponent of an entry is evaluated per pixel in the pixel-relative form
+// (staged_exponent, |e - e_exact| ~ 5e-7) and the opacity multiplied in afterwards; the forward's come from the matrix core (~1e-5), so
+// the two halves can disagree on an entry whose alpha lies within 1e-5 of 1/255 (weight <= 0.4 %).  Round 4 built
+// the backward on the matrix core with the forward's polynomial - identical decisions, every gradient test green - and it was 26 % slower:
+// tools/experiments/render_bwd_matrix_exponent_round4.hip.txt.
 //
 // Phase 1, lane = pixel: the walk of backward.cu:441-556 with everything that is not the per-pixel recurrence taken out.
 // Going back to front, with T_i the transmittance in front of entry i, w_i = alpha_i T_i and cd_i = c_i . dL/dpixel,
@@ -500,15 +500,15 @@ int launch_render_fwd(const GeomState& g, const uint2* pairs, ImageState& img, i
 // with 63 active lanes commits seven 36-byte records (one L2 transaction per record, as before).
 // Per entry: ~28 + ~9 vector instructions instead of ~44 + 28 for the per-entry cross-lane reduction of round 2
 // (v_permlane32/16_swap + DPP butterfly), which is gone.
-struct StagedBx {                 // one survivor of the staged batch (one LDS address per entry in the walk)
+struct StagedB {                 // one survivor of the staged batch (one LDS address per entry in the walk)
   float4 a;                      // x, y, conic.x', conic.z'   (conic pre-multiplied for the exp2 argument)
   float4 b;                      // conic.y', opacity, r, g
   float4 c;                      // b, list position (bits), Gaussian id (bits), -
 };
 struct SlotB { float2 xy; uint32_t id, pad; };   // splat centre and id of a phase-2 slot
-struct BwdLdsX {                  // per wave: 7.5 KiB
+struct BwdLds {                  // per wave: 7.5 KiB
   uint2 qa[RQ_QA];               // candidate ring of the front end: (Gaussian id, list position)
-  StagedBx st[64];                // staged batch
+  StagedB st[64];                // staged batch
   union {
     float2 M[7][65];             // (w, h) per slot and pixel; row stride 65 keeps phase 2's row reads conflict-free
     float part[8][72];           // phase 2: row partials [row][slot * 9 + value] (columns 63.. belong to the idle lanes)
@@ -517,7 +517,7 @@ struct BwdLdsX {                  // per wave: 7.5 KiB
   SlotB slot[8];
 };
 
-__global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_exact_kernel(const uint2* __restrict__ ranges,
+__global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_kernel(const uint2* __restrict__ ranges,
                                                                const uint2* __restrict__ pairs,
                                                                const float4* __restrict__ splat, int W, int H, TileMap tm,
                                                                const float* __restrict__ bg, const float* __restrict__ final_T,
@@ -559,9 +559,9 @@ __global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_exact_kerne
   if (start == 0) return;
 
   const float rx0 = (float)(tx * GM_TILE + (wave & 1) * 8), ry0 = (float)(ty * GM_TILE + (wave >> 1) * 8);
-  __shared__ BwdLdsX l_b[WPW];
-  BwdLdsX& B = l_b[WPW == 4 ? wave : 0];
-  BwdLdsX& L = B;
+  __shared__ BwdLds l_b[WPW];
+  BwdLds& B = l_b[WPW == 4 ? wave : 0];
+  BwdLds& L = B;
   // phase 2 geometry of this lane: slot es (7: idle), pixel row r; dL/dpixel of the row's eight pixels stays in registers
   const int es = lane & 7, r = lane >> 3, esc = min(es, 6);
   float2 dq[8]; float dqb[8];
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_exact_kerne
       const unsigned long long kb = __ballot(keep);
       const int ns = __popcll(kb);
       if (keep) {
-        StagedBx& o = B.st[(int)lanes_below(kb)];
+        StagedB& o = B.st[(int)lanes_below(kb)];
         o.a = make_float4(cur.a.x, cur.a.y, (-0.5f * LOG2E) * cur.a.z, (-0.5f * LOG2E) * cur.b.x);
         o.b = make_float4((-LOG2E) * cur.a.w, cur.b.y, cur.b.z, cur.b.w);
         o.c = make_float4(cur.c, __uint_as_float(cur.pos), __uint_as_float(cur.id), 0.f);   // 0-based list position == reference `contributor`
@@ -719,255 +719,6 @@ __global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_exact_kerne
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// Backward blend, round 4: the exponents come from the matrix core, as in the forward.
-//
-// Same two phases per wave as above (lane = pixel walk leaving (w, h) per used entry in an LDS slot matrix; lane = (pixel row,
-// slot) fold of the nine sums of seven slots and ONE atomic instruction for their seven 36-byte records).  What changed is where
-// opacity * G comes from: the staged batch carries the forward's coefficient table (stage_poly: the same function, the same
-// arithmetic), groups of 16 staged entries get their 16 x 64 exponents e' from three chained v_mfma_f32_32x32x2_f32
-// (poly_exponents), and 2^e' IS opacity * G.  Consequences:
-//   * the decision alpha >= 1/255 is taken on the very number the forward took it on - the set of entries a pixel uses in the
-//     backward pass is the set that contributed to it in the forward pass, as in the reference, where backward.cu:455-481 repeats
-//     forward.cu:330-344 (round 3 evaluated a different, more accurate form here and could disagree on an entry in a few 10^5);
-//   * per staged entry the walk sheds the five packed-f32 instructions of the per-pixel exponent, the opacity product and two of
-//     five LDS reads: 16 instead of 24 vector instructions for an entry a pixel uses, 4 instead of 10 for one nobody uses.
-// A group's sixteen entries are sixteen copies of the entry body with a static accumulator index; the phase-2 flush, which can
-// fall due after any of them, is ONE copy behind a re-entrant switch (the group is left at entry k and re-entered at k + 1).
-struct StagedB { float4 c; float2 xy; uint32_t pos, pad; };   // (r, g, b, Gaussian id bits), splat centre, list position
-struct BwdLds {                  // per wave: 9.7 KiB
-  uint2 qa[RQ_QA];               // candidate ring of the front end: (Gaussian id, list position)
-  float ct[4 * 6 * 32];          // coefficient table of the staged batch (stage_poly)
-  StagedB st[64];                // staged batch (ONE record per entry: one LDS base address per group of 16, immediate offsets from it)
-  union {
-    float2 M[7][65];             // (w, h) per slot and pixel; row stride 65 keeps phase 2's row reads conflict-free
-    float part[8][72];           // phase 2: row partials [row][slot * 9 + value] (columns 63.. belong to the idle lanes)
-    struct { float2 rg[64]; } dpt;                 // kernel start only: dL/dpixel (r, g) of every pixel
-  };
-  float dpb[64];                 // dL/dpixel (b) of every pixel: read again by every phase 2 (the (r, g) pairs of a lane's row stay in registers;
-                                 // all 24 values there would cost the fourth wave per SIMD)
-  SlotB slot[8];
-};
-
-__global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_kernel(const uint2* __restrict__ ranges,
-                                                               const uint2* __restrict__ pairs,
-                                                               const float4* __restrict__ splat, int W, int H, TileMap tm,
-                                                               const float* __restrict__ bg, const float* __restrict__ final_T,
-                                                               const uint32_t* __restrict__ n_contrib,
-                                                               const float* __restrict__ dL_dpix, float* __restrict__ grad_acc,
-                                                               const uint32_t* __restrict__ counters, int mode) {
-  constexpr int WPW = GM_RENDER_BWD_WPW;
-  const int lane = threadIdx.x & 63;
-  const int wave = WPW == 4 ? (int)(threadIdx.x >> 6) : (int)((blockIdx.x >> 3) & 3);
-  const int tile_block = WPW == 4 ? (int)blockIdx.x : (int)(((blockIdx.x >> 5) << 3) | (blockIdx.x & 7));
-  int tx, ty, parent;
-  uint32_t child_bit;
-  if ((int)counters[GM_CNT_POLICY] != mode || counters[GM_CNT_REFUSED] != 0u) return;   // lists were built under another emission policy: contribute nothing
-  if (!tm.locate(tile_block, tx, ty, parent, child_bit)) return;
-  if (tm.s == 1) child_bit = quadrant_bit(tx, ty, wave);
-  const uint2 range = ranges[parent];
-  const int n = (int)(range.y - range.x);
-  if (n == 0) return;
-  const uint2* list = pairs + range.x;           // (key, Gaussian id) per list entry
-  const size_t HW = (size_t)H * W;
-
-  const int px = tx * GM_TILE + (wave & 1) * 8 + (lane & 7);
-  const int py = ty * GM_TILE + (wave >> 1) * 8 + (lane >> 3);
-  const bool inside = px < W && py < H;
-  const size_t pid = inside ? (size_t)W * py + px : 0;
-  const float T_final = inside ? final_T[pid] : 0.f;
-  float T = T_final;
-  const int last = inside ? (int)n_contrib[pid] : 0;
-  const float dpr = inside ? dL_dpix[pid] : 0.f, dpg = inside ? dL_dpix[HW + pid] : 0.f, dpb = inside ? dL_dpix[2 * HW + pid] : 0.f;
-  float A = T_final * (bg[0] * dpr + bg[1] * dpg + bg[2] * dpb);      // A_i + T_final bg . dL/dpixel (see above)
-  int max_last = last;
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) max_last = max(max_last, __shfl_xor(max_last, d));
-  const int start = __builtin_amdgcn_readfirstlane(max_last);   // list entries this wave has to visit (positions start-1 .. 0)
-  if (start == 0) return;
-
-  const float rx0 = (float)(tx * GM_TILE + (wave & 1) * 8), ry0 = (float)(ty * GM_TILE + (wave >> 1) * 8);
-  __shared__ BwdLds l_b[WPW];
-  BwdLds& B = l_b[WPW == 4 ? wave : 0];
-  BwdLds& L = B;
-  // the lane's monomials (B operand) and the expansion point, exactly as in render_fwd_kernel
-  const float ccx = (float)(lane & 7) - 3.5f, ccy = (float)((lane >> 3) & 3) - 1.5f;
-  const bool khi = lane >= 32;
-  const float B0 = khi ? ccx * ccy : ccx * ccx, B1 = khi ? ccx : ccy * ccy, B2 = khi ? 1.0f : ccy;
-  const float ucx = rx0 + 3.5f, vcy = ry0 + 1.5f;
-#pragma unroll
-  for (int i = 0; i < 12; i++) B.ct[64 * i + lane] = 0.f;            // rows without an entry are multiplied all the same: finite
-  // phase 2 geometry of this lane: slot es (7: idle), pixel row r; dL/dpixel of the row's eight pixels stays in registers
-  const int es = lane & 7, r = lane >> 3, esc = min(es, 6);
-  float2 dq[8];
-  B.dpt.rg[lane] = make_float2(dpr, dpg); B.dpb[lane] = dpb;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int i = 0; i < 8; i++) dq[i] = B.dpt.rg[r * 8 + i];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  const float rowy = ry0 + (float)r;
-  const int cl = min(lane, 62), ce = cl / 9, ck = cl - 9 * ce;      // commit role of this lane: value ck of slot ce
-  int m = 0;                                                          // slots in use (wave-uniform)
-  float2* mrow = &B.M[0][lane];
-  SlotB* mslot = &B.slot[0];
-
-  auto phase2 = [&](const int cnt) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const float2 c = B.slot[esc].xy;
-    const float x0 = c.x - rx0, dy = c.y - rowy;
-    v2f s01 = {0.f, 0.f};
-    float s2 = 0.f, s3 = 0.f, s4 = 0.f, s6 = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const float2 v = B.M[esc][r * 8 + i];                       // (w, h) of pixel i of this lane's row
-      const float dx = x0 - (float)i, hx = v.y * dx;
-      const v2f ww = {v.x, v.x}, drg = {dq[i].x, dq[i].y};
-      s3 += v.y; s4 += hx;
-      s6 = __builtin_fmaf(hx, dx, s6);
-      s01 = ww * drg + s01;
-      s2 = __builtin_fmaf(v.x, B.dpb[r * 8 + i], s2);
-    }
-    const v2f s34 = {s3, s4};
-    const float s5 = dy * s34.x, s7 = dy * s34.y, s8 = dy * s5;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // every lane has read M before `part` (same storage) is written
-    __builtin_amdgcn_wave_barrier();
-    float* prow = &B.part[r][es * 9];
-    prow[0] = s01.x; prow[1] = s01.y; prow[2] = s2; prow[3] = s34.x; prow[4] = s34.y; prow[5] = s5; prow[6] = s6; prow[7] = s7; prow[8] = s8;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    float tot = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; q++) tot += B.part[q][cl];
-    const uint32_t gid = B.slot[ce].id;
-    if (lane < 63 && ce < cnt) atomicAdd(grad_acc + (size_t)gid * GM_ACC_STRIDE + ck, tot);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // `part` has been read before phase 1 writes M again
-    __builtin_amdgcn_wave_barrier();
-  };
-
-  // Same front end as render_fwd_kernel, walking the list back to front: chunk lane j <-> position start-1-kpos-j
-  // (positions below 0 re-read entry 0 and are not "mine"); candidates enter the ring in descending list position.
-  int kpos = 0;                                  // entries scanned so far (from the back)
-  uint32_t qa_head = 0, qa_cnt = 0;
-  uint2 kv[RQ_K];
-  auto scan = [&]() {
-    bool go = true;
-#pragma unroll
-    for (int k = 0; k < RQ_K; k++) {
-      go = go && kpos < start && qa_cnt + 64u <= (uint32_t)RQ_QA;
-      if (go) {
-        const int p = start - 1 - kpos - lane;
-        const bool mine = p >= 0 && (kv[k].x & child_bit) != 0u;
-        const unsigned long long bal = __ballot(mine);
-        if (mine) L.qa[(qa_head + qa_cnt + lanes_below(bal)) & (RQ_QA - 1)] = make_uint2(kv[k].y, (uint32_t)p);
-        qa_cnt += (uint32_t)__popcll(bal);
-        kpos += 64;
-      }
-    }
-  };
-  auto load_keys = [&]() {
-#pragma unroll
-    for (int k = 0; k < RQ_K; k++) kv[k] = list[max(start - 1 - kpos - k * 64 - lane, 0)];
-  };
-  auto pop = [&](int& count) {
-    count = (int)min(qa_cnt, 64u);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const uint2 cand = lane < count ? L.qa[(qa_head + (uint32_t)lane) & (RQ_QA - 1)] : make_uint2(0u, 0u);
-    qa_head += (uint32_t)count; qa_cnt -= (uint32_t)count;
-    return issue_gather(splat, cand);
-  };
-  // one staged entry at one pixel: e = e' of the entry at this lane's pixel, j = its index in the staged batch (wave-uniform)
-  auto entry = [&](const float e, const int j) {
-    const float oG = __builtin_amdgcn_exp2f(e);                        // opacity * G: the number the forward compared with 1/255
-    const int pos = (int)B.st[j].pos;
-    const bool valid = (pos < last) && (oG >= 1.0f / 255.0f);
-    if (!__any(valid)) return;
-    const float4 C = B.st[j].c;
-    const float2 xy = B.st[j].xy;
-    const float oGe = valid ? oG : 0.0f;                             // a lane that skips the entry: alpha 0, every update the identity
-    const float al = __builtin_amdgcn_fmed3f(oGe, 0.0f, 0.99f);      // alpha = min(0.99, opacity G)
-    const float inv = __builtin_amdgcn_rcpf(1.f - al);               // 1 / (1 - alpha)
-    const float cd = __builtin_fmaf(C.z, dpb, __builtin_fmaf(C.y, dpg, C.x * dpr));
-    T = T * inv;                                                     // transmittance in front of the entry
-    const float wv = al * T;
-    const float dL_dalpha = T * cd - A * inv;
-    A = __builtin_fmaf(wv, cd, A);
-    *mrow = make_float2(wv, oGe * dL_dalpha);                        // M[m][lane]: w ; h = G dL/dG with dL/dG = opacity dL/dalpha
-    mslot->xy = xy;                                                  // slot[m] (uniform address, uniform value)
-    mslot->id = __float_as_uint(C.w);
-    mrow += 65; mslot += 1;
-    m += 1;
-  };
-  load_keys();
-  scan();
-  load_keys();
-  auto step = [&](Gather& cur, int& n0, const int n1, Gather& nxt, int& n2) -> bool {      // see render_fwd_kernel
-    if (n0 == 0 && n1 == 0 && qa_cnt == 0u && kpos >= start) return false;
-    __builtin_amdgcn_s_waitcnt(0x0F73);                                  // vmcnt(3)
-    scan();
-    load_keys();
-    nxt = pop(n2);
-    if (n0 > 0) {
-      // A pixel takes part in this batch only if its last contributor lies above the batch's lowest position: cull against
-      // the bounding box of those pixels.  Lane = y * 8 + x.
-      const int pos_lo = __builtin_amdgcn_readlane((int)cur.pos, n0 - 1);
-      const unsigned long long live = __ballot(last > pos_lo);
-      float cx0 = rx0, cx1 = rx0 + 7.0f, cy0 = ry0, cy1 = ry0 + 7.0f;
-      if (live != 0ull) {
-        uint32_t cols = (uint32_t)live | (uint32_t)(live >> 32);
-        cols |= cols >> 16; cols |= cols >> 8; cols &= 0xFFu;
-        cx0 = rx0 + (float)(__ffs((int)cols) - 1);
-        cx1 = rx0 + (float)(31 - __clz((int)cols));
-        cy0 = ry0 + (float)((__ffsll(live) - 1) >> 3);
-        cy1 = ry0 + (float)((63 - __clzll((long long)live)) >> 3);
-      }
-      const bool keep = live != 0ull && lane < n0 && may_touch(cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, cx0, cx1, cy0, cy1);
-      const unsigned long long kb = __ballot(keep);
-      const int ns = __popcll(kb);
-      if (keep) {                                                        // compacted, in walk order
-        const int slot = (int)lanes_below(kb);
-        stage_poly(B.ct, slot, cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, ucx, vcy);
-        StagedB& o = B.st[slot];
-        o.c = make_float4(cur.b.z, cur.b.w, cur.c, __uint_as_float(cur.id));
-        o.xy = make_float2(cur.a.x, cur.a.y);
-        o.pos = cur.pos;                                                 // 0-based list position == reference `contributor`
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      for (int j0 = 0; j0 < ns; j0 += 16) {
-        const v16f E = poly_exponents(B.ct, j0, lane, B0, B1, B2);
-        int rem = min(16, ns - j0);                                      // entries of the group still to do (wave-uniform)
-        int t = 0;                                                       // next entry of the group
-        do {
-          switch (t) {
-#define GM_BWD_ENTRY(k) case k: entry(E[k], j0 + k); t = k + 1; rem -= 1; if (m == 7 || rem == 0) break; [[fallthrough]];
-            GM_BWD_ENTRY(0) GM_BWD_ENTRY(1) GM_BWD_ENTRY(2) GM_BWD_ENTRY(3) GM_BWD_ENTRY(4) GM_BWD_ENTRY(5) GM_BWD_ENTRY(6) GM_BWD_ENTRY(7)
-            GM_BWD_ENTRY(8) GM_BWD_ENTRY(9) GM_BWD_ENTRY(10) GM_BWD_ENTRY(11) GM_BWD_ENTRY(12) GM_BWD_ENTRY(13) GM_BWD_ENTRY(14)
-#undef GM_BWD_ENTRY
-            default: entry(E[15], j0 + 15); t = 16; rem = 0; break;
-          }
-          if (m == 7) { phase2(7); m = 0; mrow = &B.M[0][lane]; mslot = &B.slot[0]; }
-        } while (rem > 0);
-      }
-    }
-    return true;
-  };
-  int n0, n1, n2 = 0;
-  Gather g0 = pop(n0), g1 = pop(n1), g2 = g1;
-  for (;;) {
-    if (!step(g0, n0, n1, g2, n2)) break;
-    if (!step(g1, n1, n2, g0, n0)) break;
-    if (!step(g2, n2, n0, g1, n1)) break;
-  }
-  if (m > 0) phase2(m);
-}
-
-static bool g_bwd_exact = false;                          // verification aid (tests only): round 3's backward blend
-extern "C" void gm_debug_backward_exact_exponent(int on) { g_bwd_exact = on != 0; }
-
 int launch_render_bwd(const GeomState& g, const uint2* pairs, ImageState& img, int W, int H, int mode,
                       const float* background, const float* dL_dpix, int debug, hipStream_t s) {
   StageScope sc(ST_RENDER_BWD, s);
@@ -977,14 +728,9 @@ int launch_render_bwd(const GeomState& g, const uint2* pairs, ImageState& img, i
     hipLaunchKernelGGL(tile_work_kernel, dim3(tg.ptiles), dim3(256), 0, s, img.n_contrib, W, H, tg.pgx, tg.s, img.tile_work);
     hipLaunchKernelGGL(tile_order_work_kernel, dim3(1), dim3(1024), 0, s, img.tile_work, tg.ptiles, img.tile_order_bwd);
   }
-  if (tg.ptiles > 0) {
-    if (g_bwd_exact)
-      hipLaunchKernelGGL(render_bwd_exact_kernel, dim3(tm.blocks() * (4 / GM_RENDER_BWD_WPW)), dim3(64 * GM_RENDER_BWD_WPW), 0, s, img.ranges, pairs, g.splat, W, H, tm,
-                         background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc, g.counters, mode);
-    else
-      hipLaunchKernelGGL(render_bwd_kernel, dim3(tm.blocks() * (4 / GM_RENDER_BWD_WPW)), dim3(64 * GM_RENDER_BWD_WPW), 0, s, img.ranges, pairs, g.splat, W, H, tm,
-                         background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc, g.counters, mode);
-  }
+  if (tg.ptiles > 0)
+    hipLaunchKernelGGL(render_bwd_kernel, dim3(tm.blocks() * (4 / GM_RENDER_BWD_WPW)), dim3(64 * GM_RENDER_BWD_WPW), 0, s, img.ranges, pairs, g.splat, W, H, tm,
+                       background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc, g.counters, mode);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }

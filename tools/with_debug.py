@@ -1,7 +1,6 @@
 #!/usr/bin/env python
 """python tools/with_debug.py <switch>[,<switch>...] <script.py> [args...]: run a script (bench.py, a tool) with verification builds of the
 blend kernels switched on (the switches are exported by libgmesh_hip.so but are not part of the public header; the product never sets them):
-  bwd_exact   gm_debug_backward_exact_exponent(1): round 3's backward blend (per-pixel exponent)
   fwd_exact   gm_debug_forward_exact_exponent(1):  forward blend with the per-pixel exponent
   none        nothing (same command line shape for A/B loops)"""
 import ctypes
@@ -15,9 +14,7 @@ from gaussianmesh_amd import _lib
 
 lib = ctypes.CDLL(_lib.lib()._name)
 for sw in sys.argv[1].split(","):
-    if sw == "bwd_exact":
-        lib.gm_debug_backward_exact_exponent(1)
-    elif sw == "fwd_exact":
+    if sw == "fwd_exact":
         lib.gm_debug_forward_exact_exponent(1)
     elif sw != "none":
         raise SystemExit("unknown switch %r" % sw)
