@@ -475,6 +475,9 @@ int launch_render_fwd(const GeomState& g, const uint2* pairs, ImageState& img, i
 // Backward blend.
 #define GM_ACC_STRIDE 12   // floats per Gaussian in grad_acc: dcolor rgb (0-2), moments of h: 1, dx, dy, dx^2, dx dy, dy^2 (3-8)
 
+#ifndef GM_BWD_PREFETCH
+#define GM_BWD_PREFETCH 1        // staged records of the backward walk read one entry ahead (A/B: tools/ab_flags.sh gm_render ... "-DGM_BWD_PREFETCH=0")
+#endif
 #ifndef GM_RENDER_BWD_WPW
 #define GM_RENDER_BWD_WPW 1      // waves per workgroup of the backward blend: 4 (one workgroup per 16-px tile) or 1 (one per 8x8 quadrant)
 #endif
@@ -680,8 +683,18 @@ __global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_kernel(cons
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+#if GM_BWD_PREFETCH
+      // software pipeline of the staged records: entry j + 1's three LDS reads are in flight while entry j is walked - the launch
+      // ends on a few heavy waves that run alone on their SIMD, and a lone wave otherwise waits out the LDS latency of every entry
+      float4 nRA = B.st[0].a, nRB = B.st[0].b, nRC = B.st[0].c;
+#endif
       for (int j = 0; j < ns; j++) {
+#if GM_BWD_PREFETCH
+        const float4 RA = nRA, RB = nRB, RC = nRC;
+        { const int jn = min(j + 1, ns - 1); nRA = B.st[jn].a; nRB = B.st[jn].b; nRC = B.st[jn].c; }
+#else
         const float4 RA = B.st[j].a, RB = B.st[j].b, RC = B.st[j].c;
+#endif
         v2f dd;
         const float e = staged_exponent(RA, RB.x, pix, dd);             // power * log2(e), pixel-relative form (the forward kernel's polynomial
                                                                          // agrees to ~1e-5; its decisions can differ on an entry in a few 10^5)
