@@ -53,6 +53,46 @@ def test_bench_eight_ranks_walk_the_c4_view_split(tmp_path):
     assert seen == set(range(64))
 
 
+def test_c4_at_full_size_eight_ranks_on_one_gpu(tmp_path):
+    """BASELINE config C4 AT ITS SIZE - the 1 M-Gaussian deformed scene, 1920x1080, 64-camera trajectory, 8 views per rank - with
+    the eight ranks of `bench.py --gpus 8 --cameras 64` sharing the one GPU of the test box (gloo for the exchange; the images do
+    not depend on the transport).  Not a measurement: what it shows is that the full-size multi-rank configuration runs end to end
+    (one-time broadcast of the 0.3-GB cloud, batched vertex-position broadcasts, every rank deriving (R, S) itself, sync-free
+    four-stream loop) and that a rank renders exactly what a single process renders for its view: rank r walks cameras 8r .. 8r+7,
+    the 64 views are covered once, no frame is lost to an overflow, and the last images of two ranks are bit-identical to
+    single-process renders of those (frame, camera) pairs."""
+    P, W, H, F, steps, warm = 1_000_000, 1920, 1080, 64, 8, 0
+    out = _launch(tmp_path, 8, dict(GM_BENCH_SHARE_DEVICE="1", GM_BENCH_BACKEND="gloo"), P, W, H, F, steps, warm)
+    assert out["n_gpus"] == 8 and out["config"]["gaussians"] == P and out["config"]["width"] == W and out["value"] > 0
+    ex = out["config"]["exchange"]
+    assert ex["steps_per_broadcast"] == 8 and ex["bytes_per_step"] == 7500 * 12 and len(ex["ms_per_step_by_rank"]) == 8
+    seen = set()
+    for r in range(8):
+        d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        assert d["views"].tolist() == list(range(8 * r, 8 * r + 8)) and int(d["overflows"]) == 0 and np.isfinite(d["image"]).all()
+        seen.update(d["views"].tolist())
+    assert seen == set(range(64))
+    sys.path.insert(0, ROOT)
+    import bench
+    from gpu_utils import T
+    from gaussianmesh_amd import multiview, rasterizer as Rz, scenes
+    from gaussianmesh_amd.deform import mesh_rs, pack_mesh_state
+    host = bench.build_scene(P, W, H, F)
+    g = {k: T(host[k]) for k in ("weights", "pos", "cov", "opac", "shs", "verts")}
+    g["tri"] = T(host["tri"], dtype=torch.int32)
+    last = warm + steps - 1
+    for r in (0, 5):
+        d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        v = multiview.view_for_step(last, F, r, 8)
+        assert int(d["view"]) == v == 8 * r + 7 and int(d["frame"]) == last % F
+        cam = scenes.orbit_camera(v, F, W, H)
+        ct = {n: T(cam[n]) for n in ("view", "proj", "campos")}
+        state = mesh_rs(g["verts"], T(host["mesh"][last % F][:, 0:3]), T(host["faces"], dtype=torch.int32), want_state=True)[2]
+        _, color, *_ = Rz.forward_deformed_begin(torch.ones(3, device="cuda"), g["tri"], g["weights"], pack_mesh_state(state, g["verts"]), g["cov"], g["pos"],
+                                                 g["shs"], g["opac"], ct["view"], ct["proj"], cam["tanx"], cam["tany"], H, W, 3, ct["campos"]).finish()
+        assert np.array_equal(d["image"], color.cpu().numpy()), "rank %d did not render view %d of frame %d" % (r, v, last % F)
+
+
 @pytest.mark.parametrize("batch", [None, 1, 3])          # None: bench.py's own default at N > 1 (8)
 def test_bench_two_ranks_render_their_own_views(tmp_path, batch):
     _two_ranks(tmp_path, batch, dict(GM_BENCH_SHARE_DEVICE="1", GM_BENCH_BACKEND="gloo"))
