@@ -299,7 +299,7 @@ def c5_leg(steps, warm, Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, sync_free=
         torch.cuda.synchronize()
         forced = {"rows_before": rows0, "rows_after": int(tr.g._bc.shape[0]), "densify_and_prune_ms": round(t_split, 3),
                   "ms_per_iter_after": 1e3 * (time.perf_counter() - td) / 20, "iterations_redone_after": tr.redone,
-                  "selection": "rows whose mean view-space gradient is in the top 2 % (threshold %.3g)" % thr}
+                  "selection": "rows whose mean view-space gradient is in the top 2 percent (threshold %.3g)" % thr}
     lf = float(torch.stack(losses[:5]).mean()); ll = float(torch.stack(losses[-20:]).mean())
     out = {"ms_per_iter": 1e3 * el / steps, "iters": steps, "warmup": 0, "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
            "iterations_redone": tr.redone, "gaussians": Nfg + Nbg, "trainable": Nfg, "trainable_at_end": int(tr.g._bc.shape[0]), "width": W, "height": H,
