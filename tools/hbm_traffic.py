@@ -13,7 +13,7 @@ STAGES = [  # stage, (kernel name fragment, launches per frame)
     ("depth_sort", [("bk_hist_kernel<true, 11, 4,", 1), ("bk_scan_kernel<true, 11>", 1), ("bk_scatter_kernel<true, 11, 4,", 1), ("bucket_sort_kernel", 1)]),
     ("duplicate", [("duplicate_kernel<1, 2>", 1)]),
     ("tile_sort", [("bk_hist_kernel<false, 11, 8,", 1), ("bk_scan_kernel<false, 11>", 1), ("bk_scatter_kernel<false, 11, 8,", 1)]),
-    ("render", [("render_fwd_kernel<false, false>", 1)]),
+    ("render", [("render_fwd_kernel<false, false", 1)]),
 ]
 
 
