@@ -441,6 +441,8 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
 
 static unsigned long long* g_render_trace = nullptr;      // debugging aid (tools/wave_trace.py), never set by the package
 extern "C" void gm_debug_render_trace(void* buffer) { g_render_trace = reinterpret_cast<unsigned long long*>(buffer); }
+static float* g_bwd_front_T = nullptr;                   // verification aid (tests only): see render_bwd_kernel
+extern "C" void gm_debug_backward_front_T(void* plane) { g_bwd_front_T = reinterpret_cast<float*>(plane); }
 static bool g_fwd_exact = false;                          // verification aid (tests only): the EXACT build of the forward blend
 extern "C" void gm_debug_forward_exact_exponent(int on) { g_fwd_exact = on != 0; }
 
@@ -526,7 +528,7 @@ __global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_kernel(cons
                                                                const float* __restrict__ bg, const float* __restrict__ final_T,
                                                                const uint32_t* __restrict__ n_contrib,
                                                                const float* __restrict__ dL_dpix, float* __restrict__ grad_acc,
-                                                               const uint32_t* __restrict__ counters, int mode) {
+                                                               const uint32_t* __restrict__ counters, int mode, float* __restrict__ front_T) {
   constexpr int WPW = GM_RENDER_BWD_WPW;
   const int lane = threadIdx.x & 63;
   const int wave = WPW == 4 ? (int)(threadIdx.x >> 6) : (int)((blockIdx.x >> 3) & 3);
@@ -729,6 +731,10 @@ __global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_kernel(cons
     if (!step(g2, n2, n0, g1, n1)) break;
   }
   if (m > 0) phase2(m);
+  // verification aid (gm_debug_backward_front_T; null on the product path): the transmittance the walk arrives at in FRONT of a pixel's
+  // first entry.  It is final_T divided by (1 - alpha) of every entry the backward took for the pixel: 1 up to rounding when those
+  // are the entries the forward blended, off by a factor (1 - alpha) >= 0.4 % for every entry the two halves disagree about.
+  if (front_T && inside) front_T[pid] = T;
 }
 
 
@@ -743,7 +749,7 @@ int launch_render_bwd(const GeomState& g, const uint2* pairs, ImageState& img, i
   }
   if (tg.ptiles > 0)
     hipLaunchKernelGGL(render_bwd_kernel, dim3(tm.blocks() * (4 / GM_RENDER_BWD_WPW)), dim3(64 * GM_RENDER_BWD_WPW), 0, s, img.ranges, pairs, g.splat, W, H, tm,
-                       background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc, g.counters, mode);
+                       background, img.final_T, img.n_contrib, dL_dpix, g.grad_acc, g.counters, mode, g_bwd_front_T);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }
