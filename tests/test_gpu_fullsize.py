@@ -301,5 +301,5 @@ def test_backward_takes_the_entries_the_forward_blended_c2_size():
           "median deviation of the others %.2g" % (off, covered, float(dev.max()), float(dev[dev <= 1e-3].median())))
     assert covered > 0.2 * W * H and torch.isfinite(front).all()
     assert float(dev[dev <= 1e-3].max()) <= 1e-3 and float(dev[dev <= 1e-3].median()) <= 2e-5         # rounding of the reciprocals only
-    assert off <= 2e-4 * W * H, off                        # a pixel with an entry on the threshold: a few hundred of 2 M, each a 0.4 % weight
+    assert off <= 64, off                                  # pixels with an entry on the threshold (measured: 6 of 1.3 M covered pixels), each a 0.4 % weight
     assert float(dev.max()) <= 0.05                        # never more than a handful of threshold entries on one pixel
