@@ -215,7 +215,12 @@ __device__ __forceinline__ v16f poly_exponents(const float* __restrict__ ct, int
   E = __builtin_amdgcn_mfma_f32_32x32x2f32(A2, B2, E, 0, 0, 0);
   return E;
 }
-#define GM_FWD_SUB 4              // survivors whose alpha evaluations interleave (2: 8 VGPRs fewer, no faster)
+#ifndef GM_FWD_SUB
+#define GM_FWD_SUB 4
+#endif
+#ifndef GM_FWD_SETS
+#define GM_FWD_SETS 3             // register sets of gathered records in rotation in the forward blend (2: A/B, see render_fwd_kernel)
+#endif              // survivors whose alpha evaluations interleave (2: 8 VGPRs fewer, no faster)
 struct FwdLds {                  // per wave: 5.25 KiB
   uint2 qa[RQ_QA];               // candidate ring: (Gaussian id, list position)
   float ct[4 * 6 * 32];          // [group of 16 survivors][monomial][MFMA row]: lane l of MFMA step m reads ct[192 g + 64 m + l]
@@ -321,13 +326,17 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
       if (TRACE) { tr_iters++; tr_cand += n0; }
       const unsigned long long live = __ballot(T > 0.0f);
       if (live == 0ull) return false;
-      if (n0 == 0 && n1 == 0 && qa_cnt == 0u && kpos >= n) return false;
+      if (n0 == 0 && n1 == 0 && qa_cnt == 0u && kpos >= n) return false;             // (two register sets: n1 is passed as 0)
       // cull against the bounding box of the pixels that are still live (lane = y * 8 + x; scalar bit arithmetic)
       uint32_t cols = (uint32_t)live | (uint32_t)(live >> 32);
       cols |= cols >> 16; cols |= cols >> 8; cols &= 0xFFu;
       const float cx0 = rx0 + (float)(__ffs((int)cols) - 1), cx1 = rx0 + (float)(31 - __clz((int)cols));
       const float cy0 = ry0 + (float)((__ffsll(live) - 1) >> 3), cy1 = ry0 + (float)((63 - __clzll((long long)live)) >> 3);
+#if GM_FWD_SETS == 2
+      __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0): the keys and the gather issued last iteration
+#else
       __builtin_amdgcn_s_waitcnt(0x0F73);                                  // vmcnt(3): all but the gather issued last iteration
+#endif
       scan();
       load_keys();
       nxt = pop(n2);
@@ -343,7 +352,7 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
           stage_poly(L.ct, slot, cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, ucx, vcy);
           // (r, g, b, w): w = the opacity in the EXACT build, otherwise (the opacity lives in the polynomial) the 1-based list position
           // the backward state wants - one broadcast read per survivor for colour AND n_contrib
-          L.sb[slot] = make_float4(cur.b.z, cur.b.w, cur.c, EXACT ? cur.b.y : __uint_as_float(cur.pos + 1u));
+          L.sb[slot] = make_float4(cur.b.z, cur.b.w, cur.c, EXACT ? cur.b.y : (STATE ? __uint_as_float(cur.pos + 1u) : 0.f));
           if (EXACT) {
             x_ra[68 * (WPW == 4 ? wave : 0) + slot] = make_float4(cur.a.x, cur.a.y, (-0.5f * LOG2E) * cur.a.z, (-0.5f * LOG2E) * cur.b.x);
             x_bq[68 * (WPW == 4 ? wave : 0) + slot] = (-LOG2E) * cur.a.w;
@@ -413,6 +422,16 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
       }
       return true;
     };
+#if GM_FWD_SETS == 2
+    // two register sets: the batch issued in iteration i is consumed in iteration i + 1 (an iteration is 0.3 - 2 us, an L2 hit
+    // 0.2 - 0.4 us); nine registers fewer than with a third set in flight - with GM_FWD_SUB = 2 the image-only kernel fits 96 VGPRs
+    int n0, n1 = 0;
+    Gather g0 = pop(n0), g1 = g0;
+    for (;;) {
+      if (!step(g0, n0, 0, g1, n1)) break;
+      if (!step(g1, n1, 0, g0, n0)) break;
+    }
+#else
     int n0, n1, n2 = 0;
     Gather g0 = pop(n0), g1 = pop(n1), g2 = g1;
     for (;;) {
@@ -420,6 +439,7 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
       if (!step(g1, n1, n2, g0, n0)) break;
       if (!step(g2, n2, n0, g1, n1)) break;
     }
+#endif
   }
   if (hint && work > 0 && lane == 0)                                     // (gm_tile_order.h: the next frames' dispatch order)
     atomicMax(&hint[1 + parent], (epoch[0] << 20) | min((uint32_t)work, GM_HINT_WORK_MASK));
