@@ -219,7 +219,7 @@ __device__ __forceinline__ v16f poly_exponents(const float* __restrict__ ct, int
 #define GM_FWD_SUB 4
 #endif
 #ifndef GM_FWD_SETS
-#define GM_FWD_SETS 3             // register sets of gathered records in rotation in the forward blend (2: A/B, see render_fwd_kernel)
+#define GM_FWD_SETS 2             // register sets of gathered records in rotation in the forward blend (3: round 2-3, see render_fwd_kernel)
 #endif              // survivors whose alpha evaluations interleave (2: 8 VGPRs fewer, no faster)
 struct FwdLds {                  // per wave: 5.25 KiB
   uint2 qa[RQ_QA];               // candidate ring: (Gaussian id, list position)
@@ -423,8 +423,12 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
       return true;
     };
 #if GM_FWD_SETS == 2
-    // two register sets: the batch issued in iteration i is consumed in iteration i + 1 (an iteration is 0.3 - 2 us, an L2 hit
-    // 0.2 - 0.4 us); nine registers fewer than with a third set in flight - with GM_FWD_SUB = 2 the image-only kernel fits 96 VGPRs
+    // TWO register sets (round 4): the batch issued in iteration i is consumed in iteration i + 1 (an iteration is 0.3 - 2 us, an L2
+    // hit 0.2 - 0.4 us) and every load issued before an iteration has landed at its top (vmcnt(0)).  Nine registers fewer than with a
+    // third set in flight: the image-only kernel needs 95 VGPRs instead of 111 - FIVE waves per SIMD instead of four - and the
+    // pipelined loop gains 3.2 % (4820 -> 4980 frames/s, A/B in one call, profiles/r04_ab_sets.txt; the training forward, 104 VGPRs,
+    // stays at four waves and gains 3 % from the shorter iteration).  Round 2 chose three sets for a lone wave's latency; what the
+    // loop is short of is resident waves.
     int n0, n1 = 0;
     Gather g0 = pop(n0), g1 = g0;
     for (;;) {
