@@ -221,11 +221,10 @@ __device__ __forceinline__ v16f poly_exponents(const float* __restrict__ ct, int
 #ifndef GM_FWD_SETS
 #define GM_FWD_SETS 2             // register sets of gathered records in rotation in the forward blend (3: round 2-3, see render_fwd_kernel)
 #endif              // survivors whose alpha evaluations interleave (2: 8 VGPRs fewer, no faster)
-struct FwdLds {                  // per wave: 5.25 KiB
+struct FwdLds {                  // per wave: 5.1 KiB
   uint2 qa[RQ_QA];               // candidate ring: (Gaussian id, list position)
   float ct[4 * 6 * 32];          // [group of 16 survivors][monomial][MFMA row]: lane l of MFMA step m reads ct[192 g + 64 m + l]
   float4 sb[68];                 // (r, g, b, opacity) per survivor (+ 4 entries of padding with opacity 0 behind the last)
-  uint32_t sp[68];               // list position + 1 per survivor (n_contrib; STATE only)
 };
 
 // STATE = false: image-only frame (GM_FWD_IMAGE_ONLY) - final_T / n_contrib, which only a backward pass reads, are neither
@@ -278,6 +277,7 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
     FwdLds& L = L_w[WPW == 4 ? wave : 0];
     __shared__ float4 x_ra[EXACT ? 68 * WPW : 1];                               // EXACT: (x, y, a', c') and b' per survivor
     __shared__ float x_bq[EXACT ? 68 * WPW : 1];
+    __shared__ uint32_t x_sp[EXACT ? 68 * WPW : 1];                             //        list position + 1 (its place in the colour record holds the opacity)
     const v2f pixf = {(float)px, (float)py};
     // B operand of the three MFMA steps: monomials (cx^2, cx cy) / (cy^2, cx) / (cy, 1) of this lane's pixel column; k = lane / 32
     const float ccx = (float)(lane & 7) - 3.5f, ccy = (float)((lane >> 3) & 3) - 1.5f;
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
             x_ra[68 * (WPW == 4 ? wave : 0) + slot] = make_float4(cur.a.x, cur.a.y, (-0.5f * LOG2E) * cur.a.z, (-0.5f * LOG2E) * cur.b.x);
             x_bq[68 * (WPW == 4 ? wave : 0) + slot] = (-LOG2E) * cur.a.w;
           }
-          if (STATE && EXACT) L.sp[slot] = cur.pos + 1u;                  // 1-based list position: n_contrib
+          if (STATE && EXACT) x_sp[68 * (WPW == 4 ? wave : 0) + slot] = cur.pos + 1u;   // 1-based list position: n_contrib
         }
         // survivors are taken four at a time: the up to three slots behind the last must come out as alpha = 0
         if (lane < 4 && ns + lane < 64) pad_poly(L.ct, ns + lane);
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
             uint32_t SP[SUB];
             if (STATE) {
 #pragma unroll
-              for (int t = 0; t < SUB; t++) SP[t] = EXACT ? L.sp[j + SUB * q + t] : __float_as_uint(S[t].w);
+              for (int t = 0; t < SUB; t++) SP[t] = EXACT ? x_sp[68 * (WPW == 4 ? wave : 0) + j + SUB * q + t] : __float_as_uint(S[t].w);
             }
             float al[SUB];
 #pragma unroll
