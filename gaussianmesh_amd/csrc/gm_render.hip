@@ -501,6 +501,9 @@ int launch_render_fwd(const GeomState& g, const uint2* pairs, ImageState& img, i
 // Backward blend.
 #define GM_ACC_STRIDE 12   // floats per Gaussian in grad_acc: dcolor rgb (0-2), moments of h: 1, dx, dy, dx^2, dx dy, dy^2 (3-8)
 
+#ifndef GM_BWD_SETS
+#define GM_BWD_SETS 3              // register sets of gathered records in rotation in the backward blend (A/B: 2)
+#endif
 #ifndef GM_BWD_PREFETCH
 #define GM_BWD_PREFETCH 1        // staged records of the backward walk read one entry ahead (A/B: tools/ab_flags.sh gm_render ... "-DGM_BWD_PREFETCH=0")
 #endif
@@ -678,7 +681,11 @@ __global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_kernel(cons
   load_keys();
   auto step = [&](Gather& cur, int& n0, const int n1, Gather& nxt, int& n2) -> bool {      // see render_fwd_kernel
     if (n0 == 0 && n1 == 0 && qa_cnt == 0u && kpos >= start) return false;
+#if GM_BWD_SETS == 2
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0)
+#else
     __builtin_amdgcn_s_waitcnt(0x0F73);                                  // vmcnt(3)
+#endif
     scan();
     load_keys();
     nxt = pop(n2);
@@ -747,6 +754,14 @@ __global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_kernel(cons
     }
     return true;
   };
+#if GM_BWD_SETS == 2
+  int n0, n1 = 0;
+  Gather g0 = pop(n0), g1 = g0;
+  for (;;) {
+    if (!step(g0, n0, 0, g1, n1)) break;
+    if (!step(g1, n1, 0, g0, n0)) break;
+  }
+#else
   int n0, n1, n2 = 0;
   Gather g0 = pop(n0), g1 = pop(n1), g2 = g1;
   for (;;) {
@@ -754,6 +769,7 @@ __global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_kernel(cons
     if (!step(g1, n1, n2, g0, n0)) break;
     if (!step(g2, n2, n0, g1, n1)) break;
   }
+#endif
   if (m > 0) phase2(m);
   // verification aid (gm_debug_backward_front_T; null on the product path): the transmittance the walk arrives at in FRONT of a pixel's
   // first entry.  It is final_T divided by (1 - alpha) of every entry the backward took for the pixel: 1 up to rounding when those
