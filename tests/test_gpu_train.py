@@ -205,27 +205,6 @@ def test_trainer_sync_free_free_running_trajectory_stays_inside_the_adam_bound()
     assert (ta.max_radii2D - tb.max_radii2D).abs().max() <= 1 and (ta.denom - tb.denom).abs().max() <= 1      # radii may flip by one
 
 
-def test_two_trainers_do_not_share_sync_free_state():
-    """rasterizer.SyncFreeState is per owner and current per thread: a trainer's capacity guess and unverified forwards are
-    invisible to another trainer, to code outside step(), and to another thread."""
-    import threading
-    from gaussianmesh_amd import rasterizer as Rz
-    assert Rz.current_sync_free() is None
-    a, b = Rz.SyncFreeState(), Rz.SyncFreeState()
-    seen = []
-    with a:
-        assert Rz.current_sync_free() is a
-        t = threading.Thread(target=lambda: seen.append(Rz.current_sync_free()))
-        t.start(); t.join()
-        with b:
-            assert Rz.current_sync_free() is b
-        assert Rz.current_sync_free() is a
-    assert Rz.current_sync_free() is None and seen == [None]
-    a.note_count("dev", 1000)
-    assert b.capacity == {} and a.capacity["dev"] == int(1000 * a.growth) + 4096
-    assert not hasattr(Rz, "_sync_free")
-
-
 def test_densify_stats_kernel_matches_the_reference_statements():
     from gaussianmesh_amd.model_ops import densify_stats
     g = torch.Generator(device="cuda").manual_seed(0)

@@ -45,3 +45,24 @@ def test_iteration_schedule_is_the_reference_loops():
     assert white == [500, 3000]
     # the first 1000 iterations (BASELINE config C5): densify at 600, 800 - and 1000, where the degree goes from 0 to 1 first
     assert [it for it in range(1, 1001) if plans[it]["densify"]] == [600, 800, 1000] and plans[1000]["oneup"]
+
+
+def test_two_trainers_do_not_share_sync_free_state():
+    """rasterizer.SyncFreeState is per owner and current per thread: a trainer's capacity guess and unverified forwards are
+    invisible to another trainer, to code outside step(), and to another thread."""
+    import threading
+    from gaussianmesh_amd import rasterizer as Rz
+    assert Rz.current_sync_free() is None
+    a, b = Rz.SyncFreeState(), Rz.SyncFreeState()
+    seen = []
+    with a:
+        assert Rz.current_sync_free() is a
+        t = threading.Thread(target=lambda: seen.append(Rz.current_sync_free()))
+        t.start(); t.join()
+        with b:
+            assert Rz.current_sync_free() is b
+        assert Rz.current_sync_free() is a
+    assert Rz.current_sync_free() is None and seen == [None]
+    a.note_count("dev", 1000)
+    assert b.capacity == {} and a.capacity["dev"] == int(1000 * a.growth) + 4096
+    assert not hasattr(Rz, "_sync_free")
