@@ -102,6 +102,7 @@ class Trainer:
         self.sync_state = SyncFreeState(enabled=self.sync_free)
         self.keep_grads = False
         self.last_grads = None
+        self.adam_active_only = True             # FusedAdam touches only the SH coefficients of the degrees switched on so far (False: all)
         self._sh_degree_seen = int(getattr(gaussians, "active_sh_degree", 3))     # highest SH degree a gradient has been taken at
         self.redone = 0                          # iterations repeated because the instance count outgrew the binning buffer
         self.resizes = 0                         # topology changes applied (resize and everything built on it)
@@ -337,7 +338,7 @@ class Trainer:
             # FusedAdam does not even read them ("active", gm_adam_step_active) - 45 of a Gaussian's 60 parameters at degree 0
             for gr in self.optimizer.param_groups:
                 if gr.get("period") == 48:
-                    gr["active"] = 3 * (self._sh_degree_seen + 1) ** 2 if self._sh_degree_seen < 3 else 0
+                    gr["active"] = 3 * (self._sh_degree_seen + 1) ** 2 if (self.adam_active_only and self._sh_degree_seen < 3) else 0
             self.optimizer.step()
         self.optimizer.zero_grad(set_to_none=True)
         return loss.detach(), pkg

@@ -270,3 +270,34 @@ def test_reference_schedule_loop_small():
     f = out["forced_densify"]
     assert f["rows_after"] > f["rows_before"] and f["rows_after"] - f["rows_before"] == 4 * round((f["rows_after"] - f["rows_before"]) / 4)
     assert out["topology_changes"] >= 1 and f["ms_per_iter_after"] > 0 and f["iterations_redone_after"] <= 4
+
+
+def test_adam_on_the_active_sh_coefficients_is_the_full_update_end_to_end():
+    """Two trainers over the SH-degree ramp (degree 0, then 1, then 2: oneupSHdegree between iterations, as train_mesh_gaussian.py:70-71
+    does every 1000), one letting FusedAdam skip the coefficients above the highest degree seen so far, one updating all 48 per row:
+    from equal state every iteration ends in bit-identical SH parameters and moments - the rasterizer's backward writes exact zeros
+    above the active degree, with and without the background rows sharing the parameter's storage."""
+    build, bg, cams = _bg_scene(N=3000)
+    from gaussianmesh_amd.train import Trainer
+    gt = torch.rand((3, 96, 160), device="cuda")
+    zero = torch.zeros(3, device="cuda")
+    ma, mb = build(), build()
+    ma.active_sh_degree = mb.active_sh_degree = 0
+    ta = Trainer(ma, densify_stats=True, sync_free=True, bg_gaussian=bg)
+    tb = Trainer(mb, densify_stats=True, sync_free=True, bg_gaussian=bg)
+    tb.adam_active_only = False
+    f0 = ma._features.detach().clone()
+    for i in range(9):
+        if i in (3, 6):
+            ma.oneupSHdegree(); mb.oneupSHdegree()
+        tb.copy_state_from(ta)
+        ta.step(cams[i % 5], gt, zero); tb.step(cams[i % 5], gt, zero)
+        ga = next(g for g in ta.optimizer.param_groups if g.get("period") == 48)
+        gb = next(g for g in tb.optimizer.param_groups if g.get("period") == 48)
+        assert ga["active"] == 3 * (ma.active_sh_degree + 1) ** 2 and gb["active"] == 0, i
+        nc = (ma.active_sh_degree + 1) ** 2
+        for k in ("m", "values"):
+            assert float(ga[k][0][:, nc:].abs().max()) == 0.0 and float(gb[k][0][:, nc:].abs().max()) == 0.0, (i, k)     # never touched / updated with zeros
+            assert float((ga[k][0][:, :nc] - gb[k][0][:, :nc]).abs().max()) <= 1e-5 * float(gb[k][0].abs().max()), (i, k)   # (float-atomic order of the two backward passes)
+        assert torch.equal(ma._features.detach()[:, nc:], f0[:, nc:]) and torch.equal(mb._features.detach()[:, nc:], f0[:, nc:]), i
+    assert ma.active_sh_degree == 2 and not torch.equal(ma._features.detach()[:, :9], f0[:, :9])
