@@ -6,7 +6,8 @@ from gaussianmesh_amd import scenes
 from oracle import oracle
 from test_gpu_parity import _grads_gpu, _rel
 worst_f, worst_g, bad = 0.0, 0.0, 0
-for seed in range(24):
+NSEEDS = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+for seed in range(NSEEDS):
     rng = np.random.default_rng(100 + seed)
     P = int(rng.integers(50, 3000))
     lo = float(10 ** rng.uniform(-2.3, -1)); hi = lo * float(10 ** rng.uniform(0.3, 1.6))
