@@ -35,7 +35,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s me
 
 STAGES = ["mesh_rs", "deform", "sh_colors", "preprocess", "depth_sort", "duplicate", "tile_sort", "ranges", "render"]
 # stages that are ONE kernel launch per frame (gm_profile_* brackets it alone): the candidates for `roofline`, the dominant KERNEL
-KERNEL_OF_STAGE = {"mesh_rs": "gm::mesh_rs_kernel", "deform": "gm::deform_shade_kernel<true,true>", "duplicate": "gm::duplicate_kernel",
+KERNEL_OF_STAGE = {"mesh_rs": "gm::mesh_rs_kernel", "deform": "gm::deform_shade_kernel<true,true,false>", "duplicate": "gm::duplicate_kernel",
                    "render": "gm::render_fwd_kernel", "sh_colors": "gm::sh_colors_kernel", "preprocess": "gm::preprocess_fwd_kernel"}
 
 
@@ -87,6 +87,11 @@ def algorithmic_bytes(stage, P, V, R, W, H, Vm, M=16, list_tiles=2040):
         # bucket partition (key read twice, (key, id) written once) + in-LDS bucket sort ((key, id) in; id, count out; count gather)
         # + the move of every visible Gaussian's 16-byte emission record into depth order (read + write): DESIGN.md section 3's 76 MB
         "depth_sort": P * 8 + V * 8 + V * (8 + 4 + 4 + 4) + V * 32 + (P // 4096 + 1) * hist * 4,
+        # direct depth placement (DepthPlan): the fused pass writes (key, id) + the emission record once, into the bucket's slab,
+        # instead of the per-Gaussian key and record arrays; the depth order is then the bucket counters and the in-LDS bucket sort
+        # (slab in; id and record out) - no partition, no gather
+        "deform_pre_direct": P * (12 + 12 + 36 + 12 + 12 * M + 4) + Vm * 96 + V * 48 + P * 8 + V * 24,
+        "depth_sort_direct": V * (8 + 16) + V * (4 + 16) + 2048 * (4 + 4) + 16384 * 4,
         "duplicate": V * (4 + 4) + V * 16 + R * 8,                                  # counts + ids in order, bin records, (key, id) out
         "tile_sort": (R * (4 + 8 + 8) + (R // 4096 + 1) * hist * 4) * (1 if one_pass else 2) + list_tiles * 8,
         "ranges": list_tiles * 12,                                                  # tile_order_kernel: ranges in, dispatch order out
@@ -372,6 +377,10 @@ def main():
                     "camera index) as <dir>/rank<r>.npz: lets a test verify that each rank rendered its own views")
     ap.add_argument("--analytic-rs", action="store_true", help="take the per-vertex (R, S) of every animation frame from the analytic "
                     "deformation (precomputed tables) instead of computing them from the deformed mesh inside the frame (gm_mesh_rs)")
+    ap.add_argument("--depth-plan", action="store_true", help="edit loop: direct depth placement over the view stream's DepthPlan (the fused pass "
+                    "appends every Gaussian to its depth bucket; no bk_hist / bk_scan / bk_scatter, no record gather).  Measured: the ordering "
+                    "stages drop from 0.153 to 0.125 ms, the fused pass grows by 0.016 ms and the pipelined loop is 2 %% slower (DESIGN.md "
+                    "section 3) - off by default")
     ap.add_argument("--no-work-hint", action="store_true", help="dispatch the blend's tiles by list length instead of by what they cost "
                     "in recent frames (gm_forward_1_geom's work_hint)")
     ap.add_argument("--exchange-batch", type=int, default=None, help="loop steps whose mesh tables are produced (and at N > 1 "
@@ -464,6 +473,8 @@ def main():
 
     # one work-hint buffer for the view stream of this rank: consecutive frames are neighbouring cameras of the orbit
     hint = None if args.no_work_hint else Rz.new_work_hint(W, H, dev)
+    # ... and one DepthPlan: from the second frame on the fused pass places the Gaussians in their depth buckets itself
+    dplan = Rz.new_depth_plan(dev) if (args.depth_plan and not args.unfused) else None
     pending = {}
     unchecked = []
     views_walked = []                            # camera index of every loop step this rank issued (--check-dir)
@@ -548,11 +559,11 @@ def main():
         if begin_only and not args.unfused:      # one enqueue: deform + colour + preprocess + depth sort + instance count
             return Rz.forward_deformed_begin(bg, g["tri"], g["weights"], packed, g["cov"], g["pos"], g["shs"], g["opac"], c["view"],
                                              c["proj"], c["tanx"], c["tany"], H, W, 3, c["campos"], False, workspace=workspace,
-                                             want_count=args.exact_count)
+                                             want_count=args.exact_count, depth_plan=dplan)
         if not args.unfused:                     # same path, completed at once (per-stage timing pass)
             nr, color, radii, _, _, _ = Rz.forward_deformed_begin(bg, g["tri"], g["weights"], packed, g["cov"], g["pos"], g["shs"], g["opac"],
                                                                   c["view"], c["proj"], c["tanx"], c["tany"], H, W, 3, c["campos"], False,
-                                                                  workspace=workspace).finish(image_only=image_only, work_hint=hint)
+                                                                  workspace=workspace, depth_plan=dplan).finish(image_only=image_only, work_hint=hint)
             stats["R"] = nr
             stats["radii"] = radii
             return color
@@ -656,6 +667,7 @@ def main():
                                                           "slowest_over_fastest_rank": round(max(per_rank_s) / max(min(per_rank_s), 1e-12), 4),
                                                           "cores_per_rank": None if pinned is None else len(pinned)},
                    "emission_policy": Rz.get_default_emission_policy(W, H), "image_only": image_only, "work_hint": hint is not None,
+                   "depth_plan": dplan is not None, "frames_refused_by_direct_placement": None if dplan is None else dplan.refused,
                    "frames_redone": stats["overflows"],          # sync-free frames that outgrew their binning buffer (rendered again, exactly)
                    "parallelism": "views x%d" % world},
     }
@@ -687,7 +699,9 @@ def main():
             lib.gm_profile_read(s.encode(), C.byref(ms), C.byref(n))
             if n.value:
                 per[s] = ms.value / nprof               # ms per frame (a stage may be several launches)
-        bytes_key = lambda st: "deform_pre" if (st == "deform" and not args.unfused) else st
+        direct = dplan is not None
+        bytes_key = lambda st: (("deform_pre_direct" if direct else "deform_pre") if (st == "deform" and not args.unfused) else
+                                ("depth_sort_direct" if (st == "depth_sort" and direct) else st))
         stage_bytes = lambda st: algorithmic_bytes(bytes_key(st), P, V, Rn, W, H, Vm, list_tiles=list_tiles)
         # `roofline` = the dominant KERNEL of the frame: the longest of the stages that are one launch each (the ordering stages are
         # 4 + 3 launches of at most 30 us each; they are under stage_roofline)

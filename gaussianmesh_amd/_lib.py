@@ -46,6 +46,10 @@ SIGNATURES = {
     "gm_pack_mesh_state": (i32, [i32, vp, vp, vp, vp]),
     "gm_forward_0_deformed_async": (i32, [i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp,
                                           i32, vp, vp, vp]),
+    "gm_forward_0_deformed_stream_async": (i32, [i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp,
+                                                 i32, vp, vp, vp, vp, vp, i32]),
+    "gm_depth_plan_bytes": (sz, []),
+    "gm_depth_slab_bytes": (sz, [i32]),
     "gm_forward_1_geom": (i32, [i32, vp, vp, vp, i32, i32, i64, vp, i32, i32, vp, i32, vp, vp, i32, vp]),
     "gm_forward_status_async": (i32, [vp, i32, vp, vp]),
     "gm_deform_shade_packed": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

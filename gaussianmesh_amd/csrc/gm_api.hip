@@ -164,12 +164,30 @@ int gm_forward_0_async(int emission_policy, void* geom_buffer, int P, int D, int
   return order_and_count(g, P, debug, a.stream, num_rendered_host, count_event);
 }
 
+size_t gm_depth_plan_bytes(void) { return sizeof(uint32_t) * GM_PLAN_WORDS; }
+size_t gm_depth_slab_bytes(int P) {
+  DepthSlab d = DepthSlab::from(nullptr, (size_t)(P > 0 ? P : 1));
+  return (size_t)d.end + 256;
+}
+
 int gm_forward_0_deformed_async(int emission_policy, void* geom_buffer, int P, int deg, int M, int width, int height, const int* tri,
                                 const float* w, const float* packed, const float* cov, const float* pos, const float* shs,
                                 const float* opacities, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                                 float tan_fovx, float tan_fovy, float* pos_out, float* cov6_out, float* rgb_out, int* radii, int debug,
                                 void* stream, int* num_rendered_host, void* count_event) {
+  return gm_forward_0_deformed_stream_async(emission_policy, geom_buffer, P, deg, M, width, height, tri, w, packed, cov, pos, shs, opacities,
+                                            viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, pos_out, cov6_out, rgb_out, radii, debug, stream,
+                                            num_rendered_host, count_event, nullptr, nullptr, 0);
+}
+
+int gm_forward_0_deformed_stream_async(int emission_policy, void* geom_buffer, int P, int deg, int M, int width, int height, const int* tri,
+                                       const float* w, const float* packed, const float* cov, const float* pos, const float* shs,
+                                       const float* opacities, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                                       float tan_fovx, float tan_fovy, float* pos_out, float* cov6_out, float* rgb_out, int* radii,
+                                       int debug, void* stream, int* num_rendered_host, void* count_event, void* depth_slab,
+                                       unsigned int* depth_plan, int direct) {
   if (int rc = check_policy(emission_policy)) return rc;
+  if (direct && (!depth_slab || !depth_plan)) { set_error("gm_forward_0_deformed_stream: direct placement needs depth_slab and depth_plan"); return GM_ERR_INVALID_ARG; }
   if (P < 0 || width <= 0 || height <= 0) { set_error("invalid sizes P=%d W=%d H=%d", P, width, height); return GM_ERR_INVALID_ARG; }
   if (P == 0) { if (num_rendered_host) *num_rendered_host = 0; return GM_OK; }
   if (deg < 0 || deg > 3 || M != 16) { set_error("gm_forward_0_deformed: needs SH rows of M == 16 coefficients, degree 0..3"); return GM_ERR_INVALID_ARG; }
@@ -184,9 +202,18 @@ int gm_forward_0_deformed_async(int emission_policy, void* geom_buffer, int P, i
   a.stream = reinterpret_cast<hipStream_t>(stream);
   if (TileGrid(width, height, emission_policy).ptiles > 65536) { set_error("too many list tiles for emission policy %d", emission_policy); return GM_ERR_INVALID_ARG; }
   GeomState g = GeomState::from(geom_buffer, (size_t)P);
+  if (direct) {
+    DepthSlab d = DepthSlab::from(depth_slab, (size_t)P);
+    if (int rc = launch_arm_direct(g, d, depth_plan, a.stream)) return rc;
+    if (int rc = launch_deform_shade_pre(a, g, radii, deg, tri, w, packed, cov, pos, shs, pos_out, cov6_out, rgb_out, &d)) return rc;
+    if (debug_stop_after() == 1) return GM_OK;
+    return launch_depth_order_direct(g, d, depth_plan, P, debug, a.stream, num_rendered_host, reinterpret_cast<hipEvent_t>(count_event));
+  }
   if (int rc = launch_arm_counters(g, a.stream)) return rc;
   if (int rc = launch_deform_shade_pre(a, g, radii, deg, tri, w, packed, cov, pos, shs, pos_out, cov6_out, rgb_out)) return rc;
-  return order_and_count(g, P, debug, a.stream, num_rendered_host, count_event);
+  if (int rc = order_and_count(g, P, debug, a.stream, num_rendered_host, count_event)) return rc;
+  if (depth_plan && debug_stop_after() != 1) return launch_publish_depth_plan(g, depth_plan, a.stream);
+  return GM_OK;
 }
 
 int gm_forward_1_geom(int emission_policy, void* geom_buffer, void* binning_buffer, void* image_buffer, int P, int num_rendered,

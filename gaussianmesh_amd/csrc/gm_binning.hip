@@ -75,8 +75,10 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
   for (uint32_t i = blockIdx.x * BN_THREADS + threadIdx.x; i < acc_words; i += gridDim.x * BN_THREADS) acc[i] = 0u;
   // the counts were made under another policy (it changed between the forward halves), or the instance total exceeds the
   // caller's binning capacity: emit nothing rather than overrun; every list stays empty (tile_ranges / bk_scan see the flag)
-  if ((int)counters[GM_CNT_POLICY] != mode || counters[GM_CNT_RENDERED] > capacity) {
-    if (threadIdx.x == 0) counters[GM_CNT_REFUSED] = 1u;
+  // ... or the direct depth placement could not order the frame (status 2: the caller begins it again on the partition path)
+  const uint32_t direct_fail = counters[GM_CNT_DIRECT_FAIL];
+  if ((int)counters[GM_CNT_POLICY] != mode || counters[GM_CNT_RENDERED] > capacity || direct_fail) {
+    if (threadIdx.x == 0) counters[GM_CNT_REFUSED] = direct_fail ? 2u : 1u;
     return;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) counters[GM_CNT_REFUSED] = 0u;      // (a refused attempt on these buffers may have left it set)

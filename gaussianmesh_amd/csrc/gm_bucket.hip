@@ -96,6 +96,11 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
   return woff + incl - v;
 }
 
+// agent-scope accesses to memory that kernels of OTHER streams read or write while this one runs (the view stream's DepthPlan): they
+// bypass the XCD-local L2s, which are not coherent with each other inside a launch
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // Depth-bucket mapping (gm_common.h, GM_COARSE_*): coarse bin c = key >> 20 owns buckets [base[c], base[c] + nb[c]) and
 // subdivides its 2^20 key values linearly among them.  Monotone in the key, so (bucket, key inside the bucket, id) order is
 // (key, id) order.
@@ -110,7 +115,9 @@ __device__ __forceinline__ uint32_t depth_bucket(const DepthMap& m, uint32_t key
 // non-empty bin gets exactly one.  Returns the number of buckets (0: nothing visible).
 __device__ __forceinline__ uint32_t block_build_depth_map(const uint32_t* __restrict__ slots, const uint32_t* __restrict__ coarse, DepthMap& m,
                                                           uint32_t* wsum /*[4]*/, uint32_t* s_tmp /*[4]*/, uint32_t* __restrict__ dmap,
-                                                          uint32_t* __restrict__ bmap, uint32_t* __restrict__ counters, bool publish) {
+                                                          uint32_t* __restrict__ bmap, uint32_t* __restrict__ counters, int publish) {
+  // publish: 0 nothing, 1 table + bucket ranges + counters (the partition's histogram launch), 2 the table alone (direct placement:
+  // the table is for LATER frames, this frame's counters come from direct_plan_kernel)
   constexpr int PER = GM_COARSE_BINS / BK_THREADS;                  // 8 consecutive coarse bins per thread
   {                                    // instance total (num_rendered), visible count, first / last coarse bin in use from the slots
     static_assert(GM_SLOTS == BK_THREADS, "one slot per thread");
@@ -187,11 +194,11 @@ __device__ __forceinline__ uint32_t block_build_depth_map(const uint32_t* __rest
   for (int j = 0; j < PER; j++) {
     const uint32_t c = threadIdx.x * PER + j;
     m.base[c] = (uint16_t)excl; m.nb[c] = (uint16_t)nbk[j];
-    if (publish) dmap[c] = (excl << 16) | nbk[j];
+    if (publish) st_agent(dmap + c, (excl << 16) | nbk[j]);
     excl += nbk[j];
   }
   __syncthreads();
-  if (publish) {
+  if (publish == 1) {
     // bucket -> coarse bin: the last bin whose first bucket is <= b (empty bins share their successor's first bucket)
     for (uint32_t bk = threadIdx.x; bk < total_b; bk += BK_THREADS) {
       uint32_t lo = 0, hi = GM_COARSE_BINS;                          // invariant: base[lo] <= bk, (hi == BINS or base[hi] > bk)
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(WAVES * 64) void bk_hist_kernel(const void* __restr
   uint32_t n = n_host;
   if (n_dev) n = min(n, *n_dev);
   if constexpr (MSD) {               // (the launch's extra, last workgroup only publishes the mapping, the bucket count and num_rendered)
-    if (block_build_depth_map(slots, coarse, s_map.m, s_w, s_tmp, dmap, bmap, counters, blockIdx.x == gridDim.x - 1) == 0u) return;
+    if (block_build_depth_map(slots, coarse, s_map.m, s_w, s_tmp, dmap, bmap, counters, blockIdx.x == gridDim.x - 1 ? 1 : 0) == 0u) return;
   }
   auto digit = [&](uint32_t key) -> uint32_t {
     if constexpr (MSD) return depth_bucket(s_map.m, key);
@@ -528,25 +535,78 @@ __device__ __forceinline__ void chunk_add(uint32_t* __restrict__ chunk_inst, uin
 // One workgroup per bucket of the MSD partition: (key, id) pairs [start, end) of p1 -> final order.
 // Outputs: order0[start..end) = ids in (key, id) order, bin_sorted[start..end) = emission records of those ids,
 // chunk_inst[run] += instance counts of the sorted positions of that run.  p0[start..end) is scratch for the slow path.
-__global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t* __restrict__ counters,
+// DIRECT (direct depth placement): bucket b's entries are the first (end - start) of its slab, p1 + b * cap and bins + b * cap, in
+// ARRIVAL order (the preprocess kernel's atomics), so position says nothing about the id: the bucket's key range is taken from the
+// entries themselves (the table that placed them is an earlier frame's), equal keys are ordered by comparing ids, and what the
+// one-word sort cannot do - a key range above 20 bits, a pile of more than BS_BIN_MAX equal keys - refuses the frame
+// (counters[GM_CNT_DIRECT_FAIL]; the caller renders it again on the partition path).  The record is read from the workgroup's own
+// slab: contiguous memory, every fetched line used.
+template <bool DIRECT>
+__global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(uint32_t* __restrict__ counters,
                                                                   const uint32_t* __restrict__ bmap, const uint32_t* __restrict__ bucket_start,
                                                                   uint2* __restrict__ p1, uint2* __restrict__ p0, uint32_t* __restrict__ order0,
                                                                   const uint32_t* __restrict__ tiles, const uint4* __restrict__ bins,
                                                                   uint4* __restrict__ bin_sorted, uint32_t* __restrict__ chunk_inst,
-                                                                  unsigned long long* __restrict__ trace) {
+                                                                  unsigned long long* __restrict__ trace, uint32_t cap,
+                                                                  const uint32_t* __restrict__ slots, const uint32_t* __restrict__ coarse,
+                                                                  const uint32_t* __restrict__ hdr, uint32_t* __restrict__ plan) {
   const unsigned long long t_begin = trace ? wall_clock64() : 0ull;
   __shared__ uint32_t wcnt[BK_WAVES][256];
   __shared__ uint32_t dstart[256];
   __shared__ uint32_t lkey[BS_CAP];                                 // (key - first key) << 12 | position in the bucket: 16 KiB
   __shared__ uint32_t wsum[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (DIRECT && blockIdx.x == gridDim.x - 1) {
+    // the launch's extra workgroup, beside the sorting ones: this frame's coarse histogram -> the table the stream's LATER frames place
+    // their Gaussians with (slot = this frame's sequence number % slots; stamp 0 while the words change, the sequence number after)
+    static_assert(sizeof(DepthMap) <= sizeof(lkey), "the builder's map lives in the sort's key array");
+    DepthMap& m = *reinterpret_cast<DepthMap*>(lkey);
+    const uint32_t seq = hdr[0], slot = seq % GM_PLAN_SLOTS;
+    uint32_t* stamp = plan + 2 + slot;
+    if (threadIdx.x == 0) st_agent(stamp, 0u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // (the store has left before the table words do)
+    __syncthreads();
+    block_build_depth_map(slots, coarse, m, wsum, dstart, plan + 2 + GM_PLAN_SLOTS + (size_t)slot * GM_COARSE_BINS, nullptr, nullptr, 2);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      st_agent(stamp, seq);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      atomicMax(plan, seq);
+    }
+    return;
+  }
   const uint32_t nb = counters[GM_CNT_VISIBLE] ? counters[GM_CNT_NBUCKETS] : 0u;
   const uint32_t b = blockIdx.x;
   uint32_t start = 0, end = 0;
   if (b < nb) { start = bucket_start[b]; end = bucket_start[b + 1]; }
   const uint32_t n = end - start;
   if (n == 0u) return;
-  const uint2 krange = reinterpret_cast<const uint2*>(bmap)[b];     // {first key of the bucket, bits of (key - first key) inside it}
+  if (DIRECT) {
+    if (counters[GM_CNT_DIRECT_FAIL] != 0u) return;                 // (the frame is refused already)
+    p1 += (size_t)b * cap; bins += (size_t)b * cap; start = 0;      // the bucket's slab; `end - start` stays n, outputs go to obase + p
+  }
+  const uint32_t obase = DIRECT ? bucket_start[b] : start;
+  uint2 krange = make_uint2(0u, 0u);
+  if (!DIRECT) krange = reinterpret_cast<const uint2*>(bmap)[b];    // {first key of the bucket, bits of (key - first key) inside it}
+  const uint32_t rounds_all = (n + 255u) / 256u;
+  if (DIRECT) {                                                     // the range of the keys that arrived
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+    for (uint32_t p = threadIdx.x; p < n; p += BK_THREADS) { const uint32_t k = p1[p].x; kmin = min(kmin, k); kmax = max(kmax, k); }
+    kmin = ~wave_max_u32(~kmin); kmax = wave_max_u32(kmax);
+    if (lane == 0) { dstart[wave] = kmin; dstart[4 + wave] = kmax; }
+    __syncthreads();
+    kmin = min(min(dstart[0], dstart[1]), min(dstart[2], dstart[3]));
+    kmax = max(max(dstart[4], dstart[5]), max(dstart[6], dstart[7]));
+    __syncthreads();
+    const uint32_t width = kmax - kmin;
+    krange = make_uint2(kmin, width ? 32u - (uint32_t)__clz((int)width) : 0u);
+    if (krange.y > 20u) {                                           // (workgroup-uniform) the word has 20 bits for the key
+      if (threadIdx.x == 0) counters[GM_CNT_DIRECT_FAIL] = 1u;
+      return;
+    }
+  }
+  (void)rounds_all;
   DigitSpec ds;
   ds.sub = krange.x; ds.shift = 0; ds.mask = 0xFFFFFFFFu;
   const uint32_t low_bits = krange.y;
@@ -600,6 +660,10 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t*
         if (lane == 0) atomicMax(&dstart[0], mx);
       }
       __syncthreads();
+      if (DIRECT && dstart[0] > BS_BIN_MAX) {          // a pile of equal depths: the stable passes below need id order on entry
+        if (threadIdx.x == 0) counters[GM_CNT_DIRECT_FAIL] = 1u;
+        return;
+      }
       if (dstart[0] <= BS_BIN_MAX) {                   // workgroup-uniform
 #pragma unroll
         for (int r = 0; r < BS_ROUNDS; r++) {
@@ -617,7 +681,13 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t*
               const uint32_t d = min(key[r] >> hs, (uint32_t)BS_BINS - 1u);
               const uint32_t lo = hist[d], hi = d + 1u < (uint32_t)BS_BINS ? hist[d + 1u] : n;
               uint32_t below = 0;
-              for (uint32_t j = lo; j < hi; j++) below += lkey[j] < key[r] ? 1u : 0u;
+              for (uint32_t j = lo; j < hi; j++) {
+                const uint32_t wj = lkey[j];
+                bool less = wj < key[r];
+                if (DIRECT && ((wj ^ key[r]) >> 12) == 0u && wj != key[r])        // equal keys: ascending id (rare)
+                  less = p1[wj & 0xFFFu].y < p1[key[r] & 0xFFFu].y;
+                below += less ? 1u : 0u;
+              }
               rank[r] = lo + below;
             }
           }
@@ -712,14 +782,14 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(const uint32_t*
         if (p < n) {
           // the one random access per Gaussian of the whole ordering: its emission record travels to its sorted position
           const uint32_t id = p1[start + (key[r] & 0xFFFu)].y;
-          const uint4 rec = bins[id];
+          const uint4 rec = bins[DIRECT ? (key[r] & 0xFFFu) : id];
           uint32_t c = bin_count(rec);
           if (c == GM_BIN_COUNT_SAT) c = tiles[id];
-          order0[start + p] = id;
-          bin_sorted[start + p] = rec;
+          order0[obase + p] = id;
+          bin_sorted[obase + p] = rec;
           inst = c;
         }
-        chunk_add(chunk_inst, start + (wave * rounds + r) * 64u, lane, inst);
+        chunk_add(chunk_inst, obase + (wave * rounds + r) * 64u, lane, inst);
       }
     }
   } else {
@@ -847,9 +917,153 @@ int launch_depth_order(GeomState& g, int P, int debug, hipStream_t s, int* num_r
   hipLaunchKernelGGL((bk_scatter_kernel<true, DB, WAVES, ROUNDS>), dim3(nblk), dim3(WAVES * 64), 0, s, g.depth_key, g.dpairs[1], (uint32_t)P, nullptr, ds,
                      g.hist, nullptr, 0u, nullptr, 0, nullptr, g.dmap, g.counters, nullptr, nullptr, scatter_trace(true), nullptr);
   GM_LAUNCH_CHECK(debug, s);
-  hipLaunchKernelGGL(bucket_sort_kernel, dim3(1 << DB), dim3(BK_THREADS), 0, s, g.counters, g.bmap, g.bucket_start, g.dpairs[1], g.dpairs[0], g.order,
-                     g.tiles_touched, g.bin, g.bin_sorted, g.chunk_inst, g_bucket_trace);
+  hipLaunchKernelGGL(bucket_sort_kernel<false>, dim3(1 << DB), dim3(BK_THREADS), 0, s, g.counters, g.bmap, g.bucket_start, g.dpairs[1], g.dpairs[0], g.order,
+                     g.tiles_touched, g.bin, g.bin_sorted, g.chunk_inst, g_bucket_trace, 0u, nullptr, nullptr, nullptr, nullptr);
   GM_LAUNCH_CHECK(debug, s);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// C. Direct depth placement (gm_common.h, DepthSlab / GM_PLAN_*): frames of one view stream share a DepthPlan, a ring of
+//    GM_PLAN_SLOTS depth tables.  Per frame:
+//      arm_direct_kernel     zeroes the frame's accumulators and bucket counters, draws the frame's sequence number and copies the
+//                            newest complete table of the plan into the frame's own dmap (a table in the plan may be replaced while
+//                            this frame runs: frames of a stream are in flight on several HIP streams);
+//      the fused preprocess  appends every visible Gaussian to its bucket's slab (gm_deform.hip, direct_place);
+//      direct_plan_kernel    one workgroup: totals -> counters, bucket counts -> bucket_start, overflow / no table -> the frame is
+//                            refused, and this frame's coarse histogram -> the stream's next table (slot = sequence % slots);
+//      bucket_sort_kernel<true>.
+//    Three launches and the random record gather less than A.  The writer protocol of a table: stamp = 0, table words, stamp =
+//    sequence, newest = max(newest, sequence), all agent-scope with release fences between; a reader checks the stamp before and
+//    after its copy.  A slot is rewritten GM_PLAN_SLOTS frames later - the copy of a frame that far behind would be torn, and is
+//    caught by the stamp.
+__global__ __launch_bounds__(256) void arm_direct_kernel(uint4* __restrict__ arm, uint32_t arm_vec, uint4* __restrict__ cnt, uint32_t cnt_vec,
+                                                          uint32_t* __restrict__ hdr, uint32_t* __restrict__ plan, uint32_t* __restrict__ dmap,
+                                                          uint32_t cap) {
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < arm_vec; i += gridDim.x * 256) arm[i] = z;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < cnt_vec; i += gridDim.x * 256) cnt[i] = z;
+  if (blockIdx.x != 0) return;
+  __shared__ uint32_t s_v;
+  __shared__ uint32_t s_first[257];
+  if (threadIdx.x == 0) {
+    hdr[0] = atomicAdd(plan + 1, 1u) + 1u;
+    s_v = ld_agent(plan);
+  }
+  __syncthreads();
+  const uint32_t v = s_v, slot = v % GM_PLAN_SLOTS;
+  const uint32_t* stamp = plan + 2 + slot;
+  const uint32_t* table = plan + 2 + GM_PLAN_SLOTS + (size_t)slot * GM_COARSE_BINS;
+  constexpr int PER = GM_COARSE_BINS / 256;
+  bool ok = v != 0u && ld_agent(stamp) == v;
+  uint32_t w[PER];
+#pragma unroll
+  for (int j = 0; j < PER; j++) w[j] = ok ? ld_agent(table + threadIdx.x * PER + j) : 0u;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");            // (the words are in before the stamp is looked at again)
+  ok = ok && ld_agent(stamp) == v;
+  // Whatever the memory system did to the copy, it is USED only if it is a table: first buckets non-decreasing and equal to the
+  // running sum of the bucket counts (base[c + 1] == base[c] + nb[c], base[0] == 0, at most 2048 buckets).  Any word sequence with
+  // that property maps keys to buckets monotonically, which is all the order of the frame depends on.
+  s_first[threadIdx.x] = w[0] >> 16;
+  if (threadIdx.x == 0) s_first[256] = 0xFFFFFFFFu;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    const uint32_t next = j + 1 < PER ? (w[j + 1 < PER ? j + 1 : j] >> 16) : s_first[threadIdx.x + 1];
+    const uint32_t sum = (w[j] >> 16) + (w[j] & 0xFFFFu);
+    ok = ok && (next == 0xFFFFFFFFu ? sum <= (1u << GM_BUCKET_BITS) : next == sum);
+  }
+  if (threadIdx.x == 0) ok = ok && (w[0] >> 16) == 0u;
+  ok = __syncthreads_and(ok ? 1 : 0) != 0;
+#pragma unroll
+  for (int j = 0; j < PER; j++) dmap[threadIdx.x * PER + j] = ok ? w[j] : 0u;       // (no table: everything to bucket 0, refused below)
+  if (threadIdx.x == 0) { hdr[1] = ok ? 1u : 0u; hdr[2] = cap; }
+}
+
+// one workgroup on the frame's critical path: the preprocess kernel's totals -> counters, the bucket counters -> bucket_start, and the
+// verdict (no table / a bucket above its slab: refused)
+__global__ __launch_bounds__(BK_THREADS) void direct_plan_kernel(const uint32_t* __restrict__ slots, uint32_t* __restrict__ counters,
+                                                                  uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ hdr,
+                                                                  const uint32_t* __restrict__ cnt, uint32_t cap) {
+  __shared__ uint32_t s_w[4];
+  __shared__ uint32_t s_part[8];
+  constexpr int PER = (1 << GM_BUCKET_BITS) / BK_THREADS;
+  static_assert(GM_SLOTS == BK_THREADS, "one slot per thread");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint2 sl = *reinterpret_cast<const uint2*>(slots + GM_SLOT_STRIDE * threadIdx.x);      // {instances, visible}
+  const uint32_t valid = hdr[1];
+  uint32_t c[PER], sum = 0;
+  bool over = false;
+#pragma unroll
+  for (int j = 0; j < PER; j++) c[j] = cnt[(size_t)(threadIdx.x * PER + j) * GM_SLAB_CNT_STRIDE];
+#pragma unroll
+  for (int j = 0; j < PER; j++) { over = over || c[j] > cap; sum += c[j]; }
+  const uint32_t inst = wave_sum_u32(sl.x), vis = wave_sum_u32(sl.y);
+  if (lane == 0) { s_part[wave] = inst; s_part[4 + wave] = vis; }
+  uint32_t total;
+  uint32_t excl = block_exclusive_scan_256(sum, s_w, total);         // (its barrier publishes s_part too)
+#pragma unroll
+  for (int j = 0; j < PER; j++) { bucket_start[threadIdx.x * PER + j] = excl; excl += c[j]; }
+  const uint32_t visible = (s_part[4] + s_part[5]) + (s_part[6] + s_part[7]);
+  const bool fail = __syncthreads_or(over ? 1 : 0) != 0 || valid == 0u || total != visible;
+  if (threadIdx.x == 0) {
+    bucket_start[1 << GM_BUCKET_BITS] = total;
+    counters[GM_CNT_RENDERED] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+    counters[GM_CNT_VISIBLE] = visible;
+    counters[GM_CNT_NBUCKETS] = 1u << GM_BUCKET_BITS;
+    if (fail) counters[GM_CNT_DIRECT_FAIL] = 1u;
+  }
+}
+
+// partition path with a plan: the table bk_hist_kernel has just built goes to the stream's next frames
+__global__ __launch_bounds__(256) void publish_plan_kernel(const uint32_t* __restrict__ dmap, const uint32_t* __restrict__ counters,
+                                                            uint32_t* __restrict__ plan) {
+  __shared__ uint32_t s_seq;
+  if (counters[GM_CNT_VISIBLE] == 0u) return;                       // (nothing visible: the histogram launch wrote no table)
+  if (threadIdx.x == 0) {
+    s_seq = atomicAdd(plan + 1, 1u) + 1u;
+    st_agent(plan + 2 + s_seq % GM_PLAN_SLOTS, 0u);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  const uint32_t seq = s_seq, slot = seq % GM_PLAN_SLOTS;
+  uint32_t* table = plan + 2 + GM_PLAN_SLOTS + (size_t)slot * GM_COARSE_BINS;
+  for (int c = threadIdx.x; c < GM_COARSE_BINS; c += 256) st_agent(table + c, dmap[c]);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    st_agent(plan + 2 + slot, seq);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    atomicMax(plan, seq);
+  }
+}
+
+int launch_arm_direct(GeomState& g, DepthSlab& d, uint32_t* plan, hipStream_t s) {
+  const uint32_t arm_vec = (uint32_t)(g.arm_words / 4), cnt_vec = (uint32_t)(((size_t)GM_SLAB_CNT_STRIDE << GM_BUCKET_BITS) / 4);
+  hipLaunchKernelGGL(arm_direct_kernel, dim3(64), dim3(256), 0, s, reinterpret_cast<uint4*>(g.slots), arm_vec, reinterpret_cast<uint4*>(d.cnt), cnt_vec,
+                     d.hdr, plan, g.dmap, d.cap);
+  GM_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_depth_order_direct(GeomState& g, DepthSlab& d, uint32_t* plan, int P, int debug, hipStream_t s, int* num_rendered_host, hipEvent_t count_event) {
+  (void)P;
+  StageScope sc(ST_DEPTH_SORT, s);
+  hipLaunchKernelGGL(direct_plan_kernel, dim3(1), dim3(BK_THREADS), 0, s, g.slots, g.counters, g.bucket_start, d.hdr, d.cnt, d.cap);
+  GM_LAUNCH_CHECK(debug, s);
+  if (num_rendered_host) {
+    GM_HIP(hipMemcpyAsync(num_rendered_host, g.counters + GM_CNT_RENDERED, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (count_event) GM_HIP(hipEventRecord(count_event, s));
+  }
+  hipLaunchKernelGGL(bucket_sort_kernel<true>, dim3((1 << GM_BUCKET_BITS) + 1), dim3(BK_THREADS), 0, s, g.counters, g.bmap, g.bucket_start, d.pairs, g.dpairs[0],
+                     g.order, g.tiles_touched, d.recs, g.bin_sorted, g.chunk_inst, g_bucket_trace, d.cap, g.slots, g.coarse, d.hdr, plan);
+  GM_LAUNCH_CHECK(debug, s);
+  return 0;
+}
+
+int launch_publish_depth_plan(GeomState& g, uint32_t* plan, hipStream_t s) {
+  hipLaunchKernelGGL(publish_plan_kernel, dim3(1), dim3(256), 0, s, g.dmap, g.counters, plan);
+  GM_HIP(hipGetLastError());
   return 0;
 }
 

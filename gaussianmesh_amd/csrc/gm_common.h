@@ -111,8 +111,7 @@ __host__ __device__ __forceinline__ uint32_t coarse_index(uint32_t bin, uint32_t
 #define GM_CNT_NBUCKETS 5            // depth buckets in use
 #define GM_CNT_CMIN 6                // first / last coarse bin that holds a visible key
 #define GM_CNT_CMAX 7
-#define GM_CNT_GROUP 8               // [8] digit-group totals of the scan in flight
-#define GM_CNT_DONE 16               // [9] arrival counters of the scan in flight (re-armed by its last workgroup)
+#define GM_CNT_DIRECT_FAIL 8         // direct depth placement (DepthSlab below) could not order this frame: emission is refused with status 2
 #define GM_CNT_COUNT 32
 #define GM_SLOTS 256                 // atomic slots {instance sum, visible count, 2047 - first coarse bin, last coarse bin} filled by the preprocess kernel
 #define GM_SLOT_STRIDE 32            // words between slots: one 128-byte line each (atomics on one line serialise in the memory-side atomic unit)
@@ -186,6 +185,40 @@ struct GeomState {              // per-Gaussian state (P-sized)
     return g;
   }
   size_t arm_words;
+  char* end;
+};
+
+// Direct depth placement (edit-loop frames of one view stream, gm_forward_0_deformed_stream_async): the fused preprocess kernel
+// looks every visible Gaussian's depth bucket up in a table built from an EARLIER frame of the stream (any monotone table gives the
+// same order; only the balance of the buckets depends on it) and appends (key, id) and the emission record to that bucket's slab.
+// bk_hist / bk_scan / bk_scatter of the depth partition and the random gather of the records disappear (gm_bucket.hip, "C.").
+#define GM_PLAN_SLOTS 16             // tables a DepthPlan keeps: the writer of sequence number q uses slot q % 16, readers take the newest complete one
+#define GM_PLAN_WORDS (2 + GM_PLAN_SLOTS + GM_PLAN_SLOTS * GM_COARSE_BINS)     // {newest sequence, sequence allocator}, stamps, tables
+#define GM_SLAB_CNT_STRIDE 32        // words between bucket counters: one 128-byte line each (see GM_SLOT_STRIDE)
+#define GM_SLAB_HDR_WORDS 64         // {sequence number of the frame, table valid, bucket capacity}
+static inline uint32_t slab_capacity(size_t P) {       // entries a bucket's slab holds: 16x the mean of P keys over 2048 buckets, 256 .. 4096 (the in-LDS sort's limit)
+  size_t c = 256;
+  while (c < 4096 && c * 128 < P) c <<= 1;
+  return (uint32_t)c;
+}
+struct DepthSlab {              // per frame in flight (caller-owned, gm_depth_slab_bytes(P))
+  uint32_t* hdr;                // [GM_SLAB_HDR_WORDS]
+  uint32_t* cnt;                // [2048][GM_SLAB_CNT_STRIDE] entries appended to each bucket (zeroed by the arm kernel)
+  uint2* pairs;                 // [2048][cap] (depth key, id) in arrival order
+  uint4* recs;                  // [2048][cap] emission records, same positions
+  uint32_t cap;
+  static DepthSlab from(void* buf, size_t P) {
+    char* p = reinterpret_cast<char*>(buf);
+    DepthSlab d;
+    constexpr size_t ND = size_t(1) << GM_BUCKET_BITS;
+    d.cap = slab_capacity(P);
+    d.hdr = carve<uint32_t>(p, GM_SLAB_HDR_WORDS);
+    d.cnt = carve<uint32_t>(p, ND * GM_SLAB_CNT_STRIDE);
+    d.pairs = carve<uint2>(p, ND * d.cap);
+    d.recs = carve<uint4>(p, ND * d.cap);
+    d.end = p;
+    return d;
+  }
   char* end;
 };
 
@@ -292,6 +325,10 @@ int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], uint32_t* hist, uint3
 // count_event (optional) is recorded right behind that copy.
 int launch_depth_order(GeomState& g, int P, int debug, hipStream_t s, int* num_rendered_host, hipEvent_t count_event);
 int launch_arm_counters(GeomState& g, hipStream_t s);                               // zero slots + counters (first launch of a forward)
+// direct depth placement: arm (zero + table snapshot into g.dmap), and - after the fused preprocess - bucket starts, the next table, the sort
+int launch_arm_direct(GeomState& g, DepthSlab& d, uint32_t* plan, hipStream_t s);
+int launch_depth_order_direct(GeomState& g, DepthSlab& d, uint32_t* plan, int P, int debug, hipStream_t s, int* num_rendered_host, hipEvent_t count_event);
+int launch_publish_depth_plan(GeomState& g, uint32_t* plan, hipStream_t s);        // classic path: leave this frame's table for the stream's next frames
 int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, int tile_cull, size_t capacity, int debug, hipStream_t s);
 int launch_tile_sort(GeomState& g, BinningState& b, ImageState& img, size_t n, const uint32_t* n_dev, int tiles, bool* order_done,
                      uint32_t* work_hint, int debug, hipStream_t s);      // order_done: img.tile_order was written too (one-pass case)
@@ -312,7 +349,8 @@ int launch_deform_shade(int N, int deg, int M, const int* tri, const float* w, c
                         const float* cov, const float* pos, const float* shs, const float* campos, float* pos_out,
                         float* cov6_out, float* rgb_out, float* cov_out, float* rot_out, hipStream_t s);
 int launch_deform_shade_pre(const RasterArgs& r, GeomState& g, int* radii, int deg, const int* tri, const float* w, const float* packed,
-                            const float* cov, const float* pos, const float* shs, float* pos_out, float* cov6_out, float* rgb_out);
+                            const float* cov, const float* pos, const float* shs, float* pos_out, float* cov6_out, float* rgb_out,
+                            const struct DepthSlab* slab = nullptr);
 int launch_pack_mesh_state(int Vm, const float* state, const float* verts, float* packed, hipStream_t s);
 int launch_deform_shade_packed(int N, int deg, int M, const int* tri, const float* w, const float* packed, const float* cov,
                                const float* pos, const float* shs, const float* campos, float* pos_out, float* cov6_out,

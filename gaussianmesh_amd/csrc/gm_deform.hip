@@ -129,8 +129,57 @@ struct FusedPre {
   PreCam cam;
   const float* opac;
   float4* splat; int* radii_int; int* radii_out; uint32_t* tiles; uint4* bin; uint32_t* counters; uint32_t* slots; uint32_t* coarse; uint8_t* clamped; uint32_t* depth_key;
+  // DIRECT (gm_common.h, DepthSlab): the frame's snapshot of the stream's depth table and the bucket slabs the records are appended to
+  const uint32_t* dmap; uint32_t* slab_cnt; uint2* slab_pairs; uint4* slab_recs; uint32_t slab_cap;
 };
-template <bool PACKED, bool PRE>
+
+// Direct depth placement: the wave's visible Gaussians are appended to their depth buckets' slabs.  One returning atomic per
+// DISTINCT bucket of the wave (neighbours in memory are neighbours on the mesh: a wave usually spans two or three buckets), issued
+// together; lanes whose bucket has not come up after GM_DIRECT_GROUPS rounds of the grouping loop (a cloud whose ids carry no
+// locality) take a position on their own.  An entry beyond the slab's capacity is dropped - the counter still counts it and the
+// frame is refused (direct_plan_kernel, gm_bucket.hip).
+#ifndef GM_DIRECT_GROUPS
+#define GM_DIRECT_GROUPS 6
+#endif
+struct DirectSlot { uint32_t bucket, base, rank; int leader; };
+// first half, as soon as the depth key is known: bucket lookup, grouping, the returning atomics.  Nothing here waits for them - the
+// emission count that follows (hundreds of instructions) runs while they are in flight.
+__device__ __forceinline__ DirectSlot direct_reserve(const FusedPre& fp, uint32_t dkey) {
+  const bool vis = dkey != 0xFFFFFFFFu;
+  const int lane = threadIdx.x & 63;
+  DirectSlot d;
+  d.bucket = 0;
+  if (vis) {
+    const uint32_t e = fp.dmap[(dkey >> GM_COARSE_SHIFT) & (GM_COARSE_BINS - 1)];
+    d.bucket = (e >> 16) + (((dkey & ((1u << GM_COARSE_SHIFT) - 1u)) * (e & 0xFFFFu)) >> GM_COARSE_SHIFT);
+    d.bucket = min(d.bucket, (1u << GM_BUCKET_BITS) - 1u);   // (bins behind the table's last bucket: the last bucket - still monotone)
+  }
+  unsigned long long todo = __ballot(vis);
+  uint32_t nsame = 1;
+  d.rank = 0; d.leader = lane;
+#pragma unroll 1
+  for (int it = 0; it < GM_DIRECT_GROUPS && todo; it++) {
+    const int l = __ffsll(todo) - 1;
+    const uint32_t bl = (uint32_t)__builtin_amdgcn_readlane((int)d.bucket, l);
+    const unsigned long long same = __ballot(vis && d.bucket == bl);
+    if (vis && d.bucket == bl) { d.rank = lanes_below(same); d.leader = l; nsame = (uint32_t)__popcll(same); }
+    todo &= ~same;
+  }
+  d.base = 0;
+  if (vis && d.leader == lane) d.base = atomicAdd(fp.slab_cnt + (size_t)d.bucket * GM_SLAB_CNT_STRIDE, nsame);
+  return d;
+}
+// second half: the leaders' positions reach their groups, the entry goes to its slab
+__device__ __forceinline__ void direct_store(const FusedPre& fp, const DirectSlot& d, uint32_t id, uint32_t dkey, const uint4& bin) {
+  const uint32_t pos = (uint32_t)__shfl((int)d.base, d.leader) + d.rank;
+  if (dkey != 0xFFFFFFFFu && pos < fp.slab_cap) {
+    const size_t at = (size_t)d.bucket * fp.slab_cap + pos;
+    fp.slab_pairs[at] = make_uint2(dkey, id);
+    fp.slab_recs[at] = bin;
+  }
+}
+
+template <bool PACKED, bool PRE, bool DIRECT = false>
 __global__ __launch_bounds__(64) void deform_shade_kernel(int N, int deg, const int* __restrict__ tri, const float* __restrict__ w,
                                                           const float* __restrict__ dV, const float* __restrict__ Rv,
                                                           const float* __restrict__ Sv, const float* __restrict__ cov,
@@ -237,20 +286,26 @@ __global__ __launch_bounds__(64) void deform_shade_kernel(int N, int deg, const 
   }
   // ---- forward preprocess of the deformed Gaussian (colors_precomp / cov3D_precomp input mode)
   uint32_t tiles = 0, dkey = 0xFFFFFFFFu;
+  uint4 dbin = make_uint4(0u, 0u, 0u, 0u);
+  PreGeom pg;
+  bool vis = false;
   if (PRE && live) {
-    int radius_i = 0;
-    uint4 bin = make_uint4(0u, 0u, 0u, 0u);
     const V3 p = {npos[0], npos[1], npos[2]};
     const float c3[6] = {O[0], O[1], O[2], O[4], O[5], O[8]};
-    PreGeom pg;
-    if (pre_project(fp.cam, p, c3, pg)) {
+    vis = pre_project(fp.cam, p, c3, pg);
+    if (vis) dkey = __float_as_uint(pg.depth);
+  }
+  DirectSlot slot;
+  if (PRE && DIRECT) slot = direct_reserve(fp, dkey);          // (whole wave)
+  if (PRE && live) {
+    int radius_i = 0;
+    if (vis) {
       const float opac = fp.opac[i];
       fp.splat[3 * i + 0] = make_float4(pg.pix, pg.piy, pg.conx, pg.cony);
       fp.splat[3 * i + 1] = make_float4(pg.conz, opac, col[0], col[1]);
       fp.splat[3 * i + 2] = make_float4(col[2], pg.depth, 0.f, 0.f);
       radius_i = (int)pg.radius;
-      pre_emit(fp.cam, pg, opac, tiles, bin);
-      dkey = __float_as_uint(pg.depth);
+      pre_emit(fp.cam, pg, opac, tiles, dbin);
     }
     // Written once, where it is read: the radius goes to the caller's array (the internal copy exists for callers that pass none);
     // the clamp flags and the per-Gaussian instance count are read by the backward pass and by the emission of a rectangle with
@@ -258,10 +313,13 @@ __global__ __launch_bounds__(64) void deform_shade_kernel(int N, int deg, const 
     // (9 of 349 bytes per Gaussian in a kernel that runs at the HBM's pace)
     if (fp.radii_out) fp.radii_out[i] = radius_i; else fp.radii_int[i] = radius_i;
     if (tiles >= GM_BIN_COUNT_SAT) fp.tiles[i] = tiles;
-    fp.bin[i] = bin;
-    fp.depth_key[i] = dkey;
+    if (!DIRECT) {
+      fp.bin[i] = dbin;
+      fp.depth_key[i] = dkey;
+    }
     if (i == 0) fp.counters[GM_CNT_POLICY] = (uint32_t)fp.cam.tile_cull;
   }
+  if (PRE && DIRECT) direct_store(fp, slot, (uint32_t)i, dkey, dbin);
   if (PRE) slot_accumulate(fp.slots, fp.coarse, tiles, dkey);
   if (!pos_out) return;                          // wave-uniform
   __syncthreads();                               // everyone is done reading the staged inputs: reuse LDS for the outputs
@@ -328,7 +386,8 @@ int launch_deform_shade_packed(int N, int deg, int M, const int* tri, const floa
 }
 
 int launch_deform_shade_pre(const RasterArgs& r, GeomState& g, int* radii, int deg, const int* tri, const float* w, const float* packed,
-                            const float* cov, const float* pos, const float* shs, float* pos_out, float* cov6_out, float* rgb_out) {
+                            const float* cov, const float* pos, const float* shs, float* pos_out, float* cov6_out, float* rgb_out,
+                            const DepthSlab* slab) {
   const int N = r.P;
   if (N <= 0) return 0;
   if (!aligned16(shs) || !aligned16(cov) || !aligned16(packed) ||
@@ -344,11 +403,17 @@ int launch_deform_shade_pre(const RasterArgs& r, GeomState& g, int* radii, int d
   fp.opac = r.opacities;
   fp.splat = g.splat; fp.radii_int = g.radii; fp.radii_out = radii; fp.tiles = g.tiles_touched; fp.bin = g.bin; fp.counters = g.counters; fp.slots = g.slots; fp.coarse = g.coarse;
   fp.clamped = g.clamped; fp.depth_key = g.depth_key;
+  fp.dmap = g.dmap; fp.slab_cnt = nullptr; fp.slab_pairs = nullptr; fp.slab_recs = nullptr; fp.slab_cap = 0;
+  if (slab) { fp.slab_cnt = slab->cnt; fp.slab_pairs = slab->pairs; fp.slab_recs = slab->recs; fp.slab_cap = slab->cap; }
   // (measured: fewer resident workgroups per CU - 8 / 6 / 5 instead of 12, by padding this allocation - make the kernel 10 / 24 / 52 %
   // slower and the four-stream loop 6 / 13 / 21 %: it needs every wave it can get to keep enough bytes in flight)
   const size_t lds_bytes = sizeof(float) * 64 * 48;
-  hipLaunchKernelGGL((deform_shade_kernel<true, true>), dim3((N + 63) / 64), dim3(64), lds_bytes, r.stream, N, deg, tri, w, packed, nullptr,
-                     nullptr, cov, pos, shs, r.cam_pos, pos_out, cov6_out, rgb_out, nullptr, nullptr, fp);
+  if (slab)
+    hipLaunchKernelGGL((deform_shade_kernel<true, true, true>), dim3((N + 63) / 64), dim3(64), lds_bytes, r.stream, N, deg, tri, w, packed, nullptr,
+                       nullptr, cov, pos, shs, r.cam_pos, pos_out, cov6_out, rgb_out, nullptr, nullptr, fp);
+  else
+    hipLaunchKernelGGL((deform_shade_kernel<true, true>), dim3((N + 63) / 64), dim3(64), lds_bytes, r.stream, N, deg, tri, w, packed, nullptr,
+                       nullptr, cov, pos, shs, r.cam_pos, pos_out, cov6_out, rgb_out, nullptr, nullptr, fp);
   GM_LAUNCH_CHECK(r.debug, r.stream);
   return 0;
 }

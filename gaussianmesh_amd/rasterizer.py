@@ -208,6 +208,23 @@ def new_work_hint(width, height, device):
     return torch.zeros((_lib.lib().gm_work_hint_bytes(width, height) // 4,), dtype=torch.int32, device=device)
 
 
+class DepthPlan:
+    """Depth-bucket tables of ONE view stream (consecutive cameras of an orbit / an edit session), handed to
+    forward_deformed_begin(depth_plan=...): from the stream's second frame on the fused pass places every visible Gaussian in
+    its depth bucket itself (gm_forward_0_deformed_stream_async, direct placement) instead of running the depth partition.
+    Never changes an image: a frame the direct placement refuses (check() -> not fitted) is begun again on the partition path
+    by finish().  `refused` counts those frames."""
+
+    def __init__(self, device):
+        self.buf = torch.zeros((_lib.lib().gm_depth_plan_bytes() // 4,), dtype=torch.int32, device=device)
+        self.primed = False
+        self.refused = 0
+
+
+def new_depth_plan(device):
+    return DepthPlan(device)
+
+
 class PendingForward:
     """Handle returned by rasterize_forward_begin() / forward_deformed_begin(): everything up to the instance count is
     enqueued.  finish() waits for the count (one 4-byte pinned-memory read-back, normally long complete), sizes the
@@ -223,6 +240,9 @@ class PendingForward:
         self.known_count = None
         self.image_only = False
         self.work_hint = None
+        self.direct = False              # begun with direct depth placement (DepthPlan); rebegin re-issues the first half on the partition path
+        self.rebegin = None
+        self.refusal = 0                 # status word 3 of the checked frame: 1 capacity / policy, 2 direct placement
 
     def _geom(self, binning, num_rendered, capacity, status=None):
         lib = _lib.lib()
@@ -277,6 +297,11 @@ class PendingForward:
                 self.binning = binning
                 self.result = (-1, self.color, self.radii, self.geom, binning, self.img)
                 return self.result
+        if self.direct and self.refusal == 2 and self.rebegin is not None:
+            # the direct depth placement refused the frame (no table yet / stale table / piles of equal depths): the first half again,
+            # on the partition path, into the same buffers; the exact path below completes it
+            self.rebegin()
+            self.direct, self.refusal, self.known_count, self.count_host = False, 0, None, None
         with _on(device), torch.cuda.stream(self.stream):
             if sync_free and ws is None and capacity > 0 and a["P"] > 0 and self.status_event is None and self.checked is None:
                 binning = torch.empty((lib.gm_binning_bytes(capacity),), dtype=torch.uint8, device=device)
@@ -313,6 +338,19 @@ class PendingForward:
                 if self.count_host is not None and len(_PINNED_POOL) < 64:
                     _PINNED_POOL.append(self.count_host)
             self._geom(binning, num_rendered, 0)
+            if self.direct and self.rebegin is not None:
+                # a direct-placement frame completed without the sync-free status protocol: look at its status here (one more
+                # host wait on a path that waits for the count anyway) and take the partition path if it was refused
+                st = torch.zeros((4,), dtype=torch.int32).pin_memory()
+                _lib.check(lib.gm_forward_status_async(_ptr(self.geom), a["P"], st.data_ptr(), self.stream.cuda_stream))
+                self.stream.synchronize()
+                if int(st[3]) == 2:
+                    self.rebegin()
+                    _lib.check(lib.gm_forward_status_async(_ptr(self.geom), a["P"], st.data_ptr(), self.stream.cuda_stream))
+                    self.stream.synchronize()
+                    num_rendered = int(st[0])
+                    self._geom(binning, num_rendered, 0)          # (the instance total does not depend on the depth path)
+                self.direct = False
             self.status_event = None
             if a.get("prefiltered") and a["P"] > 0:         # the reference traps the kernel (auxiliary.h:155-159); here: an error
                 st = torch.zeros((4,), dtype=torch.int32).pin_memory()
@@ -344,6 +382,7 @@ class PendingForward:
         if ws is None:
             st = self.status_host
             nr, refused, violated = int(st[0]), int(st[3]), int(st[1])
+            self.refusal = refused
             self.known_count = nr
             if len(_PINNED_STATUS) < 64:
                 _PINNED_STATUS.append(st)
@@ -354,6 +393,7 @@ class PendingForward:
             return self.checked
         st = ws.pinned_status()
         nr, refused = int(st[0]), int(st[3])
+        self.refusal = refused
         self.known_count = nr
         self.checked = ((not refused), nr)
         if int(st[1]) and self.args.get("prefiltered"):
@@ -448,13 +488,15 @@ def rasterize_forward(bg, means3D, colors, opacity, scales, rotations, scale_mod
 
 def forward_deformed_begin(bg, tri, weights, packed, cov, pos, shs, opacity, viewmatrix, projmatrix, tan_fovx, tan_fovy,
                            image_height, image_width, degree, campos, debug=False, workspace=None, want_deformed=False,
-                           emission_policy=None, want_count=True):
+                           emission_policy=None, want_count=True, depth_plan=None):
     """Edit-loop frame, first half (gm_forward_0_deformed_async): mesh-driven deformation + rotated-direction SH colour +
     forward preprocess + depth order + instance count in one enqueue, no host synchronisation.  `packed` is
     deform.pack_mesh_state() of the frame.  Returns a PendingForward; .finish() completes the frame
     (gm_forward_1_geom) and returns (num_rendered, color, radii, geom, binning, img).  With want_deformed the handle
     also carries .deformed = (pos' [N,3], cov6 [N,6], rgb [N,3]).  want_count=False (loops that complete their frames with
-    finish(sync_free=True)): the 4-byte copy of the instance count to the host is not enqueued either."""
+    finish(sync_free=True)): the 4-byte copy of the instance count to the host is not enqueued either.
+    depth_plan (new_depth_plan(), one per view stream): see DepthPlan; complete such frames with finish(sync_free=True) and
+    check() them, or the status of a refused frame goes unseen."""
     lib = _lib.lib()
     device = pos.device
     if device.type != "cuda":
@@ -482,12 +524,22 @@ def forward_deformed_begin(bg, tri, weights, packed, cov, pos, shs, opacity, vie
             event = _count_event(stream) if want_count else None
             if not want_count:
                 count_host = None
-            _lib.check(lib.gm_forward_0_deformed_async(policy, _ptr(geom), P, int(degree), M, W, H, _ptr(tri), _ptr(weights), _ptr(packed),
-                                                       _ptr(cov), _ptr(pos), _ptr(shs), _ptr(opacity), _ptr(viewmatrix), _ptr(projmatrix),
-                                                       _ptr(campos), float(tan_fovx), float(tan_fovy), dp[0], dp[1], dp[2], _ptr(radii),
-                                                       int(bool(debug)), stream.cuda_stream,
-                                                       None if count_host is None else count_host.data_ptr(),
-                                                       None if event is None else event.cuda_event))
+            direct = depth_plan is not None and depth_plan.primed and P > 0
+            slab = None
+            if direct:
+                nbytes = lib.gm_depth_slab_bytes(P)
+                slab = workspace.get("slab", nbytes, device) if workspace is not None else torch.empty((nbytes,), dtype=torch.uint8, device=device)
+
+            def begin(direct_now, count_ptr, event_ptr):
+                _lib.check(lib.gm_forward_0_deformed_stream_async(
+                    policy, _ptr(geom), P, int(degree), M, W, H, _ptr(tri), _ptr(weights), _ptr(packed), _ptr(cov), _ptr(pos), _ptr(shs),
+                    _ptr(opacity), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), dp[0], dp[1], dp[2],
+                    _ptr(radii), int(bool(debug)), stream.cuda_stream, count_ptr, event_ptr, _ptr(slab) if direct_now else None,
+                    None if depth_plan is None else depth_plan.buf.data_ptr(), 1 if direct_now else 0))
+
+            begin(direct, None if count_host is None else count_host.data_ptr(), None if event is None else event.cuda_event)
+            if depth_plan is not None and P > 0:
+                depth_plan.primed = True               # (this frame, whichever path it took, leaves a table behind)
     except Exception:
         if workspace is not None:
             workspace.release(h)
@@ -495,6 +547,14 @@ def forward_deformed_begin(bg, tri, weights, packed, cov, pos, shs, opacity, vie
     h.args = dict(device=device, P=P, W=W, H=H, bg=bg, debug=int(bool(debug)),
                   keep=(tri, weights, packed, cov, pos, shs, opacity, viewmatrix, projmatrix, campos))
     h.geom, h.img, h.color, h.radii, h.count_host, h.event, h.deformed = geom, img, color, radii, count_host, event, deformed
+    if direct:
+        h.direct = True
+
+        def rebegin():
+            depth_plan.refused += 1
+            with _on(device):
+                begin(False, None, None)
+        h.rebegin = rebegin
     return h
 
 

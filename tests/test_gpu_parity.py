@@ -927,8 +927,10 @@ def test_pipelined_deformed_loop_renders_every_frame_exactly():
     pipelined_deformed_loop(20000, 320, 200, 8, 640)
 
 
-def pipelined_deformed_loop(P, W, H, F, frames, nstreams=4, ahead=2, lag=3):
-    """(also run at the bench's own size by tools/verify_loop_images.py)"""
+def pipelined_deformed_loop(P, W, H, F, frames, nstreams=4, ahead=2, lag=3, plan=False, cam_stride=3):
+    """(also run at the bench's own size by tools/verify_loop_images.py)
+    plan: the loop's frames share a DepthPlan (direct depth placement); a frame it refuses is rendered again by finish(), as a
+    caller would, and compared like every other one.  Returns the plan (its .refused says how many)."""
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
@@ -948,14 +950,16 @@ def pipelined_deformed_loop(P, W, H, F, frames, nstreams=4, ahead=2, lag=3):
         cam = scenes.orbit_camera(k, F, W, H)
         cams.append((T(cam["view"]), T(cam["proj"]), cam["tanx"], cam["tany"], T(cam["campos"])))
 
-    def begin(i, ws=None):
-        t, c = i % F, cams[(3 * i) % F]                    # mesh frame and camera move at different rates: 8 x 8 combinations
+    depth_plan = Rz.new_depth_plan(bg.device) if plan else None
+
+    def begin(i, ws=None, dplan=None):
+        t, c = i % F, cams[(cam_stride * i) % F]           # mesh frame and camera move at different rates: 8 x 8 combinations
         packed = mesh_rs_packed(g["verts"], v1[t], faces, adjacency)
         return Rz.forward_deformed_begin(bg, g["tri"], g["weights"], packed, g["cov"], g["pos"], g["shs"], g["opac"], c[0], c[1], c[2], c[3],
-                                         H, W, 3, c[4], False, workspace=ws, want_count=ws is None)
+                                         H, W, 3, c[4], False, workspace=ws, want_count=ws is None, depth_plan=dplan)
     ref = {}
     for i in range(min(frames, F * F)):                     # the (mesh frame, camera) pairs the loop visits
-        key = (i % F, (3 * i) % F)
+        key = (i % F, (cam_stride * i) % F)
         if key not in ref:
             ref[key] = begin(i).finish()[1].clone()
     hint = Rz.new_work_hint(W, H, bg.device)
@@ -977,12 +981,16 @@ def pipelined_deformed_loop(P, W, H, F, frames, nstreams=4, ahead=2, lag=3):
     def verify():
         j, h, img = done.pop(0)
         ok, _ = h.check()
-        assert ok, "frame %d outgrew a buffer sized for the heaviest frame" % j
-        if not torch.equal(img, ref[(j % F, (3 * j) % F)]):
+        if not ok and plan and h.refusal == 2:              # the direct placement refused the frame: again, on the partition path
+            img = h.finish(image_only=True, work_hint=hint)[1]
+            torch.cuda.synchronize()
+        else:
+            assert ok, "frame %d outgrew a buffer sized for the heaviest frame" % j
+        if not torch.equal(img, ref[(j % F, (cam_stride * j) % F)]):
             bad.append(j)
     for i in range(frames):
         with torch.cuda.stream(streams[i % nstreams]):
-            pending[i] = begin(i, ws[i % nws])
+            pending[i] = begin(i, ws[i % nws], depth_plan)
         if i - ahead in pending:
             complete(i - ahead)
         while len(done) > lag:
@@ -992,6 +1000,7 @@ def pipelined_deformed_loop(P, W, H, F, frames, nstreams=4, ahead=2, lag=3):
     while done:
         verify()
     assert not bad, "%d of %d pipelined frames differ from the synchronous render: %s" % (len(bad), frames, bad[:8])
+    return depth_plan
 
 
 def test_splat_centred_on_a_pixel_is_not_dropped(oracle):

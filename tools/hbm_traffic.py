@@ -9,12 +9,17 @@ import sys
 
 STAGES = [  # stage, (kernel name fragment, launches per frame)
     ("mesh_rs", [("mesh_rs_kernel", 1)]),
-    ("deform", [("deform_shade_kernel<true, true>", 1)]),
-    ("depth_sort", [("bk_hist_kernel<true, 11, 4,", 1), ("bk_scan_kernel<true, 11>", 1), ("bk_scatter_kernel<true, 11, 4,", 1), ("bucket_sort_kernel", 1)]),
+    ("deform", [("deform_shade_kernel<true, true, false>", 1)]),
+    ("depth_sort", [("bk_hist_kernel<true, 11, 4,", 1), ("bk_scan_kernel<true, 11>", 1), ("bk_scatter_kernel<true, 11, 4,", 1), ("bucket_sort_kernel<false>", 1)]),
     ("duplicate", [("duplicate_kernel<1, 2>", 1)]),
     ("tile_sort", [("bk_hist_kernel<false, 11, 8,", 1), ("bk_scan_kernel<false, 11>", 1), ("bk_scatter_kernel<false, 11, 8,", 1)]),
     ("render", [("render_fwd_kernel<false, false", 1)]),
 ]
+
+
+# `python bench.py --depth-plan` (direct depth placement): the fused pass appends to the bucket slabs, the depth order is three launches
+DIRECT = {"deform": [("deform_shade_kernel<true, true, true>", 1)],
+          "depth_sort": [("arm_direct_kernel", 1), ("direct_plan_kernel", 1), ("bucket_sort_kernel<true>", 1)]}
 
 
 def parse(path):
@@ -31,10 +36,12 @@ def parse(path):
     return out
 
 
-def main(pmc_txt, out_json, gaussians, width, height):
+def main(pmc_txt, out_json, gaussians, width, height, mode="partition"):
     c = parse(pmc_txt)
     stages = {}
     for st, ks in STAGES:
+        if mode == "direct":
+            ks = DIRECT.get(st, ks)
         f = w = 0.0
         names = []
         for frag, n in ks:
