@@ -186,21 +186,25 @@ _QUEUE_WARNED = [False]
 
 def _note_stream(stream):
     """Frames pipelined over three or more HIP streams only overlap if the runtime has a hardware queue for each: HIP multiplexes
-    streams onto FOUR queues by default and streams that share one serialise (four streams: 3460 frames/s on 4 queues, 4350-4590
-    on 8).  GPU_MAX_HW_QUEUES is read when the HIP runtime starts, so a library cannot set it for its
-    caller: warn, once, when it sees the third stream and the variable is not set."""
+    streams onto FOUR queues by default and streams that share one serialise (four streams: 4160 frames/s on 4 queues, 5010 on 8,
+    DESIGN.md section 5).  The package exports GPU_MAX_HW_QUEUES=8 when it is imported (gaussianmesh_amd/__init__.py) unless the
+    caller has set it; that only helps if the HIP runtime had not made its first call yet.  Warn, once, when the third stream shows
+    up and the package's own setting came after torch had initialised the device."""
     if _QUEUE_WARNED[0]:
         return
     _STREAMS_SEEN.add(stream.cuda_stream)
     if len(_STREAMS_SEEN) >= 3:
         _QUEUE_WARNED[0] = True
-        import os
         import warnings
-        if "GPU_MAX_HW_QUEUES" not in os.environ:
-            warnings.warn("gaussianmesh_amd: frames are being issued on %d HIP streams but GPU_MAX_HW_QUEUES is not set; the runtime "
-                          "multiplexes streams onto 4 hardware queues by default and streams sharing a queue serialise. Export "
-                          "GPU_MAX_HW_QUEUES=8 before the process starts HIP (before importing torch)." % len(_STREAMS_SEEN), RuntimeWarning,
-                          stacklevel=3)
+        import gaussianmesh_amd as _pkg
+        if getattr(_pkg, "QUEUES_SET_ON_IMPORT", False) and _HIP_UP_AT_IMPORT:
+            warnings.warn("gaussianmesh_amd: frames are being issued on %d HIP streams, but the HIP runtime was already running when this "
+                          "package exported GPU_MAX_HW_QUEUES=8; the runtime multiplexes streams onto 4 hardware queues by default and "
+                          "streams sharing a queue serialise. Import gaussianmesh_amd (or export GPU_MAX_HW_QUEUES=8) before the first "
+                          "torch.cuda call." % len(_STREAMS_SEEN), RuntimeWarning, stacklevel=3)
+
+
+_HIP_UP_AT_IMPORT = torch.cuda.is_initialized()
 
 
 def new_work_hint(width, height, device):

@@ -86,3 +86,18 @@ def test_operator_argument_rules_match_reference():
     assert GaussianRasterizationSettings._fields[:12] == ("image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier",
                                                           "viewmatrix", "projmatrix", "sh_degree", "campos", "prefiltered", "debug")
     assert GaussianRasterizationSettings._fields[12:] == ("work_hint",) and rs.work_hint is None
+
+
+def test_import_exports_the_hardware_queue_setting():
+    """HIP multiplexes streams onto four hardware queues unless GPU_MAX_HW_QUEUES says otherwise, and a four-stream frame loop loses
+    17 % to that: importing the package exports 8 - read by the runtime at its first call, which comes later -
+    and leaves a caller's own setting alone."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import os, gaussianmesh_amd as g; print(os.environ['GPU_MAX_HW_QUEUES'], g.QUEUES_SET_ON_IMPORT)"
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.stdout.split() == ["8", "True"], out.stderr[-500:]
+    env["GPU_MAX_HW_QUEUES"] = "4"
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.stdout.split() == ["4", "False"], out.stderr[-500:]
