@@ -220,7 +220,10 @@ int gm_forward_1_geom(int emission_policy, void* geom_buffer, void* binning_buff
                       int64_t binning_capacity, const float* background, int width, int height, float* out_color, int debug, void* stream,
                       int* status_host, int flags, unsigned int* work_hint) {
   if (int rc = check_policy(emission_policy)) return rc;
-  if (flags & ~GM_FWD_IMAGE_ONLY) { set_error("unknown flags 0x%x", flags); return GM_ERR_INVALID_ARG; }
+  if (flags & ~(GM_FWD_IMAGE_ONLY | GM_FWD_EXACT_EXPONENT)) { set_error("unknown flags 0x%x", flags); return GM_ERR_INVALID_ARG; }
+  if ((flags & GM_FWD_IMAGE_ONLY) && (flags & GM_FWD_EXACT_EXPONENT)) {
+    set_error("GM_FWD_EXACT_EXPONENT is for a forward a backward pass follows: not together with GM_FWD_IMAGE_ONLY"); return GM_ERR_INVALID_ARG;
+  }
   if (P < 0 || width <= 0 || height <= 0) { set_error("invalid sizes P=%d W=%d H=%d", P, width, height); return GM_ERR_INVALID_ARG; }
   if (!image_buffer || !out_color || !background) { set_error("null image_buffer / out_color / background"); return GM_ERR_INVALID_ARG; }
   const bool device_count = num_rendered < 0;          // sync-free: the count stays on the device, bounded by the capacity
@@ -256,7 +259,7 @@ int gm_forward_1_geom(int emission_policy, void* geom_buffer, void* binning_buff
   }
   if (debug_stop_after() == 4) return GM_OK;
   return launch_render_fwd(g, b.pairs[slot], img, width, height, mode, background, out_color, status_host, (flags & GM_FWD_IMAGE_ONLY) != 0,
-                           work_hint, debug, st);
+                           work_hint, debug, st, (flags & GM_FWD_EXACT_EXPONENT) != 0);
 }
 
 int gm_forward_status_async(void* geom_buffer, int P, int* status_host, void* stream) {

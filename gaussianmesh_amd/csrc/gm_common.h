@@ -336,7 +336,7 @@ int launch_tile_ranges(const GeomState& g, BinningState& b, int slot, ImageState
 int launch_tile_order(ImageState& img, int tiles, uint32_t* work_hint, int debug, hipStream_t s);          // ranges -> tile_order
 int launch_render_fwd(const GeomState& g, const uint2* pairs, ImageState& img, int W, int H, int mode,
                       const float* background, float* out_color, int* status_host, bool image_only, uint32_t* work_hint, int debug,
-                      hipStream_t s);
+                      hipStream_t s, bool exact_exponent = false);
 int launch_render_bwd(const GeomState& g, const uint2* pairs, ImageState& img, int W, int H, int mode,
                       const float* background, const float* dL_dpix, int debug, hipStream_t s);   // accumulates into g.grad_acc
 

@@ -232,7 +232,7 @@ struct FwdLds {                  // per wave: 5.1 KiB
 #ifndef GM_RENDER_FWD_WPW
 #define GM_RENDER_FWD_WPW 1      // waves per workgroup of the forward blend: 1 (one workgroup per 8x8 quadrant) or 4 (one per 16-px tile)
 #endif
-// EXACT (verification build, gm_debug_forward_exact_exponent; never on the product path): the exponents of a group come from the
+// EXACT (GM_FWD_EXACT_EXPONENT: the forward of a training step; gm_debug_forward_exact_exponent forces it for every frame): the exponents of a group come from the
 // pixel-relative form of round 2 / of the backward kernel (staged_exponent: |e - e_exact| ~ 5e-7) instead of the matrix core's
 // polynomial (~1e-5).  Everything else - lists, cull, decisions, recurrence - is the same code, so the two builds may differ only
 // where an entry's alpha or a pixel's T sits within the polynomial's error of a threshold (tests/test_gpu_parity.py).
@@ -467,18 +467,18 @@ static unsigned long long* g_render_trace = nullptr;      // debugging aid (tool
 extern "C" void gm_debug_render_trace(void* buffer) { g_render_trace = reinterpret_cast<unsigned long long*>(buffer); }
 static float* g_bwd_front_T = nullptr;                   // verification aid (tests only): see render_bwd_kernel
 extern "C" void gm_debug_backward_front_T(void* plane) { g_bwd_front_T = reinterpret_cast<float*>(plane); }
-static bool g_fwd_exact = false;                          // verification aid (tests only): the EXACT build of the forward blend
+static bool g_fwd_exact = false;                          // verification aid (tests only): the EXACT build of the forward blend for EVERY frame
 extern "C" void gm_debug_forward_exact_exponent(int on) { g_fwd_exact = on != 0; }
 
 int launch_render_fwd(const GeomState& g, const uint2* pairs, ImageState& img, int W, int H, int mode,
                       const float* background, float* out_color, int* status_host, bool image_only, uint32_t* work_hint, int debug,
-                      hipStream_t s) {
+                      hipStream_t s, bool exact_exponent) {
   StageScope sc(ST_RENDER, s);
   const TileGrid tg(W, H, mode);
   const TileMap tm{tg.gx, tg.gy, tg.pgx, tg.pgy, tg.s, img.tile_order};
   if (tg.ptiles > 0) {
     const dim3 grid(tm.blocks() * (4 / GM_RENDER_FWD_WPW)), block(64 * GM_RENDER_FWD_WPW);     // one wave (8x8 quadrant) per workgroup
-    if (g_fwd_exact)
+    if (g_fwd_exact || exact_exponent)
       hipLaunchKernelGGL((render_fwd_kernel<true, false, true>), grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
                          background, out_color, img.final_T, img.n_contrib, nullptr, g.counters, status_host, work_hint, img.epoch);
     else if (g_render_trace)

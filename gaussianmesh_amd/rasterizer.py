@@ -243,6 +243,7 @@ class PendingForward:
         self.result = None
         self.known_count = None
         self.image_only = False
+        self.exact_exponent = False
         self.work_hint = None
         self.direct = False              # begun with direct depth placement (DepthPlan); rebegin re-issues the first half on the partition path
         self.rebegin = None
@@ -253,12 +254,19 @@ class PendingForward:
         a = self.args
         _lib.check(lib.gm_forward_1_geom(self.policy, _ptr(self.geom), _ptr(binning), _ptr(self.img), a["P"], num_rendered, capacity,
                                          _ptr(a["bg"]), a["W"], a["H"], _ptr(self.color), a["debug"], self.stream.cuda_stream,
-                                         None if status is None else status.data_ptr(), 1 if self.image_only else 0,
+                                         None if status is None else status.data_ptr(),
+                                         (1 if self.image_only else 0) | (2 if self.exact_exponent else 0),
                                          None if self.work_hint is None else self.work_hint.data_ptr()))
 
-    def finish(self, sync_free=False, capacity=0, image_only=False, work_hint=None):
+    def finish(self, sync_free=False, capacity=0, image_only=False, work_hint=None, exact_exponent=False):
         """See _finish().  A failure anywhere in here (allocation, a C-side error) releases the workspace: one failed frame must
-        not leave it marked in flight for ever."""
+        not leave it marked in flight for ever.
+        exact_exponent (GM_FWD_EXACT_EXPONENT): the forward of a training step - the blend evaluates its exponents with the
+        backward pass's per-pixel expression, so that both halves take the same alpha >= 1/255 decisions (the autograd operator
+        sets it whenever a gradient is required)."""
+        if exact_exponent and image_only:
+            raise _lib.GmeshError("exact_exponent is for a forward that a backward pass follows: not together with image_only")
+        self.exact_exponent = self.exact_exponent or bool(exact_exponent)      # (a repeated finish() of a refused frame keeps it)
         try:
             return self._finish(sync_free, capacity, image_only, work_hint)
         except Exception:
@@ -729,7 +737,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                         rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, workspace=ws, emission_policy=policy,
                                         force_M=force_M)
             if cap > 0:
-                num_rendered, color, radii, geom, binning, img = h.finish(sync_free=True, capacity=cap, work_hint=rs.work_hint)
+                num_rendered, color, radii, geom, binning, img = h.finish(sync_free=True, capacity=cap, work_hint=rs.work_hint, exact_exponent=True)
                 num_rendered = cap                        # the binning layout is that of the capacity
                 if len(sf.unchecked) >= _SYNC_FREE_MAX_UNCHECKED:
                     raise _lib.GmeshError("sync-free training: %d forwards were issued without SyncFreeState.verify(); every "
@@ -737,7 +745,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                                           % _SYNC_FREE_MAX_UNCHECKED)
                 sf.unchecked.append(h)
             else:
-                num_rendered, color, radii, geom, binning, img = h.finish(image_only=not needs_grad, work_hint=rs.work_hint)   # image_only: no backward will follow
+                # image_only: no backward will follow; exact_exponent: one will, and takes the decisions this forward took
+                num_rendered, color, radii, geom, binning, img = h.finish(image_only=not needs_grad, work_hint=rs.work_hint, exact_exponent=needs_grad)
                 if sf is not None:
                     sf.note_count(means3D.device, num_rendered)
         except Exception:

@@ -252,6 +252,12 @@ int gm_forward_0_deformed_stream_async(int emission_policy, void* geom_buffer, i
  * early, a short one on a silhouette is walked to its end).  It only moves work in time: images are bit-identical with and
  * without it, frames in flight on several streams may share one buffer. */
 #define GM_FWD_IMAGE_ONLY 1
+/* GM_FWD_EXACT_EXPONENT: a forward that a BACKWARD pass follows (not with GM_FWD_IMAGE_ONLY).  The blend then evaluates every
+ * exponent per pixel, with the expression gm_backward_p evaluates, instead of the matrix-core polynomial (absolute error ~1e-5 in
+ * the exponent): both halves of the training step take the SAME alpha >= 1/255 decision for every (entry, pixel), as the
+ * reference's do, whose backward.cu repeats forward.cu's expression (forward.cu:330-352, backward.cu:481-497).  Costs 17 us
+ * of a 100-us blend at 1 M Gaussians / 1080p; the image differs from the default's by <= 3e-5 outside decision thresholds. */
+#define GM_FWD_EXACT_EXPONENT 2
 int gm_forward_1_geom(int emission_policy, void* geom_buffer, void* binning_buffer, void* image_buffer, int P, int num_rendered,
                       int64_t binning_capacity, const float* background, int width, int height, float* out_color, int debug, void* stream,
                       int* status_host, int flags, unsigned int* work_hint);

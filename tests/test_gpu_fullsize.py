@@ -206,8 +206,18 @@ def test_c2_full_size_gradients_vs_oracle(oracle):
     bw = oracle.backward_full(sc, cam, bg, fw, dpix, D=3)
     color, radii, g = _grads_gpu(sc, cam, bg, dpix, 3, False, False)          # the product's default emission policy
     assert np.array_equal(radii, fw["geo"]["radii"])
-    assert np.array_equal(color, ex["color"])                                # policies agree bit for bit
-    assert_forward_gate(fw, color, W, H, 1e-4, "C2", plain_tol=5e-5)
+    # the operator's forward of a step that needs a gradient runs with the backward's exponent (GM_FWD_EXACT_EXPONENT): same build under
+    # the reference policy -> policies agree bit for bit; both builds pass the strict gate
+    import ctypes as C
+    lib = C.CDLL(_lib.lib()._name)
+    lib.gm_debug_forward_exact_exponent(1)
+    try:
+        ex_exact = _forward(sc, cam, bg, tile_cull=0)
+    finally:
+        lib.gm_debug_forward_exact_exponent(0)
+    assert np.array_equal(color, ex_exact["color"])
+    assert_forward_gate(fw, color, W, H, 1e-4, "C2 (training forward)", plain_tol=2.5e-5)
+    assert_forward_gate(fw, ex["color"], W, H, 1e-4, "C2", plain_tol=5e-5)
     _check_all_grads(g, bw, 1e-3)
 
 
@@ -269,37 +279,66 @@ def test_c3_bench_path_full_size_vs_oracle(oracle):
         assert_forward_gate(fw, out[2][1], W, H, 1e-4, "C3 frame %d" % t, plain_tol=5e-5)
 
 
-def test_backward_takes_the_entries_the_forward_blended_c2_size():
-    """The two blend kernels evaluate an entry's exponent differently (forward: polynomial on the matrix core, ~1e-5; backward: per pixel,
-    ~5e-7), so they can disagree about alpha >= 1/255 for an entry that sits on the threshold (in the reference backward.cu repeats
-    forward.cu's expression and they cannot).  MEASURED here at BASELINE config C2's size (500 k Gaussians, 1920x1080, SH 3): the backward walk
-    reconstructs the transmittance in front of every pixel's first entry by dividing final_T by (1 - alpha) of each entry it takes -
-    exactly 1 (up to the rounding of a few hundred reciprocals) when it took the entries the forward blended, off by >= 0.39 % per
-    entry the halves disagree about.  The plane comes out of the backward kernel itself (gm_debug_backward_front_T)."""
+def _front_T_after_backward(run_backward, H, W):
+    """the transmittance in front of every pixel's first entry as the backward walk reconstructs it (final_T divided by 1 - alpha of each
+    entry it takes): exactly 1, up to the rounding of a few hundred reciprocals, when it took the entries the forward blended; off by
+    >= 0.39 % per entry the halves disagree about.  The plane comes out of the backward kernel itself (gm_debug_backward_front_T)."""
     import ctypes as C
+    from gaussianmesh_amd import _lib
+    lib = C.CDLL(_lib.lib()._name)
+    front = torch.ones((H, W), dtype=torch.float32, device="cuda")
+    lib.gm_debug_backward_front_T(C.c_void_p(front.data_ptr()))
+    try:
+        run_backward()
+        torch.cuda.synchronize()
+    finally:
+        lib.gm_debug_backward_front_T(None)
+    assert torch.isfinite(front).all()
+    return (front - 1.0).abs()
+
+
+def test_training_step_halves_take_the_same_entries_c2_size():
+    """In the reference backward.cu repeats forward.cu's expression, so the two halves of a training step take the same alpha >= 1/255
+    decision for every (entry, pixel).  Here the forward of a step that needs a gradient runs with GM_FWD_EXACT_EXPONENT - the blend
+    evaluates its exponents with the backward kernel's per-pixel expression instead of the matrix-core polynomial - and the halves agree
+    EXACTLY: at BASELINE config C2's size (500 k Gaussians, 1920x1080, SH 3) no covered pixel's walk deviates beyond reciprocal rounding."""
     from gpu_utils import T, settings
-    from gaussianmesh_amd import GaussianRasterizer, _lib, scenes
+    from gaussianmesh_amd import GaussianRasterizer, scenes
     sc = scenes.make_cloud(500_000, seed=0)
     W, H = 1920, 1080
     cam = scenes.orbit_camera(3, 64, W, H)
     bg = np.zeros(3, np.float32)
-    lib = C.CDLL(_lib.lib()._name)
-    front = torch.ones((H, W), dtype=torch.float32, device="cuda")
     means = T(sc["means"], True); m2d = torch.zeros_like(means, requires_grad=True)
     rast = GaussianRasterizer(settings(cam, bg, 3))
     color, radii = rast(means, m2d, T(sc["opac"], True), shs=T(sc["shs"], True), scales=T(sc["scales"], True), rotations=T(sc["rots"], True))
-    lib.gm_debug_backward_front_T(C.c_void_p(front.data_ptr()))
-    try:
-        (color * torch.randn_like(color)).sum().backward()
-        torch.cuda.synchronize()
-    finally:
-        lib.gm_debug_backward_front_T(None)
-    dev = (front - 1.0).abs()
+    dev = _front_T_after_backward(lambda: (color * torch.randn_like(color)).sum().backward(), H, W)
     covered = int((color.detach().sum(0) > 0).sum())
+    print("training step (exact-exponent forward), C2 size: largest deviation of the reconstructed front transmittance %.3g over %d covered "
+          "pixels, median %.2g" % (float(dev.max()), covered, float(dev.median())))
+    assert covered > 0.2 * W * H
+    assert float(dev.max()) <= 1e-3 and float(dev.median()) <= 2e-5            # rounding of the reciprocals only: no entry taken by one half alone
+
+
+def test_backward_after_a_matrix_core_forward_c2_size():
+    """The low-level pair rasterize_forward (no flag: exponents from the polynomial on the matrix core, ~1e-5) + rasterize_backward
+    (per pixel, ~5e-7): the halves CAN disagree about an entry that sits on the alpha = 1/255 threshold.  MEASURED at C2's size:
+    6 of 1.3 M covered pixels, each a 0.4 % weight - why the operator sets GM_FWD_EXACT_EXPONENT when a gradient is required."""
+    from gpu_utils import T
+    from gaussianmesh_amd import rasterizer as Rz, scenes
+    sc = scenes.make_cloud(500_000, seed=0)
+    W, H = 1920, 1080
+    cam = scenes.orbit_camera(3, 64, W, H)
+    bg = T(np.zeros(3, np.float32))
+    a = (bg, T(sc["means"]), None, T(sc["opac"]), T(sc["scales"]), T(sc["rots"]), 1.0, None, T(cam["view"]), T(cam["proj"]), cam["tanx"], cam["tany"])
+    nr, color, radii, geom, binning, img = Rz.rasterize_forward(*a, H, W, T(sc["shs"]), 3, T(cam["campos"]), False, False)
+    g = torch.randn_like(color)
+    dev = _front_T_after_backward(lambda: Rz.rasterize_backward(bg, a[1], radii, None, a[4], a[5], 1.0, None, a[8], a[9], cam["tanx"], cam["tany"], g,
+                                                                T(sc["shs"]), 3, T(cam["campos"]), geom, nr, binning, img, False), H, W)
+    covered = int((color.sum(0) > 0).sum())
     off = int((dev > 1e-3).sum())
-    print("front-of-list transmittance after the backward walk (C2 size): %d of %d covered pixels off by more than 1e-3 (largest %.3g); "
-          "median deviation of the others %.2g" % (off, covered, float(dev.max()), float(dev[dev <= 1e-3].median())))
-    assert covered > 0.2 * W * H and torch.isfinite(front).all()
+    print("front-of-list transmittance after the backward walk behind a matrix-core forward (C2 size): %d of %d covered pixels off by more "
+          "than 1e-3 (largest %.3g); median deviation of the others %.2g" % (off, covered, float(dev.max()), float(dev[dev <= 1e-3].median())))
+    assert covered > 0.2 * W * H
     assert float(dev[dev <= 1e-3].max()) <= 1e-3 and float(dev[dev <= 1e-3].median()) <= 2e-5         # rounding of the reciprocals only
     assert off <= 64, off                                  # pixels with an entry on the threshold (measured: 6 of 1.3 M covered pixels), each a 0.4 % weight
     assert float(dev.max()) <= 0.05                        # never more than a handful of threshold entries on one pixel

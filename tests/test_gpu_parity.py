@@ -1123,3 +1123,15 @@ def test_forward_exact_exponent_build_differs_only_on_accounted_pixels(oracle, c
     assert_forward_gate(fw, poly["color"], W, H, FWD_TOL, "matrix-core exponent " + case, plain_tol=5e-5)
     # the backward state agrees wherever no flip happened
     assert (exact["n_contrib"] != poly["n_contrib"]).sum() <= max(4, 2e-4 * W * H)
+    if case == "small":
+        # GM_FWD_EXACT_EXPONENT (what the operator sets for a forward a backward follows) selects that build for ONE frame; it is refused
+        # together with GM_FWD_IMAGE_ONLY
+        from gpu_utils import T
+        from gaussianmesh_amd import rasterizer as Rz
+        a = (T(bg), T(sc["means"]), None, T(sc["opac"]), T(sc["scales"]), T(sc["rots"]), 1.0, None, T(cam["view"]), T(cam["proj"]), cam["tanx"],
+             cam["tany"], H, W, T(sc["shs"]), 3, T(cam["campos"]), False, False)
+        flagged = Rz.rasterize_forward_begin(*a, emission_policy=2).finish(exact_exponent=True)[1].cpu().numpy()
+        plain = Rz.rasterize_forward_begin(*a, emission_policy=2).finish()[1].cpu().numpy()
+        assert np.array_equal(flagged, exact["color"]) and np.array_equal(plain, poly["color"])
+        with pytest.raises(_lib.GmeshError):
+            Rz.rasterize_forward_begin(*a, emission_policy=2).finish(exact_exponent=True, image_only=True)
