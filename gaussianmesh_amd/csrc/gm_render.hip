@@ -349,7 +349,7 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
         // half centres into the MFMA's A layout, colour + opacity, list position
         if (keep) {
           const int slot = (int)lanes_below(kb);
-          stage_poly(L.ct, slot, cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, ucx, vcy);
+          if (!EXACT) stage_poly(L.ct, slot, cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, ucx, vcy);
           // (r, g, b, w): w = the opacity in the EXACT build, otherwise (the opacity lives in the polynomial) the 1-based list position
           // the backward state wants - one broadcast read per survivor for colour AND n_contrib
           L.sb[slot] = make_float4(cur.b.z, cur.b.w, cur.c, EXACT ? cur.b.y : (STATE ? __uint_as_float(cur.pos + 1u) : 0.f));
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
           if (STATE && EXACT) x_sp[68 * (WPW == 4 ? wave : 0) + slot] = cur.pos + 1u;   // 1-based list position: n_contrib
         }
         // survivors are taken four at a time: the up to three slots behind the last must come out as alpha = 0
-        if (lane < 4 && ns + lane < 64) pad_poly(L.ct, ns + lane);
+        if (!EXACT && lane < 4 && ns + lane < 64) pad_poly(L.ct, ns + lane);
         if (lane < 4) L.sb[ns + lane] = make_float4(0.f, 0.f, 0.f, 0.f);     // (their colours are multiplied by that 0: they must be finite)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
