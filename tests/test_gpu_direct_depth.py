@@ -52,7 +52,7 @@ def _frame(g, cams, t, k, W, H, bg, plan=None, ws=None, **kw):
                                      c[3], H, W, 3, c[4], False, workspace=ws, depth_plan=plan, **kw)
 
 
-@pytest.mark.parametrize("P,W,H", [(3000, 160, 96), (60000, 480, 320)])
+@pytest.mark.parametrize("P,W,H", [(70, 64, 48), (3000, 160, 96), (60000, 480, 320)])
 def test_lists_do_not_depend_on_the_depth_path(P, W, H):
     """every frame of an orbit, twice: partition path and direct placement (table of the frame before).  Visible order, instance
     stream (keys and ids) and image bit-identical; the exact completion path notices a refused frame by itself."""
