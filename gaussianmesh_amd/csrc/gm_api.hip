@@ -322,8 +322,10 @@ int gm_backward_p(int emission_policy, int P, int D, int M, int R, const float* 
   FILL_ARGS(a, emission_policy)
   if (int rc = check_raster_args(a)) return rc;
   if (P == 0) return GM_OK;
-  if (!geom_buffer || !image_buffer || !dL_dpix || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor ||
-      !dL_dmean3D || !dL_dcov3D || (shs && !dL_dsh) || (scales && (!dL_dscale || !dL_drot))) {
+  // intermediates a caller may decline: dL/dconic always, dL/dcolour when the colours come from SH rows, dL/dcov3D when the covariances
+  // come from scale / rotation
+  if (!geom_buffer || !image_buffer || !dL_dpix || !dL_dmean2D || !dL_dopacity || (!shs && !dL_dcolor) ||
+      !dL_dmean3D || (!scales && !dL_dcov3D) || (shs && !dL_dsh) || (scales && (!dL_dscale || !dL_drot))) {
     set_error("gm_backward: null buffer"); return GM_ERR_INVALID_ARG;
   }
   GeomState g = GeomState::from(geom_buffer, (size_t)P);

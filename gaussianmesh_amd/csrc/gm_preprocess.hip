@@ -288,9 +288,11 @@ __device__ __forceinline__ void preprocess_bwd_body(const PreBwdArgs& a, const i
     gop = (m0 != 0.f) ? m0 / op : 0.f;
   }
   const float gcx = -0.5f * acc1.z, gcy = -0.5f * acc1.w, gcw = -0.5f * m2yy;
-  a.dL_dcolor[3 * (size_t)idx] = acc0.x; a.dL_dcolor[3 * (size_t)idx + 1] = acc0.y; a.dL_dcolor[3 * (size_t)idx + 2] = acc0.z;
+  // dL/dcolour, dL/dconic and (below) dL/dcov3D are consumed right here when the inputs are SH rows and scale / rotation: a caller
+  // that does not want them passes NULL (52 of ~600 bytes per Gaussian not written)
+  if (a.dL_dcolor) { a.dL_dcolor[3 * (size_t)idx] = acc0.x; a.dL_dcolor[3 * (size_t)idx + 1] = acc0.y; a.dL_dcolor[3 * (size_t)idx + 2] = acc0.z; }
   a.dL_dmean2D[3 * (size_t)idx] = g2dx; a.dL_dmean2D[3 * (size_t)idx + 1] = g2dy; a.dL_dmean2D[3 * (size_t)idx + 2] = 0.f;
-  reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(gcx, gcy, 0.f, gcw);
+  if (a.dL_dconic) reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(gcx, gcy, 0.f, gcw);
   a.dL_dopacity[idx] = gop;
   if (visible) {
     const V3 mean = {a.means[3 * (size_t)idx], a.means[3 * (size_t)idx + 1], a.means[3 * (size_t)idx + 2]};
@@ -446,7 +448,7 @@ __device__ __forceinline__ void preprocess_bwd_body(const PreBwdArgs& a, const i
 #pragma unroll
   for (int k = 0; k < 3; k++) a.dL_dmean3D[3 * (size_t)idx + k] = dmean[k];
 #pragma unroll
-  for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = dcov[k];
+  for (int k = 0; k < 6; k++) if (a.dL_dcov3D) a.dL_dcov3D[6 * (size_t)idx + k] = dcov[k];
   if (a.scales) {  // ---- computeCov3D backward, backward.cu:278-341
     float dsc[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0};
     if (visible) {

@@ -572,10 +572,12 @@ def forward_deformed_begin(bg, tri, weights, packed, cov, pos, shs, opacity, vie
 
 def rasterize_backward(bg, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
                        tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos, geom, num_rendered, binning, img, debug,
-                       emission_policy=None):
+                       emission_policy=None, skip_intermediates=False):
     """RasterizeGaussiansBackwardCUDA of the reference bridge (rasterize_points.py:276-401): returns
     (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations).
-    emission_policy: the policy the forward that filled geom / binning / img ran under."""
+    emission_policy: the policy the forward that filled geom / binning / img ran under.
+    skip_intermediates (the autograd operator): dL_dcolors when the colours come from SH rows and dL_dcov3D when the covariances come
+    from scale / rotation are not computed into memory (returned as None), nor is the internal dL/dconic."""
     lib = _lib.lib()
     device = means3D.device
     P = means3D.shape[0]
@@ -591,8 +593,11 @@ def rasterize_backward(bg, means3D, radii, colors, scales, rotations, scale_modi
     H, W = dpix.shape[1], dpix.shape[2]
     M = sh.shape[1] if sh is not None else 0
     with _on(device):
-        dmeans2D = torch.empty((P, 3), **f); dconic = torch.empty((P, 2, 2), **f); dopac = torch.empty((P, 1), **f)
-        dcolors = torch.empty((P, 3), **f); dmeans3D = torch.empty((P, 3), **f); dcov3D = torch.empty((P, 6), **f)
+        skip = bool(skip_intermediates)
+        dmeans2D = torch.empty((P, 3), **f); dopac = torch.empty((P, 1), **f); dmeans3D = torch.empty((P, 3), **f)
+        dconic = None if skip else torch.empty((P, 2, 2), **f)
+        dcolors = None if (skip and sh is not None) else torch.empty((P, 3), **f)
+        dcov3D = None if (skip and scales is not None) else torch.empty((P, 6), **f)
         dsh = torch.empty((P, M, 3), **f) if sh is not None else None
         dscales = torch.empty((P, 3), **f) if scales is not None else None
         drots = torch.empty((P, 4), **f) if scales is not None else None
@@ -774,7 +779,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             g2d, gcol, gop, g3d, gcov, gsh, gsc, grot = rasterize_backward(
                 rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
                 rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos, geom, ctx.num_rendered,
-                binning, img, rs.debug, ctx.emission_policy)
+                binning, img, rs.debug, ctx.emission_policy, skip_intermediates=True)
         except Exception:
             if rs.debug:       # diff_gaussian_rasterizater/__init__.py:102-108
                 _snapshot("snapshot_bw.dump", dict(bg=rs.bg, means3D=means3D, radii=radii, colors_precomp=colors_precomp, scales=scales,

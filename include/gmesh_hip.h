@@ -110,7 +110,9 @@ int gm_forward_1(void* geom_buffer, void* binning_buffer, void* image_buffer, in
  * dL_dcolor [P,3], dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3], dL_dscale [P,3], dL_drot [P,4].
  * Unlike the reference (which needs them zero-filled by the caller, rasterize_points.py:302-310) the
  * library zeroes every gradient output itself, so on return they hold exactly this pass's gradients.
- * dL_dsh may be NULL when shs is NULL; dL_dscale/dL_drot may be NULL when scales is NULL. */
+ * dL_dsh may be NULL when shs is NULL; dL_dscale/dL_drot may be NULL when scales is NULL.  The intermediates of the chain rule may be
+ * declined with NULL (they are then not written: 52 of ~600 bytes per Gaussian): dL_dconic always, dL_dcolor when shs is given,
+ * dL_dcov3D when scales is given. */
 int gm_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
