@@ -589,7 +589,6 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(uint32_t* __res
   const uint32_t obase = DIRECT ? bucket_start[b] : start;
   uint2 krange = make_uint2(0u, 0u);
   if (!DIRECT) krange = reinterpret_cast<const uint2*>(bmap)[b];    // {first key of the bucket, bits of (key - first key) inside it}
-  const uint32_t rounds_all = (n + 255u) / 256u;
   if (DIRECT) {                                                     // the range of the keys that arrived
     uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
     for (uint32_t p = threadIdx.x; p < n; p += BK_THREADS) { const uint32_t k = p1[p].x; kmin = min(kmin, k); kmax = max(kmax, k); }
@@ -606,7 +605,6 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(uint32_t* __res
       return;
     }
   }
-  (void)rounds_all;
   DigitSpec ds;
   ds.sub = krange.x; ds.shift = 0; ds.mask = 0xFFFFFFFFu;
   const uint32_t low_bits = krange.y;
