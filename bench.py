@@ -487,9 +487,17 @@ def main():
         `lag` steps ago, which landed long before.
         --exact-count: the host waits for the completed frame's count (one 4-byte read-back, hidden behind frame i's first half)."""
         torch.cuda.set_stream(streams[i % nstreams])     # (not `with torch.cuda.stream(...)`: entering and leaving the context costs the
+        if timeline is not None:
+            t_a = time.perf_counter()
         pending[i] = step_on_stream(i, workspaces[i % nws], begin_only=True)   # host ~20 us per frame; drain() restores the default stream)
+        if timeline is not None:
+            host_split.append((time.perf_counter() - t_a, 0.0))
+            t_a = time.perf_counter()
         prev = pending.pop(i - ahead, None)
-        return finish(prev) if prev is not None else None
+        out = finish(prev) if prev is not None else None
+        if timeline is not None:
+            host_split[-1] = (host_split[-1][0], time.perf_counter() - t_a)
+        return out
 
     def verify(h):
         ok, nr = h.check()
@@ -499,8 +507,15 @@ def main():
         stats["R"] = nr
         stats["radii"] = h.radii
 
+    timeline = [] if os.environ.get("GM_BENCH_TIMELINE") else None      # tools/region_timeline.py: an event behind every frame
+    host_split = []                                                      # ... and the host time of each step's begin / finish halves
+
     def finish(h):
         out = h.finish(sync_free=not args.exact_count, image_only=image_only, work_hint=hint)
+        if timeline is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(h.stream)
+            timeline.append((time.perf_counter(), ev))
         stats["last_image"] = out[1]
         unchecked.append(h)
         while len(unchecked) > lag:
@@ -615,13 +630,23 @@ def main():
     def timed_region(first):
         """K steps bracketed by barrier + synchronize on both sides; seconds (this rank)."""
         barrier()
+        if timeline is not None:
+            del timeline[:]
+            del host_split[:]
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record(streams[first % nstreams])
         t = time.perf_counter()
         for i in range(args.steps):
             step(first + i)
         drain()                                  # the last frame of the timed region is completed inside it
         torch.cuda.synchronize()
         barrier()
-        return time.perf_counter() - t
+        el = time.perf_counter() - t
+        if timeline is not None:
+            sys.stderr.write("region from step %d: %.3f ms; frame completions (device ms after the region opened | host ms when issued): %s\n" % (
+                first, 1e3 * el, " ".join("%.2f|%.2f" % (ev0.elapsed_time(e), 1e3 * (th - t)) for th, e in timeline)))
+            sys.stderr.write("   host us per step (begin / finish+verify): %s\n" % " ".join("%.0f/%.0f" % (1e6 * a, 1e6 * b) for a, b in host_split))
+        return el
 
     elapsed = timed_region(args.warmup)
     per_rank_s = multiview.gather_over_ranks(elapsed, dev)       # every rank's own clock around the same barriers
