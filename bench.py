@@ -71,7 +71,7 @@ def build_scene(P, W, H, frames, seed=0):
                 opac=cl["opac"], shs=cl["shs"], scales=cl["scales"], rots=cl["rots"], mesh=mesh)
 
 
-def algorithmic_bytes(stage, P, V, R, W, H, Vm, M=16, list_tiles=2040):
+def algorithmic_bytes(stage, P, V, R, W, H, Vm, M=16, list_tiles=2040, cov_bytes=36):
     """Bytes each stage has to move for THIS implementation's algorithm, precomputed colour/cov input mode."""
     hist = 2048 * 4                     # one histogram row per 4096 keys
     one_pass = list_tiles <= 2048
@@ -79,7 +79,7 @@ def algorithmic_bytes(stage, P, V, R, W, H, Vm, M=16, list_tiles=2040):
         "deform": P * (12 + 12 + 36 + 12 + 12 * M) + P * (12 + 24 + 12) + Vm * 84,     # fused deform + colour
         # deform + colour + forward preprocess in one kernel: the 48 B/Gaussian of intermediates disappear, the
         # preprocess outputs (splat 48 B per visible Gaussian; radius, count, bin, depth key 28 B) and opacity appear
-        "deform_pre": P * (12 + 12 + 36 + 12 + 12 * M + 4) + Vm * 96 + V * 48 + P * 28,
+        "deform_pre": P * (12 + 12 + cov_bytes + 12 + 12 * M + 4) + Vm * 96 + V * 48 + P * 28,
         # per-vertex (R, S) from the deformed mesh: rest + deformed positions, one-ring face ids (~6 faces x (4 + 12)), the 96-byte table row
         "mesh_rs": Vm * (24 + 96 + 96),
         "sh_colors": P * (12 + 36 + 12 * M) + P * 12,
@@ -90,7 +90,7 @@ def algorithmic_bytes(stage, P, V, R, W, H, Vm, M=16, list_tiles=2040):
         # direct depth placement (DepthPlan): the fused pass writes (key, id) + the emission record once, into the bucket's slab,
         # instead of the per-Gaussian key and record arrays; the depth order is then the bucket counters and the in-LDS bucket sort
         # (slab in; id and record out) - no partition, no gather
-        "deform_pre_direct": P * (12 + 12 + 36 + 12 + 12 * M + 4) + Vm * 96 + V * 48 + P * 8 + V * 24,
+        "deform_pre_direct": P * (12 + 12 + cov_bytes + 12 + 12 * M + 4) + Vm * 96 + V * 48 + P * 8 + V * 24,
         "depth_sort_direct": V * (8 + 16) + V * (4 + 16) + 2048 * (4 + 4) + 16384 * 4,
         "duplicate": V * (4 + 4) + V * 16 + R * 8,                                  # counts + ids in order, bin records, (key, id) out
         "tile_sort": (R * (4 + 8 + 8) + (R // 4096 + 1) * hist * 4) * (1 if one_pass else 2) + list_tiles * 8,
@@ -377,6 +377,7 @@ def main():
                     "camera index) as <dir>/rank<r>.npz: lets a test verify that each rank rendered its own views")
     ap.add_argument("--analytic-rs", action="store_true", help="take the per-vertex (R, S) of every animation frame from the analytic "
                     "deformation (precomputed tables) instead of computing them from the deformed mesh inside the frame (gm_mesh_rs)")
+    ap.add_argument("--no-cov6", action="store_true", help="edit loop: hand the rest covariances over as [N,3,3] even when they are bit-symmetric")
     ap.add_argument("--depth-plan", action="store_true", help="edit loop: direct depth placement over the view stream's DepthPlan (the fused pass "
                     "appends every Gaussian to its depth bucket; no bk_hist / bk_scan / bk_scatter, no record gather).  Measured: the ordering "
                     "stages drop from 0.153 to 0.125 ms, the fused pass grows by 0.016 ms and the pipelined loop is 2 %% slower (DESIGN.md "
@@ -452,6 +453,12 @@ def main():
             g[k] = torch.empty(shp, dtype=dt, device=dev)
     # the animation ("mesh") stays on rank 0; its frames are broadcast one at a time inside the timed loop
     multiview.broadcast_cloud({k: v for k, v in g.items() if k != "mesh"}, src=0)
+    # the rest covariances as their six distinct entries where every matrix is symmetric bit for bit (one-time, like the mesh tables'
+    # packing): the fused pass then reads 24 instead of 36 bytes per Gaussian and computes what it computes from [N,3,3]
+    from gaussianmesh_amd.deform import pack_cov6
+    g["cov_in"] = (None if args.no_cov6 else pack_cov6(g["cov"]))
+    if g["cov_in"] is None:
+        g["cov_in"] = g["cov"]
     Vm = g["verts"].shape[0]
     # per-frame ARAP-style deformation: (R, S) of every vertex come from the deformed mesh of that frame (gm_mesh_rs,
     # the device counterpart of pyACAP.GetRS), on the rank that owns the animation
@@ -572,11 +579,11 @@ def main():
             views_walked.append((i, vi))
         c = cam_t[vi]
         if begin_only and not args.unfused:      # one enqueue: deform + colour + preprocess + depth sort + instance count
-            return Rz.forward_deformed_begin(bg, g["tri"], g["weights"], packed, g["cov"], g["pos"], g["shs"], g["opac"], c["view"],
+            return Rz.forward_deformed_begin(bg, g["tri"], g["weights"], packed, g["cov_in"], g["pos"], g["shs"], g["opac"], c["view"],
                                              c["proj"], c["tanx"], c["tany"], H, W, 3, c["campos"], False, workspace=workspace,
                                              want_count=args.exact_count, depth_plan=dplan)
         if not args.unfused:                     # same path, completed at once (per-stage timing pass)
-            nr, color, radii, _, _, _ = Rz.forward_deformed_begin(bg, g["tri"], g["weights"], packed, g["cov"], g["pos"], g["shs"], g["opac"],
+            nr, color, radii, _, _, _ = Rz.forward_deformed_begin(bg, g["tri"], g["weights"], packed, g["cov_in"], g["pos"], g["shs"], g["opac"],
                                                                   c["view"], c["proj"], c["tanx"], c["tany"], H, W, 3, c["campos"], False,
                                                                   workspace=workspace, depth_plan=dplan).finish(image_only=image_only, work_hint=hint)
             stats["R"] = nr
@@ -603,7 +610,7 @@ def main():
         # (gm_deform_shade_packed -> gm_forward_0/1) renders for the same frame: bit-identical image and radii
         c = cam_t[multiview.view_for_step(0, F, rank, world)]
         pk = pack_mesh_state(g["mesh"][0], g["verts"])
-        nr_f, col_f, rad_f, *_ = Rz.forward_deformed_begin(bg, g["tri"], g["weights"], pk, g["cov"], g["pos"], g["shs"], g["opac"], c["view"],
+        nr_f, col_f, rad_f, *_ = Rz.forward_deformed_begin(bg, g["tri"], g["weights"], pk, g["cov_in"], g["pos"], g["shs"], g["opac"], c["view"],
                                                            c["proj"], c["tanx"], c["tany"], H, W, 3, c["campos"], False).finish(image_only=image_only)
         pos_u, cov6_u, rgb_u = deform_shade_packed(g["tri"], g["weights"], pk, g["cov"], g["pos"], g["shs"], c["campos"], deg=3)
         nr_u, col_u, rad_u, *_ = Rz.rasterize_forward(bg, pos_u, rgb_u, g["opac"], None, None, 1.0, cov6_u, c["view"], c["proj"], c["tanx"],
@@ -692,7 +699,7 @@ def main():
                                                           "slowest_over_fastest_rank": round(max(per_rank_s) / max(min(per_rank_s), 1e-12), 4),
                                                           "cores_per_rank": None if pinned is None else len(pinned)},
                    "emission_policy": Rz.get_default_emission_policy(W, H), "image_only": image_only, "work_hint": hint is not None,
-                   "depth_plan": dplan is not None, "frames_refused_by_direct_placement": None if dplan is None else dplan.refused,
+                   "cov6": bool(g["cov_in"].dim() == 2 and g["cov_in"].shape[-1] == 6), "depth_plan": dplan is not None, "frames_refused_by_direct_placement": None if dplan is None else dplan.refused,
                    "frames_redone": stats["overflows"],          # sync-free frames that outgrew their binning buffer (rendered again, exactly)
                    "parallelism": "views x%d" % world},
     }
@@ -727,7 +734,8 @@ def main():
         direct = dplan is not None
         bytes_key = lambda st: (("deform_pre_direct" if direct else "deform_pre") if (st == "deform" and not args.unfused) else
                                 ("depth_sort_direct" if (st == "depth_sort" and direct) else st))
-        stage_bytes = lambda st: algorithmic_bytes(bytes_key(st), P, V, Rn, W, H, Vm, list_tiles=list_tiles)
+        stage_bytes = lambda st: algorithmic_bytes(bytes_key(st), P, V, Rn, W, H, Vm, list_tiles=list_tiles,
+                                                   cov_bytes=24 if g["cov_in"].shape[-1] == 6 and g["cov_in"].dim() == 2 else 36)
         # `roofline` = the dominant KERNEL of the frame: the longest of the stages that are one launch each (the ordering stages are
         # 4 + 3 launches of at most 30 us each; they are under stage_roofline)
         dom = max((st for st in per if st in KERNEL_OF_STAGE), key=per.get)

@@ -185,8 +185,11 @@ int gm_forward_0_deformed_stream_async(int emission_policy, void* geom_buffer, i
                                        const float* opacities, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                                        float tan_fovx, float tan_fovy, float* pos_out, float* cov6_out, float* rgb_out, int* radii,
                                        int debug, void* stream, int* num_rendered_host, void* count_event, void* depth_slab,
-                                       unsigned int* depth_plan, int direct) {
+                                       unsigned int* depth_plan, int flags) {
   if (int rc = check_policy(emission_policy)) return rc;
+  if (flags & ~(GM_STREAM_DIRECT | GM_STREAM_COV6)) { set_error("gm_forward_0_deformed_stream: unknown flags 0x%x", flags); return GM_ERR_INVALID_ARG; }
+  const int direct = flags & GM_STREAM_DIRECT;
+  const bool cov6 = (flags & GM_STREAM_COV6) != 0;
   if (direct && (!depth_slab || !depth_plan)) { set_error("gm_forward_0_deformed_stream: direct placement needs depth_slab and depth_plan"); return GM_ERR_INVALID_ARG; }
   if (P < 0 || width <= 0 || height <= 0) { set_error("invalid sizes P=%d W=%d H=%d", P, width, height); return GM_ERR_INVALID_ARG; }
   if (P == 0) { if (num_rendered_host) *num_rendered_host = 0; return GM_OK; }
@@ -205,12 +208,12 @@ int gm_forward_0_deformed_stream_async(int emission_policy, void* geom_buffer, i
   if (direct) {
     DepthSlab d = DepthSlab::from(depth_slab, (size_t)P);
     if (int rc = launch_arm_direct(g, d, depth_plan, a.stream)) return rc;
-    if (int rc = launch_deform_shade_pre(a, g, radii, deg, tri, w, packed, cov, pos, shs, pos_out, cov6_out, rgb_out, &d)) return rc;
+    if (int rc = launch_deform_shade_pre(a, g, radii, deg, tri, w, packed, cov, pos, shs, pos_out, cov6_out, rgb_out, &d, cov6)) return rc;
     if (debug_stop_after() == 1) return GM_OK;
     return launch_depth_order_direct(g, d, depth_plan, P, debug, a.stream, num_rendered_host, reinterpret_cast<hipEvent_t>(count_event));
   }
   if (int rc = launch_arm_counters(g, a.stream)) return rc;
-  if (int rc = launch_deform_shade_pre(a, g, radii, deg, tri, w, packed, cov, pos, shs, pos_out, cov6_out, rgb_out)) return rc;
+  if (int rc = launch_deform_shade_pre(a, g, radii, deg, tri, w, packed, cov, pos, shs, pos_out, cov6_out, rgb_out, nullptr, cov6)) return rc;
   if (int rc = order_and_count(g, P, debug, a.stream, num_rendered_host, count_event)) return rc;
   if (depth_plan && debug_stop_after() != 1) return launch_publish_depth_plan(g, depth_plan, a.stream);
   return GM_OK;

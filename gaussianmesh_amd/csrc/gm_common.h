@@ -350,7 +350,7 @@ int launch_deform_shade(int N, int deg, int M, const int* tri, const float* w, c
                         float* cov6_out, float* rgb_out, float* cov_out, float* rot_out, hipStream_t s);
 int launch_deform_shade_pre(const RasterArgs& r, GeomState& g, int* radii, int deg, const int* tri, const float* w, const float* packed,
                             const float* cov, const float* pos, const float* shs, float* pos_out, float* cov6_out, float* rgb_out,
-                            const struct DepthSlab* slab = nullptr);
+                            const struct DepthSlab* slab = nullptr, bool cov6 = false);
 int launch_pack_mesh_state(int Vm, const float* state, const float* verts, float* packed, hipStream_t s);
 int launch_deform_shade_packed(int N, int deg, int M, const int* tri, const float* w, const float* packed, const float* cov,
                                const float* pos, const float* shs, const float* campos, float* pos_out, float* cov6_out,

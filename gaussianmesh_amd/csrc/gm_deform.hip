@@ -131,6 +131,7 @@ struct FusedPre {
   float4* splat; int* radii_int; int* radii_out; uint32_t* tiles; uint4* bin; uint32_t* counters; uint32_t* slots; uint32_t* coarse; uint8_t* clamped; uint32_t* depth_key;
   // DIRECT (gm_common.h, DepthSlab): the frame's snapshot of the stream's depth table and the bucket slabs the records are appended to
   const uint32_t* dmap; uint32_t* slab_cnt; uint2* slab_pairs; uint4* slab_recs; uint32_t slab_cap;
+  int cov6;                     // the rest covariances come as [N][6] (a caller whose matrices are bit-symmetric: deform.pack_cov6)
 };
 
 // Direct depth placement: the wave's visible Gaussians are appended to their depth buckets' slabs.  One returning atomic per
@@ -215,8 +216,15 @@ __global__ __launch_bounds__(64) void deform_shade_kernel(int N, int deg, const 
   // the covariance row goes straight to registers (36 B per lane, the wave's 2304 B are contiguous): staging it as well
   // would cost 2.25 KiB of LDS per wave, i.e. two resident waves per CU
   float C[9];
+  if (PRE && fp.cov6) {                            // (wave-uniform) rest covariance as its six distinct entries xx xy xz yy yz zz: 24 B per lane
+    float c6[6];
 #pragma unroll
-  for (int k = 0; k < 9; k++) C[k] = live ? cov[i * 9 + k] : 0.f;
+    for (int k = 0; k < 6; k++) c6[k] = live ? cov[i * 6 + k] : 0.f;
+    C[0] = c6[0]; C[1] = c6[1]; C[2] = c6[2]; C[3] = c6[1]; C[4] = c6[3]; C[5] = c6[4]; C[6] = c6[2]; C[7] = c6[4]; C[8] = c6[5];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; k++) C[k] = live ? cov[i * 9 + k] : 0.f;
+  }
   float d[3], Rb[9], Sb[9];
   if (PACKED) {
     const float4* tab = reinterpret_cast<const float4*>(dV);
@@ -387,7 +395,7 @@ int launch_deform_shade_packed(int N, int deg, int M, const int* tri, const floa
 
 int launch_deform_shade_pre(const RasterArgs& r, GeomState& g, int* radii, int deg, const int* tri, const float* w, const float* packed,
                             const float* cov, const float* pos, const float* shs, float* pos_out, float* cov6_out, float* rgb_out,
-                            const DepthSlab* slab) {
+                            const DepthSlab* slab, bool cov6) {
   const int N = r.P;
   if (N <= 0) return 0;
   if (!aligned16(shs) || !aligned16(cov) || !aligned16(packed) ||
@@ -403,6 +411,7 @@ int launch_deform_shade_pre(const RasterArgs& r, GeomState& g, int* radii, int d
   fp.opac = r.opacities;
   fp.splat = g.splat; fp.radii_int = g.radii; fp.radii_out = radii; fp.tiles = g.tiles_touched; fp.bin = g.bin; fp.counters = g.counters; fp.slots = g.slots; fp.coarse = g.coarse;
   fp.clamped = g.clamped; fp.depth_key = g.depth_key;
+  fp.cov6 = cov6 ? 1 : 0;
   fp.dmap = g.dmap; fp.slab_cnt = nullptr; fp.slab_pairs = nullptr; fp.slab_recs = nullptr; fp.slab_cap = 0;
   if (slab) { fp.slab_cnt = slab->cnt; fp.slab_pairs = slab->pairs; fp.slab_recs = slab->recs; fp.slab_cap = slab->cap; }
   // (measured: fewer resident workgroups per CU - 8 / 6 / 5 instead of 12, by padding this allocation - make the kernel 10 / 24 / 52 %

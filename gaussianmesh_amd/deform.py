@@ -86,6 +86,16 @@ def deform_shade(tri, w, dV, Rv, Sv, cov, pos, shs, campos, deg=3, want_cov_rot=
     return (pos_o, cov6, rgb, cov_o, rot_o) if want_cov_rot else (pos_o, cov6, rgb)
 
 
+def pack_cov6(cov):
+    """Rest covariances [N,3,3] (or [N,9]) -> [N,6] rows xx xy xz yy yz zz for forward_deformed_begin (GM_STREAM_COV6), or None when
+    some matrix is not symmetric BIT FOR BIT: the fused pass reads the mirrored entries from the six, which reproduces the [N,9] call
+    exactly only then (the reference multiplies with the full matrix, edittool/__init__.py:300-340)."""
+    c = cov.detach().reshape(-1, 3, 3)
+    if not (torch.equal(c[:, 0, 1], c[:, 1, 0]) and torch.equal(c[:, 0, 2], c[:, 2, 0]) and torch.equal(c[:, 1, 2], c[:, 2, 1])):
+        return None
+    return torch.stack((c[:, 0, 0], c[:, 0, 1], c[:, 0, 2], c[:, 1, 1], c[:, 1, 2], c[:, 2, 2]), dim=1).to(torch.float32).contiguous()
+
+
 def pack_mesh_state(state, verts, out=None):
     """gm_pack_mesh_state: [Vm,21] frame state (V1 | R | S) and rest pose verts [Vm,3] -> gather table [Vm,24]."""
     lib = _lib.lib()

@@ -507,6 +507,8 @@ def forward_deformed_begin(bg, tri, weights, packed, cov, pos, shs, opacity, vie
     (gm_forward_1_geom) and returns (num_rendered, color, radii, geom, binning, img).  With want_deformed the handle
     also carries .deformed = (pos' [N,3], cov6 [N,6], rgb [N,3]).  want_count=False (loops that complete their frames with
     finish(sync_free=True)): the 4-byte copy of the instance count to the host is not enqueued either.
+    cov: the rest covariances [N,3,3] / [N,9], or [N,6] from deform.pack_cov6() (bit-symmetric matrices: 12 bytes per Gaussian
+    less to read, identical results).
     depth_plan (new_depth_plan(), one per view stream): see DepthPlan; complete such frames with finish(sync_free=True) and
     check() them, or the status of a refused frame goes unseen."""
     lib = _lib.lib()
@@ -536,6 +538,7 @@ def forward_deformed_begin(bg, tri, weights, packed, cov, pos, shs, opacity, vie
             event = _count_event(stream) if want_count else None
             if not want_count:
                 count_host = None
+            cov6 = cov is not None and cov.dim() == 2 and cov.shape[1] == 6       # deform.pack_cov6(): GM_STREAM_COV6
             direct = depth_plan is not None and depth_plan.primed and P > 0
             slab = None
             if direct:
@@ -547,7 +550,7 @@ def forward_deformed_begin(bg, tri, weights, packed, cov, pos, shs, opacity, vie
                     policy, _ptr(geom), P, int(degree), M, W, H, _ptr(tri), _ptr(weights), _ptr(packed), _ptr(cov), _ptr(pos), _ptr(shs),
                     _ptr(opacity), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), dp[0], dp[1], dp[2],
                     _ptr(radii), int(bool(debug)), stream.cuda_stream, count_ptr, event_ptr, _ptr(slab) if direct_now else None,
-                    None if depth_plan is None else depth_plan.buf.data_ptr(), 1 if direct_now else 0))
+                    None if depth_plan is None else depth_plan.buf.data_ptr(), (1 if direct_now else 0) | (2 if cov6 else 0)))
 
             begin(direct, None if count_host is None else count_host.data_ptr(), None if event is None else event.cuda_event)
             if depth_plan is not None and P > 0:

@@ -213,14 +213,14 @@ int gm_forward_0_deformed_async(int emission_policy, void* geom_buffer, int P, i
 /* The same first half for the frames of ONE VIEW STREAM (consecutive cameras of an orbit, an edit session: the edit tool's render
  * loop).  depth_plan (gm_depth_plan_bytes() bytes, zeroed once by the caller, shared by the stream's frames - also by frames in
  * flight on different HIP streams) carries depth-bucket tables from frame to frame.
- *   direct != 0: the pass itself appends every visible Gaussian to its depth bucket, looked up in the newest table earlier frames
+ *   flags & GM_STREAM_DIRECT: the pass itself appends every visible Gaussian to its depth bucket, looked up in the newest table earlier frames
  *     left in the plan (depth_slab: gm_depth_slab_bytes(P) bytes of scratch PER FRAME IN FLIGHT, like geom_buffer); the depth
  *     partition's three launches and the gather of the emission records disappear.  The (depth, id) order does not depend on the table,
  *     only the balance of the buckets does.  A frame the direct placement cannot order - no table yet, a table too stale for this view
  *     (a bucket above its slab), piles of equal depths - is REFUSED: its second half renders the background and status word 3 reads 2
  *     (gm_forward_1_geom's status_host / gm_forward_status_async; num_rendered_host is the correct total either way); begin it again
- *     with direct == 0.
- *   direct == 0: the partition path of gm_forward_0_deformed_async, which also leaves its table in the plan (depth_slab unused,
+ *     without the flag.
+ *   without GM_STREAM_DIRECT: the partition path of gm_forward_0_deformed_async, which also leaves its table in the plan (depth_slab unused,
  *     may be NULL): how a stream's first frame and refused frames are rendered.
  * Images, radii and lists are those of gm_forward_0_deformed_async, bit for bit. */
 size_t gm_depth_plan_bytes(void);
@@ -230,7 +230,11 @@ int gm_forward_0_deformed_stream_async(int emission_policy, void* geom_buffer, i
                                        const float* opacities, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                                        float tan_fovx, float tan_fovy, float* pos_out, float* cov6_out, float* rgb_out, int* radii,
                                        int debug, void* stream, int* num_rendered_host, void* count_event, void* depth_slab,
-                                       unsigned int* depth_plan, int direct);
+                                       unsigned int* depth_plan, int flags);
+#define GM_STREAM_DIRECT 1   /* direct depth placement, see above */
+#define GM_STREAM_COV6 2     /* cov holds the rest covariances as [N][6] rows xx xy xz yy yz zz instead of [N][9]: for clouds whose 3x3
+                              * matrices are symmetric BIT FOR BIT (the six mirrored reads then return the same floats and every result
+                              * is the one of the [N][9] call); 12 of the pass's 340 bytes per Gaussian less */
 
 /* Second half of a forward without the per-Gaussian input pointers gm_forward_1 does not read: instance emission, tile
  * sort, tile ranges, blend.

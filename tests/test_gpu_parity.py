@@ -575,6 +575,20 @@ def test_fused_deform_forward_equals_unfused_chain(oracle, N):
         assert nr1 == nr0 and torch.equal(radii1, radii0) and torch.equal(color1, color0)
         if want:
             assert torch.equal(h.deformed[0], pos) and torch.equal(h.deformed[1], cov6) and torch.equal(h.deformed[2], rgb)
+    # the rest covariances handed over as [N,6] (GM_STREAM_COV6: these matrices are M M^T products, symmetric bit for bit): the same frame,
+    # deformed cloud included; a matrix that is not bit-symmetric is not packed
+    from gaussianmesh_amd.deform import pack_cov6
+    c6 = pack_cov6(g["cov"])
+    assert c6 is not None and c6.shape == (N, 6)
+    h = Rz.forward_deformed_begin(bg, g["tri"], g["w"], packed, c6, g["pos"], g["shs"], g["opac"], ct["view"], ct["proj"],
+                                  cam["tanx"], cam["tany"], H, W, 3, ct["campos"], want_deformed=True)
+    nr1, color1, radii1, *_ = h.finish()
+    torch.cuda.synchronize()
+    assert nr1 == nr0 and torch.equal(radii1, radii0) and torch.equal(color1, color0)
+    assert torch.equal(h.deformed[0], pos) and torch.equal(h.deformed[1], cov6) and torch.equal(h.deformed[2], rgb)
+    skew = g["cov"].clone().reshape(N, 3, 3)
+    skew[7, 0, 1] = torch.nextafter(skew[7, 0, 1], skew[7, 0, 1] + 1)
+    assert pack_cov6(skew) is None
     # a frame begun without the count copy (what a sync-free loop does): completed exactly all the same (the count is fetched
     # on demand), and after an overflow the status words supply it
     fb = lambda **kw: Rz.forward_deformed_begin(bg, g["tri"], g["w"], packed, g["cov"], g["pos"], g["shs"], g["opac"], ct["view"], ct["proj"],
