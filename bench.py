@@ -78,19 +78,19 @@ def algorithmic_bytes(stage, P, V, R, W, H, Vm, M=16, list_tiles=2040, cov_bytes
     return {
         "deform": P * (12 + 12 + 36 + 12 + 12 * M) + P * (12 + 24 + 12) + Vm * 84,     # fused deform + colour
         # deform + colour + forward preprocess in one kernel: the 48 B/Gaussian of intermediates disappear, the
-        # preprocess outputs (splat 48 B per visible Gaussian; radius, count, bin, depth key 28 B) and opacity appear
-        "deform_pre": P * (12 + 12 + cov_bytes + 12 + 12 * M + 4) + Vm * 96 + V * 48 + P * 28,
+        # preprocess outputs (splat record 36 B per visible Gaussian; radius, count, bin, depth key 28 B) and opacity appear
+        "deform_pre": P * (12 + 12 + cov_bytes + 12 + 12 * M + 4) + Vm * 96 + V * 36 + P * 28,
         # per-vertex (R, S) from the deformed mesh: rest + deformed positions, one-ring face ids (~6 faces x (4 + 12)), the 96-byte table row
         "mesh_rs": Vm * (24 + 96 + 96),
         "sh_colors": P * (12 + 36 + 12 * M) + P * 12,
-        "preprocess": P * (12 + 24 + 4 + 12) + V * 48,
+        "preprocess": P * (12 + 24 + 4 + 12) + V * 36,
         # bucket partition (key read twice, (key, id) written once) + in-LDS bucket sort ((key, id) in; id, count out; count gather)
         # + the move of every visible Gaussian's 16-byte emission record into depth order (read + write): DESIGN.md section 3's 76 MB
         "depth_sort": P * 8 + V * 8 + V * (8 + 4 + 4 + 4) + V * 32 + (P // 4096 + 1) * hist * 4,
         # direct depth placement (DepthPlan): the fused pass writes (key, id) + the emission record once, into the bucket's slab,
         # instead of the per-Gaussian key and record arrays; the depth order is then the bucket counters and the in-LDS bucket sort
         # (slab in; id and record out) - no partition, no gather
-        "deform_pre_direct": P * (12 + 12 + cov_bytes + 12 + 12 * M + 4) + Vm * 96 + V * 48 + P * 8 + V * 24,
+        "deform_pre_direct": P * (12 + 12 + cov_bytes + 12 + 12 * M + 4) + Vm * 96 + V * 36 + P * 8 + V * 24,
         "depth_sort_direct": V * (8 + 16) + V * (4 + 16) + 2048 * (4 + 4) + 16384 * 4,
         "duplicate": V * (4 + 4) + V * 16 + R * 8,                                  # counts + ids in order, bin records, (key, id) out
         "tile_sort": (R * (4 + 8 + 8) + (R // 4096 + 1) * hist * 4) * (1 if one_pass else 2) + list_tiles * 8,
@@ -821,14 +821,14 @@ def main():
                                                         c["tanx"], c["tany"], H, W, g["shs"], 3, c["campos"], False, False)
         Vf = int((rad_fb > 0).sum().item()); Rf = int(nr_fb)
         fb_bytes = {
-            "preprocess": P * (12 + 12 + 16 + 4) + Vf * 12 * 16 + Vf * 48 + P * 28 + Vf * 27,     # inputs, SH rows, splat record, radius/count/bin/key, cov3D + clamped
+            "preprocess": P * (12 + 12 + 16 + 4) + Vf * 12 * 16 + Vf * 36 + P * 28 + Vf * 27,     # inputs, SH rows, splat record, radius/count/bin/key, cov3D + clamped
             "depth_sort": algorithmic_bytes("depth_sort", P, Vf, Rf, W, H, Vm, list_tiles=list_tiles),
             "duplicate": algorithmic_bytes("duplicate", P, Vf, Rf, W, H, Vm, list_tiles=list_tiles),
             "tile_sort": algorithmic_bytes("tile_sort", P, Vf, Rf, W, H, Vm, list_tiles=list_tiles),
             "ranges": algorithmic_bytes("ranges", P, Vf, Rf, W, H, Vm, list_tiles=list_tiles),
             "render": Rf * 40 + W * H * (12 + 8),                                                  # + final_T, n_contrib
             "render_bwd": Rf * 40 + W * H * 20 + Vf * 48,                                           # lists + records, dL/dpixel + T + n_contrib, grad_acc record
-            "preprocess_bwd": Vf * 559,                                                              # 303 read + 256 written per visible Gaussian
+            "preprocess_bwd": Vf * 507,                                                              # 303 read + 256 written per visible Gaussian, minus the 52 bytes of intermediates (dL/dconic, dL/dcolour, dL/dcov3D) the operator declines
         }
         tot_fb = sum(fb_bytes[k] for k in per_fb)
         sec = out["fwd_bwd"]["ms_per_iter"] * 1e-3

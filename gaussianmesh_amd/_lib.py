@@ -36,6 +36,7 @@ SIGNATURES = {
                             vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "gm_mark_visible": (i32, [i32, vp, vp, vp, vp, vp]),
     "gm_geom_field": (vp, [vp, i32, C.c_char_p]),
+    "gm_splat_floats": (i32, []),
     "gm_image_field": (vp, [vp, i32, i32, C.c_char_p]),
     "gm_binning_field": (vp, [vp, i64, i32, i32, i32, C.c_char_p]),
     "gm_knn_workspace_bytes": (sz, [i32]),

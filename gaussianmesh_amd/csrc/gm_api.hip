@@ -363,9 +363,11 @@ int gm_mark_visible(int P, const float* means3D, const float* viewmatrix, const 
   return launch_mark_visible(P, means3D, viewmatrix, present, reinterpret_cast<hipStream_t>(stream));
 }
 
+int gm_splat_floats(void) { return GM_SPLAT_STRIDE; }
 void* gm_geom_field(void* geom_buffer, int P, const char* name) {
   GeomState g = GeomState::from(geom_buffer, (size_t)(P > 0 ? P : 1));
   if (!strcmp(name, "splat")) return g.splat;
+  if (!strcmp(name, "depth_key")) return g.depth_key;
   if (!strcmp(name, "radii")) return g.radii;
   if (!strcmp(name, "tiles_touched")) return g.tiles_touched;
   if (!strcmp(name, "cov3D")) return g.cov3D;

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
       const uint32_t x0 = rx & 0xFFFu, y0 = (rx >> 16) & 0xFFFu, w = ry & 0xFFFu, h = (ry >> 16) & 0xFFFu;
       const uint32_t px0 = x0 >> S, py0 = y0 >> S, pw = ((x0 + w - 1) >> S) - px0 + 1, ph = ((y0 + h - 1) >> S) - py0 + 1;
       const float inv_w = 1.0f / (float)pw;
-      const float4 s0 = splat[3 * (size_t)g], s1 = splat[3 * (size_t)g + 1];
+      const float4 s0 = splat_row(splat, (size_t)g, 0), s1 = splat_row(splat, (size_t)g, 1);
       const TileCull tc = tile_cull_setup(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, (float)(x0 * GM_TILE), (float)((x0 + w) * GM_TILE - 1),
                                           (float)(y0 * GM_TILE), (float)((y0 + h) * GM_TILE - 1));
       uint32_t run = o;

@@ -132,8 +132,29 @@ __host__ __device__ __forceinline__ uint32_t bin_count(const uint4& b) {       /
   return ((b.x >> 12) & 0xFu) | ((b.x >> 28) << 4) | (((b.y >> 12) & 0xFu) << 8) | ((b.y >> 28) << 12);
 }
 
+// The blend kernels' record of a Gaussian: x, y, conic.x, conic.y | conic.z, opacity, r, g | b - nine floats, 36 bytes, records back
+// to back (GM_SPLAT_STRIDE 9: what the preprocess kernels write and the blends gather is what is used; 12 = the 48-byte record of
+// rounds 1-4 with the depth and two pads behind b, 16-byte aligned rows).  Rows are accessed as 16-byte vectors at 4-byte alignment.
+#ifndef GM_SPLAT_STRIDE
+#define GM_SPLAT_STRIDE 9
+#endif
+typedef float gm_f4u __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ float4 splat_row(const float4* splat, size_t id, int row) {          // row 0 or 1
+  const gm_f4u v = *reinterpret_cast<const gm_f4u*>(reinterpret_cast<const float*>(splat) + GM_SPLAT_STRIDE * id + 4 * row);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float splat_blue(const float4* splat, size_t id) { return reinterpret_cast<const float*>(splat)[GM_SPLAT_STRIDE * id + 8]; }
+__device__ __forceinline__ void splat_store(float4* splat, size_t id, float x, float y, float conx, float cony, float conz, float opacity,
+                                            float r, float g, float b, float depth) {
+  float* p = reinterpret_cast<float*>(splat) + GM_SPLAT_STRIDE * id;
+  *reinterpret_cast<gm_f4u*>(p) = gm_f4u{x, y, conx, cony};
+  *reinterpret_cast<gm_f4u*>(p + 4) = gm_f4u{conz, opacity, r, g};
+  if (GM_SPLAT_STRIDE >= 12) *reinterpret_cast<gm_f4u*>(p + 8) = gm_f4u{b, depth, 0.f, 0.f};
+  else p[8] = b;
+}
+
 struct GeomState {              // per-Gaussian state (P-sized)
-  float4* splat;                // [P][3]: {x,y,con.x,con.y} {con.z,opacity,r,g} {b,depth,0,0}
+  float4* splat;                // [P][GM_SPLAT_STRIDE floats]: splat_row / splat_blue / splat_store above
   int* radii;                   // internal radii when the caller passes none
   uint32_t* tiles_touched;      // [P]
   uint4* bin;                   // [P] emission record (bin_pack below): candidate tile rectangle, instance count and, for rectangles
@@ -158,7 +179,7 @@ struct GeomState {              // per-Gaussian state (P-sized)
     char* p = reinterpret_cast<char*>(buf);
     GeomState g;
     constexpr size_t ND = size_t(1) << GM_BUCKET_BITS;
-    g.splat = carve<float4>(p, 3 * P);
+    g.splat = reinterpret_cast<float4*>(carve<float>(p, GM_SPLAT_STRIDE * P + 4));
     g.radii = carve<int>(p, P);
     g.tiles_touched = carve<uint32_t>(p, P);
     g.bin = carve<uint4>(p, P);

@@ -309,9 +309,7 @@ __global__ __launch_bounds__(64) void deform_shade_kernel(int N, int deg, const 
     int radius_i = 0;
     if (vis) {
       const float opac = fp.opac[i];
-      fp.splat[3 * i + 0] = make_float4(pg.pix, pg.piy, pg.conx, pg.cony);
-      fp.splat[3 * i + 1] = make_float4(pg.conz, opac, col[0], col[1]);
-      fp.splat[3 * i + 2] = make_float4(col[2], pg.depth, 0.f, 0.f);
+      splat_store(fp.splat, i, pg.pix, pg.piy, pg.conx, pg.cony, pg.conz, opac, col[0], col[1], col[2], pg.depth);
       radius_i = (int)pg.radius;
       pre_emit(fp.cam, pg, opac, tiles, dbin);
     }

@@ -150,9 +150,7 @@ __global__ __launch_bounds__(TH) void preprocess_fwd_kernel(const PreArgs a) {
     }
     a.clamped[idx] = clampbits;
     const float opac = DMA ? in_op : a.opac[idx];
-    a.splat[3 * (size_t)idx + 0] = make_float4(pix, piy, pg.conx, pg.cony);
-    a.splat[3 * (size_t)idx + 1] = make_float4(pg.conz, opac, col[0], col[1]);
-    a.splat[3 * (size_t)idx + 2] = make_float4(col[2], pg.depth, 0.f, 0.f);
+    splat_store(a.splat, (size_t)idx, pix, piy, pg.conx, pg.cony, pg.conz, opac, col[0], col[1], col[2], pg.depth);
     radius_i = (int)pg.radius;
     pre_emit(cam, pg, opac, tiles, bin);
     dkey = __float_as_uint(pg.depth);
@@ -280,7 +278,7 @@ __device__ __forceinline__ void preprocess_bwd_body(const PreBwdArgs& a, const i
   const float dcol[3] = {acc0.x, acc0.y, acc0.z};
   float g2dx = 0.f, g2dy = 0.f, gop = 0.f;
   if (visible) {
-    const float4 s0 = a.splat[3 * (size_t)idx], s1 = a.splat[3 * (size_t)idx + 1];
+    const float4 s0 = splat_row(a.splat, (size_t)idx, 0), s1 = splat_row(a.splat, (size_t)idx, 1);
     const float cx = s0.z, cy = s0.w, cz = s1.x, op = s1.y;
     const float m0 = acc0.w, m1x = acc1.x, m1y = acc1.y;
     g2dx = -(0.5f * a.W) * (cx * m1x + cy * m1y);

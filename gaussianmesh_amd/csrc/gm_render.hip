@@ -149,8 +149,7 @@ __device__ __forceinline__ float staged_exponent(const float4& RA, float bq, v2f
 
 __device__ __forceinline__ Gather issue_gather(const float4* __restrict__ splat, uint2 cand) {
   Gather g;
-  const float4* rec = splat + 3 * (size_t)cand.x;
-  g.a = rec[0]; g.b = rec[1]; g.c = rec[2].x;
+  g.a = splat_row(splat, (size_t)cand.x, 0); g.b = splat_row(splat, (size_t)cand.x, 1); g.c = splat_blue(splat, (size_t)cand.x);
   g.id = cand.x; g.pos = cand.y;
   return g;
 }

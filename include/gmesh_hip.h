@@ -138,7 +138,9 @@ int gm_mark_visible(int P, const float* means3D, const float* viewmatrix, const 
 /* Read-only views into the opaque scratch buffers (tests / debugging; the reference exposes the
  * same data as the GeometryState/ImageState/BinningState structs, RAST/rasterizer_impl.h:29-65).
  * Each returns a device pointer inside the given buffer, or NULL for an unknown name.
- *   geom:    "splat" float[P][12] = {x,y,conic.x,conic.y | conic.z,opacity,r,g | b,depth,0,0},
+ *   geom:    "splat" float[P][gm_splat_floats()] = {x,y,conic.x,conic.y | conic.z,opacity,r,g | b} (9 floats: the record the blend
+ *            kernels gather), "depth_key" uint32[P] (float bits of the view-space depth, 0xFFFFFFFF for a culled Gaussian; not
+ *            written by the direct depth placement),
  *            "radii" int32[P] (internal copy: filled only by a forward that was given NO radii array; gm_backward reads it when it
  *            is given none either - pass the forward's array otherwise), "tiles_touched" uint32[P] (gm_forward_0_deformed_async
  *            fills it only for rectangles of 65535 instances or more: the count rides in the emission record), "cov3D" float[P][6],
@@ -150,6 +152,7 @@ int gm_mark_visible(int P, const float* means3D, const float* viewmatrix, const 
  *            (depth, id): column 1 is the reference's point_list, column 0 its sorted tile keys (child mask: policy 0/1
  *            = 1; policy 2 = the 4 x 4 8-pixel quadrants of the 32-px list tile, bit 4 qy + qx; policy 3 = the 4 x 4
  *            16-px tiles of the 64-px list tile, bit 4 ty + tx) */
+int gm_splat_floats(void);
 void* gm_geom_field(void* geom_buffer, int P, const char* name);
 void* gm_image_field(void* image_buffer, int W, int H, const char* name);
 void* gm_binning_field(void* binning_buffer, int64_t R, int W, int H, int emission_policy, const char* name);

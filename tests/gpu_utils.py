@@ -62,7 +62,9 @@ def forward_state(scene, cam, bg, D=3, use_precomp_cov=False, use_precomp_color=
     out = dict(R=nr, color=color.cpu().numpy(), radii=radii.cpu().numpy(), geom=geom, binning=binning, img=img)
     if P > 0:
         gp = lambda n: lib.gm_geom_field(geom.data_ptr(), P, n.encode())
-        out["splat"] = _view(geom, gp("splat"), P * 12, torch.float32).reshape(P, 12)
+        SF = lib.gm_splat_floats()                       # 9: x, y, conic xyz.., opacity, rgb (helpers below index it by name)
+        out["splat"] = _view(geom, gp("splat"), P * SF, torch.float32).reshape(P, SF)
+        out["depth_key"] = _view(geom, gp("depth_key"), P, torch.int32).astype(np.uint32)
         out["tiles"] = _view(geom, gp("tiles_touched"), P, torch.int32).astype(np.uint32)
         out["cov3D"] = _view(geom, gp("cov3D"), P * 6, torch.float32).reshape(P, 6)
         out["clamped"] = _view(geom, gp("clamped"), P, torch.uint8)

@@ -46,7 +46,7 @@ def _check_list_invariants(st, cam, mode=0):
     keys = st["tile_keys"].astype(np.int64)
     assert (np.diff(keys) >= 0).all() and keys.max() < T
     # inside a tile: depth non-decreasing, ties broken by ascending Gaussian id (the reference's stable sort)
-    depth_bits = st["splat"][:, 9].view(np.uint32).astype(np.int64)[st["point_list"]]
+    depth_bits = st["depth_key"].astype(np.int64)[st["point_list"]]
     same = keys[1:] == keys[:-1]
     dd = np.diff(depth_bits)
     assert (dd[same] >= 0).all()

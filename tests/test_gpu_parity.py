@@ -37,7 +37,7 @@ def _check_geometry(orc, st, fw, scene, use_precomp_color):
     con = np.concatenate([sp[:, 2:4], sp[:, 4:5]], 1)
     assert np.array_equal(con[vis].view(np.uint32), g["conic_op"][vis, :3].view(np.uint32))
     assert np.array_equal(sp[vis, 5], g["conic_op"][vis, 3])
-    assert np.array_equal(sp[vis, 9].view(np.uint32), g["depths"][vis].view(np.uint32))
+    assert np.array_equal(st["depth_key"][vis], g["depths"][vis].view(np.uint32)) and (st["depth_key"][~vis] == 0xFFFFFFFF).all()
     rgb = np.concatenate([sp[:, 6:8], sp[:, 8:9]], 1)
     assert np.array_equal(rgb[vis].view(np.uint32), g["rgb"][vis].view(np.uint32))
     if not use_precomp_color:
