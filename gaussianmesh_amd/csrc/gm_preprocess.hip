@@ -299,17 +299,38 @@ __device__ __forceinline__ void preprocess_bwd_body(const PreBwdArgs& a, const i
     for (int k = 0; k < 6; k++) c3[k] = a.cov3D[6 * (size_t)idx + k];
     {  // ---- computeCov2DCUDA, backward.cu:144-274
       const float dcx = gcx, dcy = gcy, dcz = gcw;
-      V3 t; float T0[3], T1[3], xm, ym, ca, cb, cc;
+      V3 t; float T0[3], T1[3], xm, ym;
       cov2d_T(mean, a.fx, a.fy, a.tanx, a.tany, a.view, t, T0, T1, xm, ym);
-      cov2d_from_T(T0, T1, c3, ca, cb, cc);
-      ca += 0.3f; cc += 0.3f;
-      const float denom = ca * cc - cb * cb;
-      float dL_da = 0, dL_db = 0, dL_dc = 0;
-      const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
-      if (denom2inv != 0) {
-        dL_da = denom2inv * (-cc * cc * dcx + 2 * cb * cc * dcy + (denom - ca * cc) * dcz);
-        dL_dc = denom2inv * (-ca * ca * dcz + 2 * ca * cb * dcy + (denom - ca * cc) * dcx);
-        dL_db = denom2inv * 2 * (cb * cc * dcx - (denom + 2 * cb * cb) * dcy + ca * cb * dcz);
+      // conic -> cov2D (backward.cu:196-215) in BINARY64.  The three derivatives are quadratic forms in (a, b, c) whose terms cancel by
+      // det / (a c): for a 100:1 needle seen at an angle a c / det ~ 500 and the float32 statement of the reference loses the second
+      // to third digit of dL/dscale, dL/drot and dL/dmean (tools/needle_stages.py: the float64 blend-stage gradients through the
+      // float32 formula are 4e-3 ... 1.2e-2 of the tensor's size away from float64 autograd; with THIS block in binary64 - the
+      // covariance entries from the float32 T and cov3D, the determinant, the three derivatives - 5e-5 ... 6e-4).  ~60 double
+      // operations per Gaussian in a kernel that waits for memory.  On well-conditioned splats the result is the float32 one to 1e-6.
+      double dL_da_d = 0, dL_db_d = 0, dL_dc_d = 0;
+      {
+        const double V0[3] = {c3[0], c3[1], c3[2]}, V1[3] = {c3[1], c3[3], c3[4]}, V2[3] = {c3[2], c3[4], c3[5]};
+        double A0[3], A1[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          A0[k] = (double)T0[0] * V0[k] + (double)T0[1] * V1[k] + (double)T0[2] * V2[k];
+          A1[k] = (double)T1[0] * V0[k] + (double)T1[1] * V1[k] + (double)T1[2] * V2[k];
+        }
+        const double ca = A0[0] * T0[0] + A0[1] * T0[1] + A0[2] * T0[2] + 0.3;
+        const double cb = A1[0] * T0[0] + A1[1] * T0[1] + A1[2] * T0[2];
+        const double cc = A1[0] * T1[0] + A1[1] * T1[1] + A1[2] * T1[2] + 0.3;
+        const double denom = ca * cc - cb * cb;
+        const float d2f = (float)(denom * denom) + 0.0000001f;                  // (the reciprocal itself is well-conditioned: float32)
+        const double denom2inv = (double)(1.0f / d2f);
+        if (denom2inv != 0) {
+          const double dcx_d = dcx, dcy_d = dcy, dcz_d = dcz;
+          dL_da_d = denom2inv * (-cc * cc * dcx_d + 2 * cb * cc * dcy_d - cb * cb * dcz_d);          // (denom - a c = -b^2)
+          dL_dc_d = denom2inv * (-ca * ca * dcz_d + 2 * ca * cb * dcy_d - cb * cb * dcx_d);
+          dL_db_d = denom2inv * 2 * (cb * cc * dcx_d - (ca * cc + cb * cb) * dcy_d + ca * cb * dcz_d);   // (denom + 2 b^2 = a c + b^2)
+        }
+      }
+      const float dL_da = (float)dL_da_d, dL_db = (float)dL_db_d, dL_dc = (float)dL_dc_d;
+      {
         dcov[0] = (T0[0] * T0[0] * dL_da + T0[0] * T1[0] * dL_db + T1[0] * T1[0] * dL_dc);
         dcov[3] = (T0[1] * T0[1] * dL_da + T0[1] * T1[1] * dL_db + T1[1] * T1[1] * dL_dc);
         dcov[5] = (T0[2] * T0[2] * dL_da + T0[2] * T1[2] * dL_db + T1[2] * T1[2] * dL_dc);

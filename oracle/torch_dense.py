@@ -148,5 +148,6 @@ def render(means, opac, view, proj, campos, W, H, tanx, tany, bg, D=3, shs=None,
     out = (C + T[:, None] * bg[None, :]).transpose(0, 1).reshape(3, H, W)
     aux = dict(radii=torch.where(vis, radius, torch.zeros_like(radius)).to(torch.int32), final_T=T.detach(),
                n_contrib=ncontrib, conic=conic.detach(), xy=torch.stack([px, py], 1).detach(), rgb=col.detach(),
-               depth=t[:, 2].detach(), cov2=torch.stack([a, b, cc], 1).detach())
-    return out, aux
+               depth=t[:, 2].detach(), cov2=torch.stack([a, b, cc], 1).detach(),
+               live=dict(conic=conic, px=px, py=py))    # non-detached intermediates: retain_grad() them before backward to get the
+    return out, aux                                     # float64 truth of dL/dconic and dL/d(pixel position) (tools/needle_stages.py)

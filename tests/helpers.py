@@ -19,6 +19,29 @@ def small_scene(P=300, W=48, H=40, seed=0, D=3, scale_lo=0.05, scale_hi=0.6, cam
     return sc, cam
 
 
+def fuzz_scene(seed):
+    """The random scene of tools/fuzz_oracle_parity.py / tests/test_gpu_fuzz_parity.py for a seed: 50-3000 Gaussians, 17-160 x 17-120 pixels,
+    random orbit camera / background / SH degree / input mode; EVERY THIRD SEED stretches the first axis of every splat ten-fold
+    (100:1 needles: the ill-conditioned regime of DESIGN.md section 2).  Returns (scene, cam, bg, D, pre_cov, pre_col, dL_dpix)."""
+    rng = np.random.default_rng(100 + seed)
+    P = int(rng.integers(50, 3000))
+    lo = float(10 ** rng.uniform(-2.3, -1)); hi = lo * float(10 ** rng.uniform(0.3, 1.6))
+    sc = scenes.make_cloud(P, seed=seed, scale_lo=lo, scale_hi=hi)
+    if seed % 3 == 0:
+        sc["scales"][:, 0] *= 10.0
+    W = int(rng.integers(17, 160)); H = int(rng.integers(17, 120))
+    cam = scenes.orbit_camera(int(rng.integers(0, 16)), 16, W, H, radius=float(rng.uniform(2.0, 9.0)))
+    bg = rng.random(3).astype(np.float32)
+    D = int(rng.integers(0, 4))
+    pre_cov, pre_col = bool(seed % 2), bool((seed // 2) % 2)
+    if pre_cov:
+        sc["cov3D_precomp"] = scenes.strip_symmetric(scenes.cov3d_from_scale_rot(sc["scales"], sc["rots"])).astype(np.float32)
+    if pre_col:
+        sc["colors_precomp"] = rng.random((P, 3)).astype(np.float32)
+    dpix = rng.normal(size=(3, H, W)).astype(np.float32)
+    return sc, cam, bg, D, pre_cov, pre_col, dpix
+
+
 def account_outlier_pixels(fw, color, W, H, tol=1e-4, mask=None):
     """Flip accounting for the forward gate (north_star: <= 1e-4 max-abs per pixel).
 

@@ -5,25 +5,11 @@ import numpy as np, torch
 from gaussianmesh_amd import scenes
 from oracle import oracle
 from test_gpu_parity import _grads_gpu, _rel
+from helpers import fuzz_scene
 worst_f, worst_g, bad = 0.0, 0.0, 0
 NSEEDS = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 for seed in range(NSEEDS):
-    rng = np.random.default_rng(100 + seed)
-    P = int(rng.integers(50, 3000))
-    lo = float(10 ** rng.uniform(-2.3, -1)); hi = lo * float(10 ** rng.uniform(0.3, 1.6))
-    sc = scenes.make_cloud(P, seed=seed, scale_lo=lo, scale_hi=hi)
-    if seed % 3 == 0:
-        sc["scales"][:, 0] *= 10.0
-    W = int(rng.integers(17, 160)); H = int(rng.integers(17, 120))
-    cam = scenes.orbit_camera(int(rng.integers(0, 16)), 16, W, H, radius=float(rng.uniform(2.0, 9.0)))
-    bg = rng.random(3).astype(np.float32)
-    D = int(rng.integers(0, 4))
-    pre_cov, pre_col = bool(seed % 2), bool((seed // 2) % 2)
-    if pre_cov:
-        sc["cov3D_precomp"] = scenes.strip_symmetric(scenes.cov3d_from_scale_rot(sc["scales"], sc["rots"])).astype(np.float32)
-    if pre_col:
-        sc["colors_precomp"] = rng.random((P, 3)).astype(np.float32)
-    dpix = rng.normal(size=(3, H, W)).astype(np.float32)
+    sc, cam, bg, D, pre_cov, pre_col, dpix = fuzz_scene(seed); P, W, H = sc["means"].shape[0], cam["W"], cam["H"]
     fw = oracle.forward_full(sc, cam, bg, D=D, use_precomp_cov=pre_cov, use_precomp_color=pre_col)
     bw = oracle.backward_full(sc, cam, bg, fw, dpix, D=D, use_precomp_cov=pre_cov, use_precomp_color=pre_col)
     color, radii, g = _grads_gpu(sc, cam, bg, dpix, D, pre_cov, pre_col)
