@@ -40,14 +40,55 @@ KERNEL_OF_STAGE = {"mesh_rs": "gm::mesh_rs_kernel", "deform": "gm::deform_shade_
 
 
 # The frame loop rotates over four HIP streams; the runtime multiplexes streams onto 4 hardware queues by default, and streams
-# that share a queue serialise against each other (4 streams on 4 queues: 3460 frames/s, on 8 queues: 4300).  Must be set
-# before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# that share a queue serialise against each other (4 streams on 4 queues: 3460 frames/s, on 8 queues: 4300): GPU_MAX_HW_QUEUES=8.
 # N > 1: RCCL sets up its xGMI peer buffers through HIP IPC handles, and the host driver of these nodes supports only the dmabuf
-# flavour: with the legacy mode left on, the first collective fails with `hipIpcGetMemHandle: invalid argument`.  The image
-# exports it; set here as well (before HIP starts) so that a launch from a clean environment - the driver's torch.distributed.run,
-# a test's subprocess - runs in the same mode.  Harmless at N = 1.
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# flavour: with the legacy mode left on, the first collective fails with `hipIpcGetMemHandle: invalid argument`
+# (HSA_ENABLE_IPC_MODE_LEGACY=0; the image exports it, set here as well so that a launch from a clean environment - the driver's
+# torch.distributed.run, a test's subprocess - runs in the same mode; harmless at N = 1).  Both must be in the environment before
+# the HIP runtime initialises; the package does not touch the environment on import, the integrator - here bench.py - calls
+# configure_runtime() (GM_NO_RUNTIME_CONFIG=1 leaves the environment to the launcher).
+import gaussianmesh_amd
+RUNTIME = gaussianmesh_amd.configure_runtime(hw_queues=8, ipc_dmabuf=True)
+
+
+class DistStage:
+    """Failure surface of the N > 1 start-up (round 5): the first RCCL collectives this code ever issues are the driver's scaling
+    run.  A stage that raises, or that is still running after `seconds` (a hang inside a collective never returns to Python: a timer
+    thread watches it), ends the process with ONE parseable JSON line - {"error", "stage", "rank", "rank_env"} - on stdout (rank 0)
+    or stderr (other ranks) and a non-zero exit code, instead of a traceback on one rank and a silent hang on the others."""
+
+    def __init__(self, stage, rank, world, seconds, debug_file=None):
+        self.stage, self.rank, self.world, self.seconds, self.debug_file = stage, rank, world, seconds, debug_file
+        self.timer = None
+
+    def report(self, err, code):
+        tail = None
+        try:
+            if self.debug_file and os.path.exists(self.debug_file):
+                tail = open(self.debug_file, errors="replace").read()[-1500:]
+        except OSError:
+            pass
+        env = {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG", "NCCL_DEBUG_FILE", "MASTER_ADDR", "MASTER_PORT", "WORLD_SIZE",
+                                              "RANK", "LOCAL_RANK", "GM_BENCH_BACKEND", "GPU_MAX_HW_QUEUES", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES")}
+        line = json.dumps({"error": str(err)[-2000:], "stage": self.stage, "rank": self.rank, "n_gpus": self.world,
+                           "rank_env": dict(env, nccl_debug_tail=tail), "metric": "frames/sec (fwd), 1M Gaussians @1080p, deform+render", "value": None})
+        (sys.stdout if self.rank == 0 else sys.stderr).write(line + "\n")
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(code)                           # (not sys.exit: a rank stuck in a collective has threads that never join)
+
+    def __enter__(self):
+        import threading
+        self.timer = threading.Timer(self.seconds, lambda: self.report("stage still running after %.0f s (hang)" % self.seconds, 3))
+        self.timer.daemon = True
+        self.timer.start()
+        return self
+
+    def __exit__(self, et, ev, tb):
+        self.timer.cancel()
+        if et is not None and not issubclass(et, (SystemExit, KeyboardInterrupt)):
+            import traceback
+            self.report("%s: %s | %s" % (et.__name__, ev, "".join(traceback.format_tb(tb)[-2:]).replace("\n", " ")), 2)
+        return False
 
 
 def build_scene(P, W, H, frames, seed=0):
@@ -390,6 +431,10 @@ def main():
     ap.add_argument("--backward-state", action="store_true", help="have the blend also write the per-pixel final transmittance / "
                     "contributor count (the state only a backward pass reads); the edit loop is forward-only and renders "
                     "with GM_FWD_IMAGE_ONLY by default")
+    ap.add_argument("--no-discard-region", action="store_true", help="time the FIRST region of K steps behind the W warm-up steps (rounds 1-4) "
+                    "instead of running one discarded region of K steps in front of the timed one")
+    ap.add_argument("--no-variants", dest="variants", action="store_false", help="N = 1: leave out the two extra regions that time the loop with "
+                    "the backward state written / with [N,3,3] rest covariances (`variants` of the bench line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fwd-bwd", action="store_true")
     ap.add_argument("--no-c5", action="store_true", help="leave out the C5 legs (the 3 M-Gaussian 4K training loop: the reference's first 1000 "
@@ -412,7 +457,6 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     # one block of host cores per rank (before the HIP runtime and RCCL start their threads); GM_RANK_AFFINITY=0 leaves it to the OS
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     pinned = multiview.pin_rank_to_cores(local_rank, local_world)
@@ -424,14 +468,27 @@ def main():
     if os.environ.get("GM_BENCH_SHARE_DEVICE") == "1":
         local_rank = 0
     backend = os.environ.get("GM_BENCH_BACKEND", "nccl")
-    torch.cuda.set_device(local_rank)
+    have_gpu = torch.cuda.is_available()
+    if have_gpu:
+        torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist_timeout = float(os.environ.get("GM_BENCH_DIST_TIMEOUT", "120"))
+    rccl_log = None
     if world > 1:
+        from datetime import timedelta
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        # RCCL's own warnings of this rank in a file of its own (its tail goes into the error line of a failed start-up)
+        log_dir = args.check_dir or os.path.join("/tmp", "gm_bench_rccl_%s" % os.environ.get("MASTER_PORT", "0"))
+        os.makedirs(log_dir, exist_ok=True)
+        rccl_log = os.path.join(log_dir, "rccl_rank%d.log" % rank)
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
+        os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
+        with DistStage("rccl_init" if backend == "nccl" else backend + "_init", rank, world, dist_timeout + 30, rccl_log):
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=timedelta(seconds=dist_timeout))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world, timeout=timedelta(seconds=dist_timeout))
+    assert have_gpu, "bench.py needs a GPU (the HIP path has no CPU fallback)"
     lib = _lib.lib()
     if args.policy is not None:
         Rz.set_default_emission_policy(args.policy)
@@ -452,7 +509,16 @@ def main():
         for k, (shp, dt) in shapes.items():
             g[k] = torch.empty(shp, dtype=dt, device=dev)
     # the animation ("mesh") stays on rank 0; its frames are broadcast one at a time inside the timed loop
-    multiview.broadcast_cloud({k: v for k, v in g.items() if k != "mesh"}, src=0)
+    n_ranks_seen = 1
+    if world > 1:
+        # the first collectives: the cloud (0.3 GB in eleven broadcasts) and an all-reduce of ones - proof in the bench line that the
+        # backend saw all N ranks.  Completed (device synchronised) inside the guarded stage: RCCL reports asynchronously
+        with DistStage("first_broadcast", rank, world, dist_timeout + 30, rccl_log):
+            multiview.broadcast_cloud({k: v for k, v in g.items() if k != "mesh"}, src=0)
+            n_ranks_seen = int(round(multiview.sum_over_ranks(1.0, dev)))
+            torch.cuda.synchronize()
+            if n_ranks_seen != world:
+                raise RuntimeError("all-reduce of ones over %d ranks returned %d" % (world, n_ranks_seen))
     # the rest covariances as their six distinct entries where every matrix is symmetric bit for bit (one-time, like the mesh tables'
     # packing): the fused pass then reads 24 instead of 36 bytes per Gaussian and computes what it computes from [N,3,3]
     from gaussianmesh_amd.deform import pack_cov6
@@ -655,17 +721,44 @@ def main():
             sys.stderr.write("   host us per step (begin / finish+verify): %s\n" % " ".join("%.0f/%.0f" % (1e6 * a, 1e6 * b) for a, b in host_split))
         return el
 
-    elapsed = timed_region(args.warmup)
+    # One DISCARDED region of the same K steps in front of the timed one (round 5, asked for by the round-4 review): the first
+    # region after the long device-bound setup runs 3-6 % slower than every region behind it (profiles/r04_region_timeline.txt: the
+    # host needs 100-170 us per frame instead of 70 for its first ten to fifteen frames, and steps W .. W+K-1 are the orbit's
+    # heaviest stretch), and that first region was the one the driver scored.  It is warm-up, bracketed by the same barriers, and
+    # reported (config.discarded_region_frames_per_s); --no-discard-region restores the old behaviour.
+    first = args.warmup
+    discarded_fps = None
+    if not args.no_discard_region:
+        discarded_fps = world * args.steps / multiview.max_over_ranks(timed_region(first), dev)
+        first += args.steps
+    elapsed = timed_region(first)
     per_rank_s = multiview.gather_over_ranks(elapsed, dev)       # every rank's own clock around the same barriers
     elapsed = multiview.max_over_ranks(elapsed, dev)
     fps = world * args.steps / elapsed
     repeats = []
+    variants = {}
     single_stream_ms = None
     if world == 1:
-        nxt = args.warmup + args.steps
+        nxt = first + args.steps
         for _ in range(max(0, args.repeats)):    # the same region again: run-to-run spread of the pipelined loop
             repeats.append(args.steps / timed_region(nxt))
             nxt += args.steps
+        # the same loop in the two configurations the headline does not use (both disclosed in `config`): with the per-pixel backward
+        # state written as the reference's forward always does (forward.cu:369-370), and with the rest covariances handed over as
+        # [N,3,3] (the reference's deform_gaussian signature) instead of the six distinct entries
+        if args.variants and not args.unfused and dplan is None:
+            keep_io, keep_cov = image_only, g["cov_in"]
+            if image_only:
+                image_only = False
+                timed_region(nxt); nxt += args.steps                    # (the workspaces' image buffers grow: one untimed pass)
+                variants["backward_state"] = args.steps / timed_region(nxt); nxt += args.steps
+                image_only = keep_io
+            if g["cov_in"] is not g["cov"]:
+                g["cov_in"] = g["cov"]
+                timed_region(nxt); nxt += args.steps
+                variants["cov9"] = args.steps / timed_region(nxt); nxt += args.steps
+                g["cov_in"] = keep_cov
+            timed_region(nxt); nxt += args.steps
         # latency of one frame: the same frames one after the other on one stream, each completed before the next begins
         nlat = min(args.steps, 100)
         torch.cuda.synchronize()
@@ -678,11 +771,11 @@ def main():
         single_stream_ms = 1e3 * (time.perf_counter() - t1) / nlat
     gc.enable()
     if args.check_dir:
-        last = args.warmup + args.steps - 1
+        last = first + args.steps - 1
         os.makedirs(args.check_dir, exist_ok=True)
         np.savez(os.path.join(args.check_dir, "rank%d.npz" % rank), step=last, frame=last % F, view=multiview.view_for_step(last, F, rank, world),
                  image=stats["last_image"].cpu().numpy(), overflows=stats["overflows"],
-                 views=np.array([v for (k, v) in views_walked if args.warmup <= k < args.warmup + args.steps], np.int64))   # timed steps only
+                 views=np.array([v for (k, v) in views_walked if first <= k < first + args.steps], np.int64))   # timed steps only
 
     out = {
         "metric": "frames/sec (fwd), 1M Gaussians @1080p, deform+render", "value": fps, "unit": "frames/s",
@@ -692,7 +785,7 @@ def main():
                                "render %dx%d, %d-camera orbit, views sharded by rank" % (P, W, H, F),
                    "gaussians": P, "width": W, "height": H, "sh_degree": 3, "views_per_step_per_gpu": 1,
                    "vertex_rs": "analytic tables" if args.analytic_rs else "gm_mesh_rs per frame", "hip_streams": nstreams,
-                   "exchange": None if pipe is None else {"steps_per_broadcast": pipe.batch, "bytes_per_step": exchange_bytes, "broadcasts": pipe.broadcasts,
+                   "exchange": None if pipe is None else {"n_ranks_seen": n_ranks_seen, "backend": backend if world > 1 else None, "steps_per_broadcast": pipe.batch, "bytes_per_step": exchange_bytes, "broadcasts": pipe.broadcasts,
                                                           "payload": "per-vertex (R, S) tables" if args.analytic_rs else "deformed vertex positions; (R, S) by gm_mesh_rs on every rank",
                                                           # a slow rank is visible here: each rank's own time for the region / steps
                                                           "ms_per_step_by_rank": [round(1e3 * t / args.steps, 4) for t in per_rank_s],
@@ -703,6 +796,12 @@ def main():
                    "frames_redone": stats["overflows"],          # sync-free frames that outgrew their binning buffer (rendered again, exactly)
                    "parallelism": "views x%d" % world},
     }
+    out["config"]["discarded_region_frames_per_s"] = None if discarded_fps is None else round(discarded_fps, 1)
+    out["config"]["runtime"] = RUNTIME
+    if variants:
+        out["variants"] = {k: round(v, 1) for k, v in variants.items()}
+        out["variants"]["note"] = ("frames/s of the same pipelined loop with the per-pixel final_T / n_contrib written (backward_state) and with "
+                                   "[N,3,3] rest covariances instead of the packed [N,6] (cov9); `value` is image-only + cov6")
     if repeats:
         out["repeats"] = {"frames_per_s": [round(x, 1) for x in repeats], "median": float(np.median(repeats + [fps]))}
     if single_stream_ms is not None:

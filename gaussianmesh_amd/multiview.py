@@ -159,6 +159,16 @@ def max_over_ranks(value, device):
     return float(t.item())
 
 
+def sum_over_ranks(value, device):
+    """SUM all-reduce of a python float (bench.py: an all-reduce of ones = the number of ranks the backend saw)."""
+    rank, ws = world()
+    if ws == 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
 def gather_over_ranks(value, device):
     """Every rank's python float, as a list indexed by rank (timing diagnostics: a slow rank shows in the bench line)."""
     rank, ws = world()

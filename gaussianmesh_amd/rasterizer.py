@@ -187,24 +187,26 @@ _QUEUE_WARNED = [False]
 def _note_stream(stream):
     """Frames pipelined over three or more HIP streams only overlap if the runtime has a hardware queue for each: HIP multiplexes
     streams onto FOUR queues by default and streams that share one serialise (four streams: 4160 frames/s on 4 queues, 5010 on 8,
-    DESIGN.md section 5).  The package exports GPU_MAX_HW_QUEUES=8 when it is imported (gaussianmesh_amd/__init__.py) unless the
-    caller has set it; that only helps if the HIP runtime had not made its first call yet.  Warn, once, when the third stream shows
-    up and the package's own setting came after torch had initialised the device."""
+    DESIGN.md section 5).  gaussianmesh_amd.configure_runtime() exports GPU_MAX_HW_QUEUES=8 when the integrator calls it before the
+    first HIP call (the package itself never touches the environment).  Warn, once, when the third stream shows up and the variable is
+    not set (or was set too late to be read)."""
     if _QUEUE_WARNED[0]:
         return
     _STREAMS_SEEN.add(stream.cuda_stream)
     if len(_STREAMS_SEEN) >= 3:
         _QUEUE_WARNED[0] = True
+        import os
         import warnings
         import gaussianmesh_amd as _pkg
-        if getattr(_pkg, "QUEUES_SET_ON_IMPORT", False) and _HIP_UP_AT_IMPORT:
-            warnings.warn("gaussianmesh_amd: frames are being issued on %d HIP streams, but the HIP runtime was already running when this "
-                          "package exported GPU_MAX_HW_QUEUES=8; the runtime multiplexes streams onto 4 hardware queues by default and "
-                          "streams sharing a queue serialise. Import gaussianmesh_amd (or export GPU_MAX_HW_QUEUES=8) before the first "
-                          "torch.cuda call." % len(_STREAMS_SEEN), RuntimeWarning, stacklevel=3)
+        cfg = _pkg.RUNTIME_CONFIG
+        if "GPU_MAX_HW_QUEUES" not in os.environ or (cfg.get("hw_queues") and not cfg.get("applied") and "AFTER" in cfg.get("note", "")):
+            warnings.warn("gaussianmesh_amd: frames are being issued on %d HIP streams, but GPU_MAX_HW_QUEUES was not set before the HIP "
+                          "runtime started; the runtime multiplexes streams onto 4 hardware queues by default and streams sharing a queue "
+                          "serialise (-17 %% on the four-stream loop). Call gaussianmesh_amd.configure_runtime() (or export "
+                          "GPU_MAX_HW_QUEUES=8) before the first torch.cuda call." % len(_STREAMS_SEEN), RuntimeWarning, stacklevel=3)
 
 
-_HIP_UP_AT_IMPORT = torch.cuda.is_initialized()
+
 
 
 def new_work_hint(width, height, device):

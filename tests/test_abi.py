@@ -88,16 +88,20 @@ def test_operator_argument_rules_match_reference():
     assert GaussianRasterizationSettings._fields[12:] == ("work_hint",) and rs.work_hint is None
 
 
-def test_import_exports_the_hardware_queue_setting():
+def test_import_has_no_side_effects_and_configure_runtime_is_opt_in():
     """HIP multiplexes streams onto four hardware queues unless GPU_MAX_HW_QUEUES says otherwise, and a four-stream frame loop loses
-    17 % to that: importing the package exports 8 - read by the runtime at its first call, which comes later -
-    and leaves a caller's own setting alone."""
+    17 % to that (INTEGRATION.md E).  Importing the package leaves the environment alone (round 5; it used to export the variable);
+    configure_runtime() exports 8 - read by the runtime at its first call, which comes later - leaves a caller's own setting alone and
+    is switched off by GM_NO_RUNTIME_CONFIG=1."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = "import os, gaussianmesh_amd as g; print(os.environ['GPU_MAX_HW_QUEUES'], g.QUEUES_SET_ON_IMPORT)"
-    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
-    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
-    assert out.stdout.split() == ["8", "True"], out.stderr[-500:]
-    env["GPU_MAX_HW_QUEUES"] = "4"
-    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
-    assert out.stdout.split() == ["4", "False"], out.stderr[-500:]
+    code = ("import os, gaussianmesh_amd as g; a = os.environ.get('GPU_MAX_HW_QUEUES'); r = g.configure_runtime(ipc_dmabuf=True); "
+            "print(a, os.environ.get('GPU_MAX_HW_QUEUES'), r['applied'], os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'))")
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "HSA_ENABLE_IPC_MODE_LEGACY", "GM_NO_RUNTIME_CONFIG")}
+    run = lambda e: subprocess.run([sys.executable, "-c", code], cwd=root, env=e, capture_output=True, text=True, timeout=300)
+    out = run(env)
+    assert out.stdout.split() == ["None", "8", "True", "0"], out.stderr[-500:]
+    out = run(dict(env, GPU_MAX_HW_QUEUES="4"))
+    assert out.stdout.split() == ["4", "4", "False", "0"], out.stderr[-500:]
+    out = run(dict(env, GM_NO_RUNTIME_CONFIG="1"))
+    assert out.stdout.split() == ["None", "None", "False", "None"], out.stderr[-500:]

@@ -80,7 +80,7 @@ def test_c4_at_full_size_eight_ranks_on_one_gpu(tmp_path):
     host = bench.build_scene(P, W, H, F)
     g = {k: T(host[k]) for k in ("weights", "pos", "cov", "opac", "shs", "verts")}
     g["tri"] = T(host["tri"], dtype=torch.int32)
-    last = warm + steps - 1
+    last = warm + 2 * steps - 1                  # (bench.py runs one discarded region of `steps` in front of the timed one)
     for r in (0, 5):
         d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
         v = multiview.view_for_step(last, F, r, 8)
@@ -117,7 +117,7 @@ def _two_ranks(tmp_path, batch, env_extra):
     host = bench.build_scene(P, W, H, F)
     g = {k: T(host[k]) for k in ("weights", "pos", "cov", "opac", "shs", "verts")}
     g["tri"] = T(host["tri"], dtype=torch.int32)
-    last = warm + steps - 1
+    last = warm + 2 * steps - 1                  # (bench.py runs one discarded region of `steps` in front of the timed one)
     views = set()
     for r in range(2):
         d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))

@@ -22,15 +22,21 @@
 #define REP16(x) REP4(x) REP4(x) REP4(x) REP4(x)
 
 enum Cls { FMA, FMA_DEP, MUL, ADD, PK_FMA, PK_MUL, EXP, LOG, RCP, SQRT, CNDMASK, CMP, CMP_CNDMASK, MED3, READLANE, MBCNT, DS_B128_BCAST, DS_B128_LANE, DS_B32_LANE,
-           DS_B64_LANE, FWD_BODY, BWD_BODY, NCLS };
+           DS_B64_LANE, FWD_BODY, BWD_BODY,
+           AND_B32, OR_B32, NOT_B32, ASHR_I32, SUB_U32, MAX_U32, MIN_F32, MAX_F32, MOV_B32, BFI_B32, AND_OR_B32, CNDMASK_SGPR, CNDMASK_CONST0, MUL_SGPR, CMP_SGPR, CMPX, FMAC_F32, FWD_BODY_B, FWD_BODY_A, NCLS };
 static const char* cls_name[NCLS] = {"v_fma_f32 (16 independent)", "v_fma_f32 (dependent chain)", "v_mul_f32", "v_add_f32", "v_pk_fma_f32", "v_pk_mul_f32",
                                      "v_exp_f32", "v_log_f32", "v_rcp_f32", "v_sqrt_f32", "v_cndmask_b32 (vcc)", "v_cmp_ge_f32 (-> vcc)",
                                      "v_cmp_ge_f32 + v_cndmask_b32 pair", "v_med3_f32", "v_readlane_b32 (-> sgpr)", "v_mbcnt_lo/hi pair",
                                      "ds_read_b128, one address per wave (broadcast)", "ds_read_b128, lane-linear", "ds_read_b32, lane-linear",
                                      "ds_read_b64, lane-linear",
-                                     "forward-blend body, cycles per SURVIVOR (15 VALU as compiled here)", "backward-blend phase-1 body, cycles per ENTRY (28 VALU+3 ds_read+1 ds_write)"};
+                                     "forward-blend body, cycles per SURVIVOR (15 VALU as compiled here)", "backward-blend phase-1 body, cycles per ENTRY (28 VALU+3 ds_read+1 ds_write)",
+                                     "v_and_b32", "v_or_b32", "v_not_b32", "v_ashrrev_i32 (31)", "v_sub_u32", "v_max_u32", "v_min_f32", "v_max_f32", "v_mov_b32", "v_bfi_b32",
+                                     "v_and_or_b32", "v_cndmask_b32_e64 (mask in an SGPR pair)", "v_cndmask_b32 v, 0, v, vcc", "v_mul_f32 with an SGPR operand",
+                                     "v_cmp_ge_f32_e64 (-> SGPR pair)", "v_cmpx_ge_f32 (-> exec, always true)", "v_fmac_f32 (VOP2)",
+                                     "forward-blend body B: selects as integer masks (C++), cycles per SURVIVOR",
+                                     "forward-blend body A: stop through EXEC (asm), cycles per SURVIVOR"};
 // instructions per block of the class (for the per-instruction figures)
-static const int cls_insts[NCLS] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 16, 8};
+static const int cls_insts[NCLS] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 16, 8, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 16, 16};
 
 template <int C>
 __global__ __launch_bounds__(256) void probe_kernel(int iters, unsigned long long* __restrict__ out, float seed) {
@@ -106,6 +112,106 @@ __global__ __launch_bounds__(256) void probe_kernel(int iters, unsigned long lon
     } else if (C == DS_B64_LANE) {
       REP16(asm volatile("ds_read_b64 %0, %4\n ds_read_b64 %1, %4 offset:512\n ds_read_b64 %2, %4 offset:1024\n ds_read_b64 %3, %4 offset:1536\n s_waitcnt lgkmcnt(0)\n"
                          : "=v"(p0), "=v"(p1), "=v"(p2), "=v"(p3) : "v"(lane_addr64) : "memory");)
+    } else if (C == AND_B32 || C == OR_B32 || C == SUB_U32 || C == MAX_U32 || C == MIN_F32 || C == MAX_F32 || C == FMAC_F32) {
+      if (C == AND_B32) { ONE16("v_and_b32", ", %16") } else if (C == OR_B32) { ONE16("v_or_b32", ", %16") } else if (C == SUB_U32) { ONE16("v_sub_u32", ", %16") }
+      else if (C == MAX_U32) { ONE16("v_max_u32", ", %16") } else if (C == MIN_F32) { ONE16("v_min_f32", ", %16") } else if (C == MAX_F32) { ONE16("v_max_f32", ", %16") }
+      else { ONE16("v_fmac_f32", ", %16") }
+    } else if (C == NOT_B32) { ONE16("v_not_b32", "")
+    } else if (C == BFI_B32) { ONE16("v_bfi_b32", ", %16, %17")
+    } else if (C == AND_OR_B32) { ONE16("v_and_or_b32", ", %16, %17")
+    } else if (C == ASHR_I32 || C == MOV_B32 || C == CNDMASK_CONST0) {
+#define PRE16(OP, PRE, TAIL) \
+      REP4(asm volatile(OP " %0, " PRE "%0" TAIL "\n" OP " %1, " PRE "%1" TAIL "\n" OP " %2, " PRE "%2" TAIL "\n" OP " %3, " PRE "%3" TAIL "\n" \
+                        OP " %4, " PRE "%4" TAIL "\n" OP " %5, " PRE "%5" TAIL "\n" OP " %6, " PRE "%6" TAIL "\n" OP " %7, " PRE "%7" TAIL "\n" \
+                        OP " %8, " PRE "%8" TAIL "\n" OP " %9, " PRE "%9" TAIL "\n" OP " %10, " PRE "%10" TAIL "\n" OP " %11, " PRE "%11" TAIL "\n" \
+                        OP " %12, " PRE "%12" TAIL "\n" OP " %13, " PRE "%13" TAIL "\n" OP " %14, " PRE "%14" TAIL "\n" OP " %15, " PRE "%15" TAIL "\n" \
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8), "+v"(a9), "+v"(a10), "+v"(a11), \
+                          "+v"(a12), "+v"(a13), "+v"(a14), "+v"(a15) : "v"(b), "v"(c) : "vcc");)
+      if (C == ASHR_I32) { PRE16("v_ashrrev_i32", "31, ", "") }
+      else if (C == MOV_B32) {
+        REP16(asm volatile("v_mov_b32 %0, %4\n v_mov_b32 %1, %4\n v_mov_b32 %2, %4\n v_mov_b32 %3, %4\n" : "=v"(a0), "=v"(a1), "=v"(a2), "=v"(a3) : "v"(b));)
+      } else {
+        asm volatile("v_cmp_ge_f32 vcc, %0, %1" :: "v"(a0), "v"(b) : "vcc");
+        PRE16("v_cndmask_b32", "0, ", ", vcc")
+      }
+    } else if (C == CNDMASK_SGPR) {
+      unsigned long long msk;
+      asm volatile("v_cmp_ge_f32_e64 %0, %1, %2" : "=s"(msk) : "v"(a0), "v"(b));
+      REP4(asm volatile("v_cndmask_b32_e64 %0, %0, %16, %17\n v_cndmask_b32_e64 %1, %1, %16, %17\n v_cndmask_b32_e64 %2, %2, %16, %17\n v_cndmask_b32_e64 %3, %3, %16, %17\n"
+                        "v_cndmask_b32_e64 %4, %4, %16, %17\n v_cndmask_b32_e64 %5, %5, %16, %17\n v_cndmask_b32_e64 %6, %6, %16, %17\n v_cndmask_b32_e64 %7, %7, %16, %17\n"
+                        "v_cndmask_b32_e64 %8, %8, %16, %17\n v_cndmask_b32_e64 %9, %9, %16, %17\n v_cndmask_b32_e64 %10, %10, %16, %17\n v_cndmask_b32_e64 %11, %11, %16, %17\n"
+                        "v_cndmask_b32_e64 %12, %12, %16, %17\n v_cndmask_b32_e64 %13, %13, %16, %17\n v_cndmask_b32_e64 %14, %14, %16, %17\n v_cndmask_b32_e64 %15, %15, %16, %17\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8), "+v"(a9), "+v"(a10), "+v"(a11),
+                          "+v"(a12), "+v"(a13), "+v"(a14), "+v"(a15) : "v"(b), "s"(msk));)
+    } else if (C == MUL_SGPR) {
+      float sb = __builtin_amdgcn_readfirstlane(__float_as_int(b)) ? 0.999f : 0.5f;
+      REP4(asm volatile("v_mul_f32 %0, %16, %0\n v_mul_f32 %1, %16, %1\n v_mul_f32 %2, %16, %2\n v_mul_f32 %3, %16, %3\n"
+                        "v_mul_f32 %4, %16, %4\n v_mul_f32 %5, %16, %5\n v_mul_f32 %6, %16, %6\n v_mul_f32 %7, %16, %7\n"
+                        "v_mul_f32 %8, %16, %8\n v_mul_f32 %9, %16, %9\n v_mul_f32 %10, %16, %10\n v_mul_f32 %11, %16, %11\n"
+                        "v_mul_f32 %12, %16, %12\n v_mul_f32 %13, %16, %13\n v_mul_f32 %14, %16, %14\n v_mul_f32 %15, %16, %15\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8), "+v"(a9), "+v"(a10), "+v"(a11),
+                          "+v"(a12), "+v"(a13), "+v"(a14), "+v"(a15) : "s"(sb));)
+    } else if (C == CMP_SGPR) {
+      unsigned long long m0, m1, m2, m3;
+      REP16(asm volatile("v_cmp_ge_f32_e64 %0, %4, %8\n v_cmp_ge_f32_e64 %1, %5, %8\n v_cmp_ge_f32_e64 %2, %6, %8\n v_cmp_ge_f32_e64 %3, %7, %8\n"
+                         : "=s"(m0), "=s"(m1), "=s"(m2), "=s"(m3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b));)
+      s0 += (int)(m0 ^ m1 ^ m2 ^ m3);
+    } else if (C == CMPX) {
+      // |x| >= 0 is true for every non-NaN lane: EXEC stays full
+      REP16(asm volatile("v_cmpx_ge_f32_e64 vcc, |%0|, 0\n v_cmpx_ge_f32_e64 vcc, |%1|, 0\n v_cmpx_ge_f32_e64 vcc, |%2|, 0\n v_cmpx_ge_f32_e64 vcc, |%3|, 0\n" :: "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "vcc");)
+    } else if (C == FWD_BODY_B) {
+      // the forward body with every select spelled as an integer mask (positive floats compare like their bit patterns):
+      //   alpha:  m1 = ((C1 - bits(oG)) >> 31) [all ones when oG >= 1/255];  al = min(0.99, oG) & m1
+      //   stop:   live transmittance Tl (0 once stopped) and final transmittance Tf;  tt = Tl - al Tl;  m2 = ((C2 - bits(tt)) >> 31) [tt >= 1e-4];
+      //           w = (al Tl) & m2;  Tl = tt & m2;  Tf = min(Tf, tt | ~m2)  (v_min_f32 returns the other operand for a NaN pattern)
+      float E[16] = {a0, a1, a2, a3, a6, a7, a8, a9, a10, a11, a12, a13, a14, a15, a0, a1};
+      float Tl = a4, Tf = a4, Cb = a5; v2f Crg = p0;
+      const int C1 = 0x3B808081 - 1, C2 = 0x38D1B717 - 1;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        float4 S[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) { S[t] = q0; asm volatile("" : "+v"(S[t].x), "+v"(S[t].y), "+v"(S[t].z)); asm volatile("" : "+v"(E[4 * q + t])); }
+        float al[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const float oG = __builtin_amdgcn_exp2f(E[4 * q + t]);
+          int m1; asm("v_sub_u32 %0, %1, %2\n v_ashrrev_i32 %0, 31, %0" : "=&v"(m1) : "v"(C1), "v"(__float_as_int(oG)));
+          al[t] = __int_as_float(__float_as_int(fminf(0.99f, oG)) & m1);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const float wa = al[t] * Tl, tt = Tl - wa;
+          int m2; asm("v_sub_u32 %0, %1, %2\n v_ashrrev_i32 %0, 31, %0" : "=&v"(m2) : "v"(C2), "v"(__float_as_int(tt)));
+          const float w = __int_as_float(__float_as_int(wa) & m2);
+          Tl = __int_as_float(__float_as_int(tt) & m2);
+          int nm; asm("v_not_b32 %0, %1" : "=v"(nm) : "v"(m2));
+          Tf = fminf(Tf, __int_as_float(__float_as_int(tt) | nm));
+          Crg.x = __builtin_fmaf(S[t].x, w, Crg.x); Crg.y = __builtin_fmaf(S[t].y, w, Crg.y); Cb = __builtin_fmaf(S[t].z, w, Cb);
+        }
+      }
+      a4 = Tl + Tf; a5 = Cb; p0 = Crg;
+    } else if (C == FWD_BODY_A) {
+      // the forward body with the stop decision on the EXECUTION MASK: a pixel whose T (1 - alpha) falls below 1e-4 leaves EXEC (v_cmpx) and
+      // takes nothing any more; T then simply keeps its final value.  16 survivors in one asm block (EXEC saved and restored around it).
+      float E[16] = {a0, a1, a2, a3, a6, a7, a8, a9, a10, a11, a12, a13, a14, a15, a0, a1};
+      float T = a4, Cb = a5, Cr = p0.x, Cg = p0.y;
+      const int C1 = 0x3B808081 - 1; const float thr = 0.0001f, cap = 0.99f;
+      unsigned long long saved;
+      asm volatile("s_mov_b64 %0, exec" : "=s"(saved));
+#pragma unroll
+      for (int t = 0; t < 16; t++) {
+        float Sx = q0.x, Sy = q0.y, Sz = q0.z;
+        asm volatile("" : "+v"(Sx), "+v"(Sy), "+v"(Sz)); asm volatile("" : "+v"(E[t]));
+        float oG, m, wa, tt;
+        asm volatile("v_exp_f32 %4, %8\n v_sub_u32 %5, %9, %4\n v_ashrrev_i32 %5, 31, %5\n v_min_f32 %4, %10, %4\n v_and_b32 %4, %5, %4\n"
+                     "v_mul_f32 %6, %4, %0\n v_sub_f32 %7, %0, %6\n v_cmpx_le_f32_e64 vcc, %11, %7\n v_mov_b32 %0, %7\n"
+                     "v_fmac_f32 %1, %12, %6\n v_fmac_f32 %2, %13, %6\n v_fmac_f32 %3, %14, %6\n"
+                     : "+v"(T), "+v"(Cr), "+v"(Cg), "+v"(Cb), "=&v"(oG), "=&v"(m), "=&v"(wa), "=&v"(tt)
+                     : "v"(E[t]), "v"(C1), "v"(cap), "v"(thr), "v"(Sx), "v"(Sy), "v"(Sz) : "vcc");
+      }
+      asm volatile("s_mov_b64 exec, %0" :: "s"(saved));
+      a4 = T; a5 = Cb; p0.x = Cr; p0.y = Cg;
     } else if (C == FWD_BODY) {
       // the forward blend's per-survivor body, C++ as in gm_render.hip blend16 (GM_FWD_SUB = 4: four alpha evaluations interleaved, then the
       // T / C recurrence in list order), 16 survivors per iteration; the compiler emits 11 VALU per survivor (exp, cmp, min, cndmask, mul,
@@ -172,10 +278,20 @@ __global__ __launch_bounds__(256) void probe_kernel(int iters, unsigned long lon
 typedef void (*kern_t)(int, unsigned long long*, float);
 template <int C> static kern_t get() { return probe_kernel<C>; }
 static kern_t kernels[NCLS] = {get<0>(), get<1>(), get<2>(), get<3>(), get<4>(), get<5>(), get<6>(), get<7>(), get<8>(), get<9>(), get<10>(), get<11>(), get<12>(),
-                               get<13>(), get<14>(), get<15>(), get<16>(), get<17>(), get<18>(), get<19>(), get<20>(), get<21>()};
+                               get<13>(), get<14>(), get<15>(), get<16>(), get<17>(), get<18>(), get<19>(), get<20>(), get<21>(),
+                               get<22>(), get<23>(), get<24>(), get<25>(), get<26>(), get<27>(), get<28>(), get<29>(), get<30>(), get<31>(), get<32>(), get<33>(), get<34>(),
+                               get<35>(), get<36>(), get<37>(), get<38>(), get<39>(), get<40>()};
+
+__global__ void nan_min_kernel(float* out) {      // what v_min_f32 / v_max_f32 make of the all-ones NaN pattern (forward body B relies on min(x, NaN) = x)
+  const float nan_ = __int_as_float(0xFFFFFFFF), x = 0.25f;
+  float r0, r1, r2;
+  asm volatile("v_min_f32 %0, %3, %4\n v_min_f32 %1, %4, %3\n v_max_f32 %2, %3, %4" : "=v"(r0), "=v"(r1), "=v"(r2) : "v"(x), "v"(nan_));
+  out[0] = r0; out[1] = r1; out[2] = r2;
+}
 
 int main(int argc, char** argv) {
   int iters = argc > 1 ? atoi(argv[1]) : 2048;
+  const int first_cls = argc > 2 ? atoi(argv[2]) : 0;
   hipDeviceProp_t prop; HC(hipGetDeviceProperties(&prop, 0));
   const int cus = prop.multiProcessorCount;
   printf("# %s, %d CUs, clockRate %d kHz; %d iterations of a %d-instruction block per wave\n", prop.name, cus, prop.clockRate, iters, 64);
@@ -185,7 +301,11 @@ int main(int argc, char** argv) {
   std::vector<unsigned long long> h(slots);
   hipEvent_t e0, e1; HC(hipEventCreate(&e0)); HC(hipEventCreate(&e1));
   printf("%-62s %3s %10s %10s %10s %9s\n", "class", "W", "wave cyc", "simd cyc", "launch us", "clock MHz");
-  for (int c = 0; c < NCLS; c++) {
+  {
+    float* nm; HC(hipMalloc(&nm, 16)); hipLaunchKernelGGL(nan_min_kernel, dim3(1), dim3(64), 0, 0, nm); float hn[3]; HC(hipMemcpy(hn, nm, 12, hipMemcpyDeviceToHost));
+    printf("# v_min_f32(0.25, NaN) = %g, v_min_f32(NaN, 0.25) = %g, v_max_f32(0.25, NaN) = %g\n", hn[0], hn[1], hn[2]);
+  }
+  for (int c = first_cls; c < NCLS; c++) {
     for (int W = 1; W <= 8; W *= 2) {
       const int grid = cus * W;
       HC(hipMemset(out, 0, slots * 8));
