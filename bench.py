@@ -167,6 +167,22 @@ def measured_valu(stage, P, W, H):
     return t["stages"][stage].get("valu")
 
 
+def valu_ceiling(stage, nv, avg_ms):
+    """Vector-ALU time of a kernel against its duration.  With SQ_ACTIVE_INST_VALU in profiles/inst_mix.json (round 5: the blend
+    kernels) the busy time is measured; otherwise the instruction count is priced at the mix average of the blend kernels, 4.2 cycles
+    (measured: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4.24 forward, 4.17 backward - NOT the 2.3 cycles of a plain v_fma_f32: the mix is
+    half compares, selects, min / max, packed and transcendental instructions, tools/valu_probe)."""
+    quads = None
+    try:
+        quads = json.load(open(os.path.join(ROOT, "profiles", "inst_mix.json")))["stages"][stage].get("valu_active_quad_cycles")
+    except (OSError, KeyError):
+        pass
+    busy_ms = (4.0 * quads if quads else 4.2 * nv) / (1024 * 2.4e9) * 1e3
+    return {"vector_instructions": nv, "valu_busy_ms": busy_ms, "frac_of_kernel_time": busy_ms / avg_ms,
+            "cycles_per_instruction": (4.0 * quads / nv) if quads else 4.2,
+            "source": "static: profiles/inst_mix.json (rocprofv3 --pmc SQ_INSTS_VALU" + (", SQ_ACTIVE_INST_VALU)" if quads else "; priced at 4.2 cycles per instruction)")}
+
+
 def build_c5(Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, dev=None, sync_free=True, ncams=32, seed=0, teacher=False):
     """BASELINE config C5 on this package's training harness: Nfg Gaussians bound to the 15 k-face torus + Nbg free, frozen
     "background" Gaussians in a shell of radius 6-12 that contains the cameras, W x H, a Trainer with FusedAdam on the six
@@ -845,19 +861,19 @@ def main():
                            "traffic_source": "static: profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this "
                                              "workload; counters cannot be read inside the timed run)",
                            "algorithmic_bytes": ab, "avg_ms": per[dom],
-                           "note": ("the forward blend: bound by vector-ALU issue, not by HBM (DESIGN.md section 4: ~3.6e7 vector instructions "
-                                    "per launch = 59 us of the chip's issue slots); the HBM figure is reported because the contract asks for it")
+                           "note": ("the forward blend: bound by the vector ALU, not by HBM (DESIGN.md section 4: 3.4e7 vector instructions per launch "
+                                    "keep the chip's 1024 SIMDs busy for 59 us, SQ_ACTIVE_INST_VALU); the HBM figure is reported because the contract asks for it")
                                    if dom == "render" else
                                    ("the fused deformation / SH colour / preprocess kernel: a streaming kernel bound by HBM") if dom == "deform" else
                                    "longest single kernel of the frame"}
-        # the ceiling the dominant kernel actually runs against when it is the blend: vector-instruction ISSUE.  A wave64 vector
-        # instruction occupies its SIMD for 4 cycles; the chip has 1024 SIMDs at 2.4 GHz.  Instruction counts: static, from the PMC
-        # pass of the same workload (profiles/inst_mix.json), like `traffic`
+        # the ceiling the dominant kernel actually runs against when it is the blend: the vector ALU.  Round 5 measured what a wave64
+        # vector instruction costs its SIMD by class (tools/valu_probe: 2.3 cycles for fma / mul / add / logic, 4.1-4.3 for min / max /
+        # compare / select / packed f32 / SGPR operands, 8.1 for exp / rcp) and the kernel's own SQ_ACTIVE_INST_VALU (quad-cycles the
+        # vector ALU of a SIMD is occupied, summed over the chip): busy time = 4 x that / (1024 SIMDs x 2.4 GHz).  Static, from the PMC
+        # pass of the same workload (profiles/inst_mix.json <- profiles/r05_blend_sq_pmc.txt), like `traffic`
         nv = measured_valu(dom, P, W, H)
         if nv:
-            issue_ms = nv * 4.0 / (1024 * 2.4e9) * 1e3
-            out["roofline"]["valu_issue"] = {"vector_instructions": nv, "issue_ms_at_full_rate": issue_ms, "frac_of_issue_ceiling": issue_ms / per[dom],
-                                             "source": "static: profiles/inst_mix.json (rocprofv3 --pmc SQ_INSTS_VALU)"}
+            out["roofline"]["valu_issue"] = valu_ceiling(dom, nv, per[dom])
         # every stage, same definition (algorithmic bytes of the stage / its HIP-event time); "deform" is the fused kernel alone
         out["stage_roofline"] = {st: round(stage_bytes(st) / (per[st] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                                  for st in per if st in ("mesh_rs", "deform", "depth_sort", "duplicate", "tile_sort", "render")}
@@ -868,8 +884,8 @@ def main():
         out["frame_roofline"] = {"algorithmic_bytes": tot_bytes, "achieved": tot_bytes / (elapsed / args.steps) / 1e9,
                                  "frac": tot_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s",
                                  "single_stream_ms_per_frame": sum(per.values())}
-        if all(frame_valu):                      # the frame's other ceiling: time to issue its vector instructions on all 1024 SIMDs
-            out["frame_roofline"]["valu_issue_ms"] = sum(frame_valu) * 4.0 / (1024 * 2.4e9) * 1e3
+        if all(frame_valu):                      # the frame's other ceiling: its vector instructions at the blend's measured mix average (4.2 cycles; the streaming kernels' mix is cheaper: an upper bound)
+            out["frame_roofline"]["valu_issue_ms"] = sum(frame_valu) * 4.2 / (1024 * 2.4e9) * 1e3
             out["frame_roofline"]["valu_issue_frac"] = out["frame_roofline"]["valu_issue_ms"] / (1e3 * elapsed / args.steps)
 
     if rank == 0 and world == 1 and not args.no_fwd_bwd:
@@ -937,7 +953,10 @@ def main():
         out["fwd_bwd"]["roofline"] = {"bound": "hbm", "kernel": "render_bwd", "achieved": ach_b, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": ach_b / HBM_PEAK_GBS, "algorithmic_bytes": fb_bytes["render_bwd"], "avg_ms": per_fb["render_bwd"],
                                       "traffic": None,
-                                      "note": "the backward blend is bound by vector-ALU issue (DESIGN.md section 4), not by HBM"}
+                                      "note": "the backward blend is bound by the vector ALU (DESIGN.md section 4), not by HBM"}
+        nvb = measured_valu("render_bwd", P, W, H)
+        if nvb:
+            out["fwd_bwd"]["roofline"]["valu_issue"] = valu_ceiling("render_bwd", nvb, per_fb["render_bwd"])
         out["fwd_bwd"]["iteration_roofline"] = {"algorithmic_bytes": tot_fb, "achieved": tot_fb / sec / 1e9, "frac": tot_fb / sec / 1e9 / HBM_PEAK_GBS,
                                                 "unit": "GB/s", "sum_of_stage_ms": sum(per_fb.values())}
         # the same iteration with the training loop's photometric loss (L1 + SSIM, gm_ssim_fwd/bwd) on the rendered image
