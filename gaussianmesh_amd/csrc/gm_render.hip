@@ -504,7 +504,7 @@ int launch_render_fwd(const GeomState& g, const uint2* pairs, ImageState& img, i
 #define GM_BWD_SETS 3              // register sets of gathered records in rotation in the backward blend (A/B: 2)
 #endif
 #ifndef GM_BWD_PREFETCH
-#define GM_BWD_PREFETCH 1        // staged records of the backward walk read one entry ahead (A/B: tools/ab_flags.sh gm_render ... "-DGM_BWD_PREFETCH=0")
+#define GM_BWD_PREFETCH 2        // staged records of the backward walk read ahead: 2 = two register sets by call site (round 5), 1 = one rotating set (round 4), 0 = none
 #endif
 #ifndef GM_RENDER_BWD_WPW
 #define GM_RENDER_BWD_WPW 1      // waves per workgroup of the backward blend: 4 (one workgroup per 16-px tile) or 1 (one per 8x8 quadrant)
@@ -537,7 +537,7 @@ struct StagedB {                 // one survivor of the staged batch (one LDS ad
   float4 c;                      // b, list position (bits), Gaussian id (bits), -
 };
 struct SlotB { float2 xy; uint32_t id, pad; };   // splat centre and id of a phase-2 slot
-struct BwdLds {                  // per wave: 7.5 KiB
+struct BwdLds {                  // per wave: 7.7 KiB
   uint2 qa[RQ_QA];               // candidate ring of the front end: (Gaussian id, list position)
   StagedB st[64];                // staged batch
   union {
@@ -595,12 +595,16 @@ __global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_kernel(cons
   BwdLds& L = B;
   // phase 2 geometry of this lane: slot es (7: idle), pixel row r; dL/dpixel of the row's eight pixels stays in registers
   const int es = lane & 7, r = lane >> 3, esc = min(es, 6);
-  float2 dq[8]; float dqb[8];
+  float2 dq[8];
+  float dqb[8];
   B.dpt.rg[lane] = make_float2(dpr, dpg); B.dpt.bl[lane] = dpb;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
-  for (int i = 0; i < 8; i++) { dq[i] = B.dpt.rg[r * 8 + i]; dqb[i] = B.dpt.bl[r * 8 + i]; }
+  for (int i = 0; i < 8; i++) {
+    dq[i] = B.dpt.rg[r * 8 + i];
+    dqb[i] = B.dpt.bl[r * 8 + i];
+  }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   const float rowy = ry0 + (float)r;
@@ -708,25 +712,16 @@ __global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_kernel(cons
       const unsigned long long kb = __ballot(keep);
       const int ns = __popcll(kb);
       if (keep) {
-        StagedB& o = B.st[(int)lanes_below(kb)];
+        const int sl = (int)lanes_below(kb);
+        StagedB& o = B.st[sl];
         o.a = make_float4(cur.a.x, cur.a.y, (-0.5f * LOG2E) * cur.a.z, (-0.5f * LOG2E) * cur.b.x);
         o.b = make_float4((-LOG2E) * cur.a.w, cur.b.y, cur.b.z, cur.b.w);
         o.c = make_float4(cur.c, __uint_as_float(cur.pos), __uint_as_float(cur.id), 0.f);   // 0-based list position == reference `contributor`
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-#if GM_BWD_PREFETCH
-      // software pipeline of the staged records: entry j + 1's three LDS reads are in flight while entry j is walked - the launch
-      // ends on a few heavy waves that run alone on their SIMD, and a lone wave otherwise waits out the LDS latency of every entry
-      float4 nRA = B.st[0].a, nRB = B.st[0].b, nRC = B.st[0].c;
-#endif
-      for (int j = 0; j < ns; j++) {
-#if GM_BWD_PREFETCH
-        const float4 RA = nRA, RB = nRB, RC = nRC;
-        { const int jn = min(j + 1, ns - 1); nRA = B.st[jn].a; nRB = B.st[jn].b; nRC = B.st[jn].c; }
-#else
-        const float4 RA = B.st[j].a, RB = B.st[j].b, RC = B.st[j].c;
-#endif
+      // One staged entry of the walk (records in registers).  Returns nothing; an entry no lane takes costs the exponent and the vote.
+      auto entry = [&](const float4& RA, const float4& RB, const float4& RC) {
         v2f dd;
         const float e = staged_exponent(RA, RB.x, pix, dd);             // power * log2(e), pixel-relative form (the forward kernel's polynomial
                                                                          // agrees to ~1e-5; its decisions can differ on an entry in a few 10^5)
@@ -734,7 +729,7 @@ __global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_kernel(cons
         const float oG = RB.y * G;                                       // opacity * G (the unclamped alpha)
         const int pos = (int)__float_as_uint(RC.y);
         const bool valid = (pos < last) && (oG >= 1.0f / 255.0f);        // (alpha = min(0.99, oG) >= 1/255  <=>  oG >= 1/255)
-        if (!__any(valid)) continue;
+        if (!__any(valid)) return;
         const float oGe = valid ? oG : 0.0f;                             // a lane that skips the entry: alpha 0, every update the identity
         const float al = __builtin_amdgcn_fmed3f(oGe, 0.0f, 0.99f);      // alpha = min(0.99, opacity G)
         const float inv = __builtin_amdgcn_rcpf(1.f - al);               // 1 / (1 - alpha)
@@ -749,7 +744,34 @@ __global__ __launch_bounds__(64 * GM_RENDER_BWD_WPW) void render_bwd_kernel(cons
         mrow += 65; mslot += 1;                                          // the two LDS addresses advance as vector registers of their own:
         m += 1;                                                          // the slot count itself then lives in a scalar register
         if (m == 7) { phase2(7); m = 0; mrow = &B.M[0][lane]; mslot = &B.slot[0]; }
+      };
+#if GM_BWD_PREFETCH == 2
+      // Software pipeline of the staged records, round 5: TWO register sets by call site (the loop body is the entry twice).  Entry
+      // j + 2's three LDS reads are issued when entry j is done with its set and land while entry j + 1 is walked.  With ONE rotating set
+      // (round 4, GM_BWD_PREFETCH == 1) the compiler copies four values per entry out of the registers the prefetch is about to
+      // overwrite (opacity, b', list position, the next LDS address): 4 of the ~28 vector instructions of an entry in a kernel that keeps
+      // its SIMDs' vector ALUs 78 % busy (profiles/r05_blend_sq_pmc.txt).
+      float4 RA0 = B.st[0].a, RB0 = B.st[0].b, RC0 = B.st[0].c;
+      float4 RA1 = B.st[min(1, ns - 1)].a, RB1 = B.st[min(1, ns - 1)].b, RC1 = B.st[min(1, ns - 1)].c;
+      for (int j = 0; j < ns; j += 2) {
+        entry(RA0, RB0, RC0);
+        { const int jn = min(j + 2, ns - 1); RA0 = B.st[jn].a; RB0 = B.st[jn].b; RC0 = B.st[jn].c; }
+        if (j + 1 >= ns) break;
+        entry(RA1, RB1, RC1);
+        { const int jn = min(j + 3, ns - 1); RA1 = B.st[jn].a; RB1 = B.st[jn].b; RC1 = B.st[jn].c; }
       }
+#elif GM_BWD_PREFETCH == 1
+      // software pipeline of the staged records (round 4): entry j + 1's three LDS reads are in flight while entry j is walked - the launch
+      // ends on a few heavy waves that run alone on their SIMD, and a lone wave otherwise waits out the LDS latency of every entry
+      float4 nRA = B.st[0].a, nRB = B.st[0].b, nRC = B.st[0].c;
+      for (int j = 0; j < ns; j++) {
+        const float4 RA = nRA, RB = nRB, RC = nRC;
+        { const int jn = min(j + 1, ns - 1); nRA = B.st[jn].a; nRB = B.st[jn].b; nRC = B.st[jn].c; }
+        entry(RA, RB, RC);
+      }
+#else
+      for (int j = 0; j < ns; j++) entry(B.st[j].a, B.st[j].b, B.st[j].c);
+#endif
     }
     return true;
   };
