@@ -183,7 +183,12 @@ def valu_ceiling(stage, nv, avg_ms):
             "source": "static: profiles/inst_mix.json (rocprofv3 --pmc SQ_INSTS_VALU" + (", SQ_ACTIVE_INST_VALU)" if quads else "; priced at 4.2 cycles per instruction)")}
 
 
-def build_c5(Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, dev=None, sync_free=True, ncams=32, seed=0, teacher=False):
+# the "feature" rows of the C5 teacher that the student has misplaced (build_c5(teacher=True)): fraction of the rows, scale factor, opacity
+# logit, displacement in log-barycentric units.  GM_C5_STUDENT="fraction,scale,logit,shift" overrides it (tools/c5_densify_sweep.py).
+C5_STUDENT_BIG = (0.02, 4.0, 3.0, 2.0)
+
+
+def build_c5(Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, dev=None, sync_free=True, ncams=32, seed=0, teacher=False, scene="r05"):
     """BASELINE config C5 on this package's training harness: Nfg Gaussians bound to the 15 k-face torus + Nbg free, frozen
     "background" Gaussians in a shell of radius 6-12 that contains the cameras, W x H, a Trainer with FusedAdam on the six
     parameter groups, densification statistics, sync-free forward, and `ncams` orbit cameras.
@@ -225,33 +230,45 @@ def build_c5(Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, dev=None, sync_free=T
     pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
     colour = torch.empty((ncams, 3, H, W), device=dev); trans = torch.empty((ncams, 1, H, W), device=dev)
     zero, one = torch.zeros(3, device=dev), torch.ones(3, device=dev)
+    frac, bscale, blogit, bshift = C5_STUDENT_BIG
+    if os.environ.get("GM_C5_STUDENT"):                            # tools/c5_densify_sweep.py
+        frac, bscale, blogit, bshift = (float(x) for x in os.environ["GM_C5_STUDENT"].split(","))
     with torch.no_grad():
+        # "features" of the TEACHER: one Gaussian in fifty is `bscale` times larger than its neighbours, nearly opaque and of a saturated
+        # colour - structure at a scale of tens of pixels in every target.  The student below has these rows MISPLACED; a positional
+        # gradient needs an error that changes sign across the splat, which a splat of the wrong colour or size over a smooth target
+        # does not produce (round 4: one row over densify_grad_threshold in 2 M, see densify_note)
+        g = torch.Generator(device=dev).manual_seed(seed + 7)
+        big = torch.rand(model._bc.shape[0], device=dev, generator=g) < frac
+        if scene == "r05":
+            model._scaling[big] += math.log(bscale)
+            model._opacity[big] = blogit
+            model._features[big, 0] = 1.5 * torch.randn((int(big.sum()), 3), device=dev, generator=g)
         for k, c in enumerate(cams):
             colour[k] = render(c, model, pipe, zero, bg_gaussian=bg)["render"]
             trans[k] = (render(c, model, pipe, one, bg_gaussian=bg)["render"][:1] - colour[k][:1]).clamp(0.0, 1.0)   # C + T.1 - C
         # the student: the teacher's cloud dimmed (a quarter of its base colour, no view dependence), a quarter opaque, shrunk by a
-        # fifth and pushed around inside its faces - so that colour, opacity, scale AND position have something to learn and the
-        # view-space gradients that drive densify_and_prune are not identically zero - at SH degree 0, where the reference starts
-        g = torch.Generator(device=dev).manual_seed(seed + 7)
-        model._features[:, 0] *= 0.25
+        # fifth and pushed around inside its faces - so that colour, opacity, scale AND position have something to learn - at SH degree
+        # 0, where the reference starts; the feature rows keep their look and are pushed `bshift` times further (log-barycentric
+        # units): under-reconstructed regions whose mean view-space gradient crosses the reference's threshold, so that the topology
+        # changes of iterations 600 / 800 / 1000 split one to two percent of the rows as they do on real data
+        small = ~big if scene == "r05" else torch.ones_like(big)
+        model._features[small, 0] *= 0.25
         model._features[:, 1:] = 0.0
-        model._opacity.fill_(-1.0)
-        model._scaling += math.log(0.8)
-        model._bc += 0.5 * torch.randn(model._bc.shape, device=dev, generator=g)
-        # ... and one Gaussian in fifty stands for an under-reconstructed region: four times too large and of the wrong colour.  With
-        # 2 M small Gaussians on a 4K image nothing else reaches densify_grad_threshold = 0.0002 (the view-space gradient of a
-        # Gaussian scales with the fraction of the image it covers), and the topology changes of iterations 600 / 800 / 1000 would
-        # select no row at all
-        big = torch.rand(model._bc.shape[0], device=dev, generator=g) < 0.02
-        model._scaling[big] += math.log(4.0)
-        model._features[big, 0] = 1.5 * torch.randn((int(big.sum()), 3), device=dev, generator=g)
+        model._opacity[small] = -1.0
+        model._scaling[small] += math.log(0.8)
+        shift = torch.randn(model._bc.shape, device=dev, generator=g)
+        model._bc += torch.where((big & ~small)[:, None], bshift * shift, 0.5 * shift)
+        if scene != "r05":                       # the round-4 scene, kept for comparison across rounds (c5_r04_scene): no features in the teacher; one
+            model._scaling[big] += math.log(4.0)  # student row in fifty four times too large and of a wrong colour - ONE row over the threshold in 2 M
+            model._features[big, 0] = 1.5 * torch.randn((int(big.sum()), 3), device=dev, generator=g)
     model.active_sh_degree = 0
     tr = Trainer(model, densify_stats=True, sync_free=sync_free, bg_gaussian=bg)
     return tr, cams, (colour, trans), None
 
 
 def c5_leg(steps, warm, Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, sync_free=True, policy=None, work_hint=True, dev=None, as_reference=False,
-           ncams=32):
+           ncams=32, scene="r05"):
     """The "c5" object of the bench line.
     as_reference=False (the leg rounds 1-3 reported, kept for comparison): `steps` Trainer.step iterations after `warm` untimed ones at
     a fixed topology, SH degree 3, a zero background and one fixed random target.
@@ -268,7 +285,7 @@ def c5_leg(steps, warm, Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, sync_free=
     dev = dev or torch.device("cuda", 0)
     if policy is not None:
         Rz.set_default_emission_policy(policy)
-    tr, cams, target, zero_bg = build_c5(Nfg, Nbg, W, H, dev, sync_free, ncams=ncams, teacher=as_reference)
+    tr, cams, target, zero_bg = build_c5(Nfg, Nbg, W, H, dev, sync_free, ncams=ncams, teacher=as_reference, scene=scene)
     nc = len(cams)
     losses = []
     if not as_reference:
@@ -344,6 +361,13 @@ def c5_leg(steps, warm, Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, sync_free=
     # iterations of the same loop at the new row count.  Outside the 1000 iterations that define ms_per_iter.
     forced = None
     if steps >= 600:
+        # (iteration 1000 may just have split rows and reset the statistics: 60 more iterations of the loop give every row a statistic again)
+        for it in range(60):
+            if not stack:
+                stack = list(range(nc))
+            k = stack.pop(rng.randint(0, len(stack) - 1))
+            bgc = torch.rand(3, device=dev)
+            tr.step(cams[k], torch.addcmul(colour[k], trans[k], bgc.view(3, 1, 1)), bgc)
         gq = (tr.bc_gradient_accum / tr.denom.clamp_min(1)).reshape(-1)
         thr = float(torch.sort(gq).values[int(0.98 * (gq.numel() - 1))])
         del gq
@@ -371,7 +395,11 @@ def c5_leg(steps, warm, Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, sync_free=
            # iterations 2 .. 599: before the first topology change (iteration 1 carries the first allocations and the capacity seed)
            "ms_per_iter_before_first_densify": (1e3 * (marks[599] - marks[1]) / 598) if 599 in marks and 1 in marks else None,
            "densify_iterations_ms": [round(x, 3) for x in densify_ms],       # the WHOLE iteration that ends in densify_and_prune (no Adam step)
-           "rows_after_densify": rows_after, "topology_changes": tr.resizes,
+           "rows_after_densify": rows_after, "topology_changes": tr.resizes, "scene": scene,
+           "densify_note": ("scene r05: 2 % of the teacher's rows are features (4 x larger, opaque, saturated) that the student has misplaced; at 4K with 2 M "
+                            "Gaussians the reference's densify_grad_threshold = 0.0002 (a per-pixel loss weight of 1 / (3 H W)) is crossed by 0.04-0.05 % of the "
+                            "rows - about a thousand rows split into five at each of 600 / 800 / 1000; a 2 % split is timed as forced_densify") if scene == "r05"
+                           else "scene r04 (rounds 1-4): no features in the teacher; one row in 2 M crosses the threshold",
            "forced_densify": forced,
            "viewspace_grad_at_first_densify": dict(zip(("q50", "q90", "q99", "q999", "max", "fraction_over_threshold"), quant)),
            "workload": "C5 as train_mesh_gaussian.py runs its first %d iterations: %d mesh-bound + %d frozen free Gaussians, %dx%d, SH degree 0 "
@@ -393,7 +421,7 @@ def run_c5(args):
     Nfg, Nbg = ((2 * args.gaussians) // 3, args.gaussians // 3) if args.gaussians != 1_000_000 else (2_000_000, 1_000_000)
     steps = args.steps if args.steps != 300 else 1000
     c5 = c5_leg(steps, max(args.warmup, 5), Nfg, Nbg, W, H, sync_free=not args.exact_count, policy=args.policy, work_hint=not args.no_work_hint,
-                as_reference=not args.c5_fixed, ncams=min(args.cameras, 32))
+                as_reference=not args.c5_fixed, ncams=min(args.cameras, 32), scene=args.c5_scene)
     out = {"metric": "ms/iter (fwd+bwd+optimizer), 3M Gaussians @4K training loop", "value": c5["ms_per_iter"], "unit": "ms/iter", "n_gpus": 1,
            "steps": steps, "warmup": c5["warmup"], "ms_per_step": c5["ms_per_iter"], "higher_is_better": False, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -456,6 +484,8 @@ def main():
     ap.add_argument("--no-c5", action="store_true", help="leave out the C5 legs (the 3 M-Gaussian 4K training loop: the reference's first 1000 "
                     "iterations with their schedule, and --c5-iters iterations at a fixed topology)")
     ap.add_argument("--c5-iters", type=int, default=200)
+    ap.add_argument("--c5-scene", default="r05", choices=["r05", "r04"], help="--config c5: r05 = the teacher has features the student misplaced (densify_and_prune "
+                    "splits ~1000 rows at 600 / 800 / 1000), r04 = the scene of rounds 1-4 (one row)")
     ap.add_argument("--c5-fixed", action="store_true", help="--config c5: time the fixed-topology SH-degree-3 leg of rounds 1-3 instead of the "
                     "reference's first 1000 iterations with their schedule")
     args = ap.parse_args()
@@ -1036,6 +1066,11 @@ def main():
         # "c5": the reference's first 1000 iterations with their schedule (SH ramp, random background, densify_and_prune at 600 / 800 /
         # 1000); "c5_fixed": the fixed-topology SH-3 leg rounds 1-3 reported (--c5-iters iterations), for comparison across rounds
         out["c5"] = c5_leg(1000, 0, policy=args.policy, work_hint=not args.no_work_hint, dev=dev, as_reference=True)
+        # the same loop on the scene rounds 1-4 timed (no features in the teacher: densify_and_prune selected one row in 2 M): what this
+        # round's CODE does to the number the earlier rounds reported, separate from what the new scene does to it
+        out["c5_r04_scene"] = {k: v for k, v in c5_leg(1000, 0, policy=args.policy, work_hint=not args.no_work_hint, dev=dev, as_reference=True, scene="r04").items()
+                               if k in ("ms_per_iter", "ms_per_iter_before_first_densify", "densify_iterations_ms", "rows_after_densify", "loss_first", "loss_last",
+                                        "iterations_redone", "visible", "peak_memory_gb")}
         out["c5_fixed"] = c5_leg(max(1, args.c5_iters), 10, policy=args.policy, work_hint=not args.no_work_hint, dev=dev)
     else:
         host_keep = mesh_keep = None

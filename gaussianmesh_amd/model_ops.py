@@ -19,7 +19,7 @@ def _c(t):
 
 class _MeshActivate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, bc, distance, scaling, rotation, opacity, v1, v2, v3, normal, r, alpha, mr_weight):
+    def forward(ctx, bc, distance, scaling, rotation, opacity, v1, v2, v3, normal, r, alpha, mr_weight, joint=None):
         lib = _lib.lib()
         dev = bc.device
         if dev.type != "cuda":
@@ -27,7 +27,13 @@ class _MeshActivate(torch.autograd.Function):
         ins = [_c(t) for t in (bc, distance, scaling, rotation, opacity, v1, v2, v3, normal, r)]
         N = ins[0].shape[0]
         f = dict(dtype=torch.float32, device=dev)
-        xyz = torch.empty((N, 3), **f); scales = torch.empty((N, 3), **f); rots = torch.empty((N, 4), **f); opac = torch.empty((N, 1), **f)
+        if joint is None:
+            xyz = torch.empty((N, 3), **f); scales = torch.empty((N, 3), **f); rots = torch.empty((N, 4), **f); opac = torch.empty((N, 1), **f)
+        else:
+            # joint = persistent [N + Nb, .] buffers whose tails hold a frozen cloud's rows (renderer.render(bg_gaussian=...)): the kernel
+            # writes the leading N rows and the WHOLE buffers are the outputs - what torch.cat([activated, background]) would return,
+            # without the four per-iteration copies.  Fresh tensor objects over the same storage every call.
+            xyz, scales, rots, opac = (joint[k].view_as(joint[k]) for k in ("xyz", "scales", "rots", "opac"))
         want_mr = mr_weight is not None
         part = torch.empty(((N + 255) // 256,), **f) if want_mr else None
         with torch.cuda.device(dev):
@@ -55,13 +61,15 @@ class _MeshActivate(torch.autograd.Function):
                                                 d_bc.data_ptr(), d_dist.data_ptr(), d_scaling.data_ptr(), d_rot.data_ptr(), d_op.data_ptr(),
                                                 float(ctx.mr_weight or 0.0), None if gm is None else gm.data_ptr(),
                                                 torch.cuda.current_stream(dev).cuda_stream))
-        return d_bc, d_dist, d_scaling, d_rot, d_op, None, None, None, None, None, None, None
+        return d_bc, d_dist, d_scaling, d_rot, d_op, None, None, None, None, None, None, None, None
 
 
-def mesh_activate(bc, distance, scaling, rotation, opacity, v1, v2, v3, normal, r, alpha=4.0, mr_weight=None):
+def mesh_activate(bc, distance, scaling, rotation, opacity, v1, v2, v3, normal, r, alpha=4.0, mr_weight=None, joint=None):
     """Returns (xyz, scales, rotations, opacities) and, with mr_weight, a fifth output: mesh_restrict_loss(scales, v1, v2,
-    v3, weight=mr_weight) (utils/loss_utils.py:103-108) computed - and differentiated - inside the same two kernels."""
-    out = _MeshActivate.apply(bc, distance, scaling, rotation, opacity, v1, v2, v3, normal, r, alpha, mr_weight)
+    v3, weight=mr_weight) (utils/loss_utils.py:103-108) computed - and differentiated - inside the same two kernels.
+    joint: dict of persistent [N + Nb, .] buffers "xyz", "scales", "rots", "opac" (tails = a frozen cloud); the outputs are then the
+    whole buffers (the gradient of the tail rows is dropped)."""
+    out = _MeshActivate.apply(bc, distance, scaling, rotation, opacity, v1, v2, v3, normal, r, alpha, mr_weight, joint)
     return out if mr_weight is not None else out[:4]
 
 

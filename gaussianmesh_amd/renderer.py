@@ -109,38 +109,85 @@ class _SharedRows(torch.autograd.Function):
         return grad[:ctx.n], None
 
 
+def sh_operand(pc):
+    """The tensor a model hands to the rasterizer as `shs`: its full [N,16,3] rows, or - MeshBoundGaussians.begin_dense_dc(), while only
+    degree 0 is active - the dense [N,1,3] tensor of coefficient 0 (M = 1: the operator reads (D+1)^2 = 1 coefficient of M)."""
+    dc0 = getattr(pc, "_features_dc0", None)
+    return pc._features if dc0 is None else dc0
+
+
 def share_feature_storage(pc, bg_gaussian):
-    """One-time setup for render(..., bg_gaussian=...) in a loop: the model's SH parameter `_features` [N,16,3] becomes a view of
-    the leading rows of one buffer that also holds the (frozen) background's SH rows, so that the per-iteration
-    torch.cat([fg, bg]) of 192-byte rows (0.58 GB at 3 M Gaussians) disappears.  The parameter stays a leaf; optimizers that
-    update it in place (FusedAdam, torch.optim.*) keep the buffer current.  Call before creating the optimizer."""
-    f, b = pc._features, bg_gaussian.get_features
+    """One-time setup for render(..., bg_gaussian=...) in a loop: the model's SH operand ([N,16,3] `_features`, or the dense [N,1,3]
+    coefficient-0 tensor of begin_dense_dc()) becomes a view of the leading rows of one buffer that also holds the (frozen) background's
+    rows, so that the per-iteration torch.cat([fg, bg]) of 192-byte rows (0.58 GB at 3 M Gaussians) disappears.  The parameter stays a
+    leaf; optimizers that update it in place (FusedAdam, torch.optim.*) keep the buffer current.  Call before creating the optimizer."""
+    f = sh_operand(pc)
+    b = bg_gaussian.get_features[:, :f.shape[1]]
     whole = torch.empty((f.shape[0] + b.shape[0],) + tuple(f.shape[1:]), dtype=f.dtype, device=f.device)
     whole[:f.shape[0]].copy_(f.detach())
     whole[f.shape[0]:].copy_(b.detach())
-    pc._features = torch.nn.Parameter(whole[:f.shape[0]], requires_grad=f.requires_grad)
+    leaf = torch.nn.Parameter(whole[:f.shape[0]], requires_grad=f.requires_grad)
+    if getattr(pc, "_features_dc0", None) is not None:
+        pc._features_dc0 = leaf
+    else:
+        pc._features = leaf
     pc._features_with_bg = (whole, bg_gaussian)
 
 
 def _features_with_background(pc, bg_gaussian, shs):
     shared = getattr(pc, "_features_with_bg", None)
-    if shared is not None and shared[1] is bg_gaussian and shs is pc._features and shs.data_ptr() == shared[0].data_ptr():
+    if shared is not None and shared[1] is bg_gaussian and shs is sh_operand(pc) and shs.data_ptr() == shared[0].data_ptr():
         return _SharedRows.apply(shs, shared[0])
-    return torch.cat([shs, bg_gaussian.get_features], dim=0)
+    return torch.cat([shs, bg_gaussian.get_features[:, :shs.shape[1]]], dim=0)
+
+
+def _joint_buffers(pc, bg_gaussian):
+    """Persistent [N + Nb, .] buffers for render(..., bg_gaussian=...) on the fused route: the tails hold the frozen cloud's positions /
+    scales / rotations / opacities (written once), the fused activation writes the leading N rows every iteration, and "ss" is the
+    screen-space probe of all N + Nb rows (a leaf: its .grad is the reference's viewspace_point_tensor.grad).  Replaces five
+    torch.cat per iteration (rocprofv3, C5: eight CatArrayBatchedCopy launches, ~0.13 ms per iteration).  Rebuilt when the row count
+    changes (topology edits) or another background is given."""
+    N = pc._bc.shape[0]
+    jb = getattr(pc, "_joint_buffers", None)
+    if jb is not None and jb["N"] == N and jb["bg"] is bg_gaussian and jb["xyz"].device == pc._bc.device:
+        return jb
+    Nb = bg_gaussian.get_xyz.shape[0]
+    f = dict(dtype=torch.float32, device=pc._bc.device)
+    jb = {"N": N, "bg": bg_gaussian, "xyz": torch.empty((N + Nb, 3), **f), "scales": torch.empty((N + Nb, 3), **f), "rots": torch.empty((N + Nb, 4), **f),
+          "opac": torch.empty((N + Nb, 1), **f), "ss": torch.zeros((N + Nb, 3), requires_grad=True, **f)}
+    with torch.no_grad():
+        jb["xyz"][N:].copy_(bg_gaussian.get_xyz); jb["scales"][N:].copy_(bg_gaussian.get_scaling)
+        jb["rots"][N:].copy_(bg_gaussian.get_rotation); jb["opac"][N:].copy_(bg_gaussian.get_opacity.reshape(-1, 1))
+    import weakref
+    ref = weakref.ref(pc)
+
+    def to_model(grad, n=N):                     # pc.screenspace_points.grad keeps meaning what it means without a background cloud
+        m = ref()
+        if m is not None and m.screenspace_points.shape[0] == n:
+            m.screenspace_points.grad = grad[:n]
+        return grad
+    jb["ss"].register_hook(to_model)
+    pc._joint_buffers = jb
+    return jb
 
 
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, bg_gaussian=None):
     """gaussian_renderer/__init__.py:26-143.  Returns {"render", "viewspace_points", "visibility_filter", "radii",
     "vertex1", "vertex2", "vertex3", "scale"}."""
-    screenspace_points = pc.screenspace_points
-    if bg_gaussian is not None:
-        screenspace_points = torch.cat([screenspace_points, torch.zeros_like(bg_gaussian.get_xyz)], dim=0)
+    fused = hasattr(pc, "activated") and not pipe.compute_cov3D_python and pc._bc.is_cuda
+    joint = _joint_buffers(pc, bg_gaussian) if (fused and bg_gaussian is not None and getattr(pc, "joint_buffers", True)) else None
+    if joint is not None:
+        screenspace_points = joint["ss"]
+        screenspace_points.grad = None
+    else:
+        screenspace_points = pc.screenspace_points
+        if bg_gaussian is not None:
+            screenspace_points = torch.cat([screenspace_points, torch.zeros_like(bg_gaussian.get_xyz)], dim=0)
     rasterizer = GaussianRasterizer(_settings(viewpoint_camera, bg_color, scaling_modifier, pc.active_sh_degree, pipe.debug))
-    fused = hasattr(pc, "activated") and not pipe.compute_cov3D_python and pc.get_features.is_cuda
     mrloss = None
     if fused:                                    # one kernel for the four activations instead of ~15 elementwise ops
         mr_w = getattr(pipe, "mesh_restrict_weight", None)
-        act = pc.activated(mr_w)
+        act = pc.activated(mr_w, joint)
         means3D, scales, rotations, opacity = act[:4]
         mrloss = act[4] if mr_w is not None else None
         means2D, cov3D_precomp = screenspace_points, None
@@ -156,10 +203,16 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         if pipe.convert_SHs_python:
             colors_precomp = _python_sh_colors(pc, viewpoint_camera, means3D, pc.get_features)
         else:
-            shs = pc.get_features
+            shs = sh_operand(pc) if hasattr(pc, "_features") else pc.get_features
     else:
         colors_precomp = override_color
-    if bg_gaussian is not None:      # background cloud appended (:100-121: the reference concatenates precomputed covariances)
+    if bg_gaussian is not None and joint is not None:     # means3D / opacity / scales / rotations already ARE [fg; bg] (the joint buffers)
+        if shs is not None:
+            shs = _features_with_background(pc, bg_gaussian, shs)
+        else:
+            bgc = sh_colors(bg_gaussian.get_xyz, viewpoint_camera.camera_center, bg_gaussian.get_features, rot=None, deg=3)
+            colors_precomp = torch.cat([colors_precomp, bgc], dim=0)
+    elif bg_gaussian is not None:    # background cloud appended (:100-121: the reference concatenates precomputed covariances)
         means3D = torch.cat([means3D, bg_gaussian.get_xyz], dim=0)
         opacity = torch.cat([opacity, bg_gaussian.get_opacity], dim=0)
         if cov3D_precomp is not None:
@@ -189,7 +242,7 @@ def bg_render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, overri
     if mesh_gaussians is not None:
         screenspace_points = torch.cat([screenspace_points, mesh_gaussians.screenspace_points], dim=0)
     rasterizer = GaussianRasterizer(_settings(viewpoint_camera, bg_color, scaling_modifier, pc.active_sh_degree, pipe.debug))
-    fused = hasattr(pc, "activated") and not pipe.compute_cov3D_python and pc.get_features.is_cuda
+    fused = hasattr(pc, "activated") and not pipe.compute_cov3D_python and pc._bc.is_cuda
     mrloss = None
     if fused:                                    # one kernel for the four activations instead of ~15 elementwise ops
         mr_w = getattr(pipe, "mesh_restrict_weight", None)
@@ -270,6 +323,7 @@ class MeshBoundGaussians(torch.nn.Module):
         P = torch.nn.Parameter
         self._bc, self._distance = P(bc), P(distance)
         self._features = P(torch.cat((features_dc, features_rest), dim=1).contiguous())
+        self._features_dc0 = None                # begin_dense_dc(): the dense [N,1,3] leaf that is trained while only degree 0 is active
         self._scaling, self._rotation, self._opacity = P(scaling), P(rotation), P(opacity)
         for n, t in dict(vertex1=vertex1, vertex2=vertex2, vertex3=vertex3, normal=normal, r=r).items():
             self.register_buffer(n, t)
@@ -284,8 +338,36 @@ class MeshBoundGaussians(torch.nn.Module):
         return self._bc.shape[0]
 
     def oneupSHdegree(self):
+        if self._features_dc0 is not None:       # a Trainer that trains the dense leaf folds it back together with its Adam moments
+            owner = getattr(self, "_dense_dc_owner", None)
+            owner = owner() if owner is not None else None
+            if owner is not None:
+                owner.fold_dense_dc()
+            else:
+                self.end_dense_dc()
         if self.active_sh_degree < self.max_sh_degree:
             self.active_sh_degree += 1
+
+    def begin_dense_dc(self):
+        """While the model renders at SH degree 0 (the first 1000 iterations of train_mesh_gaussian.py:70-71) only coefficient 0 of every
+        192-byte SH row is read, differentiated and stepped - 12 bytes in whole memory sectors of four strided arrays (parameter, gradient,
+        both Adam moments).  This moves coefficient 0 into a dense [N,1,3] leaf that the rasterizer takes as `shs` with M = 1
+        (tools/sh_dc_probe.py, 2 M Gaussians at 4K: preprocess forward 0.163 -> 0.119 ms, backward 0.203 -> 0.086, the Adam step of the SH
+        group 0.353 -> 0.026).  Coefficient 0 of `_features` is stale until end_dense_dc() / oneupSHdegree() folds the leaf back;
+        get_features / _features_dc always show the current values."""
+        if self.active_sh_degree != 0:
+            raise ValueError("begin_dense_dc: only while active_sh_degree == 0")
+        if self._features_dc0 is None:
+            self._features_dc0 = torch.nn.Parameter(self._features.detach()[:, :1].clone().contiguous(), requires_grad=self._features.requires_grad)
+        return self._features_dc0
+
+    def end_dense_dc(self):
+        """Fold the dense coefficient-0 leaf back into the [N,16,3] rows (in place: shared storage and views stay valid)."""
+        if self._features_dc0 is not None:
+            with torch.no_grad():
+                self._features[:, :1].copy_(self._features_dc0)
+            self._features_dc0 = None
+        return self._features
 
     @property
     def get_scaling(self):
@@ -301,7 +383,7 @@ class MeshBoundGaussians(torch.nn.Module):
 
     @property
     def _features_dc(self):
-        return self._features[:, :1]
+        return self._features[:, :1] if self._features_dc0 is None else self._features_dc0
 
     @property
     def _features_rest(self):
@@ -309,14 +391,16 @@ class MeshBoundGaussians(torch.nn.Module):
 
     @property
     def get_features(self):
+        if self._features_dc0 is not None:       # (the python SH route and external readers; the HIP route takes renderer.sh_operand)
+            return torch.cat((self._features_dc0, self._features[:, 1:].detach()), dim=1)
         return self._features
 
-    def activated(self, mr_weight=None):
+    def activated(self, mr_weight=None, joint=None):
         """(get_xyz, get_scaling, get_rotation, get_opacity[, mesh_restrict_loss]) from one fused kernel
-        (gm_mesh_activate_fwd / _bwd)."""
+        (gm_mesh_activate_fwd / _bwd); joint: see model_ops.mesh_activate."""
         from .model_ops import mesh_activate
         return mesh_activate(self._bc, self._distance, self._scaling, self._rotation, self._opacity, self.vertex1, self.vertex2,
-                             self.vertex3, self.normal, self.r, float(self.alpha_distance), mr_weight)
+                             self.vertex3, self.normal, self.r, float(self.alpha_distance), mr_weight, joint)
 
     @property
     def get_proj_xyz(self):

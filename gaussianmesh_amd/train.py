@@ -71,21 +71,32 @@ class Trainer:
     forwards live in `self.sync_state` (a rasterizer.SyncFreeState owned by THIS trainer and current only inside its step()).
     bg_gaussian: a FrozenGaussians cloud composited behind the trainable one."""
 
-    def __init__(self, gaussians, spatial_lr_scale=1.0, densify_stats=False, sync_free=False, bg_gaussian=None, **opt):
+    def __init__(self, gaussians, spatial_lr_scale=1.0, densify_stats=False, sync_free=False, bg_gaussian=None, dense_dc=None, **opt):
+        """dense_dc (default: on for a model on the GPU at SH degree 0): while only degree 0 is active, train coefficient 0 as a dense
+        [N,1,3] tensor (MeshBoundGaussians.begin_dense_dc) instead of as 12 bytes of every 192-byte row; oneup_sh_degree() folds it -
+        and both Adam moments - back into the rows when the degree is raised."""
         o = dict(DEFAULT_OPT); o.update(opt)
         self.opt = SimpleNamespace(**o)
         self.g = gaussians
         self.bg_gaussian = bg_gaussian
+        from .renderer import sh_operand
+        if dense_dc is None:
+            dense_dc = hasattr(gaussians, "begin_dense_dc") and gaussians._features.is_cuda and int(getattr(gaussians, "active_sh_degree", 3)) == 0
+        if dense_dc:
+            import weakref
+            gaussians.begin_dense_dc()
+            gaussians._dense_dc_owner = weakref.ref(self)        # gaussians.oneupSHdegree() then folds through fold_dense_dc()
         if bg_gaussian is not None and hasattr(gaussians, "_features") and gaussians._features.is_cuda:
             from .renderer import share_feature_storage
             share_feature_storage(gaussians, bg_gaussian)        # before the optimizer captures the parameter
         s = spatial_lr_scale
+        sh_leaf = sh_operand(gaussians)
         # the reference's seven groups; "f_dc" (coefficient 0) and "f_rest" are the two learning rates of the one SH tensor
         groups = [
             {"params": [gaussians._bc], "lr": o["position_lr_init"] * s, "name": "bc"},
             {"params": [gaussians._distance], "lr": o["position_lr_init"] * s, "name": "distance"},
-            {"params": [gaussians._features], "lr": o["feature_lr"], "lr_rest": o["feature_lr"] / 20.0, "period": 48, "split": 3,
-             "name": "f_dc+f_rest"},
+            {"params": [sh_leaf], "lr": o["feature_lr"], "lr_rest": o["feature_lr"] / 20.0, "period": (3 * sh_leaf.shape[1] if sh_leaf.shape[1] > 1 else 0), "split": 3,
+             "name": "f_dc+f_rest"},             # (dense coefficient 0: no period, every element steps with feature_lr)
             {"params": [gaussians._opacity], "lr": o["opacity_lr"], "name": "opacity"},
             {"params": [gaussians._scaling], "lr": o["scaling_lr"], "name": "scaling"},
             {"params": [gaussians._rotation], "lr": o["rotation_lr"], "name": "rotation"},
@@ -136,9 +147,24 @@ class Trainer:
         if n_new and (new_buffers is None or any(k not in new_buffers for k in ("vertex1", "vertex2", "vertex3", "normal", "r"))):
             raise ValueError("Trainer.resize: appended rows need their vertex1/vertex2/vertex3/normal/r buffers")
         idx = None if keep_mask is None else keep_mask.nonzero(as_tuple=False).reshape(-1)
+        dense_dc = getattr(g, "_features_dc0", None) is not None
+        sh_rows = None
+        if dense_dc:
+            # the optimizer holds the dense coefficient-0 leaf; the [N,16,3] rows behind it (coefficients 1.. wait for their degree)
+            # follow the same row set as a buffer
+            if n_new:
+                new_rows = dict(new_rows)
+                sh_rows = new_rows["f_dc+f_rest"] if "f_dc+f_rest" in new_rows else torch.cat((new_rows.pop("f_dc"), new_rows.pop("f_rest")), dim=1)
+                new_rows["f_dc+f_rest"] = sh_rows[:, :1].contiguous()
+            with torch.no_grad():
+                store = g._features.detach() if idx is None else g._features.detach().index_select(0, idx)
+                if n_new:
+                    store = torch.cat((store, sh_rows.to(store.dtype)), dim=0)
         params = self.optimizer.resize(keep=idx, new_rows=new_rows if n_new else None)
         for name, attr in self._PARAM_OF_GROUP.items():
-            setattr(g, attr, params[name])
+            setattr(g, "_features_dc0" if (dense_dc and name == "f_dc+f_rest") else attr, params[name])
+        if dense_dc:
+            g._features = torch.nn.Parameter(store.contiguous(), requires_grad=g._features.requires_grad)
         with torch.no_grad():
             for b in self._ROW_BUFFERS:
                 old = getattr(g, b, None)
@@ -159,9 +185,9 @@ class Trainer:
         n = g._bc.shape[0]
         g.screenspace_points = torch.zeros((n, 3), dtype=g._bc.dtype, device=g._bc.device, requires_grad=True)
         if self.bg_gaussian is not None and g._features.is_cuda:
-            from .renderer import share_feature_storage
+            from .renderer import share_feature_storage, sh_operand
             share_feature_storage(g, self.bg_gaussian)
-            self.optimizer.rebind("f_dc+f_rest", g._features)
+            self.optimizer.rebind("f_dc+f_rest", sh_operand(g))
         if self.densify_stats:
             if n_new:
                 dev = g._bc.device
@@ -226,7 +252,7 @@ class Trainer:
             new_rows = {
                 "bc": torch.full((ns * N, 3), 1.0 / 3.0, dtype=g._bc.dtype, device=g._bc.device),
                 "distance": torch.zeros((ns * N, 1), dtype=g._bc.dtype, device=g._bc.device),
-                "f_dc+f_rest": rep(g._features.detach()),
+                "f_dc+f_rest": rep(g.get_features.detach()),
                 "opacity": rep(g._opacity.detach()),
                 "scaling": torch.log(rep(torch.exp(g._scaling.detach())) / (4 * 0.8)),
                 "rotation": rep(g._rotation.detach()),
@@ -289,7 +315,7 @@ class Trainer:
         plan["rows"] = the row count after the iteration."""
         plan = self.schedule(self.iteration + 1, white_background)
         if plan["oneup"] and hasattr(self.g, "oneupSHdegree"):
-            self.g.oneupSHdegree()
+            self.oneup_sh_degree()
         loss, pkg = self.step(camera, gt_image, background, stats=plan["stats"],
                               densify=(self.opt.densify_grad_threshold, 0.005, extent, plan["size_threshold"], 5) if plan["densify"] else None,
                               optimizer_step=plan["optimizer_step"])
@@ -297,6 +323,29 @@ class Trainer:
             self.reset_opacity()
         plan["rows"] = self.g._bc.shape[0]
         return loss, pkg, plan
+
+    def fold_dense_dc(self):
+        """The dense coefficient-0 leaf (dense_dc) goes back into the [N,16,3] rows together with BOTH Adam moments (the other
+        coefficients have never had a gradient: their moments are zero, exactly what the reference's Adam holds for them), and the SH
+        group steps the rows again.  Called by the model's oneupSHdegree() (train_mesh_gaussian.py:70-71)."""
+        g = self.g
+        if getattr(g, "_features_dc0", None) is None:
+            return
+        grp = next(gr for gr in self.optimizer.param_groups if gr["name"] == "f_dc+f_rest")
+        m_dc, v_dc = grp["m"][0], grp["values"][0]
+        shared = getattr(g, "_features_with_bg", None)
+        g.end_dense_dc()                                         # rows current again (in place)
+        if self.bg_gaussian is not None and shared is not None:
+            from .renderer import share_feature_storage
+            share_feature_storage(g, self.bg_gaussian)           # the ROWS share their storage with the background from here on
+        with torch.no_grad():
+            m = torch.zeros_like(g._features); v = torch.zeros_like(g._features)
+            m[:, :1].copy_(m_dc); v[:, :1].copy_(v_dc)
+        grp["params"][0], grp["m"][0], grp["values"][0] = g._features, m, v
+        grp["period"] = 3 * g._features.shape[1]
+
+    def oneup_sh_degree(self):
+        self.g.oneupSHdegree()
 
     def step(self, camera, gt_image, background, stats=True, densify=None, optimizer_step=True):
         """One iteration; returns (loss tensor, render package).  Host synchronisation: the rasterizer's instance-count
@@ -326,10 +375,10 @@ class Trainer:
         if self.densify_stats and stats:
             from .model_ops import densify_stats
             N = self.max_radii2D.shape[0]
-            densify_stats(pkg["radii"][:N], self.g.screenspace_points.grad, self.max_radii2D, self.bc_gradient_accum, self.denom)
+            densify_stats(pkg["radii"][:N], self._viewspace_grad(pkg), self.max_radii2D, self.bc_gradient_accum, self.denom)
         if self.keep_grads:                      # diagnostics / tests: the gradients this step consumed, by group name
             self.last_grads = {gr["name"]: gr["params"][0].grad for gr in self.optimizer.param_groups}
-            self.last_grads["viewspace"] = self.g.screenspace_points.grad
+            self.last_grads["viewspace"] = self._viewspace_grad(pkg)[:self.g._bc.shape[0]]
         self._sh_degree_seen = max(self._sh_degree_seen, int(getattr(self.g, "active_sh_degree", 3)))
         if densify is not None:
             self.densify_and_prune(*densify)
@@ -342,6 +391,12 @@ class Trainer:
             self.optimizer.step()
         self.optimizer.zero_grad(set_to_none=True)
         return loss.detach(), pkg
+
+    def _viewspace_grad(self, pkg):
+        """viewspace_point_tensor.grad (train_mesh_gaussian.py:119-124): of the render package's probe when it is a leaf (the joint
+        [fg; bg] probe of renderer._joint_buffers), else of the model's own (the probe went through a torch.cat)."""
+        vp = pkg["viewspace_points"]
+        return vp.grad if (vp.is_leaf and vp.grad is not None) else self.g.screenspace_points.grad
 
     def copy_state_from(self, other):
         """Make this trainer's optimisation state equal to `other`'s (same row count): parameter values (in place - views and
