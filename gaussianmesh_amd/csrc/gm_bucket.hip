@@ -564,14 +564,14 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(uint32_t* __res
     const uint32_t seq = hdr[0], slot = seq % GM_PLAN_SLOTS;
     uint32_t* stamp = plan + 2 + slot;
     if (threadIdx.x == 0) st_agent(stamp, 0u);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // (the store has left before the table words do)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // (the store has left before the table words do)
     __syncthreads();
     block_build_depth_map(slots, coarse, m, wsum, dstart, plan + 2 + GM_PLAN_SLOTS + (size_t)slot * GM_COARSE_BINS, nullptr, nullptr, 2);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     if (threadIdx.x == 0) {
       st_agent(stamp, seq);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       atomicMax(plan, seq);
     }
     return;
@@ -932,7 +932,8 @@ int launch_depth_order(GeomState& g, int P, int debug, hipStream_t s, int* num_r
 //                            refused, and this frame's coarse histogram -> the stream's next table (slot = sequence % slots);
 //      bucket_sort_kernel<true>.
 //    Three launches and the random record gather less than A.  The writer protocol of a table: stamp = 0, table words, stamp =
-//    sequence, newest = max(newest, sequence), all agent-scope with release fences between; a reader checks the stamp before and
+//    sequence, newest = max(newest, sequence), all agent-scope with AGENT-scope release / acquire fences between (a workgroup-scope fence orders
+//    nothing another XCD can observe: ADVICE round 4); a reader checks the stamp before and
 //    after its copy.  A slot is rewritten GM_PLAN_SLOTS frames later - the copy of a frame that far behind would be torn, and is
 //    caught by the stamp.
 __global__ __launch_bounds__(256) void arm_direct_kernel(uint4* __restrict__ arm, uint32_t arm_vec, uint4* __restrict__ cnt, uint32_t cnt_vec,
@@ -957,7 +958,7 @@ __global__ __launch_bounds__(256) void arm_direct_kernel(uint4* __restrict__ arm
   uint32_t w[PER];
 #pragma unroll
   for (int j = 0; j < PER; j++) w[j] = ok ? ld_agent(table + threadIdx.x * PER + j) : 0u;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");            // (the words are in before the stamp is looked at again)
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");            // (the words are in before the stamp is looked at again)
   ok = ok && ld_agent(stamp) == v;
   // Whatever the memory system did to the copy, it is USED only if it is a table: first buckets non-decreasing and equal to the
   // running sum of the bucket counts (base[c + 1] == base[c] + nb[c], base[0] == 0, at most 2048 buckets).  Any word sequence with
@@ -1022,16 +1023,16 @@ __global__ __launch_bounds__(256) void publish_plan_kernel(const uint32_t* __res
     s_seq = atomicAdd(plan + 1, 1u) + 1u;
     st_agent(plan + 2 + s_seq % GM_PLAN_SLOTS, 0u);
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   __syncthreads();
   const uint32_t seq = s_seq, slot = seq % GM_PLAN_SLOTS;
   uint32_t* table = plan + 2 + GM_PLAN_SLOTS + (size_t)slot * GM_COARSE_BINS;
   for (int c = threadIdx.x; c < GM_COARSE_BINS; c += 256) st_agent(table + c, dmap[c]);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   __syncthreads();
   if (threadIdx.x == 0) {
     st_agent(plan + 2 + slot, seq);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     atomicMax(plan, seq);
   }
 }

@@ -313,6 +313,9 @@ class Trainer:
         densify_and_prune every densification_interval iterations past densify_from_iter (N = 5, the optimizer step of that
         iteration skipped, as the reference's update_flag does), opacity reset.  Returns (loss, render package, plan) with
         plan["rows"] = the row count after the iteration."""
+        if not self.densify_stats:
+            raise ValueError("train_iteration follows the reference's schedule, densification included: build the Trainer with densify_stats=True "
+                             "(without the statistics the loop would run 599 iterations and fail in densify_and_prune at iteration 600)")
         plan = self.schedule(self.iteration + 1, white_background)
         if plan["oneup"] and hasattr(self.g, "oneupSHdegree"):
             self.oneup_sh_degree()

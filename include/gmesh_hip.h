@@ -206,7 +206,11 @@ int gm_deform_shade_packed(int N, int deg, int M, const int* tri, const float* w
  * Gaussian go straight into its projection, conic, radius and instance count without a round trip through HBM.
  * Equivalent, bit for bit, to gm_deform_shade_packed followed by gm_forward_0_async(colors_precomp = rgb_out,
  * cov3D_precomp = cov6_out, means3D = pos_out, scale_modifier 1).  pos_out / cov6_out / rgb_out: all three or all NULL.
- * Complete the frame with gm_forward_1_geom. */
+ * Complete the frame with gm_forward_1_geom.
+ * A deformed frame is FORWARD-ONLY: its geometry buffer does not hold everything gm_backward reads.  Not written by this pass (the
+ * buffer keeps whatever an earlier call left there): "clamped" (the SH clamp flags), "tiles_touched" except for saturated rectangles,
+ * the internal radii copy when `radii` is given, and - in the stream variant with a plan - "bin" and "depth_key".  Do not call
+ * gm_backward / gm_backward_p on such a buffer; differentiate through gm_deform_shade_packed + gm_forward_0_async instead. */
 int gm_forward_0_deformed_async(int emission_policy, void* geom_buffer, int P, int deg, int M, int width, int height, const int* tri,
                                 const float* w, const float* packed, const float* cov, const float* pos, const float* shs,
                                 const float* opacities, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
