@@ -14,29 +14,23 @@ namespace gm {
 __device__ __forceinline__ bool may_touch(float sx, float sy, float a, float b, float c, float op,
                                           float x0, float x1, float y0, float y1) {
   if (!(op >= 0.0039f)) return false;                 // op < 1/255 (1/255 = 0.0039216): alpha = op*G < 1/255 everywhere
+  // d = centre - pixel ranges over [dxl, dxh] x [dyl, dyh]; q is minimal at d = 0
   const float dxl = sx - x1, dxh = sx - x0, dyl = sy - y1, dyh = sy - y0;
   const float thr = 1.3862943611f * __builtin_amdgcn_logf(255.0f * op);   // 2 ln(255 op) = 2 ln2 log2(255 op)
   const float mx = fmaxf(fabsf(dxl), fabsf(dxh)), my = fmaxf(fabsf(dyl), fabsf(dyh));
   const float margin = 4e-6f * (a * mx * mx + c * my * my + 2.0f * fabsf(b) * mx * my) + 1e-3f;
-  if (dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f) return true;   // centre inside: q_min = 0 <= thr (op >= 1/255)
+  // Round 5: TWO edges instead of four.  The constrained minimum of a convex form whose free minimum (d = 0) lies outside the
+  // rectangle is on an edge that faces it: dx = ex, the end of [dxl, dxh] nearest 0, and dy = ey likewise (a point of a far edge
+  // could slide towards 0 inside the rectangle and lower q).  With 0 inside a range (ex or ey = 0) that candidate is a feasible
+  // interior line whose clamped minimum is still a point of the rectangle - never below the true minimum - and with both 0 the
+  // centre is inside and both candidates are q(0, 0) = 0.  24 vector instructions less per batch of 64 candidates in either blend.
+  const float ex = __builtin_amdgcn_fmed3f(0.f, dxl, dxh), ey = __builtin_amdgcn_fmed3f(0.f, dyl, dyh);
   const float nb_c = -b * __builtin_amdgcn_rcpf(c), nb_a = -b * __builtin_amdgcn_rcpf(a);
-  float qmin;
-  {
-    const float y = fminf(fmaxf(nb_c * dxl, dyl), dyh);
-    qmin = a * dxl * dxl + 2.f * b * dxl * y + c * y * y;
-  }
-  {
-    const float y = fminf(fmaxf(nb_c * dxh, dyl), dyh);
-    qmin = fminf(qmin, a * dxh * dxh + 2.f * b * dxh * y + c * y * y);
-  }
-  {
-    const float x = fminf(fmaxf(nb_a * dyl, dxl), dxh);
-    qmin = fminf(qmin, a * x * x + 2.f * b * x * dyl + c * dyl * dyl);
-  }
-  {
-    const float x = fminf(fmaxf(nb_a * dyh, dxl), dxh);
-    qmin = fminf(qmin, a * x * x + 2.f * b * x * dyh + c * dyh * dyh);
-  }
+  const float y = __builtin_amdgcn_fmed3f(nb_c * ex, dyl, dyh);
+  const float x = __builtin_amdgcn_fmed3f(nb_a * ey, dxl, dxh);
+  const float q1 = a * ex * ex + 2.f * b * ex * y + c * y * y;
+  const float q2 = a * x * x + 2.f * b * x * ey + c * ey * ey;
+  const float qmin = fminf(q1, q2);
   return !(qmin > thr + margin);                       // NaN-safe: keep the entry unless it is provably out of reach
 }
 

@@ -201,7 +201,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     shs = colors_precomp = None
     if override_color is None:
         if pipe.convert_SHs_python:
-            colors_precomp = _python_sh_colors(pc, viewpoint_camera, means3D, pc.get_features)
+            colors_precomp = _python_sh_colors(pc, viewpoint_camera, means3D if joint is None else means3D[:joint["N"]], pc.get_features)
         else:
             shs = sh_operand(pc) if hasattr(pc, "_features") else pc.get_features
     else:
