@@ -23,7 +23,7 @@
 
 enum Cls { FMA, FMA_DEP, MUL, ADD, PK_FMA, PK_MUL, EXP, LOG, RCP, SQRT, CNDMASK, CMP, CMP_CNDMASK, MED3, READLANE, MBCNT, DS_B128_BCAST, DS_B128_LANE, DS_B32_LANE,
            DS_B64_LANE, FWD_BODY, BWD_BODY,
-           AND_B32, OR_B32, NOT_B32, ASHR_I32, SUB_U32, MAX_U32, MIN_F32, MAX_F32, MOV_B32, BFI_B32, AND_OR_B32, CNDMASK_SGPR, CNDMASK_CONST0, MUL_SGPR, CMP_SGPR, CMPX, FMAC_F32, FWD_BODY_B, FWD_BODY_A, NCLS };
+           AND_B32, OR_B32, NOT_B32, ASHR_I32, SUB_U32, MAX_U32, MIN_F32, MAX_F32, MOV_B32, BFI_B32, AND_OR_B32, CNDMASK_SGPR, CNDMASK_CONST0, MUL_SGPR, CMP_SGPR, CMPX, FMAC_F32, FWD_BODY_B, FWD_BODY_A, FWD_GROUP_V0, FWD_GROUP_VA, NCLS };
 static const char* cls_name[NCLS] = {"v_fma_f32 (16 independent)", "v_fma_f32 (dependent chain)", "v_mul_f32", "v_add_f32", "v_pk_fma_f32", "v_pk_mul_f32",
                                      "v_exp_f32", "v_log_f32", "v_rcp_f32", "v_sqrt_f32", "v_cndmask_b32 (vcc)", "v_cmp_ge_f32 (-> vcc)",
                                      "v_cmp_ge_f32 + v_cndmask_b32 pair", "v_med3_f32", "v_readlane_b32 (-> sgpr)", "v_mbcnt_lo/hi pair",
@@ -34,9 +34,11 @@ static const char* cls_name[NCLS] = {"v_fma_f32 (16 independent)", "v_fma_f32 (d
                                      "v_and_or_b32", "v_cndmask_b32_e64 (mask in an SGPR pair)", "v_cndmask_b32 v, 0, v, vcc", "v_mul_f32 with an SGPR operand",
                                      "v_cmp_ge_f32_e64 (-> SGPR pair)", "v_cmpx_ge_f32 (-> exec, always true)", "v_fmac_f32 (VOP2)",
                                      "forward-blend body B: selects as integer masks (C++), cycles per SURVIVOR",
-                                     "forward-blend body A: stop through EXEC (asm), cycles per SURVIVOR"};
+                                     "forward-blend body A: stop through EXEC (asm), cycles per SURVIVOR",
+                                     "forward GROUP as in the kernel (3 MFMA + 16 survivors, colours from LDS), compare + select: cycles per SURVIVOR",
+                                     "forward GROUP, stop through EXEC + alpha mask + clamp-scaled exponent (asm): cycles per SURVIVOR"};
 // instructions per block of the class (for the per-instruction figures)
-static const int cls_insts[NCLS] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 16, 8, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 16, 16};
+static const int cls_insts[NCLS] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 16, 8, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 16, 16, 16, 16};
 
 template <int C>
 __global__ __launch_bounds__(256) void probe_kernel(int iters, unsigned long long* __restrict__ out, float seed) {
@@ -212,6 +214,69 @@ __global__ __launch_bounds__(256) void probe_kernel(int iters, unsigned long lon
       }
       asm volatile("s_mov_b64 exec, %0" :: "s"(saved));
       a4 = T; a5 = Cb; p0.x = Cr; p0.y = Cg;
+    } else if (C == FWD_GROUP_V0 || C == FWD_GROUP_VA) {
+      // One group of the forward blend as the kernel runs it: the A operand from LDS, three chained v_mfma_f32_32x32x2_f32, then sixteen
+      // survivors whose (r, g, b, -) come from LDS as one ds_read_b128 each (uniform address).  V0: gm_render.hip blend16 as it stands
+      // (image-only build).  VA: the alpha >= 1/255 skip as an integer mask, min(0.99, .) folded into the exponent (clamp bit of v_exp on
+      // e' - log2(0.99), the factor 0.99 in the colours and in T - 0.99 w'), the stop test through EXEC (v_cmpx: a stopped pixel leaves
+      // the wave's execution mask for the rest of the group; T keeps its final value).
+      typedef float v16f __attribute__((ext_vector_type(16)));
+      const int lane = threadIdx.x & 63;
+      const float* ctg = reinterpret_cast<const float*>(lds) + lane;
+      const float A0 = ctg[0], A1 = ctg[64], A2 = ctg[128];
+      v16f E = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      E = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, a6, E, 0, 0, 0);
+      E = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, a7, E, 0, 0, 0);
+      E = __builtin_amdgcn_mfma_f32_32x32x2f32(A2, a8, E, 0, 0, 0);
+      const float4* sb = &lds[64];
+      if (C == FWD_GROUP_V0) {
+        float T = a4, Cb = a5; v2f Crg = p0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          float4 S[4];
+#pragma unroll
+          for (int t = 0; t < 4; t++) S[t] = sb[(it & 3) * 16 + 4 * q + t];
+          float al[4];
+#pragma unroll
+          for (int t = 0; t < 4; t++) { const float oG = __builtin_amdgcn_exp2f(E[4 * q + t]); al[t] = (oG >= 1.0f / 255.0f) ? fminf(0.99f, oG) : 0.0f; }
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            const float wa = al[t] * T, tt = T - wa;
+            const bool stop = tt < 0.0001f;
+            const float w = stop ? 0.0f : wa;
+            T = stop ? -__builtin_fabsf(T) : tt;
+            const v2f rg = {S[t].x, S[t].y}, ww = {w, w};
+            Crg = rg * ww + Crg; Cb += S[t].z * w;
+          }
+        }
+        a4 = T; a5 = Cb; p0 = Crg;
+      } else {
+        float T = a4, Cb = a5, Cr = p0.x, Cg = p0.y;
+        unsigned long long saved;
+        asm volatile("s_mov_b64 %0, exec" : "=s"(saved));
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          float4 S[4];
+#pragma unroll
+          for (int t = 0; t < 4; t++) S[t] = sb[(it & 3) * 16 + 4 * q + t];
+          float x0, x1, x2, x3, m0, m1, m2, m3, tt;
+          // 0x3B81CDC6 = bits(1/255 / 0.99) : oG' = 2^(e' - log2 0.99) clamped to 1 is alpha / 0.99
+          asm volatile(
+              "v_exp_f32_e64 %0, %9 clamp\n v_exp_f32_e64 %1, %10 clamp\n v_exp_f32_e64 %2, %11 clamp\n v_exp_f32_e64 %3, %12 clamp\n"
+              "v_sub_u32 %4, 0x3b81cdc5, %0\n v_sub_u32 %5, 0x3b81cdc5, %1\n v_sub_u32 %6, 0x3b81cdc5, %2\n v_sub_u32 %7, 0x3b81cdc5, %3\n"
+              "v_ashrrev_i32 %4, 31, %4\n v_ashrrev_i32 %5, 31, %5\n v_ashrrev_i32 %6, 31, %6\n v_ashrrev_i32 %7, 31, %7\n"
+              "v_and_b32 %0, %4, %0\n v_and_b32 %1, %5, %1\n v_and_b32 %2, %6, %2\n v_and_b32 %3, %7, %3\n"
+              : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(m0), "=&v"(m1), "=&v"(m2), "=&v"(m3), "=&v"(tt)
+              : "v"(E[4 * q]), "v"(E[4 * q + 1]), "v"(E[4 * q + 2]), "v"(E[4 * q + 3]));
+#define SURV(X, SX, SY, SZ) \
+          asm volatile("v_mul_f32 %0, %0, %1\n v_fma_f32 %5, %0, %6, %1\n v_cmpx_le_f32_e64 vcc, %7, %5\n v_mov_b32 %1, %5\n" \
+                       "v_fmac_f32 %2, %8, %0\n v_fmac_f32 %3, %9, %0\n v_fmac_f32 %4, %10, %0\n" \
+                       : "+v"(X), "+v"(T), "+v"(Cr), "+v"(Cg), "+v"(Cb), "=&v"(tt) : "v"(b), "v"(c), "v"(SX), "v"(SY), "v"(SZ) : "vcc")
+          SURV(x0, S[0].x, S[0].y, S[0].z); SURV(x1, S[1].x, S[1].y, S[1].z); SURV(x2, S[2].x, S[2].y, S[2].z); SURV(x3, S[3].x, S[3].y, S[3].z);
+        }
+        asm volatile("s_mov_b64 exec, %0" :: "s"(saved));
+        a4 = T; a5 = Cb; p0.x = Cr; p0.y = Cg;
+      }
     } else if (C == FWD_BODY) {
       // the forward blend's per-survivor body, C++ as in gm_render.hip blend16 (GM_FWD_SUB = 4: four alpha evaluations interleaved, then the
       // T / C recurrence in list order), 16 survivors per iteration; the compiler emits 11 VALU per survivor (exp, cmp, min, cndmask, mul,
@@ -280,7 +345,7 @@ template <int C> static kern_t get() { return probe_kernel<C>; }
 static kern_t kernels[NCLS] = {get<0>(), get<1>(), get<2>(), get<3>(), get<4>(), get<5>(), get<6>(), get<7>(), get<8>(), get<9>(), get<10>(), get<11>(), get<12>(),
                                get<13>(), get<14>(), get<15>(), get<16>(), get<17>(), get<18>(), get<19>(), get<20>(), get<21>(),
                                get<22>(), get<23>(), get<24>(), get<25>(), get<26>(), get<27>(), get<28>(), get<29>(), get<30>(), get<31>(), get<32>(), get<33>(), get<34>(),
-                               get<35>(), get<36>(), get<37>(), get<38>(), get<39>(), get<40>()};
+                               get<35>(), get<36>(), get<37>(), get<38>(), get<39>(), get<40>(), get<41>(), get<42>()};
 
 __global__ void nan_min_kernel(float* out) {      // what v_min_f32 / v_max_f32 make of the all-ones NaN pattern (forward body B relies on min(x, NaN) = x)
   const float nan_ = __int_as_float(0xFFFFFFFF), x = 0.25f;
