@@ -186,14 +186,14 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 // compiler would fuse in one of them.  (ucx, vcy): centre of half 0 of the wave's quadrant; half 1 lies four rows below.
 #define GM_POLY_PAD -1.0e30f      // constant coefficient of a row that holds no survivor: 2^e' = 0, the entry is skipped by every pixel
 __device__ __forceinline__ void stage_poly(float* __restrict__ ct, int slot, float x, float y, float conx, float cony, float conz, float opacity,
-                                           float ucx, float vcy) {
+                                           float ucx, float vcy, float kshift = 0.0f) {
 #pragma clang fp contract(off)
   const int g = slot >> 4, sg = slot & 15;
   const float a = (-0.5f * LOG2E) * conx, b = (-LOG2E) * cony, c = (-0.5f * LOG2E) * conz;
   const float u = x - ucx, v0 = y - vcy, v1 = v0 - 4.0f;
   // log2(opacity) (v_log_f32); a conic that is not positive (an overflowing or rounded-away determinant in the preprocess) has
   // power > 0 wherever the reference evaluates it and is skipped there (forward.cu:336): the row is padded out
-  const float au = a * u, bu = b * u, lo = (conx > 0.f && conz > 0.f) ? __builtin_amdgcn_logf(opacity) : GM_POLY_PAD;
+  const float au = a * u, bu = b * u, lo = (conx > 0.f && conz > 0.f) ? __builtin_amdgcn_logf(opacity) + kshift : GM_POLY_PAD;
   float* row = &ct[192 * g + 8 * (sg >> 2) + (sg & 3)];                           // row of (half 0, survivor sg); half 1: + 4
   row[0] = a; row[4] = a; row[32] = b; row[36] = b; row[64] = c; row[68] = c;
   row[96] = -2.0f * au - b * v0;  row[100] = -2.0f * au - b * v1;
@@ -217,6 +217,9 @@ __device__ __forceinline__ v16f poly_exponents(const float* __restrict__ ct, int
 #ifndef GM_FWD_SUB
 #define GM_FWD_SUB 4
 #endif
+#ifndef GM_FWD_FOLD99
+#define GM_FWD_FOLD99 1           // matrix-core forward: min(0.99, .) folded into the exponent (2^(e' - log2 0.99) with v_exp's clamp bit IS alpha / 0.99;
+#endif                            // the factor 0.99 rides in the staged colours and in T - 0.99 w'): 10 instead of 11 vector instructions per survivor
 #ifndef GM_FWD_SETS
 #define GM_FWD_SETS 2             // register sets of gathered records in rotation in the forward blend (3: round 2-3, see render_fwd_kernel)
 #endif              // survivors whose alpha evaluations interleave (2: 8 VGPRs fewer, no faster)
@@ -348,10 +351,12 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
         // half centres into the MFMA's A layout, colour + opacity, list position
         if (keep) {
           const int slot = (int)lanes_below(kb);
-          if (!EXACT) stage_poly(L.ct, slot, cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, ucx, vcy);
+          constexpr bool FOLD = GM_FWD_FOLD99 && !EXACT;
+          if (!EXACT) stage_poly(L.ct, slot, cur.a.x, cur.a.y, cur.a.z, cur.a.w, cur.b.x, cur.b.y, ucx, vcy, FOLD ? 0.0144995696951f : 0.0f);   // -log2(0.99)
           // (r, g, b, w): w = the opacity in the EXACT build, otherwise (the opacity lives in the polynomial) the 1-based list position
           // the backward state wants - one broadcast read per survivor for colour AND n_contrib
-          L.sb[slot] = make_float4(cur.b.z, cur.b.w, cur.c, EXACT ? cur.b.y : (STATE ? __uint_as_float(cur.pos + 1u) : 0.f));
+          const float cs = FOLD ? 0.99f : 1.0f;
+          L.sb[slot] = make_float4(cs * cur.b.z, cs * cur.b.w, cs * cur.c, EXACT ? cur.b.y : (STATE ? __uint_as_float(cur.pos + 1u) : 0.f));
           if (EXACT) {
             x_ra[68 * (WPW == 4 ? wave : 0) + slot] = make_float4(cur.a.x, cur.a.y, (-0.5f * LOG2E) * cur.a.z, (-0.5f * LOG2E) * cur.b.x);
             x_bq[68 * (WPW == 4 ? wave : 0) + slot] = (-LOG2E) * cur.a.w;
@@ -396,13 +401,20 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
             for (int t = 0; t < SUB; t++) {
               // opacity * G = 2^e' in one instruction (the opacity is part of the polynomial); EXACT: min(2^e, 1) * opacity, the exponent
               // clamped at 0 by v_exp_f32's clamp bit (see above)
+              if (GM_FWD_FOLD99 && !EXACT) {
+                // al[t] = alpha / 0.99: 2^(e' - log2 0.99), clamped to 1 by v_exp's clamp bit (= min(0.99, .) of alpha), 0 where alpha < 1/255
+                const float oGp = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(E[SUB * q + t]), 0.0f, 1.0f);
+                al[t] = (oGp >= (1.0f / 255.0f) / 0.99f) ? oGp : 0.0f;
+                continue;
+              }
               const float oG = EXACT ? S[t].w * __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(E[SUB * q + t]), 0.0f, 1.0f)
                                      : __builtin_amdgcn_exp2f(E[SUB * q + t]);
               al[t] = (oG >= 1.0f / 255.0f) ? fminf(0.99f, oG) : 0.0f;                        // skip alpha < 1/255; alpha = min(0.99, .)
             }
 #pragma unroll
             for (int t = 0; t < SUB; t++) {          // in list order
-              const float wa = al[t] * T, tt = T - wa;                                      // weight alpha T; T (1 - alpha) as T - alpha T
+              // weight alpha T; T (1 - alpha) as T - alpha T.  Folded form: wa = (alpha / 0.99) T weighs colours staged as 0.99 c
+              const float wa = al[t] * T, tt = (GM_FWD_FOLD99 && !EXACT) ? __builtin_fmaf(-0.99f, wa, T) : T - wa;
               const bool stop = tt < 0.0001f;                                               // (tt == T >= 1e-4 when alpha == 0; tt < 0 once stopped)
               const float w = stop ? 0.0f : wa;
               T = stop ? -__builtin_fabsf(T) : tt;                                          // stop WITHOUT applying the entry
