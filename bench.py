@@ -1029,6 +1029,17 @@ def main():
             tr.step(cam0, gt, zero_bg)
         torch.cuda.synchronize()
         out["fwd_bwd"]["ms_per_training_iteration"] = 1e3 * (time.perf_counter() - t1) / nit
+        # the same iteration with the sync-free forward (no instance-count read-back: the host never waits inside an iteration), as C5 runs
+        del tr
+        tr = Trainer(model, sync_free=True)
+        for _ in range(10):
+            tr.step(cam0, gt, zero_bg)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(nit):
+            tr.step(cam0, gt, zero_bg)
+        torch.cuda.synchronize()
+        out["fwd_bwd"]["ms_per_training_iteration_sync_free"] = 1e3 * (time.perf_counter() - t1) / nit
         # BASELINE.json config C2: 500k Gaussians (the free-standing synthetic cloud of SURVEY.md 8d), 1080p, SH3, forward+backward
         del model, tr
         from gaussianmesh_amd import scenes as _sc
