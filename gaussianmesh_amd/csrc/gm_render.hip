@@ -396,7 +396,7 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
 #pragma unroll
               for (int t = 0; t < SUB; t++) SP[t] = EXACT ? x_sp[68 * (WPW == 4 ? wave : 0) + j + SUB * q + t] : __float_as_uint(S[t].w);
             }
-            float al[SUB];
+            float al[SUB]; bool ok[SUB];
 #pragma unroll
             for (int t = 0; t < SUB; t++) {
               // opacity * G = 2^e' in one instruction (the opacity is part of the polynomial); EXACT: min(2^e, 1) * opacity, the exponent
@@ -404,12 +404,14 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
               if (GM_FWD_FOLD99 && !EXACT) {
                 // al[t] = alpha / 0.99: 2^(e' - log2 0.99), clamped to 1 by v_exp's clamp bit (= min(0.99, .) of alpha), 0 where alpha < 1/255
                 const float oGp = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(E[SUB * q + t]), 0.0f, 1.0f);
-                al[t] = (oGp >= (1.0f / 255.0f) / 0.99f) ? oGp : 0.0f;
+                ok[t] = oGp >= (1.0f / 255.0f) / 0.99f;
+                al[t] = ok[t] ? oGp : 0.0f;
                 continue;
               }
               const float oG = EXACT ? S[t].w * __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(E[SUB * q + t]), 0.0f, 1.0f)
                                      : __builtin_amdgcn_exp2f(E[SUB * q + t]);
-              al[t] = (oG >= 1.0f / 255.0f) ? fminf(0.99f, oG) : 0.0f;                        // skip alpha < 1/255; alpha = min(0.99, .)
+              ok[t] = oG >= 1.0f / 255.0f;
+              al[t] = ok[t] ? fminf(0.99f, oG) : 0.0f;                                        // skip alpha < 1/255; alpha = min(0.99, .)
             }
 #pragma unroll
             for (int t = 0; t < SUB; t++) {          // in list order
@@ -420,7 +422,9 @@ __global__ __launch_bounds__(64 * GM_RENDER_FWD_WPW) void render_fwd_kernel(cons
               T = stop ? -__builtin_fabsf(T) : tt;                                          // stop WITHOUT applying the entry
               const v2f rg = {S[t].x, S[t].y}, ww = {w, w};
               Crg = rg * ww + Crg; Cb += S[t].z * w;
-              if (STATE) last = (w > 0.0f) ? SP[t] : last;
+              // accepted <=> alpha >= 1/255 and not stopping (a stopped pixel's T < 0 stops again): the two compares' masks combined on the
+              // scalar unit select the list position - one vector instruction where `w > 0 ? .. : ..` took two
+              if (STATE) last = (ok[t] && !stop) ? SP[t] : last;
             }
             if (!__any(T > 0.0f)) return false;
           }
