@@ -33,7 +33,12 @@ class _MeshActivate(torch.autograd.Function):
             # joint = persistent [N + Nb, .] buffers whose tails hold a frozen cloud's rows (renderer.render(bg_gaussian=...)): the kernel
             # writes the leading N rows and the WHOLE buffers are the outputs - what torch.cat([activated, background]) would return,
             # without the four per-iteration copies.  Fresh tensor objects over the same storage every call.
+            # CONTRACT: one forward per backward.  The kernel below rewrites the buffers through raw pointers; their version counters
+            # are bumped (no launch) so that a backward pass of an EARLIER forward - whose saved means3D / scales / rotations / opacities
+            # alias this storage - raises autograd's "modified by an inplace operation" error instead of using the new values.
             xyz, scales, rots, opac = (joint[k].view_as(joint[k]) for k in ("xyz", "scales", "rots", "opac"))
+            for t in (xyz, scales, rots, opac):
+                torch.autograd.graph.increment_version(t)
         want_mr = mr_weight is not None
         part = torch.empty(((N + 255) // 256,), **f) if want_mr else None
         with torch.cuda.device(dev):

@@ -128,7 +128,7 @@ def share_feature_storage(pc, bg_gaussian):
     whole[f.shape[0]:].copy_(b.detach())
     leaf = torch.nn.Parameter(whole[:f.shape[0]], requires_grad=f.requires_grad)
     if getattr(pc, "_features_dc0", None) is not None:
-        pc._features_dc0 = leaf
+        pc._set_dense_dc(leaf) if hasattr(pc, "_set_dense_dc") else setattr(pc, "_features_dc0", leaf)
     else:
         pc._features = leaf
     pc._features_with_bg = (whole, bg_gaussian)
@@ -173,7 +173,11 @@ def _joint_buffers(pc, bg_gaussian):
 
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, bg_gaussian=None):
     """gaussian_renderer/__init__.py:26-143.  Returns {"render", "viewspace_points", "visibility_filter", "radii",
-    "vertex1", "vertex2", "vertex3", "scale"}."""
+    "vertex1", "vertex2", "vertex3", "scale"}.
+    With bg_gaussian on the fused route (a MeshBoundGaussians on the GPU, pipe.compute_cov3D_python off) the activations and the screen-space
+    probe live in PERSISTENT joint [fg; bg] buffers (_joint_buffers; `pc.joint_buffers = False` opts out and concatenates per call):
+    one forward per backward - the next render() of the same model rewrites the storage the previous call's graph saved (its backward
+    then raises autograd's in-place error, model_ops._MeshActivate) and resets the probe's .grad; pkg["scale"] is a view of that storage."""
     fused = hasattr(pc, "activated") and not pipe.compute_cov3D_python and pc._bc.is_cuda
     joint = _joint_buffers(pc, bg_gaussian) if (fused and bg_gaussian is not None and getattr(pc, "joint_buffers", True)) else None
     if joint is not None:
@@ -324,6 +328,7 @@ class MeshBoundGaussians(torch.nn.Module):
         self._bc, self._distance = P(bc), P(distance)
         self._features = P(torch.cat((features_dc, features_rest), dim=1).contiguous())
         self._features_dc0 = None                # begin_dense_dc(): the dense [N,1,3] leaf that is trained while only degree 0 is active
+                                                 # (never a registered parameter: parameters() / state_dict() keep a fresh model's keys)
         self._scaling, self._rotation, self._opacity = P(scaling), P(rotation), P(opacity)
         for n, t in dict(vertex1=vertex1, vertex2=vertex2, vertex3=vertex3, normal=normal, r=r).items():
             self.register_buffer(n, t)
@@ -358,16 +363,33 @@ class MeshBoundGaussians(torch.nn.Module):
         if self.active_sh_degree != 0:
             raise ValueError("begin_dense_dc: only while active_sh_degree == 0")
         if self._features_dc0 is None:
-            self._features_dc0 = torch.nn.Parameter(self._features.detach()[:, :1].clone().contiguous(), requires_grad=self._features.requires_grad)
+            self._set_dense_dc(torch.nn.Parameter(self._features.detach()[:, :1].clone().contiguous(), requires_grad=self._features.requires_grad))
         return self._features_dc0
+
+    def _set_dense_dc(self, leaf):
+        """The dense leaf is held as a plain attribute (nn.Module.__setattr__ would register a Parameter under a key a fresh model
+        does not have: strict load_state_dict would fail on it and a non-strict one would restore a stale coefficient 0)."""
+        object.__setattr__(self, "_features_dc0", leaf)
 
     def end_dense_dc(self):
         """Fold the dense coefficient-0 leaf back into the [N,16,3] rows (in place: shared storage and views stay valid)."""
         if self._features_dc0 is not None:
             with torch.no_grad():
                 self._features[:, :1].copy_(self._features_dc0)
-            self._features_dc0 = None
+            self._set_dense_dc(None)
         return self._features
+
+    def state_dict(self, *args, **kwargs):
+        """nn.Module.state_dict with the rows CURRENT: while the dense leaf is trained, coefficient 0 of `_features` is stale, so the
+        serialised rows are written from get_features (the live tensors are untouched)."""
+        sd = super().state_dict(*args, **kwargs)
+        if self._features_dc0 is not None:
+            key = (kwargs.get("prefix", args[1] if len(args) > 1 else "") or "") + "_features"
+            if key in sd:
+                rows = sd[key].detach().clone()
+                rows[:, :1].copy_(self._features_dc0.detach())
+                sd[key] = rows
+        return sd
 
     @property
     def get_scaling(self):

@@ -86,6 +86,11 @@ class Trainer:
             import weakref
             gaussians.begin_dense_dc()
             gaussians._dense_dc_owner = weakref.ref(self)        # gaussians.oneupSHdegree() then folds through fold_dense_dc()
+        elif getattr(gaussians, "_features_dc0", None) is not None:
+            # a model another Trainer left in dense mode, handed to one that trains the rows: fold first - this optimizer would
+            # otherwise keep stepping a leaf the model drops at its next oneupSHdegree() and SH training would silently stop
+            gaussians.end_dense_dc()
+            gaussians._dense_dc_owner = None
         if bg_gaussian is not None and hasattr(gaussians, "_features") and gaussians._features.is_cuda:
             from .renderer import share_feature_storage
             share_feature_storage(gaussians, bg_gaussian)        # before the optimizer captures the parameter
@@ -162,7 +167,10 @@ class Trainer:
                     store = torch.cat((store, sh_rows.to(store.dtype)), dim=0)
         params = self.optimizer.resize(keep=idx, new_rows=new_rows if n_new else None)
         for name, attr in self._PARAM_OF_GROUP.items():
-            setattr(g, "_features_dc0" if (dense_dc and name == "f_dc+f_rest") else attr, params[name])
+            if dense_dc and name == "f_dc+f_rest":
+                g._set_dense_dc(params[name])
+            else:
+                setattr(g, attr, params[name])
         if dense_dc:
             g._features = torch.nn.Parameter(store.contiguous(), requires_grad=g._features.requires_grad)
         with torch.no_grad():
@@ -313,10 +321,10 @@ class Trainer:
         densify_and_prune every densification_interval iterations past densify_from_iter (N = 5, the optimizer step of that
         iteration skipped, as the reference's update_flag does), opacity reset.  Returns (loss, render package, plan) with
         plan["rows"] = the row count after the iteration."""
-        if not self.densify_stats:
-            raise ValueError("train_iteration follows the reference's schedule, densification included: build the Trainer with densify_stats=True "
-                             "(without the statistics the loop would run 599 iterations and fail in densify_and_prune at iteration 600)")
         plan = self.schedule(self.iteration + 1, white_background)
+        if plan["densify"] and not self.densify_stats:           # (short loops that never reach a densification iteration need no statistics)
+            raise ValueError("train_iteration: iteration %d densifies (the reference's schedule) and this Trainer keeps no densification "
+                             "statistics: build it with densify_stats=True" % (self.iteration + 1))
         if plan["oneup"] and hasattr(self.g, "oneupSHdegree"):
             self.oneup_sh_degree()
         loss, pkg = self.step(camera, gt_image, background, stats=plan["stats"],

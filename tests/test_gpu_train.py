@@ -258,7 +258,7 @@ def test_shared_feature_storage_equals_concatenation():
 def test_reference_schedule_loop_small():
     """bench.c5_leg(as_reference=True) in small: the reference's first 620 iterations as train_mesh_gaussian.py runs them - SH degree
     0, random camera and background, teacher targets composited over the background, densification statistics, densify_and_prune
-    at iteration 600 with that iteration's optimizer step skipped - on the HIP path: the loss goes down by more than 30 %, the
+    at iteration 600 with that iteration's optimizer step skipped - on the HIP path: the loss goes down (ratio 0.89 measured, gate 0.92), the
     topology change happened inside the loop and the loop went on with the new row count (scene r05: rows ARE selected by the reference's
     threshold; Trainer's dense coefficient-0 mode is on, as in every degree-0 loop)."""
     import bench
@@ -266,7 +266,7 @@ def test_reference_schedule_loop_small():
     assert out["iters"] == 620 and len(out["densify_iterations_ms"]) == 1 and len(out["rows_after_densify"]) == 1     # iteration 600 ran densify_and_prune
     assert out["rows_after_densify"][0] >= 20000
     # (round 5 scene: the teacher's feature rows keep their look in the student, which starts closer to the targets than round 4's: 0.89 here)
-    assert np.isfinite(out["loss_first"]) and out["loss_ratio"] < 0.95, out
+    assert np.isfinite(out["loss_first"]) and out["loss_ratio"] < 0.92, out     # (0.89 measured; a regression that halves the progress lands at ~0.945)
     assert out["iterations_redone"] <= 3 and out["ms_per_iter_before_first_densify"] > 0
     # the forced topology change behind the loop: 2 % of the rows split into five, originals pruned, and the loop goes on
     f = out["forced_densify"]
