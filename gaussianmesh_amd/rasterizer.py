@@ -577,12 +577,14 @@ def forward_deformed_begin(bg, tri, weights, packed, cov, pos, shs, opacity, vie
 
 def rasterize_backward(bg, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
                        tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos, geom, num_rendered, binning, img, debug,
-                       emission_policy=None, skip_intermediates=False):
+                       emission_policy=None, skip_intermediates=False, want_conic=False):
     """RasterizeGaussiansBackwardCUDA of the reference bridge (rasterize_points.py:276-401): returns
     (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations).
     emission_policy: the policy the forward that filled geom / binning / img ran under.
     skip_intermediates (the autograd operator): dL_dcolors when the colours come from SH rows and dL_dcov3D when the covariances come
-    from scale / rotation are not computed into memory (returned as None), nor is the internal dL/dconic."""
+    from scale / rotation are not computed into memory (returned as None), nor is the internal dL/dconic.
+    want_conic (tests): a ninth return value, dL_dconic [P,2,2] (slots [0,0], [0,1], [1,1] used: the blend stage's output that the
+    reference keeps internal, rasterize_points.py:305)."""
     lib = _lib.lib()
     device = means3D.device
     P = means3D.shape[0]
@@ -612,6 +614,8 @@ def rasterize_backward(bg, means3D, radii, colors, scales, rotations, scale_modi
                                      _ptr(binning), _ptr(img), _ptr(dpix), _ptr(dmeans2D), _ptr(dconic), _ptr(dopac),
                                      _ptr(dcolors), _ptr(dmeans3D), _ptr(dcov3D), _ptr(dsh), _ptr(dscales), _ptr(drots),
                                      int(bool(debug)), _stream(device)))
+    if want_conic:
+        return dmeans2D, dcolors, dopac, dmeans3D, dcov3D, dsh, dscales, drots, dconic
     return dmeans2D, dcolors, dopac, dmeans3D, dcov3D, dsh, dscales, drots
 
 

@@ -279,6 +279,60 @@ def test_c3_bench_path_full_size_vs_oracle(oracle):
         assert_forward_gate(fw, out[2][1], W, H, 1e-4, "C3 frame %d" % t, plain_tol=5e-5)
 
 
+def test_4k_policy3_lists_image_and_gradients_vs_oracle(oracle):
+    """BASELINE config C5's list geometry against the ORACLE, not only through properties (review round 5, item 5c): 200 k Gaussians on
+    a 3840x2160 grid, where the product's default emission policy is 3 - instances per 64-px parent tile, 2040 list tiles, one 11-bit
+    tile pass, keys carrying a 4 x 4 mask of 16-px children.
+      * reference policy at 4K: radii, instance count, sorted list and ranges bit-identical to the oracle's (32 400 tiles: the two-pass
+        tile sort + tile_ranges_kernel);
+      * policy 3: every instance SOME pixel accepts according to the oracle (orc_instance_needed over all 6 M reference instances) is
+        present with its child bit, nothing outside the reference's instance set is, parent lists are (depth, id) ordered; image and
+        final_T bit-identical to the reference-policy run; strict image gate against the oracle;
+      * all gradient tensors of the operator (which runs under policy 3 here) within 1e-3 of the oracle's + the element-wise gate."""
+    from gaussianmesh_amd import rasterizer as Rz, scenes
+    from test_gpu_parity import _grads_gpu
+    P, W, H = 200_000, 3840, 2160
+    assert Rz.auto_emission_policy(W, H) == 3
+    sc = scenes.make_cloud(P, seed=2)
+    cam = scenes.orbit_camera(11, 64, W, H)
+    bg = np.array([0.1, 0.3, 0.2], np.float32)
+    fw = oracle.forward_full(sc, cam, bg, D=3)
+    ex = _forward(sc, cam, bg, tile_cull=0)
+    assert np.array_equal(ex["radii"], fw["geo"]["radii"]) and ex["R"] == fw["bins"]["R"]
+    assert np.array_equal(ex["point_list"], fw["bins"]["point_list"]) and np.array_equal(ex["ranges"], fw["bins"]["ranges"])
+    cu = _forward(sc, cam, bg, tile_cull=3)
+    _check_list_invariants(cu, cam, 3)
+    assert np.array_equal(cu["radii"], ex["radii"]) and cu["R"] < 0.5 * ex["R"]
+    assert np.array_equal(cu["color"], ex["color"]) and np.array_equal(cu["final_T"], ex["final_T"])
+    # list geometry: (16-px tile, Gaussian) pairs the policy-3 keys stand for, against the reference instance set and the needed subset
+    gx = (W + 15) // 16
+    pgx = (gx + 3) >> 2
+    tile_ref = (fw["bins"]["keys"] >> np.uint64(32)).astype(np.int64)
+    ref_pairs = tile_ref * P + fw["bins"]["point_list"].astype(np.int64)
+    needed = oracle.instance_needed(W, H, fw["bins"], fw["geo"]).astype(bool)
+    par = cu["tile_keys"].astype(np.int64); gid = cu["point_list"].astype(np.int64); mask = cu["child_mask"].astype(np.int64)
+    px, py = par % pgx, par // pgx
+    got = []
+    for c in range(16):
+        sel = (mask >> c) & 1 == 1
+        t16 = ((py[sel] << 2) + (c >> 2)) * gx + (px[sel] << 2) + (c & 3)
+        got.append(t16 * P + gid[sel])
+    got = np.concatenate(got)
+    assert len(np.unique(got)) == len(got)                                    # no (tile, Gaussian) pair twice
+    assert np.isin(got, ref_pairs).all(), "policy 3 emitted an instance outside the reference's rectangle set"
+    missing = ~np.isin(ref_pairs[needed], got)
+    assert not missing.any(), "%d instances some pixel accepts are missing under policy 3" % int(missing.sum())
+    print("4K policy 3: %d instances for %d reference instances (%d of them needed by some pixel); %d (tile, Gaussian) pairs covered" % (
+        cu["R"], ex["R"], int(needed.sum()), len(got)))
+    assert_forward_gate(fw, cu["color"], W, H, 1e-4, "4K policy 3", plain_tol=5e-5)
+    dpix = np.random.default_rng(1).normal(size=(3, H, W)).astype(np.float32)
+    bw = oracle.backward_full(sc, cam, bg, fw, dpix, D=3)
+    color, radii, g = _grads_gpu(sc, cam, bg, dpix, 3, False, False)            # the operator: auto policy = 3 at this size
+    assert np.array_equal(radii, fw["geo"]["radii"])
+    assert_forward_gate(fw, color, W, H, 1e-4, "4K policy 3 (training forward)", plain_tol=2.5e-5)
+    _check_all_grads(g, bw, 1e-3)
+
+
 def _front_T_after_backward(run_backward, H, W):
     """the transmittance in front of every pixel's first entry as the backward walk reconstructs it (final_T divided by 1 - alpha of each
     entry it takes): exactly 1, up to the rounding of a few hundred reciprocals, when it took the entries the forward blended; off by

@@ -61,7 +61,7 @@ def test_ordinary_random_scenes_meet_the_bars(oracle):
         if not np.array_equal(radii, fw["geo"]["radii"]):
             problems.append((seed, "radii"))
         try:
-            assert_forward_gate(fw, color, cam["W"], cam["H"], 1e-4, "fuzz seed %d" % seed)
+            assert_forward_gate(fw, color, cam["W"], cam["H"], 1e-4, "fuzz seed %d" % seed, plain_tol=5e-5, bg=bg)
         except AssertionError as e:
             problems.append((seed, str(e)))
         rels = {k: _rel(np.asarray(g[k]).reshape(np.asarray(r).shape), r) for k, r in _tensors(bw, pre_cov, pre_col)}
@@ -82,7 +82,7 @@ def test_needle_scenes_against_the_oracle_and_float64_truth(oracle):
         if not np.array_equal(radii, fw["geo"]["radii"]):
             problems.append((seed, "radii"))
         try:
-            assert_forward_gate(fw, color, cam["W"], cam["H"], 1e-4, "needle seed %d" % seed)
+            assert_forward_gate(fw, color, cam["W"], cam["H"], 1e-4, "needle seed %d" % seed, plain_tol=5e-5, bg=bg)
         except AssertionError as e:
             problems.append((seed, str(e)))
         truth = None
@@ -108,3 +108,84 @@ def test_needle_scenes_against_the_oracle_and_float64_truth(oracle):
     print("tensors more than 1e-3 from the C oracle: %d of %d; every one of them within 1e-3 of float64 autograd: %s" % (
         n_over, len(rows), all(r[3] <= 1e-3 for r in rows if r[2] > 1e-3)))
     assert not problems, problems
+
+
+def _stage_grads_gpu(sc, cam, bg, dpix, D, pre_cov, pre_col):
+    """Forward + backward through the low-level pair, keeping the BLEND stage's outputs (dL/dmean2D, dL/dconic, dL/dcolour, dL/dopacity)
+    next to the final gradients: what the preprocess backward consumed and what it made of it."""
+    from gpu_utils import T
+    from gaussianmesh_amd import rasterizer as Rz
+    t = lambda k: T(sc[k])
+    means, opac = t("means"), t("opac")
+    shs = None if pre_col else t("shs"); colors = t("colors_precomp") if pre_col else None
+    scales = None if pre_cov else t("scales"); rots = None if pre_cov else t("rots"); cov = t("cov3D_precomp") if pre_cov else None
+    H, W = cam["H"], cam["W"]
+    a = (T(bg), means, colors, opac, scales, rots, 1.0, cov, T(cam["view"]), T(cam["proj"]), cam["tanx"], cam["tany"])
+    nr, color, radii, geom, binning, img = Rz.rasterize_forward_begin(*a, H, W, shs, D, T(cam["campos"])).finish(exact_exponent=True)
+    out = Rz.rasterize_backward(a[0], means, radii, colors, scales, rots, 1.0, cov, a[8], a[9], cam["tanx"], cam["tany"], T(dpix), shs, D,
+                                T(cam["campos"]), geom, nr, binning, img, False, want_conic=True)
+    torch.cuda.synchronize()
+    names = ("dmean2D", "dcolor", "dopacity", "dmean3D", "dcov3D", "dsh", "dscale", "drot", "dconic")
+    return {k: (None if v is None else v.cpu().numpy()) for k, v in zip(names, out)}
+
+
+def test_needle_scenes_reference_float32_block_is_the_only_divergence(oracle):
+    """The HIP preprocess backward deviates from RAST/backward.cu in ONE block by design: conic -> cov2D (backward.cu:196-215) is evaluated in
+    binary64 (gm_preprocess.hip).  gm_debug_backward_cov2d_float32 (a test switch outside the public header) restores the reference's
+    float32 statement.  Proven here ON THE GPU PATH for all twelve needle scenes, stage by stage (an end-to-end comparison cannot show it:
+    that block amplifies the ~1e-4 float-atomic noise of its inputs by a c / det ~ 500, in the HIP path and in the oracle alike):
+      1. blend stage: HIP's dL/dmean2D, dL/dconic, dL/dcolour, dL/dopacity within 1e-3 of the C oracle's (orc_render_bwd);
+      2. preprocess stage with the switch ON: the C oracle's preprocess backward (orc_preprocess_bwd, the float32 formula) applied to the
+         SAME blend-stage gradients the HIP kernel consumed reproduces HIP's dL/dmeans3D, dL/dcov3D | dL/dscales, dL/drots, dL/dSH to 1e-3
+         (measured: ~1e-6 - same inputs, same expressions, contraction off on both sides);
+      3. with the switch OFF (the product) the same comparison differs by more than 1e-3 on the recorded seeds - the binary64 block, and
+         nothing else, is what separates the product from the reference formula."""
+    import ctypes as C
+    from gaussianmesh_amd import _lib
+    lib = C.CDLL(_lib.lib()._name)
+    rows, problems, n_off_differs = [], [], 0
+    for seed in NEEDLES:
+        sc, cam, bg, D, pre_cov, pre_col, dpix = fuzz_scene(seed)
+        fw = oracle.forward_full(sc, cam, bg, D=D, use_precomp_cov=pre_cov, use_precomp_color=pre_col)
+        bw = oracle.backward_full(sc, cam, bg, fw, dpix, D=D, use_precomp_cov=pre_cov, use_precomp_color=pre_col)
+        res = {}
+        for on in (1, 0):
+            lib.gm_debug_backward_cov2d_float32(on)
+            try:
+                res[on] = _stage_grads_gpu(sc, cam, bg, dpix, D, pre_cov, pre_col)
+            finally:
+                lib.gm_debug_backward_cov2d_float32(0)
+        g = res[1]
+        # 1. the blend stage against the oracle's
+        stage = {"dmean2D": _rel(g["dmean2D"][:, :2], bw["dmean2D"][:, :2]), "dconic": _rel(g["dconic"].reshape(-1, 4)[:, [0, 1, 3]], bw["dconic"][:, [0, 1, 3]]),
+                 "dcolor": _rel(g["dcolor"], bw["dcolor"]), "dopacity": _rel(g["dopacity"].reshape(-1), bw["dopacity"].reshape(-1))}
+        for k, v in stage.items():
+            if v > 1e-3:
+                problems.append((seed, "blend stage", k, v))
+        # 2. the oracle's preprocess backward on HIP's own blend-stage gradients
+        def through_oracle(gg):
+            return oracle.preprocess_bwd(sc["means"], fw["geo"], cam["view"], cam["proj"], cam["campos"], cam["W"], cam["H"], cam["tanx"], cam["tany"],
+                                         gg["dmean2D"], gg["dconic"].reshape(-1, 4), gg["dcolor"], D=D, shs=None if pre_col else sc["shs"],
+                                         scales=None if pre_cov else sc["scales"], rots=None if pre_cov else sc["rots"])
+        def compare(gg):
+            dmean3D, dcov, dsh, dscale, drot = through_oracle(gg)
+            out = {"means": _rel(gg["dmean3D"], dmean3D)}
+            if pre_cov:
+                out["cov"] = _rel(gg["dcov3D"], dcov)
+            else:
+                out["scales"] = _rel(gg["dscale"], dscale); out["rots"] = _rel(gg["drot"], drot)
+            if not pre_col:
+                out["shs"] = _rel(gg["dsh"].reshape(dsh.shape), dsh)
+            return out
+        on_, off_ = compare(res[1]), compare(res[0])
+        for k, v in on_.items():
+            if v > 1e-3:
+                problems.append((seed, "preprocess stage, float32 block", k, v))
+        n_off_differs += 1 if max(off_.values()) > 1e-3 else 0
+        rows.append((seed, max(stage.values()), max(on_.values()), max(off_.values())))
+    print("needle scenes, stage by stage (largest error over the stage's tensors, as a fraction of the tensor's largest entry):")
+    print("  seed  blend stage vs oracle   preprocess stage vs oracle formula: float32 block | binary64 block (the product)")
+    for seed, a, b, c in rows:
+        print("  %4d  %.2e                %.2e | %.2e%s" % (seed, a, b, c, "   <-- the product deviates from the float32 formula here" if c > 1e-3 else ""))
+    assert not problems, problems
+    assert n_off_differs >= 3, "the binary64 block should separate the product from the float32 formula on the recorded needle seeds (%d)" % n_off_differs
