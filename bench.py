@@ -449,6 +449,8 @@ def main():
     ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams the frame loop alternates over (frame i runs on stream i %% streams): consecutive frames are "
                          "independent, so frame i+1's per-Gaussian stages overlap the low-occupancy tail of frame i's blend")
+    ap.add_argument("--frames-per-launch", type=int, default=1, help="K frames of the view stream per launch chain (gm_forward_deformed_batch_async): the "
+                    "static cloud is read once per K frames and every stage is one launch over them; a batch goes to stream (batch index) %% streams")
     ap.add_argument("--begin-ahead", type=int, default=2, help="frames whose first half (deformation .. depth order) is issued before the "
                     "oldest of them is completed (emission .. blend): 2 fills the four streams sooner after the barrier that opens a timed "
                     "region than 1 (20-step regions, three runs each: 4389-4504 / 4540-4554 / 4039-4518 frames/s with 1 / 2 / 3; no "
@@ -496,7 +498,7 @@ def main():
     import torch.distributed as dist
     from gaussianmesh_amd import _lib, multiview, scenes
     from gaussianmesh_amd import rasterizer as Rz
-    from gaussianmesh_amd.deform import deform_shade_packed, mesh_rs_packed, pack_mesh_state, vertex_face_adjacency
+    from gaussianmesh_amd.deform import deform_shade_packed, mesh_rs_packed, mesh_rs_packed_batch, pack_mesh_state, vertex_face_adjacency
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -586,7 +588,13 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
     lag = max(1, args.status_lag)
     ahead = max(1, args.begin_ahead)
+    KB = max(1, min(args.frames_per_launch, 4))
+    if KB > 1 and (args.unfused or args.depth_plan or args.exact_count or args.analytic_rs):
+        raise SystemExit("--frames-per-launch > 1 is the fused, sync-free path with (R, S) from gm_mesh_rs: not with --unfused / --depth-plan / --exact-count / --analytic-rs")
     nws = nstreams + ahead + lag                # frames i+1 .. i+ahead are begun before frame i is completed, and frame i's status is read `lag` frames later
+    if KB > 1:
+        lag = max(lag, 2 * KB)
+        nws = KB * (nstreams + 1) + lag         # a workspace is reused only after its frame's status has been read
     workspaces = [Rz.RasterWorkspace(growth=1.5) for _ in range(nws)]
     torch.cuda.synchronize()
 
@@ -599,12 +607,47 @@ def main():
     views_walked = []                            # camera index of every loop step this rank issued (--check-dir)
     stats["overflows"] = 0
 
+    batching = [False]                           # batches only once the sizing passes have taught the workspaces their capacity
+    batch_steps = []                             # loop steps collected for the next batch
+    nbatch = [0]
+    table_bufs = [torch.empty((KB, Vm, 24), dtype=torch.float32, device=dev) for _ in range(max(nstreams + 2, 4))] if KB > 1 else None
+
+    def launch_batch():
+        """K collected loop steps as ONE launch chain on stream (batch index) % streams: gm_mesh_rs_packed_batch (K tables) +
+        gm_forward_deformed_batch_async (arm, fused pass over the static cloud looping over the K (table, camera) pairs, depth order, emission,
+        tile pass, blend: every stage one launch with grid z = frame)."""
+        steps, b = list(batch_steps), nbatch[0]
+        del batch_steps[:]
+        nbatch[0] += 1
+        torch.cuda.set_stream(streams[b % nstreams])
+        src = [pipe.frame(i) for i in steps] if pipe is not None else [v1_frames[i % F] for i in steps]
+        tables = mesh_rs_packed_batch(g["verts"], src, g["faces"], adjacency, out=table_bufs[b % len(table_bufs)][:len(steps)])
+        cams_k = []
+        for i in steps:
+            vi = multiview.view_for_step(i, F, rank, world)
+            views_walked.append((i, vi))
+            cams_k.append(cam_t[vi])
+        hs = Rz.forward_deformed_batch(bg, g["tri"], g["weights"], tables, g["cov_in"], g["pos"], g["shs"], g["opac"], cams_k, H, W, 3,
+                                       [workspaces[i % nws] for i in steps], image_only=image_only, work_hint=hint)
+        if timeline is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(hs[0].stream)
+            timeline.append((time.perf_counter(), ev))
+        stats["last_image"] = hs[-1].color
+        unchecked.extend(hs)
+        while len(unchecked) > lag:
+            verify(unchecked.pop(0))
+        return hs[-1].color
+
     def step(i):
         """Issue frame i's first half (deform + colour + preprocess + depth order) on stream i % nstreams, THEN complete frame
         i - ahead (--begin-ahead, default 2).  Default: sync-free completion - the instance count stays on the device (binning
         buffer at the workspace's capacity, learned during warm-up), the host only reads the status words of frames completed
         `lag` steps ago, which landed long before.
         --exact-count: the host waits for the completed frame's count (one 4-byte read-back, hidden behind frame i's first half)."""
+        if KB > 1 and batching[0]:
+            batch_steps.append(i)
+            return launch_batch() if len(batch_steps) == KB else None
         torch.cuda.set_stream(streams[i % nstreams])     # (not `with torch.cuda.stream(...)`: entering and leaving the context costs the
         if timeline is not None:
             t_a = time.perf_counter()
@@ -644,6 +687,8 @@ def main():
     default_stream = torch.cuda.default_stream(dev)
 
     def drain():
+        if batch_steps:
+            launch_batch()
         for k in sorted(pending):
             finish(pending.pop(k))
         torch.cuda.set_stream(default_stream)
@@ -743,6 +788,12 @@ def main():
     gc.disable()
     for i in range(-3 * F, 0):
         step(i)
+    if KB > 1:                                   # every workspace at the stream's largest capacity (a batch's binning buffers share one layout), then batches
+        drain()
+        cap = max(ws_.capacity for ws_ in workspaces)
+        for ws_ in workspaces:
+            ws_.capacity = cap
+        batching[0] = True
     for i in range(args.warmup):
         step(i)
     drain()
@@ -829,7 +880,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "C3: %d Gaussians bound to 15k-face torus, per-frame mesh deform + SH colour + forward "
                                "render %dx%d, %d-camera orbit, views sharded by rank" % (P, W, H, F),
-                   "gaussians": P, "width": W, "height": H, "sh_degree": 3, "views_per_step_per_gpu": 1,
+                   "gaussians": P, "width": W, "height": H, "sh_degree": 3, "views_per_step_per_gpu": 1, "frames_per_launch": KB,
                    "vertex_rs": "analytic tables" if args.analytic_rs else "gm_mesh_rs per frame", "hip_streams": nstreams,
                    "exchange": None if pipe is None else {"n_ranks_seen": n_ranks_seen, "backend": backend if world > 1 else None, "steps_per_broadcast": pipe.batch, "bytes_per_step": exchange_bytes, "broadcasts": pipe.broadcasts,
                                                           "payload": "per-vertex (R, S) tables" if args.analytic_rs else "deformed vertex positions; (R, S) by gm_mesh_rs on every rank",

@@ -16,6 +16,15 @@ _lib = None
 
 vp, i32, i64, f32, f64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
 
+GM_BATCH_MAX = 4
+
+
+class BatchFrame(C.Structure):
+    """gm_batch_frame (include/gmesh_hip.h): one frame of gm_forward_deformed_batch_async."""
+    _fields_ = [("packed", vp), ("viewmatrix", vp), ("projmatrix", vp), ("cam_pos", vp), ("tan_fovx", f32), ("tan_fovy", f32),
+                ("geom_buffer", vp), ("binning_buffer", vp), ("image_buffer", vp), ("out_color", vp), ("radii", vp), ("status_host", vp)]
+
+
 # name -> (restype, argtypes); mirrors include/gmesh_hip.h one to one
 SIGNATURES = {
     "gm_abi_version": (i32, []),
@@ -53,6 +62,8 @@ SIGNATURES = {
     "gm_depth_slab_bytes": (sz, [i32]),
     "gm_forward_1_geom": (i32, [i32, vp, vp, vp, i32, i32, i64, vp, i32, i32, vp, i32, vp, vp, i32, vp]),
     "gm_forward_status_async": (i32, [vp, i32, vp, vp]),
+    "gm_forward_deformed_batch_async": (i32, [i32, i32, C.POINTER(BatchFrame), i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, i32, vp]),
+    "gm_mesh_rs_packed_batch": (i32, [i32, i32, i32, vp, C.POINTER(vp), vp, vp, vp, C.POINTER(vp), vp]),
     "gm_deform_shade_packed": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "gm_cov_to_scale_rot": (i32, [i32, vp, vp, vp, vp]),
     "gm_mesh_rs": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -104,7 +115,7 @@ def lib():
             fn = getattr(l, name)          # AttributeError if the symbol is absent -> loud failure
             fn.restype = res
             fn.argtypes = args
-        if l.gm_abi_version() != 2:
+        if l.gm_abi_version() != 3:
             raise ImportError("libgmesh_hip.so ABI version mismatch")
         _lib = l
     return _lib

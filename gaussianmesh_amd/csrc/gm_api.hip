@@ -265,6 +265,70 @@ int gm_forward_1_geom(int emission_policy, void* geom_buffer, void* binning_buff
                            work_hint, debug, st, (flags & GM_FWD_EXACT_EXPONENT) != 0);
 }
 
+int gm_forward_deformed_batch_async(int emission_policy, int K, const gm_batch_frame* frames, int P, int deg, int M, int width, int height,
+                                    const int* tri, const float* w, const float* cov, const float* pos, const float* shs, const float* opacities,
+                                    const float* background, int64_t binning_capacity, int flags, unsigned int* work_hint, int debug, void* stream) {
+  if (int rc = check_policy(emission_policy)) return rc;
+  if (K < 1 || K > GM_BATCH_MAX || !frames) { set_error("gm_forward_deformed_batch: 1..%d frames", GM_BATCH_MAX); return GM_ERR_INVALID_ARG; }
+  if (flags & ~(GM_BATCH_IMAGE_ONLY | GM_BATCH_COV6)) { set_error("gm_forward_deformed_batch: unknown flags 0x%x", flags); return GM_ERR_INVALID_ARG; }
+  if (P <= 0 || width <= 0 || height <= 0) { set_error("gm_forward_deformed_batch: invalid sizes P=%d W=%d H=%d (an empty cloud goes through the single-frame calls)", P, width, height); return GM_ERR_INVALID_ARG; }
+  if (deg < 0 || deg > 3 || M != 16) { set_error("gm_forward_deformed_batch: needs SH rows of M == 16 coefficients, degree 0..3"); return GM_ERR_INVALID_ARG; }
+  if (!tri || !w || !cov || !pos || !shs || !opacities || !background) { set_error("gm_forward_deformed_batch: null required input"); return GM_ERR_INVALID_ARG; }
+  if (binning_capacity <= 0) { set_error("gm_forward_deformed_batch: binning_capacity must be positive (sync-free second half)"); return GM_ERR_INVALID_ARG; }
+  const TileGrid tg(width, height, emission_policy);
+  if (tg.ptiles > (1 << GM_BUCKET_BITS)) {
+    set_error("gm_forward_deformed_batch: %dx%d has %d list tiles under policy %d; a batch needs the one-pass tile sort (<= 2048)", width, height, tg.ptiles, emission_policy);
+    return GM_ERR_INVALID_ARG;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  BatchFrameArgs fr[GM_BATCH_MAX];
+  BatchOfs B{};
+  B.frames = K;
+  for (int k = 0; k < K; k++) {
+    const gm_batch_frame& f = frames[k];
+    if (!f.packed || !f.viewmatrix || !f.projmatrix || !f.cam_pos || !f.geom_buffer || !f.binning_buffer || !f.image_buffer || !f.out_color) {
+      set_error("gm_forward_deformed_batch: frame %d has a null pointer", k); return GM_ERR_INVALID_ARG;
+    }
+    if ((reinterpret_cast<uintptr_t>(f.geom_buffer) | reinterpret_cast<uintptr_t>(f.binning_buffer) | reinterpret_cast<uintptr_t>(f.image_buffer)) & 255) {
+      set_error("gm_forward_deformed_batch: frame %d: scratch buffers must be 256-byte aligned", k); return GM_ERR_INVALID_ARG;
+    }
+    for (int j = 0; j < k; j++)
+      if (frames[j].geom_buffer == f.geom_buffer || frames[j].binning_buffer == f.binning_buffer || frames[j].image_buffer == f.image_buffer || frames[j].out_color == f.out_color) {
+        set_error("gm_forward_deformed_batch: frames %d and %d share a buffer", j, k); return GM_ERR_INVALID_ARG;
+      }
+    fr[k].packed = f.packed; fr[k].viewmatrix = f.viewmatrix; fr[k].projmatrix = f.projmatrix; fr[k].cam_pos = f.cam_pos;
+    fr[k].tan_fovx = f.tan_fovx; fr[k].tan_fovy = f.tan_fovy; fr[k].radii = f.radii;
+    fr[k].g = GeomState::from(f.geom_buffer, (size_t)P);
+    B.geom.d[k] = (long long)(reinterpret_cast<intptr_t>(f.geom_buffer) - reinterpret_cast<intptr_t>(frames[0].geom_buffer));
+    B.binning.d[k] = (long long)(reinterpret_cast<intptr_t>(f.binning_buffer) - reinterpret_cast<intptr_t>(frames[0].binning_buffer));
+    B.image.d[k] = (long long)(reinterpret_cast<intptr_t>(f.image_buffer) - reinterpret_cast<intptr_t>(frames[0].image_buffer));
+    B.color.d[k] = (long long)(reinterpret_cast<intptr_t>(f.out_color) - reinterpret_cast<intptr_t>(frames[0].out_color));
+    B.status[k] = f.status_host;
+  }
+  GeomState g = fr[0].g;
+  ImageState img = ImageState::from(frames[0].image_buffer, width, height);
+  BinningState b = BinningState::from(frames[0].binning_buffer, (size_t)binning_capacity);
+  if (int rc = launch_arm_counters(g, st, &B)) return rc;
+  if (int rc = launch_deform_shade_pre_batch(K, fr, P, deg, width, height, emission_policy, tri, w, cov, pos, shs, opacities, (flags & GM_BATCH_COV6) != 0, debug, st)) return rc;
+  if (int rc = launch_depth_order(g, P, debug, st, nullptr, nullptr, &B)) return rc;
+  if (int rc = launch_duplicate(g, b, P, width, height, emission_policy, (size_t)binning_capacity, debug, st, &B)) return rc;
+  bool order_done = false;
+  if (int rc = launch_tile_sort(g, b, img, (size_t)binning_capacity, g.counters + GM_CNT_RENDERED, tg.ptiles, &order_done, work_hint, debug, st, &B)) return rc;
+  if (!order_done) { set_error("gm_forward_deformed_batch: internal: the tile pass did not produce the dispatch order"); return GM_ERR_INVALID_ARG; }
+  return launch_render_fwd(g, b.pairs[sort_final_slot(tg.ptiles)], img, width, height, emission_policy, background, frames[0].out_color, frames[0].status_host,
+                           (flags & GM_BATCH_IMAGE_ONLY) != 0, work_hint, debug, st, false, &B);
+}
+
+int gm_mesh_rs_packed_batch(int K, int Vm, int nfaces, const float* V0, const float* const* V1, const int* faces, const int* adj_offsets,
+                            const int* adj_faces, float* const* packed, void* stream) {
+  if (K < 1 || K > GM_BATCH_MAX || Vm < 0 || nfaces < 0 || !V1 || !packed || (Vm > 0 && (!V0 || !adj_offsets || (nfaces > 0 && (!faces || !adj_faces))))) {
+    set_error("gm_mesh_rs_packed_batch: bad args"); return GM_ERR_INVALID_ARG;
+  }
+  for (int k = 0; k < K; k++)
+    if (Vm > 0 && (!V1[k] || !packed[k] || (reinterpret_cast<uintptr_t>(packed[k]) & 15))) { set_error("gm_mesh_rs_packed_batch: frame %d: null or unaligned pointer", k); return GM_ERR_INVALID_ARG; }
+  return launch_mesh_rs_batch(K, Vm, V0, V1, faces, adj_offsets, adj_faces, packed, reinterpret_cast<hipStream_t>(stream));
+}
+
 int gm_forward_status_async(void* geom_buffer, int P, int* status_host, void* stream) {
   if (!status_host) { set_error("status_host is null"); return GM_ERR_INVALID_ARG; }
   if (P <= 0) { status_host[0] = 0; status_host[1] = 0; status_host[2] = 0; status_host[3] = 0; return GM_OK; }

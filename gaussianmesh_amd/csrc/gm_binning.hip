@@ -39,7 +39,19 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
   return woff + incl - v;
 }
 
-int launch_arm_counters(GeomState& g, hipStream_t s) {
+// the armed blocks of the frames of a batch in one launch (a single frame: one memset)
+__global__ __launch_bounds__(256) void arm_batch_kernel(uint4* __restrict__ arm, uint32_t arm_vec, const FrameOfs go) {
+  arm = frame_ptr(arm, go);
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < arm_vec; i += gridDim.x * 256) arm[i] = z;
+}
+
+int launch_arm_counters(GeomState& g, hipStream_t s, const BatchOfs* bt) {
+  if (bt && bt->frames > 1) {
+    hipLaunchKernelGGL(arm_batch_kernel, dim3(32, 1, (uint32_t)bt->frames), dim3(256), 0, s, reinterpret_cast<uint4*>(g.slots), (uint32_t)(g.arm_words / 4), bt->geom);
+    GM_HIP(hipGetLastError());
+    return 0;
+  }
   GM_HIP(hipMemsetAsync(g.slots, 0, sizeof(uint32_t) * g.arm_words, s));
   return 0;
 }
@@ -68,7 +80,10 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
                                                                 uint32_t* __restrict__ counters, const uint32_t* __restrict__ chunk_inst,
                                                                 int gx, int pgx, int mode,
                                                                 uint32_t capacity, uint2* __restrict__ pairs_out,
-                                                                uint32_t* __restrict__ acc, uint32_t acc_words) {
+                                                                uint32_t* __restrict__ acc, uint32_t acc_words, const FrameOfs go, const FrameOfs bo) {
+  order = frame_ptr(order, go); tiles = frame_ptr(tiles, go); bin_sorted = frame_ptr(bin_sorted, go); splat = frame_ptr(splat, go);
+  counters = frame_ptr(counters, go); chunk_inst = frame_ptr(chunk_inst, go);            // frame blockIdx.z of a batch (gm_common.h FrameOfs)
+  pairs_out = frame_ptr(pairs_out, bo); acc = frame_ptr(acc, bo);
   __shared__ uint32_t wsum[BN_THREADS / 64];
   __shared__ uint32_t stage_k[DUP_STAGE], stage_v[DUP_STAGE];
   // accumulators of the tile pass that follows (bk_hist_kernel adds into them)
@@ -256,17 +271,19 @@ __global__ __launch_bounds__(BN_THREADS) void duplicate_kernel(const uint32_t* _
   }
 }
 
-int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, int mode, size_t capacity, int debug, hipStream_t s) {
+int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, int mode, size_t capacity, int debug, hipStream_t s, const BatchOfs* bt) {
   StageScope sc(ST_DUPLICATE, s);
   const TileGrid tg(W, H, mode);
+  const BatchOfs one = single_frame();
+  const BatchOfs& B = bt ? *bt : one;
   const uint32_t cap = capacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)capacity;
   if (P > 0) {
     // two Gaussians per thread while a workgroup's instances still fit its LDS stage (a run of 512 at C3's ~3 instances per
     // Gaussian), one when the cloud emits more per Gaussian (4K, near cameras): unstaged runs store partial lines
     const bool two = capacity <= (size_t)P * 5;
-#define GM_DUP(SH, PER) hipLaunchKernelGGL((duplicate_kernel<SH, PER>), dim3((P + PER * BN_THREADS - 1) / (PER * BN_THREADS)), dim3(BN_THREADS), 0, s, g.order, \
+#define GM_DUP(SH, PER) hipLaunchKernelGGL((duplicate_kernel<SH, PER>), dim3((P + PER * BN_THREADS - 1) / (PER * BN_THREADS), 1, (uint32_t)B.frames), dim3(BN_THREADS), 0, s, g.order, \
                                            g.tiles_touched, g.bin_sorted, g.splat, g.counters, g.chunk_inst, tg.gx, tg.pgx, mode, cap, b.pairs[0], b.acc, \
-                                           (uint32_t)bk_acc_words(capacity))
+                                           (uint32_t)bk_acc_words(capacity), B.geom, B.binning)
     if (two) { if (tg.s == 0) GM_DUP(0, 2); else if (tg.s == 1) GM_DUP(1, 2); else GM_DUP(2, 2); }
     else { if (tg.s == 0) GM_DUP(0, 1); else if (tg.s == 1) GM_DUP(1, 1); else GM_DUP(2, 1); }
 #undef GM_DUP

@@ -252,8 +252,12 @@ __global__ __launch_bounds__(WAVES * 64) void bk_hist_kernel(const void* __restr
                                                               const uint32_t* __restrict__ slots, uint32_t* __restrict__ hist,
                                                               uint32_t* __restrict__ acc, uint32_t* __restrict__ counters,
                                                               const uint32_t* __restrict__ coarse, uint32_t* __restrict__ dmap,
-                                                              uint32_t* __restrict__ bmap) {
+                                                              uint32_t* __restrict__ bmap, const FrameOfs go, const FrameOfs bo) {
   constexpr int ND = 1 << DB, THREADS = WAVES * 64, TILE = WAVES * ROUNDS * 64;
+  // frame blockIdx.z of a batch (gm_common.h FrameOfs): the depth partition lives in the geometry buffer, the tile pass in the binning buffer
+  in = frame_ptr(in, MSD ? go : bo); hist = frame_ptr(hist, MSD ? go : bo); acc = frame_ptr(acc, MSD ? go : bo);
+  n_dev = frame_ptr(n_dev, go); slots = frame_ptr(slots, go); counters = frame_ptr(counters, go); coarse = frame_ptr(coarse, go);
+  dmap = frame_ptr(dmap, go); bmap = frame_ptr(bmap, go);
   __shared__ uint32_t h[ND];
   __shared__ uint32_t s_tmp[4];
   __shared__ uint32_t s_w[4];
@@ -303,8 +307,11 @@ template <bool MSD, int DB>
 __global__ __launch_bounds__(BK_THREADS) void bk_scan_kernel(uint32_t* __restrict__ hist, uint32_t tile, uint32_t n_host, const uint32_t* __restrict__ n_dev,
                                                               const uint32_t* __restrict__ acc,
                                                               uint32_t* __restrict__ base_out, const uint32_t* __restrict__ counters,
-                                                              uint2* __restrict__ ranges_out, uint32_t nranges) {
+                                                              uint2* __restrict__ ranges_out, uint32_t nranges, const FrameOfs go,
+                                                              const FrameOfs bo, const FrameOfs io) {
   constexpr int ND = 1 << DB, NG = ND / 256;
+  hist = frame_ptr(hist, MSD ? go : bo); acc = frame_ptr(acc, MSD ? go : bo);
+  n_dev = frame_ptr(n_dev, go); base_out = frame_ptr(base_out, go); counters = frame_ptr(counters, go); ranges_out = frame_ptr(ranges_out, io);
   __shared__ uint32_t wsum[4];
   __shared__ uint32_t gsum[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -378,8 +385,12 @@ __global__ __launch_bounds__(WAVES * 64, 4) void bk_scatter_kernel(const void* _
                                                                  uint32_t* __restrict__ ord_out, const uint32_t* __restrict__ dmap,
                                                                  const uint32_t* __restrict__ counters, uint32_t* __restrict__ ord_hint,
                                                                  uint32_t* __restrict__ ord_epoch, unsigned long long* __restrict__ trace,
-                                                                 uint32_t* __restrict__ ord_scratch) {
+                                                                 uint32_t* __restrict__ ord_scratch, const FrameOfs go, const FrameOfs bo,
+                                                                 const FrameOfs io) {
   constexpr int ND = 1 << DB, THREADS = WAVES * 64, TILE = WAVES * ROUNDS * 64;
+  in = frame_ptr(in, MSD ? go : bo); out = frame_ptr(out, MSD ? go : bo); hist = frame_ptr(hist, MSD ? go : bo); zero_acc = frame_ptr(zero_acc, bo);
+  n_dev = frame_ptr(n_dev, go); dmap = frame_ptr(dmap, go); counters = frame_ptr(counters, go);
+  ord_ranges = frame_ptr(ord_ranges, io); ord_out = frame_ptr(ord_out, io); ord_epoch = frame_ptr(ord_epoch, io); ord_scratch = frame_ptr(ord_scratch, io);
   const unsigned long long t_begin = trace ? wall_clock64() : 0ull;      // (tools/pipeline_trace.py: per-workgroup start / end)
   if (!MSD && ord_out && blockIdx.x == gridDim.x - 1) {      // the launch's extra workgroup: dispatch order of the blend kernels
     __shared__ uint32_t o_cnt[256];                          // from the ranges the scan kernel has just published
@@ -549,8 +560,13 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_sort_kernel(uint32_t* __res
                                                                   uint4* __restrict__ bin_sorted, uint32_t* __restrict__ chunk_inst,
                                                                   unsigned long long* __restrict__ trace, uint32_t cap,
                                                                   const uint32_t* __restrict__ slots, const uint32_t* __restrict__ coarse,
-                                                                  const uint32_t* __restrict__ hdr, uint32_t* __restrict__ plan) {
+                                                                  const uint32_t* __restrict__ hdr, uint32_t* __restrict__ plan, const FrameOfs go) {
   const unsigned long long t_begin = trace ? wall_clock64() : 0ull;
+  if (!DIRECT) {                                 // frame blockIdx.z of a batch: everything lives in the geometry buffer (the direct placement is not batched)
+    counters = frame_ptr(counters, go); bmap = frame_ptr(bmap, go); bucket_start = frame_ptr(bucket_start, go); p1 = frame_ptr(p1, go); p0 = frame_ptr(p0, go);
+    order0 = frame_ptr(order0, go); tiles = frame_ptr(tiles, go); bins = frame_ptr(bins, go); bin_sorted = frame_ptr(bin_sorted, go);
+    chunk_inst = frame_ptr(chunk_inst, go);
+  }
   __shared__ uint32_t wcnt[BK_WAVES][256];
   __shared__ uint32_t dstart[256];
   __shared__ uint32_t lkey[BS_CAP];                                 // (key - first key) << 12 | position in the bucket: 16 KiB
@@ -893,15 +909,18 @@ static unsigned long long* scatter_trace(bool msd) { return g_bucket_trace ? g_b
 
 // ---------------------------------------------------------------------------------------------
 // host side
-int launch_depth_order(GeomState& g, int P, int debug, hipStream_t s, int* num_rendered_host, hipEvent_t count_event) {
+int launch_depth_order(GeomState& g, int P, int debug, hipStream_t s, int* num_rendered_host, hipEvent_t count_event, const BatchOfs* bt) {
   constexpr int DB = GM_BUCKET_BITS, WAVES = 4, ROUNDS = GM_DP_ROUNDS, TILE = WAVES * ROUNDS * 64;
   const uint32_t nblk = ((uint32_t)P + TILE - 1) / TILE;
   const uint32_t nchunks = (nblk + BK_CHUNK - 1) / BK_CHUNK;
   const DigitSpec ds{0u, 0u, 0xFFFFFFFFu};
+  const BatchOfs one = single_frame();
+  const BatchOfs& B = bt ? *bt : one;
+  const uint32_t nf = (uint32_t)B.frames;
   {
     StageScope sc(ST_DEPTH_SORT, s);
-    hipLaunchKernelGGL((bk_hist_kernel<true, DB, WAVES, ROUNDS>), dim3(nblk + 1), dim3(WAVES * 64), 0, s, g.depth_key, (uint32_t)P, nullptr, ds, g.slots, g.hist,
-                       g.acc, g.counters, g.coarse, g.dmap, g.bmap);
+    hipLaunchKernelGGL((bk_hist_kernel<true, DB, WAVES, ROUNDS>), dim3(nblk + 1, 1, nf), dim3(WAVES * 64), 0, s, g.depth_key, (uint32_t)P, nullptr, ds, g.slots, g.hist,
+                       g.acc, g.counters, g.coarse, g.dmap, g.bmap, B.geom, B.binning);
     GM_LAUNCH_CHECK(debug, s);
   }
   if (num_rendered_host) {      // the instance total is known here; the rest of the ordering overlaps the host's wait for it
@@ -909,14 +928,15 @@ int launch_depth_order(GeomState& g, int P, int debug, hipStream_t s, int* num_r
     if (count_event) GM_HIP(hipEventRecord(count_event, s));
   }
   StageScope sc(ST_DEPTH_SORT, s);
-  hipLaunchKernelGGL((bk_scan_kernel<true, DB>), dim3(nchunks, (1 << DB) / 256), dim3(BK_THREADS), 0, s, g.hist, (uint32_t)TILE, (uint32_t)P, nullptr,
-                     g.acc, g.bucket_start, g.counters, nullptr, 0u);
+  hipLaunchKernelGGL((bk_scan_kernel<true, DB>), dim3(nchunks, (1 << DB) / 256, nf), dim3(BK_THREADS), 0, s, g.hist, (uint32_t)TILE, (uint32_t)P, nullptr,
+                     g.acc, g.bucket_start, g.counters, nullptr, 0u, B.geom, B.binning, B.image);
   GM_LAUNCH_CHECK(debug, s);
-  hipLaunchKernelGGL((bk_scatter_kernel<true, DB, WAVES, ROUNDS>), dim3(nblk), dim3(WAVES * 64), 0, s, g.depth_key, g.dpairs[1], (uint32_t)P, nullptr, ds,
-                     g.hist, nullptr, 0u, nullptr, 0, nullptr, g.dmap, g.counters, nullptr, nullptr, scatter_trace(true), nullptr);
+  hipLaunchKernelGGL((bk_scatter_kernel<true, DB, WAVES, ROUNDS>), dim3(nblk, 1, nf), dim3(WAVES * 64), 0, s, g.depth_key, g.dpairs[1], (uint32_t)P, nullptr, ds,
+                     g.hist, nullptr, 0u, nullptr, 0, nullptr, g.dmap, g.counters, nullptr, nullptr, nf == 1 ? scatter_trace(true) : nullptr, nullptr,
+                     B.geom, B.binning, B.image);
   GM_LAUNCH_CHECK(debug, s);
-  hipLaunchKernelGGL(bucket_sort_kernel<false>, dim3(1 << DB), dim3(BK_THREADS), 0, s, g.counters, g.bmap, g.bucket_start, g.dpairs[1], g.dpairs[0], g.order,
-                     g.tiles_touched, g.bin, g.bin_sorted, g.chunk_inst, g_bucket_trace, 0u, nullptr, nullptr, nullptr, nullptr);
+  hipLaunchKernelGGL(bucket_sort_kernel<false>, dim3(1 << DB, 1, nf), dim3(BK_THREADS), 0, s, g.counters, g.bmap, g.bucket_start, g.dpairs[1], g.dpairs[0], g.order,
+                     g.tiles_touched, g.bin, g.bin_sorted, g.chunk_inst, nf == 1 ? g_bucket_trace : nullptr, 0u, nullptr, nullptr, nullptr, nullptr, B.geom);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }
@@ -1055,7 +1075,7 @@ int launch_depth_order_direct(GeomState& g, DepthSlab& d, uint32_t* plan, int P,
     if (count_event) GM_HIP(hipEventRecord(count_event, s));
   }
   hipLaunchKernelGGL(bucket_sort_kernel<true>, dim3((1 << GM_BUCKET_BITS) + 1), dim3(BK_THREADS), 0, s, g.counters, g.bmap, g.bucket_start, d.pairs, g.dpairs[0],
-                     g.order, g.tiles_touched, d.recs, g.bin_sorted, g.chunk_inst, g_bucket_trace, d.cap, g.slots, g.coarse, d.hdr, plan);
+                     g.order, g.tiles_touched, d.recs, g.bin_sorted, g.chunk_inst, g_bucket_trace, d.cap, g.slots, g.coarse, d.hdr, plan, FrameOfs{});
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }
@@ -1069,20 +1089,23 @@ int launch_publish_depth_plan(GeomState& g, uint32_t* plan, hipStream_t s) {
 // One stable pass over the pair stream b.pairs[from] -> b.pairs[from ^ 1].  b.acc must be zero on entry.
 template <int DB, int WAVES>
 static int tile_pass(BinningState& b, GeomState& g, int from, uint32_t n, const uint32_t* n_dev, DigitSpec ds, uint2* ranges, uint32_t nranges,
-                     bool zero_acc_after, uint32_t* order_out, uint32_t* hint, uint32_t* epoch, uint32_t* order_scratch, int debug, hipStream_t s) {
+                     bool zero_acc_after, uint32_t* order_out, uint32_t* hint, uint32_t* epoch, uint32_t* order_scratch, int debug, hipStream_t s,
+                     const BatchOfs& B) {
   constexpr int ROUNDS = GM_TP_ROUNDS;
   constexpr uint32_t TILE = WAVES * ROUNDS * 64;
   const uint32_t nblk = (n + TILE - 1) / TILE;
   const uint32_t nchunks = (nblk + BK_CHUNK - 1) / BK_CHUNK;
-  hipLaunchKernelGGL((bk_hist_kernel<false, DB, WAVES, ROUNDS>), dim3(nblk), dim3(WAVES * 64), 0, s, b.pairs[from], n, n_dev, ds, nullptr, b.hist, b.acc,
-                     g.counters, nullptr, nullptr, nullptr);
+  const uint32_t nf = (uint32_t)B.frames;
+  hipLaunchKernelGGL((bk_hist_kernel<false, DB, WAVES, ROUNDS>), dim3(nblk, 1, nf), dim3(WAVES * 64), 0, s, b.pairs[from], n, n_dev, ds, nullptr, b.hist, b.acc,
+                     g.counters, nullptr, nullptr, nullptr, B.geom, B.binning);
   GM_LAUNCH_CHECK(debug, s);
-  hipLaunchKernelGGL((bk_scan_kernel<false, DB>), dim3(nchunks ? nchunks : 1, (1 << DB) / 256), dim3(BK_THREADS), 0, s, b.hist, TILE, n, n_dev,
-                     b.acc, nullptr, g.counters, ranges, nranges);
+  hipLaunchKernelGGL((bk_scan_kernel<false, DB>), dim3(nchunks ? nchunks : 1, (1 << DB) / 256, nf), dim3(BK_THREADS), 0, s, b.hist, TILE, n, n_dev,
+                     b.acc, nullptr, g.counters, ranges, nranges, B.geom, B.binning, B.image);
   GM_LAUNCH_CHECK(debug, s);
-  hipLaunchKernelGGL((bk_scatter_kernel<false, DB, WAVES, ROUNDS>), dim3(nblk + (order_out ? 1u : 0u)), dim3(WAVES * 64), 0, s, b.pairs[from],
+  hipLaunchKernelGGL((bk_scatter_kernel<false, DB, WAVES, ROUNDS>), dim3(nblk + (order_out ? 1u : 0u), 1, nf), dim3(WAVES * 64), 0, s, b.pairs[from],
                      b.pairs[from ^ 1], n, n_dev, ds, b.hist, zero_acc_after ? b.acc : nullptr, (uint32_t)bk_acc_words(n), ranges,
-                     (int)nranges, order_out, nullptr, nullptr, hint, epoch, nblk <= 4096u ? scatter_trace(false) : nullptr, order_scratch);
+                     (int)nranges, order_out, nullptr, nullptr, hint, epoch, (nf == 1 && nblk <= 4096u) ? scatter_trace(false) : nullptr, order_scratch,
+                     B.geom, B.binning, B.image);
   GM_LAUNCH_CHECK(debug, s);
   return 0;
 }
@@ -1091,9 +1114,12 @@ static int tile_pass(BinningState& b, GeomState& g, int from, uint32_t n, const 
 // capacity).  tiles <= 2048: one 11-bit pass, result in pairs[1], ranges written by the scan.  Otherwise two 8-bit
 // passes, result in pairs[0], ranges by tile_ranges_kernel (caller).  duplicate_kernel has zeroed b.acc.
 int launch_tile_sort(GeomState& g, BinningState& b, ImageState& img, size_t n, const uint32_t* n_dev, int tiles, bool* order_done,
-                     uint32_t* work_hint, int debug, hipStream_t s) {
+                     uint32_t* work_hint, int debug, hipStream_t s, const BatchOfs* bt) {
   StageScope sc(ST_TILE_SORT, s);
   *order_done = false;
+  const BatchOfs one = single_frame();
+  const BatchOfs& B = bt ? *bt : one;
+  if (B.frames > 1 && (n == 0 || tiles > (1 << GM_BUCKET_BITS))) { set_error("batched tile sort: needs instances and at most 2048 list tiles"); return 1; }
   if (n == 0) {
     GM_HIP(hipMemsetAsync(img.ranges, 0, sizeof(uint2) * (size_t)tiles, s));
     return 0;
@@ -1104,12 +1130,12 @@ int launch_tile_sort(GeomState& g, BinningState& b, ImageState& img, size_t n, c
     *order_done = true;                 // the scatter launch carries the dispatch-order workgroup
     if (n <= (size_t(1) << 19))
       return tile_pass<GM_BUCKET_BITS, 4>(b, g, 0, (uint32_t)n, n_dev, DigitSpec{0u, 0u, (1u << GM_BUCKET_BITS) - 1u}, img.ranges, (uint32_t)tiles,
-                                          false, img.tile_order, work_hint, img.epoch, img.tile_work, debug, s);
+                                          false, img.tile_order, work_hint, img.epoch, img.tile_work, debug, s, B);
     return tile_pass<GM_BUCKET_BITS, GM_TILE_PASS_WAVES>(b, g, 0, (uint32_t)n, n_dev, DigitSpec{0u, 0u, (1u << GM_BUCKET_BITS) - 1u}, img.ranges, (uint32_t)tiles,
-                                         false, img.tile_order, work_hint, img.epoch, img.tile_work, debug, s);
+                                         false, img.tile_order, work_hint, img.epoch, img.tile_work, debug, s, B);
   }
-  if (int rc = tile_pass<8, 4>(b, g, 0, (uint32_t)n, n_dev, DigitSpec{0u, 0u, 0xFFu}, nullptr, 0u, true, nullptr, nullptr, nullptr, nullptr, debug, s)) return rc;
-  return tile_pass<8, 4>(b, g, 1, (uint32_t)n, n_dev, DigitSpec{0u, 8u, 0xFFu}, nullptr, 0u, false, nullptr, nullptr, nullptr, nullptr, debug, s);
+  if (int rc = tile_pass<8, 4>(b, g, 0, (uint32_t)n, n_dev, DigitSpec{0u, 0u, 0xFFu}, nullptr, 0u, true, nullptr, nullptr, nullptr, nullptr, debug, s, B)) return rc;
+  return tile_pass<8, 4>(b, g, 1, (uint32_t)n, n_dev, DigitSpec{0u, 8u, 0xFFu}, nullptr, 0u, false, nullptr, nullptr, nullptr, nullptr, debug, s, B);
 }
 
 }  // namespace gm

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <string>
+#include <type_traits>
 
 #define GM_TILE 16              // tile edge (pixels); reference cuda_rasterizer/config.h:15-16
 #define GM_WAVE 64
@@ -289,6 +290,24 @@ struct BinningState {           // per-instance state (R-sized)
   char* end;
 };
 
+// Frames of ONE batched forward (gm_forward_deformed_batch_async): every kernel of the chain runs with gridDim.z = frames in the batch and
+// takes frame 0's pointers plus, per caller-owned buffer kind, the byte distance of frame f's buffer from frame 0's - the scratch layouts
+// depend only on (base address mod 256, sizes), and the batch entry point insists on 256-byte aligned bases, so a field of frame f is the
+// same field of frame 0 moved by that distance.  A single-frame launch passes zeros and gridDim.z == 1.
+#define GM_BATCH_MAX 4
+struct FrameOfs { long long d[GM_BATCH_MAX]; };
+template <class T>
+__device__ __forceinline__ T* frame_ptr(T* p, const FrameOfs& o) {       // (pointer arithmetic on p itself: the result keeps p's __restrict__ provenance)
+  typedef typename std::conditional<std::is_const<T>::value, const char, char>::type B;
+  return p ? reinterpret_cast<T*>(reinterpret_cast<B*>(p) + o.d[blockIdx.z]) : p;
+}
+struct BatchOfs {                 // host side: the distances of a batch (all zero + frames == 1 for a single frame)
+  int frames;
+  FrameOfs geom, binning, image, color;
+  int* status[GM_BATCH_MAX];
+};
+static inline BatchOfs single_frame() { BatchOfs b{}; b.frames = 1; return b; }
+
 static inline int tile_bits(int tiles) {      // bits needed to hold tile ids 0..tiles-1 (>=1)
   int b = 1;
   while ((1 << b) < tiles) b++;
@@ -344,20 +363,20 @@ int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], uint32_t* hist, uint3
 // (depth, id) order of the visible Gaussians + per-bucket instance totals; counters[GM_CNT_RENDERED] = num_rendered.
 // num_rendered_host (optional, pinned): receives the count by a stream-ordered copy issued as soon as it is known;
 // count_event (optional) is recorded right behind that copy.
-int launch_depth_order(GeomState& g, int P, int debug, hipStream_t s, int* num_rendered_host, hipEvent_t count_event);
-int launch_arm_counters(GeomState& g, hipStream_t s);                               // zero slots + counters (first launch of a forward)
+int launch_depth_order(GeomState& g, int P, int debug, hipStream_t s, int* num_rendered_host, hipEvent_t count_event, const BatchOfs* bt = nullptr);
+int launch_arm_counters(GeomState& g, hipStream_t s, const BatchOfs* bt = nullptr);   // zero slots + counters (first launch of a forward)
 // direct depth placement: arm (zero + table snapshot into g.dmap), and - after the fused preprocess - bucket starts, the next table, the sort
 int launch_arm_direct(GeomState& g, DepthSlab& d, uint32_t* plan, hipStream_t s);
 int launch_depth_order_direct(GeomState& g, DepthSlab& d, uint32_t* plan, int P, int debug, hipStream_t s, int* num_rendered_host, hipEvent_t count_event);
 int launch_publish_depth_plan(GeomState& g, uint32_t* plan, hipStream_t s);        // classic path: leave this frame's table for the stream's next frames
-int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, int tile_cull, size_t capacity, int debug, hipStream_t s);
+int launch_duplicate(GeomState& g, BinningState& b, int P, int W, int H, int tile_cull, size_t capacity, int debug, hipStream_t s, const BatchOfs* bt = nullptr);
 int launch_tile_sort(GeomState& g, BinningState& b, ImageState& img, size_t n, const uint32_t* n_dev, int tiles, bool* order_done,
-                     uint32_t* work_hint, int debug, hipStream_t s);      // order_done: img.tile_order was written too (one-pass case)
+                     uint32_t* work_hint, int debug, hipStream_t s, const BatchOfs* bt = nullptr);      // order_done: img.tile_order was written too (one-pass case)
 int launch_tile_ranges(const GeomState& g, BinningState& b, int slot, ImageState& img, int R, const uint32_t* R_dev, int tiles, int debug, hipStream_t s);
 int launch_tile_order(ImageState& img, int tiles, uint32_t* work_hint, int debug, hipStream_t s);          // ranges -> tile_order
 int launch_render_fwd(const GeomState& g, const uint2* pairs, ImageState& img, int W, int H, int mode,
                       const float* background, float* out_color, int* status_host, bool image_only, uint32_t* work_hint, int debug,
-                      hipStream_t s, bool exact_exponent = false);
+                      hipStream_t s, bool exact_exponent = false, const BatchOfs* bt = nullptr);
 int launch_render_bwd(const GeomState& g, const uint2* pairs, ImageState& img, int W, int H, int mode,
                       const float* background, const float* dL_dpix, int debug, hipStream_t s);   // accumulates into g.grad_acc
 
@@ -379,6 +398,18 @@ int launch_deform_shade_packed(int N, int deg, int M, const int* tri, const floa
 int launch_cov_to_scale_rot(int N, const float* cov, float* scales, float* rots, hipStream_t s);
 int launch_mesh_rs(int Vm, const float* V0, const float* V1, const int* faces, const int* adj_offsets, const int* adj_faces, float* R,
                    float* S, float* state, float* packed, hipStream_t s);
+// the packed gather tables of `frames` deformation frames in one launch (gridDim.z = frame): V1[f] -> packed[f]
+int launch_mesh_rs_batch(int frames, int Vm, const float* V0, const float* const* V1, const int* faces, const int* adj_offsets, const int* adj_faces,
+                         float* const* packed, hipStream_t s);
+// one frame of a batched fused pass (gm_deform.hip): what differs between the frames that share one pass over the static cloud
+struct BatchFrameArgs {
+  const float *packed, *viewmatrix, *projmatrix, *cam_pos;
+  float tan_fovx, tan_fovy;
+  GeomState g;
+  int* radii;
+};
+int launch_deform_shade_pre_batch(int frames, const BatchFrameArgs* fr, int P, int deg, int W, int H, int tile_cull, const int* tri, const float* w,
+                                  const float* cov, const float* pos, const float* shs, const float* opacities, bool cov6, int debug, hipStream_t s);
 int launch_ssim_fwd(const float* img1, const float* img2, int planes, int H, int W, float* d_mu1, float* d_e11, float* d_e12,
                     float* partial, hipStream_t s);
 int launch_loss_combine(const float* partial, long long n, double c_ssim, double c_l1, double offset, float* out, hipStream_t s);

@@ -351,6 +351,172 @@ __global__ __launch_bounds__(64) void deform_shade_kernel(int N, int deg, const 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K frames of one view stream from ONE pass over the static cloud (gm_forward_deformed_batch_async).  Of the 321 bytes per Gaussian the
+// fused pass of a frame moves, 256 do not depend on the frame - face ids 12, weights 12, rest covariance 24 (36), rest position 12, SH row
+// 192, opacity 4 - and a render loop with several frames in flight streamed them from HBM once per frame.  Here a wave loads them once
+// (the SH rows stay in LDS, the rest in ~20 registers) and loops over the batch's frames: gather the frame's per-vertex table (L2
+// resident: 0.7 MB per frame), deform, rotated-direction SH colour, project, emission record -> the frame's own geometry buffer.  Every
+// expression is the one deform_shade_kernel<true, true> evaluates, in the same order, contraction off: each frame's geometry buffer comes
+// out bit for bit as from the single-frame launch (tests/test_gpu_batch.py).
+struct FusedFrame {
+  PreCam cam;
+  const float4* tab; const float* campos;
+  float4* splat; int* radii_int; int* radii_out; uint32_t* tiles; uint4* bin; uint32_t* counters; uint32_t* slots; uint32_t* coarse; uint32_t* depth_key;
+};
+struct FusedBatch { int frames, cov6; const float* opac; FusedFrame f[GM_BATCH_MAX]; };
+
+__global__ __launch_bounds__(64) void deform_shade_pre_batch_kernel(int N, int deg, const int* __restrict__ tri, const float* __restrict__ w,
+                                                                     const float* __restrict__ cov, const float* __restrict__ pos,
+                                                                     const float* __restrict__ shs, const FusedBatch fb) {
+  constexpr int DS_THREADS = 64;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float4* l_sh = reinterpret_cast<float4*>(lds);   // [64][12] granules: linear image of the block's SH rows (12 KiB)
+  const size_t row0 = (size_t)blockIdx.x * DS_THREADS;
+  const int nrows = min(DS_THREADS, N - (int)row0);
+  const int t = threadIdx.x;
+  const size_t i = row0 + t;
+  const bool live = t < nrows;
+  int t0 = 0, t1 = 0, t2 = 0; float w0 = 0.f, w1 = 0.f, w2 = 0.f, p0 = 0.f, p1 = 0.f, p2 = 0.f, opac = 0.f;
+  if (live) {
+    t0 = tri[3 * i]; t1 = tri[3 * i + 1]; t2 = tri[3 * i + 2];
+    w0 = w[3 * i]; w1 = w[3 * i + 1]; w2 = w[3 * i + 2];
+    p0 = pos[3 * i]; p1 = pos[3 * i + 1]; p2 = pos[3 * i + 2];
+    opac = fb.opac[i];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if (nrows == DS_THREADS) {
+    const char* gsh = reinterpret_cast<const char*>(shs + row0 * 48) + t * 16;
+#pragma unroll
+    for (int q = 0; q < 12; q++) dma16(gsh + q * 1024, reinterpret_cast<char*>(l_sh) + q * 1024);
+  } else if (live) {
+#pragma unroll
+    for (int c = 0; c < 12; c++) l_sh[t * 12 + c] = reinterpret_cast<const float4*>(shs)[i * 12 + c];
+  }
+  float C[9];
+  if (fb.cov6) {
+    float c6[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) c6[k] = live ? cov[i * 6 + k] : 0.f;
+    C[0] = c6[0]; C[1] = c6[1]; C[2] = c6[2]; C[3] = c6[1]; C[4] = c6[3]; C[5] = c6[4]; C[6] = c6[2]; C[7] = c6[4]; C[8] = c6[5];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; k++) C[k] = live ? cov[i * 9 + k] : 0.f;
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): the DMA has landed
+  __syncthreads();
+#pragma unroll 1
+  for (int f = 0; f < fb.frames; f++) {
+    const FusedFrame& F = fb.f[f];
+    float d[3], Rb[9], Sb[9];
+    {
+      const float4* tab = F.tab;
+      float va[24], vb[24], vc[24];
+#pragma unroll
+      for (int q = 0; q < 6; q++) {
+        const float4 a = tab[6 * (size_t)t0 + q], b = tab[6 * (size_t)t1 + q], c = tab[6 * (size_t)t2 + q];
+        va[4 * q] = a.x; va[4 * q + 1] = a.y; va[4 * q + 2] = a.z; va[4 * q + 3] = a.w;
+        vb[4 * q] = b.x; vb[4 * q + 1] = b.y; vb[4 * q + 2] = b.z; vb[4 * q + 3] = b.w;
+        vc[4 * q] = c.x; vc[4 * q + 1] = c.y; vc[4 * q + 2] = c.z; vc[4 * q + 3] = c.w;
+      }
+#pragma unroll
+      for (int k = 0; k < 3; k++) d[k] = (w0 * va[k] + w1 * vb[k]) + w2 * vc[k];
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        Rb[k] = (w0 * va[4 + k] + w1 * vb[4 + k]) + w2 * vc[4 + k];
+        Sb[k] = (w0 * va[13 + k] + w1 * vb[13 + k]) + w2 * vc[13 + k];
+      }
+    }
+    float O[9], Rt[9], npos[3], col[3];
+    {
+      float RS[9], A[9];
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) Rt[3 * a + b] = Rb[3 * b + a];
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) RS[3 * a + b] = (Rt[3 * a] * Sb[b] + Rt[3 * a + 1] * Sb[3 + b]) + Rt[3 * a + 2] * Sb[6 + b];
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) A[3 * a + b] = (RS[3 * a] * C[b] + RS[3 * a + 1] * C[3 + b]) + RS[3 * a + 2] * C[6 + b];
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) O[3 * a + b] = (A[3 * a] * RS[3 * b] + A[3 * a + 1] * RS[3 * b + 1]) + A[3 * a + 2] * RS[3 * b + 2];
+      npos[0] = p0 + d[0]; npos[1] = p1 + d[1]; npos[2] = p2 + d[2];
+      const float* campos = F.campos;
+      float dx = npos[0] - campos[0], dy = npos[1] - campos[1], dz = npos[2] - campos[2];
+      const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+      dx = dx / len; dy = dy / len; dz = dz / len;
+      const float x = (Rt[0] * dx + Rt[3] * dy) + Rt[6] * dz;
+      const float y = (Rt[1] * dx + Rt[4] * dy) + Rt[7] * dz;
+      const float z = (Rt[2] * dx + Rt[5] * dy) + Rt[8] * dz;
+      float sh[48];
+#pragma unroll
+      for (int c = 0; c < 12; c++) {
+        const float4 v = l_sh[t * 12 + c];
+        sh[4 * c] = v.x; sh[4 * c + 1] = v.y; sh[4 * c + 2] = v.z; sh[4 * c + 3] = v.w;
+      }
+#pragma unroll
+      for (int ch = 0; ch < 3; ch++) {
+        const float r = sh_channel(deg, [&](int k) { return sh[3 * k + ch]; }, x, y, z);
+        col[ch] = fmaxf(r + 0.5f, 0.0f);
+      }
+    }
+    uint32_t tiles = 0, dkey = 0xFFFFFFFFu;
+    uint4 dbin = make_uint4(0u, 0u, 0u, 0u);
+    PreGeom pg;
+    bool vis = false;
+    if (live) {
+      const V3 p = {npos[0], npos[1], npos[2]};
+      const float c3[6] = {O[0], O[1], O[2], O[4], O[5], O[8]};
+      vis = pre_project(F.cam, p, c3, pg);
+      if (vis) dkey = __float_as_uint(pg.depth);
+      int radius_i = 0;
+      if (vis) {
+        splat_store(F.splat, i, pg.pix, pg.piy, pg.conx, pg.cony, pg.conz, opac, col[0], col[1], col[2], pg.depth);
+        radius_i = (int)pg.radius;
+        pre_emit(F.cam, pg, opac, tiles, dbin);
+      }
+      if (F.radii_out) F.radii_out[i] = radius_i; else F.radii_int[i] = radius_i;
+      if (tiles >= GM_BIN_COUNT_SAT) F.tiles[i] = tiles;
+      F.bin[i] = dbin;
+      F.depth_key[i] = dkey;
+      if (i == 0) F.counters[GM_CNT_POLICY] = (uint32_t)F.cam.tile_cull;
+    }
+    slot_accumulate(F.slots, F.coarse, tiles, dkey);
+  }
+}
+
+int launch_deform_shade_pre_batch(int frames, const BatchFrameArgs* fr, int P, int deg, int W, int H, int tile_cull, const int* tri, const float* w,
+                                  const float* cov, const float* pos, const float* shs, const float* opacities, bool cov6, int debug, hipStream_t s) {
+  if (P <= 0) return 0;
+  if (frames < 1 || frames > GM_BATCH_MAX) { set_error("batched fused pass: 1..%d frames", GM_BATCH_MAX); return 1; }
+  if (!aligned16(shs) || !aligned16(cov)) { set_error("gm_forward_deformed_batch: shs / cov must be 16-byte aligned"); return 1; }
+  StageScope sc(ST_DEFORM, s);
+  FusedBatch fb{};
+  fb.frames = frames; fb.cov6 = cov6 ? 1 : 0; fb.opac = opacities;
+  for (int k = 0; k < frames; k++) {
+    const BatchFrameArgs& a = fr[k];
+    if (!aligned16(a.packed)) { set_error("gm_forward_deformed_batch: packed tables must be 16-byte aligned"); return 1; }
+    FusedFrame& F = fb.f[k];
+    F.cam.W = W; F.cam.H = H; F.cam.gx = (W + GM_TILE - 1) / GM_TILE; F.cam.gy = (H + GM_TILE - 1) / GM_TILE;
+    F.cam.tile_cull = tile_cull; F.cam.view = a.viewmatrix; F.cam.proj = a.projmatrix;
+    F.cam.tanx = a.tan_fovx; F.cam.tany = a.tan_fovy;
+    F.cam.fy = H / (2.0f * a.tan_fovy); F.cam.fx = W / (2.0f * a.tan_fovx);      // rasterizer_impl.cu:359-360
+    F.tab = reinterpret_cast<const float4*>(a.packed); F.campos = a.cam_pos;
+    const GeomState& g = a.g;
+    F.splat = g.splat; F.radii_int = g.radii; F.radii_out = a.radii; F.tiles = g.tiles_touched; F.bin = g.bin; F.counters = g.counters; F.slots = g.slots;
+    F.coarse = g.coarse; F.depth_key = g.depth_key;
+  }
+  hipLaunchKernelGGL(deform_shade_pre_batch_kernel, dim3((P + 63) / 64), dim3(64), sizeof(float) * 64 * 48, s, P, deg, tri, w, cov, pos, shs, fb);
+  GM_LAUNCH_CHECK(debug, s);
+  return 0;
+}
+
 // mesh state of one deformation frame, as broadcast to the ranks ([Vm][21] = V1 | R | S), minus the rest pose -> the
 // gather table of deform_shade_kernel<.., true>
 __global__ __launch_bounds__(256) void pack_mesh_state_kernel(int Vm, const float* __restrict__ state, const float* __restrict__ verts,

@@ -62,11 +62,14 @@ __device__ __forceinline__ void jacobi3(double A[3][3], double V[3][3]) {
 #ifndef GM_MESH_THREADS
 #define GM_MESH_THREADS 64       // one-wave workgroups: 118 of them for the 7.5 k-vertex proxy mesh instead of 30 four-wave ones (pipelined loop +0.8 %)
 #endif
+struct MeshFrames { int frames; const float* V1[GM_BATCH_MAX]; float4* packed[GM_BATCH_MAX]; };
+
 __global__ __launch_bounds__(GM_MESH_THREADS) void mesh_rs_kernel(int Vm, const float* __restrict__ V0, const float* __restrict__ V1,
                                                       const int* __restrict__ faces, const int* __restrict__ adj_offsets,
                                                       const int* __restrict__ adj_faces, float* __restrict__ R_out,
                                                       float* __restrict__ S_out, float* __restrict__ state_out,
-                                                      float4* __restrict__ packed_out) {
+                                                      float4* __restrict__ packed_out, const MeshFrames mf) {
+  if (mf.frames > 1) { V1 = mf.V1[blockIdx.z]; packed_out = mf.packed[blockIdx.z]; }      // frame blockIdx.z of a batch: its deformed mesh, its table
   const int v = blockIdx.x * GM_MESH_THREADS + threadIdx.x;
   if (v >= Vm) return;
   // M0 = sum c e e^T (symmetric), M1 = sum c e' e^T over the one-ring edges; every incident face contributes its two edges
@@ -300,8 +303,23 @@ int launch_mesh_rs(int Vm, const float* V0, const float* V1, const int* faces, c
                    float* S, float* state, float* packed, hipStream_t s) {
   if (Vm <= 0) return 0;
   StageScope sc(ST_MESH_RS, s);          // a stage of its own: bench.py's `roofline` names single kernels
+  MeshFrames mf{};
+  mf.frames = 1;
   hipLaunchKernelGGL(mesh_rs_kernel, dim3((Vm + GM_MESH_THREADS - 1) / GM_MESH_THREADS), dim3(GM_MESH_THREADS), 0, s, Vm, V0, V1, faces, adj_offsets, adj_faces, R, S, state,
-                     reinterpret_cast<float4*>(packed));
+                     reinterpret_cast<float4*>(packed), mf);
+  GM_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_mesh_rs_batch(int frames, int Vm, const float* V0, const float* const* V1, const int* faces, const int* adj_offsets, const int* adj_faces,
+                         float* const* packed, hipStream_t s) {
+  if (Vm <= 0 || frames <= 0) return 0;
+  StageScope sc(ST_MESH_RS, s);
+  MeshFrames mf{};
+  mf.frames = frames;
+  for (int f = 0; f < frames; f++) { mf.V1[f] = V1[f]; mf.packed[f] = reinterpret_cast<float4*>(packed[f]); }
+  hipLaunchKernelGGL(mesh_rs_kernel, dim3((Vm + GM_MESH_THREADS - 1) / GM_MESH_THREADS, 1, (uint32_t)frames), dim3(GM_MESH_THREADS), 0, s, Vm, V0, V1[0], faces, adj_offsets,
+                     adj_faces, nullptr, nullptr, nullptr, reinterpret_cast<float4*>(packed[0]), mf);
   GM_HIP(hipGetLastError());
   return 0;
 }

@@ -219,6 +219,11 @@ __device__ __forceinline__ v16f poly_exponents(const float* __restrict__ ct, int
 // Alternates that were compile-time switches until round 6 (three register sets, unfolded clamp, 256-thread workgroups) and their
 // numbers: tools/experiments/render_blend_compile_time_alternates_round5.hip.txt.
 #define GM_FWD_SUB 4              // survivors whose alpha evaluations interleave in the forward recurrence
+struct RenderFrames {            // the frames of a batched forward blend (gridDim.z): buffer distances + where each frame's status words go
+  int frames;
+  FrameOfs go, bo, io, co;
+  int* status[GM_BATCH_MAX];
+};
 struct FwdLds {                  // per wave: 5.1 KiB
   uint2 qa[RQ_QA];               // candidate ring: (Gaussian id, list position)
   float ct[4 * 6 * 32];          // [group of 16 survivors][monomial][MFMA row]: lane l of MFMA step m reads ct[192 g + 64 m + l]
@@ -238,8 +243,13 @@ __global__ __launch_bounds__(64) void render_fwd_kernel(const uint2* __restrict_
                                                         float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                                                         unsigned long long* __restrict__ trace,
                                                         const uint32_t* __restrict__ counters, int* __restrict__ status_host,
-                                                        uint32_t* __restrict__ hint, const uint32_t* __restrict__ epoch) {
+                                                        uint32_t* __restrict__ hint, const uint32_t* __restrict__ epoch, const RenderFrames rf) {
   const unsigned long long t_start = TRACE ? wall_clock64() : 0ull;
+  // frame blockIdx.z of a batch (gm_common.h FrameOfs; a single frame: zero distances, its status words through status_host)
+  ranges = frame_ptr(ranges, rf.io); pairs = frame_ptr(pairs, rf.bo); splat = frame_ptr(splat, rf.go); tm.order = frame_ptr(tm.order, rf.io);
+  out_color = frame_ptr(out_color, rf.co); counters = frame_ptr(counters, rf.go); epoch = frame_ptr(epoch, rf.io);
+  if (STATE) { final_T = frame_ptr(final_T, rf.io); n_contrib = frame_ptr(n_contrib, rf.io); }
+  if (rf.frames > 1) status_host = rf.status[blockIdx.z];
   int tr_iters = 0, tr_cand = 0;
   // One 8x8 pixel quadrant = one wave = one workgroup (placed and retired on its own); ids 8 apart share an XCD:
   // id = ((tile slot j) * 4 + quadrant) * 8 + xcd.
@@ -463,24 +473,31 @@ extern "C" void gm_debug_forward_exact_exponent(int on) { g_fwd_exact = on != 0;
 
 int launch_render_fwd(const GeomState& g, const uint2* pairs, ImageState& img, int W, int H, int mode,
                       const float* background, float* out_color, int* status_host, bool image_only, uint32_t* work_hint, int debug,
-                      hipStream_t s, bool exact_exponent) {
+                      hipStream_t s, bool exact_exponent, const BatchOfs* bt) {
   StageScope sc(ST_RENDER, s);
   const TileGrid tg(W, H, mode);
   const TileMap tm{tg.gx, tg.gy, tg.pgx, tg.pgy, tg.s, img.tile_order};
+  RenderFrames rf{};
+  rf.frames = 1;
+  if (bt) {
+    rf.frames = bt->frames; rf.go = bt->geom; rf.bo = bt->binning; rf.io = bt->image; rf.co = bt->color;
+    for (int f = 0; f < GM_BATCH_MAX; f++) rf.status[f] = bt->status[f];
+  }
+  if (rf.frames > 1 && tg.ptiles <= 0) { set_error("batched blend: empty tile grid"); return 1; }
   if (tg.ptiles > 0) {
-    const dim3 grid(tm.blocks() * 4), block(64);     // one wave (8x8 quadrant) per workgroup
+    const dim3 grid(tm.blocks() * 4, 1, (uint32_t)rf.frames), block(64);     // one wave (8x8 quadrant) per workgroup
     if (g_fwd_exact || exact_exponent)
       hipLaunchKernelGGL((render_fwd_kernel<true, false, true>), grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
-                         background, out_color, img.final_T, img.n_contrib, nullptr, g.counters, status_host, work_hint, img.epoch);
+                         background, out_color, img.final_T, img.n_contrib, nullptr, g.counters, status_host, work_hint, img.epoch, rf);
     else if (g_render_trace)
       hipLaunchKernelGGL((render_fwd_kernel<true, true>), grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
-                         background, out_color, img.final_T, img.n_contrib, g_render_trace, g.counters, status_host, work_hint, img.epoch);
+                         background, out_color, img.final_T, img.n_contrib, g_render_trace, g.counters, status_host, work_hint, img.epoch, rf);
     else if (image_only)
       hipLaunchKernelGGL((render_fwd_kernel<false, false>), grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
-                         background, out_color, img.final_T, img.n_contrib, nullptr, g.counters, status_host, work_hint, img.epoch);
+                         background, out_color, img.final_T, img.n_contrib, nullptr, g.counters, status_host, work_hint, img.epoch, rf);
     else
       hipLaunchKernelGGL((render_fwd_kernel<true, false>), grid, block, 0, s, img.ranges, pairs, g.splat, W, H, tm,
-                         background, out_color, img.final_T, img.n_contrib, nullptr, g.counters, status_host, work_hint, img.epoch);
+                         background, out_color, img.final_T, img.n_contrib, nullptr, g.counters, status_host, work_hint, img.epoch, rf);
   } else if (status_host) {
     GM_HIP(hipMemcpyAsync(status_host, g.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   }

@@ -184,6 +184,34 @@ def mesh_rs_packed(rest_vertices, deformed_vertices, faces, adjacency, out=None)
     return packed
 
 
+def mesh_rs_packed_batch(rest_vertices, deformed_vertices_list, faces, adjacency, out=None):
+    """gm_mesh_rs_packed_batch: the gather tables of up to GM_BATCH_MAX deformed meshes in ONE launch (the frames of a
+    rasterizer.forward_deformed_batch); deformed_vertices_list: K tensors [Vm,3]; out: optional [K,Vm,24] tensor.  Returns the K tables
+    (views of one [K,Vm,24] tensor), each bit for bit what mesh_rs_packed makes of its mesh."""
+    lib = _lib.lib()
+    device = rest_vertices.device
+    if device.type != "cuda":
+        raise _lib.GmeshError("mesh_rs_packed_batch needs tensors on a HIP (cuda) device; there is no CPU path")
+    K = len(deformed_vertices_list)
+    if not 1 <= K <= _lib.GM_BATCH_MAX:
+        raise ValueError("mesh_rs_packed_batch: 1..%d frames" % _lib.GM_BATCH_MAX)
+    V0 = _f(rest_vertices)
+    V1 = [_f(v) for v in deformed_vertices_list]
+    Vm = V0.shape[0]
+    if faces.dtype is not torch.int32 or not faces.is_contiguous():
+        faces = faces.detach().contiguous().to(torch.int32)
+    off, adj = adjacency
+    packed = out if out is not None else torch.empty((K, Vm, 24), dtype=torch.float32, device=device)
+    import ctypes as C
+    from .rasterizer import _on, _stream
+    pv = (C.c_void_p * K)(*[v.data_ptr() for v in V1])
+    pp = (C.c_void_p * K)(*[packed[k].data_ptr() for k in range(K)])
+    with _on(device):
+        _lib.check(lib.gm_mesh_rs_packed_batch(K, Vm, faces.shape[0], V0.data_ptr(), pv, faces.data_ptr(), off.data_ptr(), adj.data_ptr(), pp,
+                                               _stream(device)))
+    return [packed[k] for k in range(K)]
+
+
 def mesh_rs(rest_vertices, deformed_vertices, faces, adjacency=None, want_state=False):
     """gm_mesh_rs: per-vertex (R, S) [Vm,3,3] of a deformed proxy mesh, the pair pyACAP.GetRS hands to
     SingleObjectDeform.deform_gaussian (edittool/__init__.py:109-113): cotangent-weighted one-ring least-squares

@@ -575,6 +575,76 @@ def forward_deformed_begin(bg, tri, weights, packed, cov, pos, shs, opacity, vie
     return h
 
 
+def forward_deformed_batch(bg, tri, weights, packed_list, cov, pos, shs, opacity, cameras, image_height, image_width, degree, workspaces,
+                           image_only=True, work_hint=None, emission_policy=None, debug=False):
+    """K frames of one view stream in ONE launch chain (gm_forward_deformed_batch_async): the static cloud is read from HBM once for the
+    batch and every stage is one launch over the K frames.  packed_list: the K gather tables (deform.mesh_rs_packed_batch);
+    cameras: K dicts / objects with view, proj, campos (device tensors), tanx, tany; workspaces: K RasterWorkspace, one per frame, each with
+    a learned capacity (frames of this stream completed through finish() before: the batch is sync-free only).  Returns K PendingForward
+    handles in the state finish(sync_free=True) leaves them in: .result = (-1, color, radii, geom, binning, img); check() each of them -
+    a frame whose instance count outgrew the batch's capacity is refused (image = background) and finish() renders it again, exactly,
+    through the single-frame second half.  Each frame comes out bit for bit as from forward_deformed_begin(...).finish(sync_free=True)."""
+    lib = _lib.lib()
+    device = pos.device
+    if device.type != "cuda":
+        raise _lib.GmeshError("gaussianmesh_amd rasterizer needs tensors on a HIP (cuda) device; there is no CPU path")
+    K = len(packed_list)
+    if not (1 <= K <= _lib.GM_BATCH_MAX) or len(cameras) != K or len(workspaces) != K:
+        raise ValueError("forward_deformed_batch: 1..%d frames, one camera and one workspace each" % _lib.GM_BATCH_MAX)
+    if len({id(w_) for w_ in workspaces}) != K:
+        raise ValueError("forward_deformed_batch: the frames of a batch need distinct workspaces")
+    policy = _pol(emission_policy, image_width, image_height)
+    P, M = pos.shape[0], shs.shape[1]
+    if tri.dtype is not torch.int32 or not tri.is_contiguous():
+        tri = tri.detach().contiguous().to(torch.int32)
+    weights, cov, pos, shs, opacity, bg = (_prep(t, device) for t in (weights, cov, pos, shs, opacity, bg))
+    H, W = int(image_height), int(image_width)
+    stream = _current_stream(device)
+    _note_stream(stream)
+    cap = max(ws.capacity for ws in workspaces)
+    if cap <= 0:
+        raise _lib.GmeshError("forward_deformed_batch: the workspaces have no capacity yet - complete one frame of the stream through "
+                              "forward_deformed_begin(...).finish() first (the batch is sync-free: it cannot size the binning buffers)")
+    cov6 = cov is not None and cov.dim() == 2 and cov.shape[1] == 6
+    get = lambda c, k: c[k] if isinstance(c, dict) else getattr(c, k)
+    handles, frames, keep = [], (_lib.BatchFrame * K)(), []
+    try:
+        with _on(device), torch.cuda.stream(stream):
+            nbin = lib.gm_binning_bytes(cap)
+            for k in range(K):
+                ws, c = workspaces[k], cameras[k]
+                h = PendingForward(policy=policy, workspace=ws, stream=stream)
+                ws.acquire(h)
+                handles.append(h)
+                ws.capacity = cap
+                color = torch.empty((3, H, W), dtype=torch.float32, device=device)
+                radii = torch.empty((P,), dtype=torch.int32, device=device)
+                geom, img, _ = _scratch(ws, P, W, H, device)
+                binning = ws.get("binning", nbin, device)
+                view, proj, campos, packed = (_prep(t, device) for t in (get(c, "view"), get(c, "proj"), get(c, "campos"), packed_list[k]))
+                keep.append((view, proj, campos, packed))
+                f = frames[k]
+                f.packed, f.viewmatrix, f.projmatrix, f.cam_pos = packed.data_ptr(), view.data_ptr(), proj.data_ptr(), campos.data_ptr()
+                f.tan_fovx, f.tan_fovy = float(get(c, "tanx")), float(get(c, "tany"))
+                f.geom_buffer, f.binning_buffer, f.image_buffer = geom.data_ptr(), binning.data_ptr(), img.data_ptr()
+                f.out_color, f.radii, f.status_host = color.data_ptr(), radii.data_ptr(), ws.pinned_status().data_ptr()
+                h.args = dict(device=device, P=P, W=W, H=H, bg=bg, debug=int(bool(debug)), keep=(tri, weights, cov, pos, shs, opacity, keep[-1]))
+                h.geom, h.img, h.color, h.radii, h.count_host, h.event, h.deformed, h.binning = geom, img, color, radii, None, None, None, binning
+                h.image_only, h.work_hint = bool(image_only), work_hint
+            _lib.check(lib.gm_forward_deformed_batch_async(policy, K, frames, P, int(degree), M, W, H, _ptr(tri), _ptr(weights), _ptr(cov), _ptr(pos), _ptr(shs),
+                                                           _ptr(opacity), _ptr(bg), cap, (1 if image_only else 0) | (2 if cov6 else 0),
+                                                           None if work_hint is None else work_hint.data_ptr(), int(bool(debug)), stream.cuda_stream))
+            for h in handles:
+                h.status_event = h.workspace.status_event()
+                h.status_event.record(stream)
+                h.result = (-1, h.color, h.radii, h.geom, h.binning, h.img)
+    except Exception:
+        for h in handles:
+            h.workspace.release(h)
+        raise
+    return handles
+
+
 def rasterize_backward(bg, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
                        tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos, geom, num_rendered, binning, img, debug,
                        emission_policy=None, skip_intermediates=False, want_conic=False):

@@ -43,7 +43,7 @@ extern "C" {
 #define GM_ERR_BUFFER 3        /* a caller-provided buffer is too small */
 
 /* ABI version of this header; bumped on any signature change. */
-#define GM_ABI_VERSION 2
+#define GM_ABI_VERSION 3
 int gm_abi_version(void);
 const char* gm_last_error(void);
 
@@ -275,6 +275,39 @@ int gm_forward_1_geom(int emission_policy, void* geom_buffer, void* binning_buff
                       int64_t binning_capacity, const float* background, int width, int height, float* out_color, int debug, void* stream,
                       int* status_host, int flags, unsigned int* work_hint);
 int gm_forward_status_async(void* geom_buffer, int P, int* status_host, void* stream);
+
+/* K frames of ONE view stream per launch chain (the edit tool replaying a deformation sequence, a camera path: the frames the render
+ * loop would otherwise keep in flight on K HIP streams).  Equivalent, frame by frame and bit for bit (radii, lists, image, status words), to
+ *   gm_forward_0_deformed_stream_async(policy, frame.geom_buffer, ..., frame.packed, ..., frame.viewmatrix, ..., flags & GM_BATCH_COV6)
+ *   gm_forward_1_geom(policy, frame.geom_buffer, frame.binning_buffer, frame.image_buffer, P, -1, binning_capacity, background, ...,
+ *                     frame.out_color, debug, stream, frame.status_host, flags & GM_BATCH_IMAGE_ONLY, work_hint)
+ * for each of the K frames, but
+ *   - the static cloud (face ids, weights, rest covariance and position, SH rows, opacity: 256 of the 321 bytes per Gaussian the fused pass
+ *     of a frame moves) is read from HBM ONCE for the batch: one pass loops over the frames' (gather table, camera) pairs
+ *     (edittool/__init__.py:103-131, 421-472: what one frame consumes; RAST/forward.cu:155-256), and
+ *   - every later stage is ONE launch over the K frames (grid z = frame): a batch is 12 launches instead of 12 K, each K times as large.
+ * Sync-free second half only (the instance counts stay on the device; binning_capacity instances per frame; a frame that outgrows it is
+ * refused in its own status words and rendered again by the caller through the single-frame calls).  1 <= K <= GM_BATCH_MAX; M == 16;
+ * emission policies with at most 2048 list tiles (the one-pass tile sort); every scratch buffer base 256-byte aligned; the frames'
+ * buffers distinct.  Like every deformed frame: forward only. */
+#define GM_BATCH_MAX 4
+#define GM_BATCH_IMAGE_ONLY 1    /* as GM_FWD_IMAGE_ONLY */
+#define GM_BATCH_COV6 2          /* as GM_STREAM_COV6 */
+typedef struct gm_batch_frame {
+  const float* packed;           /* [Vm][24] gather table of this frame (gm_mesh_rs_packed / gm_mesh_rs_packed_batch / gm_pack_mesh_state) */
+  const float* viewmatrix; const float* projmatrix; const float* cam_pos;
+  float tan_fovx, tan_fovy;
+  void* geom_buffer; void* binning_buffer; void* image_buffer;      /* gm_geom_bytes(P) / gm_binning_bytes(binning_capacity) / gm_image_bytes(W, H) */
+  float* out_color;              /* [3,H,W] */
+  int* radii;                    /* [P], may be NULL */
+  int* status_host;              /* 4 x int32, page-locked, may be NULL */
+} gm_batch_frame;
+int gm_forward_deformed_batch_async(int emission_policy, int K, const gm_batch_frame* frames, int P, int deg, int M, int width, int height,
+                                    const int* tri, const float* w, const float* cov, const float* pos, const float* shs, const float* opacities,
+                                    const float* background, int64_t binning_capacity, int flags, unsigned int* work_hint, int debug, void* stream);
+/* gm_mesh_rs_packed for the K deformed meshes of such a batch in one launch: V1[k] -> packed[k] (host arrays of K device pointers). */
+int gm_mesh_rs_packed_batch(int K, int Vm, int nfaces, const float* V0, const float* const* V1, const int* faces, const int* adj_offsets,
+                            const int* adj_faces, float* const* packed, void* stream);
 
 /* Per-vertex rotation / stretch of a deformed proxy mesh: replaces pyACAP.GetRS(rest vertices, deformed vertices, ...) at
  * edittool/__init__.py:102, 109 (pyACAP is a binary missing from the reference tree, so the contract is the one its call

@@ -15,7 +15,7 @@ def test_library_exports_every_header_symbol():
     for n in names:
         assert hasattr(l, n), n
     assert set(names) == set(_lib.SIGNATURES), "python signatures out of sync with include/gmesh_hip.h"
-    assert l.gm_abi_version() == 2
+    assert l.gm_abi_version() == 3
 
 
 def test_scratch_sizes_scale_linearly():
