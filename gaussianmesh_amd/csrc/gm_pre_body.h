@@ -162,27 +162,6 @@ __device__ __forceinline__ void pre_emit(const PreCam& a, const PreGeom& g, floa
         bqy0 = (int)fmaxf(ceilf((g.piy - ey - 7.f) * 0.125f), -1e9f) - 4 * py0; bqy1 = (int)fminf(floorf((g.piy + ey) * 0.125f), 1e9f) - 4 * py0;
       }
       uint32_t qw[2] = {0u, 0u};                                        // qw[pj]: quadrant masks of parents (px0, py0 + pj) | (px0 + 1, py0 + pj) << 16
-      if (all_quad) {
-        // Round 6, (wave-uniform): the quadrants of the rectangle's tiles inside the ellipse's bounding box, in closed form - no row
-        // spans.  The exact per-row tile reach that the general rule below intersects the box with removed 0.2 % of the instances
-        // (2 957 660 against 2 964 618 at C3) for ~360 of this pass's ~1660 vector instructions per wave, and since the frames of a
-        // batch share one pass over the static cloud (gm_deform.hip deform_shade_pre_batch_kernel) this pass runs at the vector
-        // ALU's pace, not the memory's.  Still conservative (box of {alpha >= 1/255} contains it): images are unchanged.
-        if (tc.mode != 0) {
-          const int qxa = max(2 * (x0 - 2 * px0), bqx0), qxb = min(2 * (x1 - 2 * px0) - 1, bqx1);      // quadrant columns / rows 0..7 of the 2 x 2 parents
-          const int qya = max(2 * (y0 - 2 * py0), bqy0), qyb = min(2 * (y1 - 2 * py0) - 1, bqy1);
-          if (qxa <= qxb && qya <= qyb) {
-            const uint32_t c8 = ((1u << (qxb - qxa + 1)) - 1u) << qxa, r8 = ((1u << (qyb - qya + 1)) - 1u) << qya;
-            const uint32_t clo = c8 & 0xFu, chi = c8 >> 4;
-            // quadrant row ql of a parent -> bit 4 ql: a 4-bit column mask times that lands in every selected row's nibble
-            const uint32_t ra = r8 & 0xFu, rb = r8 >> 4;
-            const uint32_t sa = (ra & 1u) | ((ra & 2u) << 3) | ((ra & 4u) << 6) | ((ra & 8u) << 9);
-            const uint32_t sb = (rb & 1u) | ((rb & 2u) << 3) | ((rb & 4u) << 6) | ((rb & 8u) << 9);
-            qw[0] = (sa * clo) | ((sa * chi) << 16);
-            qw[1] = (sb * clo) | ((sb * chi) << 16);
-          }
-        }
-      } else {
       const int pr_last = tc.mode != 0 ? (y1 - 1) >> 1 : (y0 >> 1) - 1;
       for (int pr = y0 >> 1; pr <= pr_last; pr++) {
         const int ty = 2 * pr;
@@ -217,7 +196,6 @@ __device__ __forceinline__ void pre_emit(const PreCam& a, const PreGeom& g, floa
           }
           if (pr == py0) qw[0] = word; else qw[1] = word;
         }
-      }
       }
       if (ncand > 64) mask = 0ull;
       if (quad) {

@@ -10,7 +10,7 @@ i=0
 for pass in "$@"; do
   i=$((i+1))
   rm -rf /tmp/pmc_${tag}_$i
-  timeout ${PMC_TIMEOUT:-180} rocprofv3 --kernel-trace --pmc $pass -d /tmp/pmc_${tag}_$i -o p -- python ${PMC_SCRIPT:-$root/bench.py} --no-cpu-baseline ${PMC_BENCH_ARGS---no-fwd-bwd} --streams 1 --exact-count --steps 6 --warmup 2 > /dev/null 2> /tmp/pmc_${tag}_$i.err
+  timeout ${PMC_TIMEOUT:-180} rocprofv3 --kernel-trace --pmc $pass -d /tmp/pmc_${tag}_$i -o p -- python ${PMC_SCRIPT:-$root/bench.py} --no-cpu-baseline ${PMC_BENCH_ARGS---no-fwd-bwd} ${PMC_MODE_ARGS---streams 1 --exact-count} --steps ${PMC_STEPS:-6} --warmup 2 > /dev/null 2> /tmp/pmc_${tag}_$i.err
   db=$(find /tmp/pmc_${tag}_$i -name "*.db" | head -1)
   echo "# pass $i: $pass" >> $out
   python $root/tools/pmc_summary.py $db ${PMC_FILTER-render} >> $out 2>&1
