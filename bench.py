@@ -413,6 +413,50 @@ def c5_leg(steps, warm, Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, sync_free=
     return out
 
 
+def c5_phases(iters=200, warm=20, Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, dev=None, ncams=32, degrees=(0, 1, 2, 3), trainer_kw=None):
+    """ms per iteration of the C5 loop at EACH SH degree the reference's schedule passes through (train_mesh_gaussian.py:70-71 raises the
+    degree every 1000 iterations: 1000 iterations at degree 0, 1000 at 1, 1000 at 2, 27 000 at 3), `iters` iterations each behind `warm`
+    untimed ones, every phase from the SAME model state (the r05 student of build_c5): random camera without replacement, random
+    background, teacher targets composited over it, statistics, Adam step - the loop of c5_leg(as_reference=True) without topology changes."""
+    import random
+    import torch
+    from gaussianmesh_amd.train import Trainer
+    dev = dev or torch.device("cuda", 0)
+    tr, cams, (colour, trans), _ = build_c5(Nfg, Nbg, W, H, dev, True, ncams=ncams, teacher=True)
+    model, bg = tr.g, tr.bg_gaussian
+    model.end_dense_dc()
+    names = ("_bc", "_distance", "_features", "_opacity", "_scaling", "_rotation")
+    snap = {k: getattr(model, k).detach().clone() for k in names}
+    del tr
+    out = {"iters": iters, "warmup": warm, "gaussians": Nfg + Nbg, "width": W, "height": H}
+    nc = len(cams)
+    for d in degrees:
+        with torch.no_grad():
+            for k in names:
+                getattr(model, k).copy_(snap[k])
+        model.active_sh_degree = d
+        tr = Trainer(model, densify_stats=True, sync_free=True, bg_gaussian=bg, **(trainer_kw or {}))
+        rng, stack = random.Random(0), []
+        t0 = None
+        for it in range(warm + iters):
+            if it == warm:
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+            if not stack:
+                stack = list(range(nc))
+            k = stack.pop(rng.randint(0, len(stack) - 1))
+            bgc = torch.rand(3, device=dev)
+            loss, pkg = tr.step(cams[k], torch.addcmul(colour[k], trans[k], bgc.view(3, 1, 1)), bgc)
+        torch.cuda.synchronize()
+        out["deg%d" % d] = round(1e3 * (time.perf_counter() - t0) / iters, 4)
+        out["deg%d_redone" % d] = tr.redone
+        if getattr(model, "_features_dc0", None) is not None:
+            model.end_dense_dc()
+        del tr, loss, pkg
+    del snap, colour, trans, cams, model, bg
+    torch.cuda.empty_cache()
+    return out
+
+
 def run_c5(args):
     """`bench.py --config c5`: the C5 training loop as the headline of its own JSON line (ms per iteration): the reference's first
     1000 iterations with their schedule (c5_leg(as_reference=True)); `--c5-fixed` times the fixed-topology SH-3 leg instead."""
@@ -1169,6 +1213,8 @@ def main():
                                if k in ("ms_per_iter", "ms_per_iter_before_first_densify", "densify_iterations_ms", "rows_after_densify", "loss_first", "loss_last",
                                         "iterations_redone", "visible", "peak_memory_gb")}
         out["c5_fixed"] = c5_leg(max(1, args.c5_iters), 10, policy=args.policy, work_hint=not args.no_work_hint, dev=dev)
+        # the loop at each SH degree of the reference's ramp (27 000 of its 30 000 iterations run at degree 3), 200 iterations each from equal state
+        out["c5_phases"] = c5_phases(max(1, args.c5_iters), 20, dev=dev)
     else:
         host_keep = mesh_keep = None
 

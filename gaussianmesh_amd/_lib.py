@@ -43,6 +43,8 @@ SIGNATURES = {
                           vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "gm_backward_p": (i32, [i32, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp,
                             vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "gm_backward_sh_step": (i32, [i32, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, f32, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                  vp, i32, vp, vp, f32, f32, f64, f64, f64, i32, i32, vp]),
     "gm_mark_visible": (i32, [i32, vp, vp, vp, vp, vp]),
     "gm_geom_field": (vp, [vp, i32, C.c_char_p]),
     "gm_splat_floats": (i32, []),

@@ -375,13 +375,13 @@ int gm_forward_1(void* geom_buffer, void* binning_buffer, void* image_buffer, in
                            debug, stream, nullptr, 0, nullptr);
 }
 
-int gm_backward_p(int emission_policy, int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
-                  const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
-                  const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
-                  const float* campos, float tan_fovx, float tan_fovy, const int* radii, void* geom_buffer,
-                  void* binning_buffer, void* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
-                  float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
-                  float* dL_dscale, float* dL_drot, int debug, void* stream) {
+static int backward_impl(int emission_policy, int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                         const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                         const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                         const float* campos, float tan_fovx, float tan_fovy, const int* radii, void* geom_buffer,
+                         void* binning_buffer, void* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
+                         float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                         float* dL_dscale, float* dL_drot, int debug, void* stream, const ShAdamArgs* sh_adam) {
   if (int rc = check_policy(emission_policy)) return rc;
   const float* opacities = reinterpret_cast<const float*>(1);   // not used by backward; satisfies the shared check
   const float* cam_pos = campos;
@@ -392,7 +392,7 @@ int gm_backward_p(int emission_policy, int P, int D, int M, int R, const float* 
   // intermediates a caller may decline: dL/dconic always, dL/dcolour when the colours come from SH rows, dL/dcov3D when the covariances
   // come from scale / rotation
   if (!geom_buffer || !image_buffer || !dL_dpix || !dL_dmean2D || !dL_dopacity || (!shs && !dL_dcolor) ||
-      !dL_dmean3D || (!scales && !dL_dcov3D) || (shs && !dL_dsh) || (scales && (!dL_dscale || !dL_drot))) {
+      !dL_dmean3D || (!scales && !dL_dcov3D) || (shs && !dL_dsh && !sh_adam) || (scales && (!dL_dscale || !dL_drot))) {
     set_error("gm_backward: null buffer"); return GM_ERR_INVALID_ARG;
   }
   GeomState g = GeomState::from(geom_buffer, (size_t)P);
@@ -405,7 +405,37 @@ int gm_backward_p(int emission_policy, int P, int D, int M, int R, const float* 
     if (int rc = launch_render_bwd(g, b.pairs[slot], img, width, height, a.tile_cull, background, dL_dpix, debug, a.stream)) return rc;
   }
   return launch_preprocess_bwd(a, g, radii, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
-                               dL_dscale, dL_drot);
+                               dL_dscale, dL_drot, sh_adam);
+}
+
+int gm_backward_p(int emission_policy, int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                  const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                  const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                  const float* campos, float tan_fovx, float tan_fovy, const int* radii, void* geom_buffer,
+                  void* binning_buffer, void* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
+                  float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                  float* dL_dscale, float* dL_drot, int debug, void* stream) {
+  return backward_impl(emission_policy, P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
+                       viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_dmean2D, dL_dconic,
+                       dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, stream, nullptr);
+}
+
+int gm_backward_sh_step(int emission_policy, int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                        float* shs, const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                        const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                        void* geom_buffer, void* binning_buffer, void* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dopacity,
+                        float* dL_dmean3D, float* dL_dcov3D, float* dL_dscale, float* dL_drot, int rows, float* exp_avg, float* exp_avg_sq,
+                        float lr_dc, float lr_rest, double beta1, double beta2, double eps, int step, int debug, void* stream) {
+  if (!shs || M != 16 || D < 0 || D > 3) { set_error("gm_backward_sh_step: needs the [P,16,3] SH operand"); return GM_ERR_INVALID_ARG; }
+  if (rows < 0 || rows > P || !exp_avg || !exp_avg_sq || step < 1) { set_error("gm_backward_sh_step: bad optimizer state (rows %d of %d, step %d)", rows, P, step); return GM_ERR_INVALID_ARG; }
+  ShAdamArgs ad;
+  ad.p = shs; ad.m = exp_avg; ad.v = exp_avg_sq; ad.rows = rows;
+  ad.b1 = (float)beta1; ad.b2 = (float)beta2; ad.c1 = (float)(1.0 - beta1); ad.c2 = (float)(1.0 - beta2); ad.eps = (float)eps;
+  const double corr = sqrt(1.0 - pow(beta2, (double)step)) / (1.0 - pow(beta1, (double)step));      // as gm_adam_step_active
+  ad.step_lo = (float)(lr_dc * corr); ad.step_hi = (float)(lr_rest * corr);
+  return backward_impl(emission_policy, P, D, M, R, background, width, height, means3D, shs, nullptr, scales, scale_modifier, rotations, cov3D_precomp,
+                       viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_dmean2D, nullptr,
+                       dL_dopacity, nullptr, dL_dmean3D, dL_dcov3D, nullptr, dL_dscale, dL_drot, debug, stream, &ad);
 }
 
 int gm_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,

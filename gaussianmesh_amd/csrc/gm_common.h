@@ -352,7 +352,7 @@ int launch_preprocess(const RasterArgs& a, GeomState& g, int* radii);
 int launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 int launch_preprocess_bwd(const RasterArgs& a, GeomState& g, const int* radii, float* dL_dmean2D, float* dL_dconic,
                           float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
-                          float* dL_dscale, float* dL_drot);   // reads g.grad_acc, writes every gradient output
+                          float* dL_dscale, float* dL_drot, const struct ShAdamArgs* sh_adam = nullptr);   // reads g.grad_acc, writes every gradient output
 
 // stable LSD radix sort of (u32 key, u32 value) pairs on key bits [0, bits), 8 bits per pass, ping-pong
 // between slot 0 and slot 1.  n_dev (optional) = device pointer to the element count; n_max = host upper bound
@@ -428,6 +428,19 @@ struct AdamTensor {
   unsigned active;             // 0: every element; else only elements with (index % period) < active (rounded up to a 16-byte granule) are touched
 };
 struct AdamTable { AdamTensor t[8]; int count; float b1, b2, eps, omb1, omb2; };   // omb = (float)(1 - beta), formed in double
+// jittor.nn.Adam's rule for one element (jittor/optim.py Adam.step), spelled with explicit fused multiply-adds so that adam_kernel
+// (gm_train.hip, contraction allowed) and the SH step fused into the preprocess backward (gm_preprocess.hip, contraction off) round alike
+__device__ __forceinline__ void adam_update(float& p, float& m, float& v, float g, float b1, float b2, float c1, float c2, float eps, float st) {
+  m = __builtin_fmaf(b1, m, c1 * g);
+  v = __builtin_fmaf(b2, v, c2 * g * g);
+  p -= st * m / (sqrtf(v) + eps);
+}
+// Adam step of the SH rows applied INSIDE the preprocess backward (gm_backward_sh_step): the row's gradient never travels through HBM
+struct ShAdamArgs {
+  float *p, *m, *v;              // the [rows,16,3] parameter (the `shs` operand's leading rows), exp_avg, exp_avg_sq
+  int rows;                      // trainable rows (the operand may continue with frozen rows behind them)
+  float b1, b2, c1, c2, eps, step_lo, step_hi;   // step_lo: coefficient 0 (the reference's "f_dc" group), step_hi: the others ("f_rest")
+};
 int launch_mesh_activate_fwd(const ActArgs& a, float* xyz, float* scales, float* rots, float* opac, float mr_weight, float* mr_partial,
                              hipStream_t s);
 int launch_mesh_activate_bwd(const ActArgs& a, const float* d_xyz, const float* d_scales, const float* d_rots, const float* d_opac,

@@ -217,6 +217,8 @@ struct PreBwdArgs {
   const float* grad_acc;                                   // [P][12] packed accumulators written by render_bwd_kernel
   float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor;  // API outputs unpacked from grad_acc
   float *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
+  ShAdamArgs adam;                                         // adam.m != null: the SH rows' Adam step happens here (gm_backward_sh_step), dL_dsh is not written
+  const uint32_t* counters;                                //   (GM_CNT_REFUSED: a refused forward's backward must not step)
   int cov2d_f32;                                           // verification aid (gm_debug_backward_cov2d_float32): conic -> cov2D in float32, as backward.cu:196-215 states it
 };
 
@@ -260,7 +262,30 @@ __global__ __launch_bounds__(TH) void preprocess_bwd_kernel(const PreBwdArgs a) 
   if (idx < a.P) preprocess_bwd_body<STAGE_SH>(a, idx, lrow);
   if (STAGE_SH) {
     __syncthreads();
-    if (DMA) {
+    if (DMA && a.adam.m) {
+      // Adam step of the block's SH rows, fused (gm_backward_sh_step): the gradient rows sit in LDS as the linear image of the block;
+      // granule i of that image <-> granule i of the parameter / moment rows, so the loop is the coalesced copy-out below with the
+      // update in between.  The parameter granule is read again from global memory (the row was fetched by this block's DMA a few
+      // microseconds ago: an L2 hit), m and v come from HBM, all three go back: 192 B of dL/dSH written and read and 192 B of parameter
+      // read per Gaussian less than the backward + adam_kernel pair.  Rows behind adam.rows (a frozen cloud sharing the operand) and
+      // the backward of a REFUSED forward (zero gradients: the iteration is repeated) are left alone.
+      const long long lim = ((long long)a.adam.rows - (long long)row0) * 12;
+      if (a.counters[GM_CNT_REFUSED] == 0u) {
+        float4* gp = reinterpret_cast<float4*>(a.adam.p) + row0 * 12;
+        float4* gm_ = reinterpret_cast<float4*>(a.adam.m) + row0 * 12;
+        float4* gv = reinterpret_cast<float4*>(a.adam.v) + row0 * 12;
+        for (int i = threadIdx.x; i < nrows * 12 && (long long)i < lim; i += TH) {
+          const float4 g4 = l4[i];
+          float4 p4 = gp[i], m4 = gm_[i], v4 = gv[i];
+          const int c = i % 12;                                    // granule of its row: elements 4 c .. 4 c + 3 of the 48
+          float* pp = &p4.x; float* mm = &m4.x; float* vv = &v4.x; const float* gg = &g4.x;
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            adam_update(pp[j], mm[j], vv[j], gg[j], a.adam.b1, a.adam.b2, a.adam.c1, a.adam.c2, a.adam.eps, (4 * c + j >= 3) ? a.adam.step_hi : a.adam.step_lo);
+          gp[i] = p4; gm_[i] = m4; gv[i] = v4;
+        }
+      }
+    } else if (DMA) {
       float4* dst = reinterpret_cast<float4*>(a.dL_dsh) + row0 * 12;
       for (int i = threadIdx.x; i < nrows * 12; i += TH) dst[i] = l4[i];
     } else {
@@ -539,7 +564,7 @@ extern "C" void gm_debug_backward_cov2d_float32(int on) { g_bwd_cov2d_f32 = on !
 
 int launch_preprocess_bwd(const RasterArgs& r, GeomState& g, const int* radii, float* dL_dmean2D, float* dL_dconic,
                           float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
-                          float* dL_dscale, float* dL_drot) {
+                          float* dL_dscale, float* dL_drot, const ShAdamArgs* sh_adam) {
   StageScope sc(ST_PREPROCESS_BWD, r.stream);
   PreBwdArgs a;
   a.P = r.P; a.D = r.D; a.M = r.M; a.W = r.W; a.H = r.H;
@@ -551,10 +576,18 @@ int launch_preprocess_bwd(const RasterArgs& r, GeomState& g, const int* radii, f
   a.fy = r.H / (2.0f * r.tan_fovy); a.fx = r.W / (2.0f * r.tan_fovx);
   a.grad_acc = g.grad_acc;
   a.cov2d_f32 = g_bwd_cov2d_f32 ? 1 : 0;
+  a.adam = ShAdamArgs{};
+  a.counters = g.counters;
+  if (sh_adam) {
+    if (!(a.shs && a.M == 16 && aligned16(a.shs) && aligned16(sh_adam->m) && aligned16(sh_adam->v)) || sh_adam->p != a.shs) {
+      set_error("gm_backward_sh_step: needs the [P,16,3] shs operand itself as the parameter, 16-byte aligned rows and moments"); return 1;
+    }
+    a.adam = *sh_adam;
+  }
   a.dL_dmean2D = dL_dmean2D; a.dL_dconic = dL_dconic; a.dL_dopacity = dL_dopacity; a.dL_dcolor = dL_dcolor;
   a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot;
   if (r.P > 0) {
-    if (a.shs && a.M == 16 && aligned16(a.shs) && aligned16(a.dL_dsh)) {
+    if (a.shs && a.M == 16 && aligned16(a.shs) && (sh_adam || aligned16(a.dL_dsh))) {
       hipLaunchKernelGGL((preprocess_bwd_kernel<true, 64, true>), dim3((r.P + 63) / 64), dim3(64), sizeof(float4) * 64 * 12, r.stream, a);
     }
     else

@@ -155,9 +155,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable tab) {
 #pragma unroll
       for (int c = 0; c < 4; c++) {
         const float st = (4u * k + c >= t.split) ? t.step_hi : t.step_lo;
-        mm[c] = b1 * mm[c] + c1 * gg[c];
-        vv[c] = b2 * vv[c] + c2 * gg[c] * gg[c];
-        pp[c] -= st * mm[c] / (sqrtf(vv[c]) + eps);
+        adam_update(pp[c], mm[c], vv[c], gg[c], b1, b2, c1, c2, eps, st);
       }
       reinterpret_cast<float4*>(t.p)[q] = p; reinterpret_cast<float4*>(t.m)[q] = m; reinterpret_cast<float4*>(t.v)[q] = v;
     }
@@ -171,9 +169,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable tab) {
 #pragma unroll
     for (int c = 0; c < 4; c++) {
       const float st = (t.period && in_period + c >= t.split) ? t.step_hi : t.step_lo;
-      mm[c] = b1 * mm[c] + c1 * gg[c];
-      vv[c] = b2 * vv[c] + c2 * gg[c] * gg[c];
-      pp[c] -= st * mm[c] / (sqrtf(vv[c]) + eps);
+      adam_update(pp[c], mm[c], vv[c], gg[c], b1, b2, c1, c2, eps, st);
     }
     reinterpret_cast<float4*>(t.p)[q] = p; reinterpret_cast<float4*>(t.m)[q] = m; reinterpret_cast<float4*>(t.v)[q] = v;
   }
@@ -182,9 +178,9 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable tab) {
     const unsigned long long e = (n4 << 2) + threadIdx.x;
     const float st = (t.period && (unsigned)(e % t.period) >= t.split) ? t.step_hi : t.step_lo;
     const float g = t.g[e];
-    const float m = b1 * t.m[e] + c1 * g, v = b2 * t.v[e] + c2 * g * g;
-    t.m[e] = m; t.v[e] = v;
-    t.p[e] -= st * m / (sqrtf(v) + eps);
+    float m = t.m[e], v = t.v[e], pe = t.p[e];
+    adam_update(pe, m, v, g, b1, b2, c1, c2, eps, st);
+    t.m[e] = m; t.v[e] = v; t.p[e] = pe;
   }
 }
 

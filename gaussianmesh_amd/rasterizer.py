@@ -647,12 +647,14 @@ def forward_deformed_batch(bg, tri, weights, packed_list, cov, pos, shs, opacity
 
 def rasterize_backward(bg, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
                        tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos, geom, num_rendered, binning, img, debug,
-                       emission_policy=None, skip_intermediates=False, want_conic=False):
+                       emission_policy=None, skip_intermediates=False, want_conic=False, sh_step=None):
     """RasterizeGaussiansBackwardCUDA of the reference bridge (rasterize_points.py:276-401): returns
     (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations).
     emission_policy: the policy the forward that filled geom / binning / img ran under.
     skip_intermediates (the autograd operator): dL_dcolors when the colours come from SH rows and dL_dcov3D when the covariances come
     from scale / rotation are not computed into memory (returned as None), nor is the internal dL/dconic.
+    sh_step (an ShStep, see below): the Adam step of the SH rows happens inside the backward (gm_backward_sh_step); dL_dsh, dL_dcolors and
+    dL_dcov3D (with scales) come back as None.
     want_conic (tests): a ninth return value, dL_dconic [P,2,2] (slots [0,0], [0,1], [1,1] used: the blend stage's output that the
     reference keeps internal, rasterize_points.py:305)."""
     lib = _lib.lib()
@@ -669,6 +671,23 @@ def rasterize_backward(bg, means3D, radii, colors, scales, rotations, scale_modi
     dpix = _prep(dL_dout_color, device)
     H, W = dpix.shape[1], dpix.shape[2]
     M = sh.shape[1] if sh is not None else 0
+    if sh_step is not None:
+        if sh is None or M != 16 or colors is not None or sh.data_ptr() != sh_step.param.data_ptr():
+            raise _lib.GmeshError("rasterize_backward(sh_step=...): the step's parameter must be the [P,16,3] shs operand of this pass")
+        with _on(device):
+            dmeans2D = torch.empty((P, 3), **f); dopac = torch.empty((P, 1), **f); dmeans3D = torch.empty((P, 3), **f)
+            dcov3D = None if scales is not None else torch.empty((P, 6), **f)
+            dscales = torch.empty((P, 3), **f) if scales is not None else None
+            drots = torch.empty((P, 4), **f) if scales is not None else None
+            _lib.check(lib.gm_backward_sh_step(_pol(emission_policy, W, H), P, int(degree), M, int(num_rendered), _ptr(bg), W, H, _ptr(means3D), _ptr(sh),
+                                               _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix),
+                                               _ptr(campos), float(tan_fovx), float(tan_fovy), _ptr(radii), _ptr(geom), _ptr(binning), _ptr(img), _ptr(dpix),
+                                               _ptr(dmeans2D), _ptr(dopac), _ptr(dmeans3D), _ptr(dcov3D), _ptr(dscales), _ptr(drots), int(sh_step.rows),
+                                               sh_step.exp_avg.data_ptr(), sh_step.exp_avg_sq.data_ptr(), float(sh_step.lr_dc), float(sh_step.lr_rest),
+                                               float(sh_step.betas[0]), float(sh_step.betas[1]), float(sh_step.eps), int(sh_step.step), int(bool(debug)),
+                                               _stream(device)))
+        sh_step.applied = True
+        return dmeans2D, None, dopac, dmeans3D, dcov3D, None, dscales, drots
     with _on(device):
         skip = bool(skip_intermediates)
         dmeans2D = torch.empty((P, 3), **f); dopac = torch.empty((P, 1), **f); dmeans3D = torch.empty((P, 3), **f)
@@ -687,6 +706,46 @@ def rasterize_backward(bg, means3D, radii, colors, scales, rotations, scale_modi
     if want_conic:
         return dmeans2D, dcolors, dopac, dmeans3D, dcov3D, dsh, dscales, drots, dconic
     return dmeans2D, dcolors, dopac, dmeans3D, dcov3D, dsh, dscales, drots
+
+
+class ShStep:
+    """The Adam step of the SH rows, to be applied INSIDE the next backward pass of the rasterizer whose `shs` operand is `param`'s storage
+    (gm_backward_sh_step): `param` [rows,16,3] (a leaf; the operand may continue with frozen rows behind it), exp_avg / exp_avg_sq
+    [rows,16,3], lr_dc for coefficient 0 and lr_rest for the others (the reference's "f_dc" / "f_rest" groups), `step` = the step being
+    taken (bias correction).  Make it current for the calling thread around backward():
+
+        with ShStep(...) as ss:
+            loss.backward()
+        ss.applied      # True: the operator took the fused route (the leaf's .grad stays None: nothing left for the optimizer to do)
+
+    One step per ShStep object: a second backward inside the block takes the ordinary route.  The backward of a refused sync-free forward
+    leaves parameter and moments untouched on the device (applied is True all the same: the caller repeats the iteration with a new one)."""
+
+    def __init__(self, param, exp_avg, exp_avg_sq, lr_dc, lr_rest, betas, eps, step):
+        if param.dim() != 3 or param.shape[1] != 16 or param.shape[2] != 3 or tuple(exp_avg.shape) != tuple(param.shape) or tuple(exp_avg_sq.shape) != tuple(param.shape):
+            raise ValueError("ShStep: parameter and moments must be [rows,16,3]")
+        for t in (param, exp_avg, exp_avg_sq):
+            if not t.is_contiguous() or t.dtype != torch.float32:
+                raise ValueError("ShStep: contiguous float32 tensors expected")
+        self.param, self.exp_avg, self.exp_avg_sq, self.rows = param, exp_avg, exp_avg_sq, int(param.shape[0])
+        self.lr_dc, self.lr_rest, self.betas, self.eps, self.step = float(lr_dc), float(lr_rest), betas, float(eps), int(step)
+        self.applied = False
+
+    def __enter__(self):
+        stack = getattr(_sync_free_tls, "sh_steps", None)
+        if stack is None:
+            stack = _sync_free_tls.sh_steps = []
+        stack.append(self)
+        return self
+
+    def __exit__(self, *exc):
+        _sync_free_tls.sh_steps.pop()
+        return False
+
+
+def current_sh_step():
+    stack = getattr(_sync_free_tls, "sh_steps", None)
+    return stack[-1] if stack else None
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):
@@ -854,11 +913,15 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, grad_out_color, _grad_radii):
         rs = ctx.raster_settings
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
+        ss = current_sh_step()
+        if ss is not None and (ss.applied or sh is None or sh.numel() == 0 or sh.dim() != 3 or sh.shape[1] != 16 or sh.data_ptr() != ss.param.data_ptr()
+                               or (colors_precomp is not None and colors_precomp.numel() > 0)):
+            ss = None                            # not this operand's step (or already taken): the ordinary route
         try:
             g2d, gcol, gop, g3d, gcov, gsh, gsc, grot = rasterize_backward(
                 rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
                 rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos, geom, ctx.num_rendered,
-                binning, img, rs.debug, ctx.emission_policy, skip_intermediates=True)
+                binning, img, rs.debug, ctx.emission_policy, skip_intermediates=True, sh_step=ss)
         except Exception:
             if rs.debug:       # diff_gaussian_rasterizater/__init__.py:102-108
                 _snapshot("snapshot_bw.dump", dict(bg=rs.bg, means3D=means3D, radii=radii, colors_precomp=colors_precomp, scales=scales,
@@ -869,7 +932,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
             raise
         has = lambda t: t is not None and t.numel() > 0
-        return (g3d, g2d, gsh if has(sh) else None, gcol if has(colors_precomp) else None, gop.reshape(ctx.opacity_shape),
+        return (g3d, g2d, gsh if (has(sh) and gsh is not None) else None, gcol if has(colors_precomp) else None, gop.reshape(ctx.opacity_shape),
                 gsc if has(scales) else None, grot if has(rotations) else None, gcov if has(cov3Ds_precomp) else None,
                 None, None)
 

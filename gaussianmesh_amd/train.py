@@ -71,10 +71,14 @@ class Trainer:
     forwards live in `self.sync_state` (a rasterizer.SyncFreeState owned by THIS trainer and current only inside its step()).
     bg_gaussian: a FrozenGaussians cloud composited behind the trainable one."""
 
-    def __init__(self, gaussians, spatial_lr_scale=1.0, densify_stats=False, sync_free=False, bg_gaussian=None, dense_dc=None, **opt):
+    def __init__(self, gaussians, spatial_lr_scale=1.0, densify_stats=False, sync_free=False, bg_gaussian=None, dense_dc=None, fused_sh_step=True, **opt):
         """dense_dc (default: on for a model on the GPU at SH degree 0): while only degree 0 is active, train coefficient 0 as a dense
         [N,1,3] tensor (MeshBoundGaussians.begin_dense_dc) instead of as 12 bytes of every 192-byte row; oneup_sh_degree() folds it -
-        and both Adam moments - back into the rows when the degree is raised."""
+        and both Adam moments - back into the rows when the degree is raised.
+        fused_sh_step (default on): at the model's FULL SH degree (27 000 of the reference's 30 000 iterations, train_mesh_gaussian.py:70-71) the
+        Adam step of the [N,16,3] rows - 48 of a Gaussian's 59 parameters - is applied inside the rasterizer's backward pass (rasterizer.ShStep,
+        gm_backward_sh_step) instead of by FusedAdam afterwards: the 192-byte gradient rows are never written or read.  Same update, element for
+        element; iterations that take no optimizer step, keep_grads and the python SH route use the ordinary path."""
         o = dict(DEFAULT_OPT); o.update(opt)
         self.opt = SimpleNamespace(**o)
         self.g = gaussians
@@ -116,6 +120,8 @@ class Trainer:
         self.sync_free = bool(sync_free)
         from .rasterizer import SyncFreeState
         self.sync_state = SyncFreeState(enabled=self.sync_free)
+        self.fused_sh_step = bool(fused_sh_step)
+        self.sh_steps_fused = 0                  # iterations whose SH step was taken inside the backward pass
         self.keep_grads = False
         self.last_grads = None
         self.adam_active_only = True             # FusedAdam touches only the SH coefficients of the degrees switched on so far (False: all)
@@ -288,7 +294,25 @@ class Trainer:
                 gr["lr"] = lr
         return lr
 
-    def _forward_backward(self, camera, gt_image, background):
+    def _sh_step(self):
+        """The SH group's step for rasterizer.ShStep, or None when this iteration's SH step is FusedAdam's: below the full degree (the dense
+        leaf / the active-coefficient step move fewer bytes there), on the CPU, without an [N,16,3] leaf."""
+        g = self.g
+        if not self.fused_sh_step or self.keep_grads or getattr(g, "_features_dc0", None) is not None:
+            return None
+        if int(getattr(g, "active_sh_degree", 0)) < int(getattr(g, "max_sh_degree", 3)) or getattr(self.pipe, "convert_SHs_python", False):
+            return None
+        grp = next((gr for gr in self.optimizer.param_groups if gr["name"] == "f_dc+f_rest"), None)
+        if grp is None:
+            return None
+        p = grp["params"][0]
+        if not p.is_cuda or p.dim() != 3 or p.shape[1] != 16 or not p.requires_grad:
+            return None
+        from .rasterizer import ShStep
+        return ShStep(p.detach(), grp["m"][0], grp["values"][0], grp["lr"], grp.get("lr_rest", grp["lr"]), self.optimizer.betas, self.optimizer.eps,
+                      self.optimizer.n_step + 1)
+
+    def _forward_backward(self, camera, gt_image, background, sh_step=False):
         g = self.g
         if g.screenspace_points.grad is not None:
             g.screenspace_points.grad = None
@@ -298,7 +322,13 @@ class Trainer:
             mr = pkg.get("mesh_restrict_loss")
             loss = loss + (mr if mr is not None else
                            mesh_restrict_loss(pkg["scale"], pkg["vertex1"], pkg["vertex2"], pkg["vertex3"], weight=self.opt.alpha_mrloss))
-        loss.backward()
+        ss = self._sh_step() if sh_step else None
+        if ss is None:
+            loss.backward()
+        else:
+            with ss:
+                loss.backward()
+        self._sh_fused = ss is not None and ss.applied
         return loss, pkg
 
     def schedule(self, iteration, white_background=False):
@@ -369,8 +399,9 @@ class Trainer:
         self.update_learning_rate()
         st = self.sync_state
         st.enabled = self.sync_free
+        will_step = optimizer_step and densify is None            # (an SH step taken inside the backward cannot be taken back)
         with st:
-            loss, pkg = self._forward_backward(camera, gt_image, background)
+            loss, pkg = self._forward_backward(camera, gt_image, background, will_step)
             attempts = 0
             while self.sync_free and not st.verify():
                 # the image was the background and the render gradients zero: the same iteration again, with the buffer
@@ -380,7 +411,7 @@ class Trainer:
                 if attempts >= 2:
                     st.enabled = False
                 self.optimizer.zero_grad(set_to_none=True)
-                loss, pkg = self._forward_backward(camera, gt_image, background)
+                loss, pkg = self._forward_backward(camera, gt_image, background, will_step)     # (the refused attempt's backward stepped nothing: device-side check)
                 if attempts >= 2:
                     break
         if self.densify_stats and stats:
@@ -400,6 +431,7 @@ class Trainer:
                 if gr.get("period") == 48:
                     gr["active"] = 3 * (self._sh_degree_seen + 1) ** 2 if (self.adam_active_only and self._sh_degree_seen < 3) else 0
             self.optimizer.step()
+            self.sh_steps_fused += 1 if getattr(self, "_sh_fused", False) else 0
         self.optimizer.zero_grad(set_to_none=True)
         return loss.detach(), pkg
 

@@ -130,6 +130,24 @@ int gm_backward_p(int emission_policy, int P, int D, int M, int R, const float* 
                   float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
                   float* dL_dscale, float* dL_drot, int debug, void* stream);
 
+/* gm_backward_p for a TRAINING step whose SH rows are the optimizer's parameter (scene/mesh_based_gaussian_model.py:242-263: the "f_dc" and
+ * "f_rest" groups of training_setup; jittor.nn.Adam): the Adam step of those rows is applied inside the backward pass instead of by
+ * gm_adam_step afterwards.  dL/dSH of a Gaussian is produced whole by the thread that owns it (RAST/backward.cu:20-139), so the 192-byte
+ * gradient row never has to travel: per trainable Gaussian 192 B of dL/dSH written + read and 192 B of parameter read disappear (at SH
+ * degree 3, where 27 000 of the reference's 30 000 iterations run, the SH group is 48 of a Gaussian's 59 parameters).
+ *   shs [P,16,3]: updated IN PLACE for rows [0, rows) (rows behind them - a frozen cloud sharing the operand - are read only);
+ *   exp_avg / exp_avg_sq [rows,16,3]: Adam's moments; lr_dc steps coefficient 0, lr_rest the others; step >= 1 = the step being taken;
+ *   the update is m = b1 m + (1 - b1) g; v = b2 v + (1 - b2) g^2; p -= lr sqrt(1 - b2^t) / (1 - b1^t) m / (sqrt(v) + eps), element for
+ *   element what gm_adam_step computes from the same gradient (culled Gaussians: g = 0, their moments decay and p moves, as in the reference).
+ * dL/dSH, dL/dcolour and dL/dconic are not produced.  The backward of a REFUSED forward (sync-free capacity overflow: zero gradients, the
+ * caller repeats the iteration) leaves parameter and moments untouched.  colors_precomp input is not supported (nothing to step). */
+int gm_backward_sh_step(int emission_policy, int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                        float* shs, const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                        const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                        void* geom_buffer, void* binning_buffer, void* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dopacity,
+                        float* dL_dmean3D, float* dL_dcov3D, float* dL_dscale, float* dL_drot, int rows, float* exp_avg, float* exp_avg_sq,
+                        float lr_dc, float lr_rest, double beta1, double beta2, double eps, int step, int debug, void* stream);
+
 /* Replaces CudaRasterizer::Rasterizer::markVisible (RAST/rasterizer.h:24-29, rasterizer_impl.cu:141-153).
  * present: uint8 [P], 1 if view-space z > 0.2. */
 int gm_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
