@@ -712,10 +712,11 @@ class ShStep:
     """The Adam step of the SH rows, to be applied INSIDE the next backward pass of the rasterizer whose `shs` operand is `param`'s storage
     (gm_backward_sh_step): `param` [rows,16,3] (a leaf; the operand may continue with frozen rows behind it), exp_avg / exp_avg_sq
     [rows,16,3], lr_dc for coefficient 0 and lr_rest for the others (the reference's "f_dc" / "f_rest" groups), `step` = the step being
-    taken (bias correction).  Make it current for the calling thread around backward():
+    taken (bias correction).  Make it current for the calling thread around the FORWARD and the backward (the operator's forward picks it up:
+    backward() runs on the autograd engine's thread):
 
         with ShStep(...) as ss:
-            loss.backward()
+            loss = f(render(...)); loss.backward()
         ss.applied      # True: the operator took the fused route (the leaf's .grad stays None: nothing left for the optimizer to do)
 
     One step per ShStep object: a second backward inside the block takes the ordinary route.  The backward of a refused sync-free forward
@@ -901,6 +902,13 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                    campos=rs.campos, prefiltered=rs.prefiltered))
                 print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
             raise
+        # an ShStep current for the calling thread whose parameter is this pass's shs operand rides on the context: backward() runs on the
+        # autograd engine's own thread, where the caller's thread-local state is not visible
+        ss = current_sh_step() if needs_grad else None
+        if ss is not None and (sh is None or sh.numel() == 0 or sh.dim() != 3 or sh.shape[1] != 16 or sh.data_ptr() != ss.param.data_ptr()
+                               or (colors_precomp is not None and colors_precomp.numel() > 0)):
+            ss = None
+        ctx.sh_step = ss
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.emission_policy = policy
@@ -913,10 +921,9 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, grad_out_color, _grad_radii):
         rs = ctx.raster_settings
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
-        ss = current_sh_step()
-        if ss is not None and (ss.applied or sh is None or sh.numel() == 0 or sh.dim() != 3 or sh.shape[1] != 16 or sh.data_ptr() != ss.param.data_ptr()
-                               or (colors_precomp is not None and colors_precomp.numel() > 0)):
-            ss = None                            # not this operand's step (or already taken): the ordinary route
+        ss = ctx.sh_step
+        if ss is not None and ss.applied:
+            ss = None                            # one step per ShStep: a second backward takes the ordinary route
         try:
             g2d, gcol, gop, g3d, gcov, gsh, gsc, grot = rasterize_backward(
                 rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,

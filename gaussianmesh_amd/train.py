@@ -316,18 +316,16 @@ class Trainer:
         g = self.g
         if g.screenspace_points.grad is not None:
             g.screenspace_points.grad = None
-        pkg = render(camera, g, self.pipe, background, bg_gaussian=self.bg_gaussian)
-        loss = photometric_loss(pkg["render"], gt_image, self.opt.lambda_dssim)
-        if self.opt.alpha_mrloss:
-            mr = pkg.get("mesh_restrict_loss")
-            loss = loss + (mr if mr is not None else
-                           mesh_restrict_loss(pkg["scale"], pkg["vertex1"], pkg["vertex2"], pkg["vertex3"], weight=self.opt.alpha_mrloss))
         ss = self._sh_step() if sh_step else None
-        if ss is None:
+        import contextlib
+        with (ss if ss is not None else contextlib.nullcontext()):
+            pkg = render(camera, g, self.pipe, background, bg_gaussian=self.bg_gaussian)
+            loss = photometric_loss(pkg["render"], gt_image, self.opt.lambda_dssim)
+            if self.opt.alpha_mrloss:
+                mr = pkg.get("mesh_restrict_loss")
+                loss = loss + (mr if mr is not None else
+                               mesh_restrict_loss(pkg["scale"], pkg["vertex1"], pkg["vertex2"], pkg["vertex3"], weight=self.opt.alpha_mrloss))
             loss.backward()
-        else:
-            with ss:
-                loss.backward()
         self._sh_fused = ss is not None and ss.applied
         return loss, pkg
 
