@@ -102,11 +102,12 @@ class _SharedRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, head, whole):
         ctx.n = head.shape[0]
-        return whole.view_as(whole)
+        ctx.set_materialize_grads(False)         # no gradient for the buffer (the SH step was taken inside the rasterizer's backward,
+        return whole.view_as(whole)              # rasterizer.ShStep) must stay NO gradient for the head: zeros would make the optimizer step it
 
     @staticmethod
     def backward(ctx, grad):
-        return grad[:ctx.n], None
+        return (None if grad is None else grad[:ctx.n]), None
 
 
 def sh_operand(pc):
