@@ -179,9 +179,10 @@ int launch_preprocess(const RasterArgs& r, GeomState& g, int* radii) {
     if (a.shs && a.M == 16 && aligned16(a.shs)) {
       hipLaunchKernelGGL((preprocess_fwd_kernel<true, 64, true>), dim3((r.P + 63) / 64), dim3(64), sizeof(float4) * 64 * 12, r.stream, a);
     }
-    else if (a.shs && a.M == 1)
-      // a dense [P,1,3] coefficient-0 tensor (the trainer's degree-0 phase, train.Trainer(dense_dc)): nothing to stage - three floats per
-      // Gaussian, coalesced as they lie - but every per-Gaussian input requested up front, as on the row path
+    else if (a.shs && (a.M == 1 || a.M == 4 || a.M == 12))
+      // a dense [P,1,3] / [P,4,3] / [P,12,3] tensor of the ACTIVE coefficients (the trainer's phases below the full SH degree,
+      // train.Trainer(dense_dc)): nothing to stage - 12 / 48 / 144 contiguous bytes per Gaussian, 16-byte loads - but every
+      // per-Gaussian input requested up front, as on the row path
       hipLaunchKernelGGL((preprocess_fwd_kernel<false, 64, true>), dim3((r.P + 63) / 64), dim3(64), 0, r.stream, a);
     else
       hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3((r.P + 255) / 256), dim3(256), 0, r.stream, a);

@@ -344,27 +344,35 @@ class MeshBoundGaussians(torch.nn.Module):
         return self._bc.shape[0]
 
     def oneupSHdegree(self):
+        owner = getattr(self, "_dense_dc_owner", None)
+        owner = owner() if owner is not None else None
         if self._features_dc0 is not None:       # a Trainer that trains the dense leaf folds it back together with its Adam moments
-            owner = getattr(self, "_dense_dc_owner", None)
-            owner = owner() if owner is not None else None
             if owner is not None:
                 owner.fold_dense_dc()
             else:
                 self.end_dense_dc()
         if self.active_sh_degree < self.max_sh_degree:
             self.active_sh_degree += 1
+        if owner is not None and getattr(owner, "dense_active", False):
+            owner.begin_dense_active()           # ... and trains the (D+1)^2 active coefficients of the NEW degree densely (below the full degree)
 
-    def begin_dense_dc(self):
-        """While the model renders at SH degree 0 (the first 1000 iterations of train_mesh_gaussian.py:70-71) only coefficient 0 of every
+    def begin_dense_dc(self, K=None):
+        """K (default (active_sh_degree + 1)^2; round 6: 1, 4 or 9 - round 5 knew K = 1 only): the leading K coefficients of every row as
+        a dense [N,K,3] leaf; the text below is round 5's for K = 1.
+        While the model renders at SH degree 0 (the first 1000 iterations of train_mesh_gaussian.py:70-71) only coefficient 0 of every
         192-byte SH row is read, differentiated and stepped - 12 bytes in whole memory sectors of four strided arrays (parameter, gradient,
         both Adam moments).  This moves coefficient 0 into a dense [N,1,3] leaf that the rasterizer takes as `shs` with M = 1
         (tools/sh_dc_probe.py, 2 M Gaussians at 4K: preprocess forward 0.163 -> 0.119 ms, backward 0.203 -> 0.086, the Adam step of the SH
         group 0.353 -> 0.026).  Coefficient 0 of `_features` is stale until end_dense_dc() / oneupSHdegree() folds the leaf back;
         get_features / _features_dc always show the current values."""
-        if self.active_sh_degree != 0:
-            raise ValueError("begin_dense_dc: only while active_sh_degree == 0")
+        K = (self.active_sh_degree + 1) ** 2 if K is None else int(K)
+        if K < (self.active_sh_degree + 1) ** 2 or K >= self._features.shape[1]:
+            raise ValueError("begin_dense_dc: K = %d coefficients cannot carry SH degree %d of %d-coefficient rows densely" % (
+                K, self.active_sh_degree, self._features.shape[1]))
+        if self._features_dc0 is not None and self._features_dc0.shape[1] != K:
+            self.end_dense_dc()
         if self._features_dc0 is None:
-            self._set_dense_dc(torch.nn.Parameter(self._features.detach()[:, :1].clone().contiguous(), requires_grad=self._features.requires_grad))
+            self._set_dense_dc(torch.nn.Parameter(self._features.detach()[:, :K].clone().contiguous(), requires_grad=self._features.requires_grad))
         return self._features_dc0
 
     def _set_dense_dc(self, leaf):
@@ -376,7 +384,7 @@ class MeshBoundGaussians(torch.nn.Module):
         """Fold the dense coefficient-0 leaf back into the [N,16,3] rows (in place: shared storage and views stay valid)."""
         if self._features_dc0 is not None:
             with torch.no_grad():
-                self._features[:, :1].copy_(self._features_dc0)
+                self._features[:, :self._features_dc0.shape[1]].copy_(self._features_dc0)
             self._set_dense_dc(None)
         return self._features
 
@@ -388,7 +396,7 @@ class MeshBoundGaussians(torch.nn.Module):
             key = (kwargs.get("prefix", args[1] if len(args) > 1 else "") or "") + "_features"
             if key in sd:
                 rows = sd[key].detach().clone()
-                rows[:, :1].copy_(self._features_dc0.detach())
+                rows[:, :self._features_dc0.shape[1]].copy_(self._features_dc0.detach())
                 sd[key] = rows
         return sd
 
@@ -406,16 +414,16 @@ class MeshBoundGaussians(torch.nn.Module):
 
     @property
     def _features_dc(self):
-        return self._features[:, :1] if self._features_dc0 is None else self._features_dc0
+        return self._features[:, :1] if self._features_dc0 is None else self._features_dc0[:, :1]
 
     @property
     def _features_rest(self):
-        return self._features[:, 1:]
+        return self.get_features[:, 1:] if self._features_dc0 is not None and self._features_dc0.shape[1] > 1 else self._features[:, 1:]
 
     @property
     def get_features(self):
         if self._features_dc0 is not None:       # (the python SH route and external readers; the HIP route takes renderer.sh_operand)
-            return torch.cat((self._features_dc0, self._features[:, 1:].detach()), dim=1)
+            return torch.cat((self._features_dc0, self._features[:, self._features_dc0.shape[1]:].detach()), dim=1)
         return self._features
 
     def activated(self, mr_weight=None, joint=None):

@@ -84,11 +84,16 @@ class Trainer:
         self.g = gaussians
         self.bg_gaussian = bg_gaussian
         from .renderer import sh_operand
+        below_full = int(getattr(gaussians, "active_sh_degree", 3)) < int(getattr(gaussians, "max_sh_degree", 3))
         if dense_dc is None:
-            dense_dc = hasattr(gaussians, "begin_dense_dc") and gaussians._features.is_cuda and int(getattr(gaussians, "active_sh_degree", 3)) == 0
+            dense_dc = hasattr(gaussians, "begin_dense_dc") and gaussians._features.is_cuda and below_full
+        dense_dc = bool(dense_dc) and below_full and hasattr(gaussians, "begin_dense_dc")
+        # round 6: the dense leaf carries the (D+1)^2 ACTIVE coefficients of whatever degree below the full one the model is at (1, 4, 9 of 16),
+        # re-made at every oneupSHdegree() with both Adam moments carried over (begin_dense_active)
+        self.dense_active = dense_dc
         if dense_dc:
             import weakref
-            gaussians.begin_dense_dc()
+            gaussians.begin_dense_dc(self.dense_width(int(gaussians.active_sh_degree)))
             gaussians._dense_dc_owner = weakref.ref(self)        # gaussians.oneupSHdegree() then folds through fold_dense_dc()
         elif getattr(gaussians, "_features_dc0", None) is not None:
             # a model another Trainer left in dense mode, handed to one that trains the rows: fold first - this optimizer would
@@ -166,7 +171,7 @@ class Trainer:
             if n_new:
                 new_rows = dict(new_rows)
                 sh_rows = new_rows["f_dc+f_rest"] if "f_dc+f_rest" in new_rows else torch.cat((new_rows.pop("f_dc"), new_rows.pop("f_rest")), dim=1)
-                new_rows["f_dc+f_rest"] = sh_rows[:, :1].contiguous()
+                new_rows["f_dc+f_rest"] = sh_rows[:, :g._features_dc0.shape[1]].contiguous()
             with torch.no_grad():
                 store = g._features.detach() if idx is None else g._features.detach().index_select(0, idx)
                 if n_new:
@@ -372,6 +377,7 @@ class Trainer:
             return
         grp = next(gr for gr in self.optimizer.param_groups if gr["name"] == "f_dc+f_rest")
         m_dc, v_dc = grp["m"][0], grp["values"][0]
+        K = m_dc.shape[1]
         shared = getattr(g, "_features_with_bg", None)
         g.end_dense_dc()                                         # rows current again (in place)
         if self.bg_gaussian is not None and shared is not None:
@@ -379,9 +385,37 @@ class Trainer:
             share_feature_storage(g, self.bg_gaussian)           # the ROWS share their storage with the background from here on
         with torch.no_grad():
             m = torch.zeros_like(g._features); v = torch.zeros_like(g._features)
-            m[:, :1].copy_(m_dc); v[:, :1].copy_(v_dc)
+            m[:, :K].copy_(m_dc); v[:, :K].copy_(v_dc)
         grp["params"][0], grp["m"][0], grp["values"][0] = g._features, m, v
         grp["period"] = 3 * g._features.shape[1]
+
+    @staticmethod
+    def dense_width(degree):
+        """Coefficients the dense leaf carries at an SH degree below the full one: (D+1)^2 rounded up to whole 16-byte granules of the row
+        (1, 4, 12 for degrees 0, 1, 2: FusedAdam steps whole granules; the three spare coefficients at degree 2 have zero gradient and
+        zero moments, so the step leaves them as they are)."""
+        return {0: 1, 1: 4, 2: 12}[int(degree)]
+
+    def begin_dense_active(self):
+        """After oneupSHdegree() folded the dense leaf into the rows: while the NEW degree is still below the model's full one, the
+        (D+1)^2 active coefficients become the dense leaf again - [N,4,3] at degree 1, [N,9,3] at degree 2 - with both Adam moments of those
+        coefficients carried over from the rows' (the new coefficients' are zero: they have never had a gradient).  The rasterizer takes the
+        leaf as `shs` with M = (D+1)^2; at the full degree the rows themselves are trained (and stepped inside the backward, fused_sh_step)."""
+        g = self.g
+        if getattr(g, "_features_dc0", None) is not None or int(g.active_sh_degree) >= int(g.max_sh_degree) or not g._features.is_cuda:
+            return
+        grp = next(gr for gr in self.optimizer.param_groups if gr["name"] == "f_dc+f_rest")
+        K = self.dense_width(int(g.active_sh_degree))
+        m_rows, v_rows = grp["m"][0], grp["values"][0]
+        leaf = g.begin_dense_dc(K)
+        if self.bg_gaussian is not None:
+            from .renderer import share_feature_storage, sh_operand
+            share_feature_storage(g, self.bg_gaussian)           # the LEAF shares its storage with the background's leading K coefficients
+            leaf = sh_operand(g)
+        grp["params"][0] = leaf
+        grp["m"][0], grp["values"][0] = m_rows[:, :K].contiguous(), v_rows[:, :K].contiguous()
+        grp["period"] = 3 * K if K > 1 else 0
+        grp.pop("active", None)
 
     def oneup_sh_degree(self):
         self.g.oneupSHdegree()
@@ -426,7 +460,7 @@ class Trainer:
             # SH coefficients above the highest degree a gradient was ever taken at have g = m = v = 0: Adam leaves them as they are,
             # FusedAdam does not even read them ("active", gm_adam_step_active) - 45 of a Gaussian's 60 parameters at degree 0
             for gr in self.optimizer.param_groups:
-                if gr.get("period") == 48:
+                if gr.get("period") == 48 and gr["params"][0].shape[1] == 16:
                     gr["active"] = 3 * (self._sh_degree_seen + 1) ** 2 if (self.adam_active_only and self._sh_degree_seen < 3) else 0
             self.optimizer.step()
             self.sh_steps_fused += 1 if getattr(self, "_sh_fused", False) else 0

@@ -306,57 +306,72 @@ def test_adam_on_the_active_sh_coefficients_is_the_full_update_end_to_end():
 
 
 def test_dense_coefficient_zero_training_equals_training_the_rows():
-    """Trainer(dense_dc=True) - at SH degree 0 coefficient 0 is a dense [N,1,3] leaf handed to the rasterizer with M = 1, stepped by an
-    Adam group of its own - against the same trainer on the [N,16,3] rows, from equal state every iteration: identical images, SH
-    gradients and moments to float-atomic order, across a topology change (rows split in both) and across oneupSHdegree(), which folds
-    the leaf and both moments back into the rows; behind the fold the two trainers ARE the same configuration."""
+    """Trainer(dense_dc=True) - below the full SH degree the ACTIVE coefficients are a dense leaf handed to the rasterizer with M = its width
+    ([N,1,3] at degree 0, [N,4,3] at degree 1, [N,12,3] at degree 2: whole 16-byte granules), stepped by an Adam group of its own - against
+    the same trainer on the [N,16,3] rows, from equal state every iteration, over the reference's whole ramp 0 -> 1 -> 2 -> 3
+    (train_mesh_gaussian.py:70-71): identical images, SH gradients and moments to float-atomic order, across two topology changes (rows
+    split in both, at degree 0 and at degree 1) and across every oneupSHdegree(), which folds the leaf and both moments back into the rows
+    and - below the full degree - re-makes it for the new degree with the moments carried over; at degree 3 the two trainers ARE the same
+    configuration."""
     build, bg, cams = _bg_scene(N=3000)
     from gaussianmesh_amd.train import Trainer
     gt = torch.rand((3, 96, 160), device="cuda")
     zero = torch.zeros(3, device="cuda")
     ma, mb = build(), build()
     ma.active_sh_degree = mb.active_sh_degree = 0
-    ta = Trainer(ma, densify_stats=True, sync_free=True, bg_gaussian=bg)                        # dense_dc: on by default at degree 0
+    ta = Trainer(ma, densify_stats=True, sync_free=True, bg_gaussian=bg)                        # dense_dc: on by default below the full degree
     tb = Trainer(mb, densify_stats=True, sync_free=True, bg_gaussian=bg, dense_dc=False)
     assert ma._features_dc0 is not None and ma._features_dc0.shape == (3000, 1, 3) and mb._features_dc0 is None
     ga = next(g for g in ta.optimizer.param_groups if g["name"] == "f_dc+f_rest")
     gb = next(g for g in tb.optimizer.param_groups if g["name"] == "f_dc+f_rest")
     assert ga["params"][0] is ma._features_dc0 and ga["period"] == 0 and gb["period"] == 48
     ta.keep_grads = tb.keep_grads = True
-    rest0 = mb._features.detach()[:, 1:].clone()
+    width = {0: 1, 1: 4, 2: 12, 3: 16}
 
-    def same_state():                                            # b <- a, group by group (the SH group: coefficient 0 and its moments)
+    def same_state():                                            # b <- a, group by group (the SH group: the leaf's coefficients and their moments)
         with torch.no_grad():
             for x, y in zip(ta.optimizer.param_groups, tb.optimizer.param_groups):
                 for k in ("params", "m", "values"):
-                    if x["name"] == "f_dc+f_rest" and x[k][0].shape[1] == 1:
-                        y[k][0][:, :1].copy_(x[k][0])
+                    if x["name"] == "f_dc+f_rest" and x[k][0].shape[1] < 16:
+                        y[k][0][:, :x[k][0].shape[1]].copy_(x[k][0])
                     else:
                         y[k][0].copy_(x[k][0])
                 y["lr"] = x["lr"]
         tb.optimizer.n_step, tb.iteration = ta.optimizer.n_step, ta.iteration
 
-    for i in range(8):
-        if i == 3:                                               # a topology change in both: every tenth row split into five
+    rows = 3000
+    for i in range(14):
+        if i in (2, 6):                                          # a topology change in both (degree 0, degree 1): every tenth row split into five
             sel = torch.zeros(ma._bc.shape[0], dtype=torch.bool, device="cuda"); sel[::10] = True
+            n_sel = int(sel.sum())
             na, nb = ta.densify_and_split(sel, 5), tb.densify_and_split(sel.clone(), 5)
-            assert na == nb == 3000 - 300 + 1500 and ma._features_dc0.shape[0] == na and ma._features.shape[0] == na
-            rest0 = mb._features.detach()[:, 1:].clone()
-        if i == 6:                                               # train_mesh_gaussian.py:70-71
+            rows = rows - n_sel + 5 * n_sel
+            assert na == nb == rows and ma._features_dc0.shape[0] == na and ma._features.shape[0] == na
+        if i in (4, 8, 11):                                      # train_mesh_gaussian.py:70-71
             ma.oneupSHdegree(); mb.oneupSHdegree()
-            assert ma._features_dc0 is None and ga["params"][0] is ma._features and ga["period"] == 48 and ma.active_sh_degree == 1
+        D = ma.active_sh_degree
+        assert D == mb.active_sh_degree == (0 if i < 4 else 1 if i < 8 else 2 if i < 11 else 3)
+        K = width[D]
+        if D < 3:
+            assert ma._features_dc0 is not None and tuple(ma._features_dc0.shape) == (rows, K, 3) and ga["params"][0].data_ptr() == ma._features_dc0.data_ptr()
+            assert ga["period"] == (0 if K == 1 else 3 * K) and tuple(ga["m"][0].shape) == (rows, K, 3)
+        else:
+            assert ma._features_dc0 is None and ga["params"][0] is ma._features and ga["period"] == 48
         same_state()
         assert torch.equal(ma.get_features.detach(), mb.get_features.detach()), i
+        rest0 = mb._features.detach()[:, K:].clone()
         la, pa = ta.step(cams[i % 5], gt, zero); lb, pb = tb.step(cams[i % 5], gt, zero)
         assert torch.equal(pa["render"], pb["render"]) and torch.equal(pa["radii"], pb["radii"]), i
         gra, grb = ta.last_grads["f_dc+f_rest"], tb.last_grads["f_dc+f_rest"]
         nc = gra.shape[1]
+        assert nc == K
         assert float((gra - grb[:, :nc]).abs().max()) <= 2e-5 * float(grb.abs().max()), i           # (float-atomic order of two backward passes)
+        assert float(grb[:, (D + 1) ** 2:].abs().max() if (D + 1) ** 2 < 16 else 0.0) == 0.0          # nothing above the active degree, in either
         for k in ("m", "values"):
             assert float((ga[k][0] - gb[k][0][:, :nc]).abs().max()) <= 2e-5 * float(gb[k][0].abs().max()), (i, k)
-        if i < 6:                                                # the rows behind the dense leaf wait, untouched, for their degree
-            assert torch.equal(ma._features.detach()[:, 1:], rest0) and torch.equal(mb._features.detach()[:, 1:], rest0), i
-    assert float((ma.get_features - mb.get_features).abs().max()) <= 1e-3          # two free steps of lr 2.5e-3 at most apart
+        if D < 3:                                                # the rows behind the dense leaf wait, untouched, for their degree
+            assert torch.equal(ma._features.detach()[:, K:], rest0) and torch.equal(mb._features.detach()[:, K:], rest0), i
+    assert float((ma.get_features - mb.get_features).abs().max()) <= 1e-3          # a few free steps of lr 2.5e-3 at most apart
 
 
 def test_sh_step_inside_the_backward_equals_fusedadam():
