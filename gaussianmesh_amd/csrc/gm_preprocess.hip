@@ -480,6 +480,16 @@ __device__ __forceinline__ void preprocess_bwd_body(const PreBwdArgs& a, const i
           for (int ch = 0; ch < 3; ch++) o[3 * i + ch] = (i < ncoef) ? wgt[i] * dRGB[ch] : 0.f;
 #pragma unroll
         for (int c = 0; c < 12; c++) lrow[c] = make_float4(o[4 * c], o[4 * c + 1], o[4 * c + 2], o[4 * c + 3]);
+      } else if (((a.M * 3) & 3) == 0 && a.M <= 16 && (reinterpret_cast<uintptr_t>(a.dL_dsh) & 15) == 0) {        // rows of whole 16-byte granules (the dense [P,4,3] / [P,12,3] leaves): 16-byte stores
+        float4* dsh4 = reinterpret_cast<float4*>(a.dL_dsh + (size_t)idx * a.M * 3);
+        float o[48];
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+#pragma unroll
+          for (int ch = 0; ch < 3; ch++) o[3 * i + ch] = (i < ncoef) ? wgt[i] * dRGB[ch] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 12; c++)
+          if (4 * c < a.M * 3) dsh4[c] = make_float4(o[4 * c], o[4 * c + 1], o[4 * c + 2], o[4 * c + 3]);
       } else {
         float* dsh = a.dL_dsh + (size_t)idx * a.M * 3;
 #pragma unroll
@@ -507,6 +517,9 @@ __device__ __forceinline__ void preprocess_bwd_body(const PreBwdArgs& a, const i
     if (STAGE_SH) {
 #pragma unroll
       for (int c = 0; c < 12; c++) lrow[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else if (((a.M * 3) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.dL_dsh) & 15) == 0) {
+      float4* dsh4 = reinterpret_cast<float4*>(a.dL_dsh + (size_t)idx * a.M * 3);
+      for (int c = 0; 4 * c < a.M * 3; c++) dsh4[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
       float* dsh = a.dL_dsh + (size_t)idx * a.M * 3;
       for (int i = 0; i < a.M * 3; i++) dsh[i] = 0.f;
