@@ -275,10 +275,14 @@ __global__ __launch_bounds__(TH) void preprocess_bwd_kernel(const PreBwdArgs a) 
         float4* gp = reinterpret_cast<float4*>(a.adam.p) + row0 * 12;
         float4* gm_ = reinterpret_cast<float4*>(a.adam.m) + row0 * 12;
         float4* gv = reinterpret_cast<float4*>(a.adam.v) + row0 * 12;
+        // below the full degree the granules behind the active coefficients have g = m = v = 0 (they never had a gradient: the degree only
+        // rises): the rule leaves them as they are, so they are not touched at all (as gm_adam_step_active)
+        const int nq = a.D >= 3 ? 12 : (3 * (a.D + 1) * (a.D + 1) + 3) >> 2;
         for (int i = threadIdx.x; i < nrows * 12 && (long long)i < lim; i += TH) {
+          const int c = i % 12;                                    // granule of its row: elements 4 c .. 4 c + 3 of the 48
+          if (c >= nq) continue;
           const float4 g4 = l4[i];
           float4 p4 = gp[i], m4 = gm_[i], v4 = gv[i];
-          const int c = i % 12;                                    // granule of its row: elements 4 c .. 4 c + 3 of the 48
           float* pp = &p4.x; float* mm = &m4.x; float* vv = &v4.x; const float* gg = &g4.x;
 #pragma unroll
           for (int j = 0; j < 4; j++)

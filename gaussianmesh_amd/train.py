@@ -75,8 +75,8 @@ class Trainer:
         """dense_dc (default: on for a model on the GPU at SH degree 0): while only degree 0 is active, train coefficient 0 as a dense
         [N,1,3] tensor (MeshBoundGaussians.begin_dense_dc) instead of as 12 bytes of every 192-byte row; oneup_sh_degree() folds it -
         and both Adam moments - back into the rows when the degree is raised.
-        fused_sh_step (default on): at the model's FULL SH degree (27 000 of the reference's 30 000 iterations, train_mesh_gaussian.py:70-71) the
-        Adam step of the [N,16,3] rows - 48 of a Gaussian's 59 parameters - is applied inside the rasterizer's backward pass (rasterizer.ShStep,
+        fused_sh_step (default on): whenever the [N,16,3] rows are trained (SH degree 2 and 3: 28 000 of the reference's 30 000 iterations,
+        train_mesh_gaussian.py:70-71) their Adam step - 48 of a Gaussian's 59 parameters - is applied inside the rasterizer's backward pass (rasterizer.ShStep,
         gm_backward_sh_step) instead of by FusedAdam afterwards: the 192-byte gradient rows are never written or read.  Same update, element for
         element; iterations that take no optimizer step, keep_grads and the python SH route use the ordinary path."""
         o = dict(DEFAULT_OPT); o.update(opt)
@@ -84,13 +84,14 @@ class Trainer:
         self.g = gaussians
         self.bg_gaussian = bg_gaussian
         from .renderer import sh_operand
-        below_full = int(getattr(gaussians, "active_sh_degree", 3)) < int(getattr(gaussians, "max_sh_degree", 3))
+        deg0 = int(getattr(gaussians, "active_sh_degree", 3))
+        low = self.dense_width(deg0) is not None and deg0 < int(getattr(gaussians, "max_sh_degree", 3))
         if dense_dc is None:
-            dense_dc = hasattr(gaussians, "begin_dense_dc") and gaussians._features.is_cuda and below_full
-        dense_dc = bool(dense_dc) and below_full and hasattr(gaussians, "begin_dense_dc")
-        # round 6: the dense leaf carries the (D+1)^2 ACTIVE coefficients of whatever degree below the full one the model is at (1, 4, 9 of 16),
-        # re-made at every oneupSHdegree() with both Adam moments carried over (begin_dense_active)
-        self.dense_active = dense_dc
+            dense_dc = hasattr(gaussians, "begin_dense_dc") and gaussians._features.is_cuda
+        # round 6: the dense leaf carries the (D+1)^2 ACTIVE coefficients at degrees 0 and 1 ([N,1,3], [N,4,3]), re-made at oneupSHdegree()
+        # with both Adam moments carried over (begin_dense_active); from degree 2 on the rows are trained, their step inside the backward
+        self.dense_active = bool(dense_dc) and hasattr(gaussians, "begin_dense_dc")
+        dense_dc = self.dense_active and low
         if dense_dc:
             import weakref
             gaussians.begin_dense_dc(self.dense_width(int(gaussians.active_sh_degree)))
@@ -300,12 +301,12 @@ class Trainer:
         return lr
 
     def _sh_step(self):
-        """The SH group's step for rasterizer.ShStep, or None when this iteration's SH step is FusedAdam's: below the full degree (the dense
-        leaf / the active-coefficient step move fewer bytes there), on the CPU, without an [N,16,3] leaf."""
+        """The SH group's step for rasterizer.ShStep, or None when this iteration's SH step is FusedAdam's: while a dense leaf is trained
+        (degrees 0 and 1), on the CPU, without an [N,16,3] leaf, on the python SH route."""
         g = self.g
         if not self.fused_sh_step or self.keep_grads or getattr(g, "_features_dc0", None) is not None:
             return None
-        if int(getattr(g, "active_sh_degree", 0)) < int(getattr(g, "max_sh_degree", 3)) or getattr(self.pipe, "convert_SHs_python", False):
+        if getattr(self.pipe, "convert_SHs_python", False):
             return None
         grp = next((gr for gr in self.optimizer.param_groups if gr["name"] == "f_dc+f_rest"), None)
         if grp is None:
@@ -391,10 +392,11 @@ class Trainer:
 
     @staticmethod
     def dense_width(degree):
-        """Coefficients the dense leaf carries at an SH degree below the full one: (D+1)^2 rounded up to whole 16-byte granules of the row
-        (1, 4, 12 for degrees 0, 1, 2: FusedAdam steps whole granules; the three spare coefficients at degree 2 have zero gradient and
-        zero moments, so the step leaves them as they are)."""
-        return {0: 1, 1: 4, 2: 12}[int(degree)]
+        """Coefficients the dense leaf carries at an SH degree, or None where the [N,16,3] rows are trained: (D+1)^2 = 1 and 4 at degrees
+        0 and 1 (12- and 48-byte rows instead of 192).  At degree 2 a dense leaf would be 9 coefficients = 108 bytes (12 with whole
+        granules): measured at 2 M Gaussians / 4K no faster than the rows (3.54 against 3.58 ms per iteration) - from there on the rows'
+        Adam step runs inside the backward pass over the active granules (fused_sh_step: 3.3 ms)."""
+        return {0: 1, 1: 4}.get(int(degree))
 
     def begin_dense_active(self):
         """After oneupSHdegree() folded the dense leaf into the rows: while the NEW degree is still below the model's full one, the
@@ -402,7 +404,8 @@ class Trainer:
         coefficients carried over from the rows' (the new coefficients' are zero: they have never had a gradient).  The rasterizer takes the
         leaf as `shs` with M = (D+1)^2; at the full degree the rows themselves are trained (and stepped inside the backward, fused_sh_step)."""
         g = self.g
-        if getattr(g, "_features_dc0", None) is not None or int(g.active_sh_degree) >= int(g.max_sh_degree) or not g._features.is_cuda:
+        if (getattr(g, "_features_dc0", None) is not None or int(g.active_sh_degree) >= int(g.max_sh_degree) or not g._features.is_cuda or
+                self.dense_width(int(g.active_sh_degree)) is None):
             return
         grp = next(gr for gr in self.optimizer.param_groups if gr["name"] == "f_dc+f_rest")
         K = self.dense_width(int(g.active_sh_degree))

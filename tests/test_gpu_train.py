@@ -306,8 +306,8 @@ def test_adam_on_the_active_sh_coefficients_is_the_full_update_end_to_end():
 
 
 def test_dense_coefficient_zero_training_equals_training_the_rows():
-    """Trainer(dense_dc=True) - below the full SH degree the ACTIVE coefficients are a dense leaf handed to the rasterizer with M = its width
-    ([N,1,3] at degree 0, [N,4,3] at degree 1, [N,12,3] at degree 2: whole 16-byte granules), stepped by an Adam group of its own - against
+    """Trainer(dense_dc=True) - at SH degrees 0 and 1 the ACTIVE coefficients are a dense leaf handed to the rasterizer with M = its width
+    ([N,1,3], [N,4,3]; from degree 2 on the rows are trained), stepped by an Adam group of its own - against
     the same trainer on the [N,16,3] rows, from equal state every iteration, over the reference's whole ramp 0 -> 1 -> 2 -> 3
     (train_mesh_gaussian.py:70-71): identical images, SH gradients and moments to float-atomic order, across two topology changes (rows
     split in both, at degree 0 and at degree 1) and across every oneupSHdegree(), which folds the leaf and both moments back into the rows
@@ -326,7 +326,7 @@ def test_dense_coefficient_zero_training_equals_training_the_rows():
     gb = next(g for g in tb.optimizer.param_groups if g["name"] == "f_dc+f_rest")
     assert ga["params"][0] is ma._features_dc0 and ga["period"] == 0 and gb["period"] == 48
     ta.keep_grads = tb.keep_grads = True
-    width = {0: 1, 1: 4, 2: 12, 3: 16}
+    width = {0: 1, 1: 4, 2: 16, 3: 16}
 
     def same_state():                                            # b <- a, group by group (the SH group: the leaf's coefficients and their moments)
         with torch.no_grad():
@@ -352,7 +352,7 @@ def test_dense_coefficient_zero_training_equals_training_the_rows():
         D = ma.active_sh_degree
         assert D == mb.active_sh_degree == (0 if i < 4 else 1 if i < 8 else 2 if i < 11 else 3)
         K = width[D]
-        if D < 3:
+        if D < 2:
             assert ma._features_dc0 is not None and tuple(ma._features_dc0.shape) == (rows, K, 3) and ga["params"][0].data_ptr() == ma._features_dc0.data_ptr()
             assert ga["period"] == (0 if K == 1 else 3 * K) and tuple(ga["m"][0].shape) == (rows, K, 3)
         else:
@@ -369,7 +369,7 @@ def test_dense_coefficient_zero_training_equals_training_the_rows():
         assert float(grb[:, (D + 1) ** 2:].abs().max() if (D + 1) ** 2 < 16 else 0.0) == 0.0          # nothing above the active degree, in either
         for k in ("m", "values"):
             assert float((ga[k][0] - gb[k][0][:, :nc]).abs().max()) <= 2e-5 * float(gb[k][0].abs().max()), (i, k)
-        if D < 3:                                                # the rows behind the dense leaf wait, untouched, for their degree
+        if D < 2:                                                # the rows behind the dense leaf wait, untouched, for their degree
             assert torch.equal(ma._features.detach()[:, K:], rest0) and torch.equal(mb._features.detach()[:, K:], rest0), i
     assert float((ma.get_features - mb.get_features).abs().max()) <= 1e-3          # a few free steps of lr 2.5e-3 at most apart
 
@@ -388,7 +388,8 @@ def test_sh_step_inside_the_backward_equals_fusedadam():
         ma, mb = build(), build()
         kw = dict(densify_stats=True, sync_free=True, bg_gaussian=bg if with_bg else None)
         ta, tb = Trainer(ma, **kw), Trainer(mb, fused_sh_step=False, **kw)
-        assert ma.active_sh_degree == 3 and ta.fused_sh_step and not tb.fused_sh_step
+        ma.active_sh_degree = mb.active_sh_degree = (3 if with_bg else 2)     # (degree 2: the fused step touches the 7 active granules of 12 only)
+        assert ta.fused_sh_step and not tb.fused_sh_step
         ga = next(g for g in ta.optimizer.param_groups if g["name"] == "f_dc+f_rest")
         gb = next(g for g in tb.optimizer.param_groups if g["name"] == "f_dc+f_rest")
         if with_bg:
