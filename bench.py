@@ -306,7 +306,7 @@ def c5_leg(steps, warm, Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, sync_free=
         out = {"ms_per_iter": 1e3 * el / steps, "iters": steps, "warmup": warm, "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
                "iterations_redone": tr.redone - redone0, "gaussians": Nfg + Nbg, "trainable": Nfg, "width": W, "height": H,
                "visible": int((pkg["radii"] > 0).sum().item()), "emission_policy": Rz.get_default_emission_policy(W, H), "sync_free": bool(sync_free),
-               "loss_first": float(losses[0]), "loss_last": float(losses[-1]), "sh_degree": 3,
+               "loss_first": float(losses[0]), "loss_last": float(losses[-1]), "sh_degree": 3, "sh_steps_inside_the_backward": tr.sh_steps_fused,
                "workload": "C5 (fixed topology): %d mesh-bound + %d frozen free Gaussians, %dx%d, render + L1/SSIM/mesh-restrict loss + backward + FusedAdam + "
                            "densification statistics, %d orbit cameras, SH degree 3, zero background, fixed random target" % (Nfg, Nbg, W, H, nc)}
         del tr, cams, target, pkg
@@ -449,6 +449,8 @@ def c5_phases(iters=200, warm=20, Nfg=2_000_000, Nbg=1_000_000, W=3840, H=2160, 
         torch.cuda.synchronize()
         out["deg%d" % d] = round(1e3 * (time.perf_counter() - t0) / iters, 4)
         out["deg%d_redone" % d] = tr.redone
+        out["deg%d_sh_operand" % d] = ("dense [N,%d,3] leaf" % tr.g._features_dc0.shape[1]) if getattr(tr.g, "_features_dc0", None) is not None else (
+            "rows [N,16,3], Adam step inside the backward" if tr.sh_steps_fused else "rows [N,16,3]")
         if getattr(model, "_features_dc0", None) is not None:
             model.end_dense_dc()
         del tr, loss, pkg
