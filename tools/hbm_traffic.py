@@ -36,23 +36,40 @@ def parse(path):
     return out
 
 
+# `python bench.py --frames-per-launch K` (gm_forward_deformed_batch_async): one fused pass per K frames, every other kernel launched with grid z = K
+# (tools/pmc_summary.py keeps those launches apart: "<name>   [grid z = K]")
+def batch_stages(K):
+    tag = "[gridz=%d]" % K
+    out = []
+    for st, ks in STAGES:
+        if st == "deform":
+            out.append((st, [("deform_shade_pre_batch_kernel", 1)]))
+        else:
+            out.append((st, [(frag + "|" + tag, n) for frag, n in ks]))
+    return out
+
+
 def main(pmc_txt, out_json, gaussians, width, height, mode="partition"):
     c = parse(pmc_txt)
     stages = {}
-    for st, ks in STAGES:
+    K = int(mode[5:]) if mode.startswith("batch") else 1
+    for st, ks in (batch_stages(K) if K > 1 else STAGES):
         if mode == "direct":
             ks = DIRECT.get(st, ks)
         f = w = 0.0
         names = []
         for frag, n in ks:
-            fk = [v for k, v in c.get("FETCH_SIZE", {}).items() if frag.replace(" ", "") in k.replace(" ", "")]
-            wk = [v for k, v in c.get("WRITE_SIZE", {}).items() if frag.replace(" ", "") in k.replace(" ", "")]
+            need = [x.replace(" ", "") for x in frag.split("|")]
+            hit = lambda k: all(x in k.replace(" ", "") for x in need) and (K > 1 or "[gridz=" not in k.replace(" ", ""))
+            fk = [v for k, v in c.get("FETCH_SIZE", {}).items() if hit(k)]
+            wk = [v for k, v in c.get("WRITE_SIZE", {}).items() if hit(k)]
             if not fk or not wk:
                 raise SystemExit("kernel %r not found in %s" % (frag, pmc_txt))
             f += n * fk[0]; w += n * wk[0]
             names.append(frag)
         stages[st] = {"kernels": names, "fetch_kib": round(f, 1), "write_kib": round(w, 1)}
-    json.dump({"source": pmc_txt, "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
+    extra = {"frames_per_launch": K, "per": "launch (K frames)"} if K > 1 else {}
+    json.dump({**extra, "source": pmc_txt, "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
                "`python bench.py --streams 1 --exact-count`; per-launch means in KiB; bytes = 1024 * (2 * FETCH_SIZE + WRITE_SIZE): "
                "FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as reported",
                "workload": {"gaussians": int(gaussians), "width": int(width), "height": int(height)}, "stages": stages},

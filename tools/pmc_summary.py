@@ -10,10 +10,14 @@ cols = [d[0] for d in c.execute(f"select * from {view} limit 1").description]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for row in c.execute(f"select * from {view}"):
     r = dict(zip(cols, row))
-    acc[r.get("kernel_name") or r.get("name")][r["counter_name"]].append(r["value"])
+    key = r.get("kernel_name") or r.get("name")
+    gz = r.get("grid_size_z")
+    if gz is not None and int(gz) > 1:                 # launches over K frames (grid z) are kept apart from single-frame launches of the same kernel
+        key = "%s   [grid z = %d]" % (key[:100], int(gz))
+    acc[key][r["counter_name"]].append(r["value"])
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 for k, d in acc.items():
     if flt and flt not in k: continue
-    print(k[:100])
+    print(k[:130])
     for n, v in sorted(d.items()):
         print("   %-32s mean %.4g  (n=%d)" % (n, sum(v) / len(v), len(v)))
