@@ -501,8 +501,6 @@ def main():
     ap.add_argument("--frames-per-launch", type=int, default=4, help="K frames of the view stream per launch chain (gm_forward_deformed_batch_async): the "
                     "static cloud is read once per K frames and every stage is one launch over them; a batch goes to stream (batch index) %% streams.  "
                     "1 = a launch chain per frame (rounds 1-5).  Measured (round 6, 300 / 20 steps): 1: 4960 / 4710 frames/s, 2: 5225 / 4980, 4: 5400 / 5170")
-    ap.add_argument("--no-batch-plan", action="store_true", help="batches of --frames-per-launch frames as the steps come; default: a region of known length is "
-                    "planned (plan_batches): the frames that do not fill a whole round of batches are spread evenly over the streams")
     ap.add_argument("--begin-ahead", type=int, default=2, help="frames whose first half (deformation .. depth order) is issued before the "
                     "oldest of them is completed (emission .. blend): 2 fills the four streams sooner after the barrier that opens a timed "
                     "region than 1 (20-step regions, three runs each: 4389-4504 / 4540-4554 / 4039-4518 frames/s with 1 / 2 / 3; no "
@@ -665,24 +663,6 @@ def main():
     table_bufs = [torch.empty((KB, Vm, 24), dtype=torch.float32, device=dev) for _ in range(max(nstreams + 2, 4))] if KB > 1 else None
 
     one_stream = [None]                          # per-stage timing pass: every batch on this stream
-    batch_plan, batch_target = [], [0]           # sizes of the next batches (plan_batches: a region of known length), size the current one waits for
-
-    def plan_batches(n):
-        """Batch sizes for a sequence of n frames whose length is known (a clip, a timed region): whole rounds of `streams` batches of KB
-        frames while they fit, then the remaining frames spread EVENLY over the streams - 20 frames on four streams are 4 x 4 + 4 x 1, every
-        stream renders five, instead of five batches of four of which one stream renders two.  --no-batch-plan: batches of KB as they come."""
-        if KB <= 1 or args.no_batch_plan:
-            return []
-        per_round = nstreams * KB
-        sizes = [KB] * (nstreams * (n // per_round))
-        rem = n % per_round
-        while rem > 0:
-            q, r = divmod(rem, nstreams)
-            rnd = [min(KB, q + (1 if k < r else 0)) for k in range(nstreams)]
-            rnd = [x for x in rnd if x > 0]
-            sizes += rnd
-            rem -= sum(rnd)
-        return sizes
 
     def launch_batch():
         """K collected loop steps as ONE launch chain on stream (batch index) % streams: gm_mesh_rs_packed_batch (K tables) +
@@ -719,12 +699,7 @@ def main():
         --exact-count: the host waits for the completed frame's count (one 4-byte read-back, hidden behind frame i's first half)."""
         if KB > 1 and batching[0]:
             batch_steps.append(i)
-            want = batch_plan.pop(0) if (not batch_target[0] and batch_plan) else (batch_target[0] or KB)
-            batch_target[0] = want
-            if len(batch_steps) >= want:
-                batch_target[0] = 0
-                return launch_batch()
-            return None
+            return launch_batch() if len(batch_steps) == KB else None
         torch.cuda.set_stream(streams[i % nstreams])     # (not `with torch.cuda.stream(...)`: entering and leaving the context costs the
         if timeline is not None:
             t_a = time.perf_counter()
@@ -766,7 +741,6 @@ def main():
     def drain():
         if batch_steps:
             launch_batch()
-        batch_target[0] = 0
         for k in sorted(pending):
             finish(pending.pop(k))
         torch.cuda.set_stream(default_stream)
@@ -883,8 +857,6 @@ def main():
             del host_split[:]
             ev0 = torch.cuda.Event(enable_timing=True)
             ev0.record(streams[first % nstreams])
-        del batch_plan[:]
-        batch_plan.extend(plan_batches(args.steps))
         t = time.perf_counter()
         for i in range(args.steps):
             step(first + i)
@@ -961,7 +933,6 @@ def main():
         "config": {"workload": "C3: %d Gaussians bound to 15k-face torus, per-frame mesh deform + SH colour + forward "
                                "render %dx%d, %d-camera orbit, views sharded by rank" % (P, W, H, F),
                    "gaussians": P, "width": W, "height": H, "sh_degree": 3, "views_per_step_per_gpu": 1, "frames_per_launch": KB,
-                   "batch_plan": (None if KB <= 1 else ("as they come" if args.no_batch_plan else "region of known length: " + "+".join(str(x) for x in plan_batches(args.steps)[:24]) + ("..." if len(plan_batches(args.steps)) > 24 else ""))),
                    "vertex_rs": "analytic tables" if args.analytic_rs else "gm_mesh_rs per frame", "hip_streams": nstreams,
                    "exchange": None if pipe is None else {"n_ranks_seen": n_ranks_seen, "backend": backend if world > 1 else None, "steps_per_broadcast": pipe.batch, "bytes_per_step": exchange_bytes, "broadcasts": pipe.broadcasts,
                                                           "payload": "per-vertex (R, S) tables" if args.analytic_rs else "deformed vertex positions; (R, S) by gm_mesh_rs on every rank",
