@@ -113,4 +113,7 @@ def test_cpp_host_program_renders_a_batch_of_deformed_frames(tmp_path, oracle):
         # radius on a rounding edge may differ and pixels move by what a 0.005-pixel shift of a splat moves them - the strict gate belongs to
         # the tests that hand the oracle the device's own deformed cloud; here: the same picture
         assert same.mean() >= 0.999, (k, float(same.mean()))
-        assert err.mean() <= 2e-4 and np.quantile(err, 0.999) <= 1e-2 and err.max() <= 0.1, k
+        if same.all():                                             # (measured: every radius equal, largest pixel error 3.3e-6)
+            assert err.max() <= 1e-4, (k, float(err.max()))
+        else:
+            assert err.mean() <= 2e-4 and np.quantile(err, 0.999) <= 1e-2 and err.max() <= 0.1, k
