@@ -500,7 +500,8 @@ def main():
                          "independent, so frame i+1's per-Gaussian stages overlap the low-occupancy tail of frame i's blend")
     ap.add_argument("--frames-per-launch", type=int, default=4, help="K frames of the view stream per launch chain (gm_forward_deformed_batch_async): the "
                     "static cloud is read once per K frames and every stage is one launch over them; a batch goes to stream (batch index) %% streams.  "
-                    "1 = a launch chain per frame (rounds 1-5).  Measured (round 6, 300 / 20 steps): 1: 4960 / 4710 frames/s, 2: 5225 / 4980, 4: 5400 / 5170")
+                    "1 = a launch chain per frame (rounds 1-5); at most 8.  Measured (round 6, 300 / 20 steps): 1: 4960 / 4710 frames/s, 2: 5225 / 4980, 4: 5330-5400 / "
+                    "5000-5170, 5: 5400 / 4930-5115, 6: 5480, 8: 5480 (on two streams 5510 / 5045): more frames per launch gain 3 %% in a long loop and nothing in a 20-frame burst")
     ap.add_argument("--begin-ahead", type=int, default=2, help="frames whose first half (deformation .. depth order) is issued before the "
                     "oldest of them is completed (emission .. blend): 2 fills the four streams sooner after the barrier that opens a timed "
                     "region than 1 (20-step regions, three runs each: 4389-4504 / 4540-4554 / 4039-4518 frames/s with 1 / 2 / 3; no "
@@ -638,7 +639,7 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
     lag = max(1, args.status_lag)
     ahead = max(1, args.begin_ahead)
-    KB = max(1, min(args.frames_per_launch, 4))
+    KB = max(1, min(args.frames_per_launch, 8))
     if args.unfused or args.depth_plan or args.exact_count or args.analytic_rs:
         KB = 1                                   # (those options are single-frame paths)
     nws = nstreams + ahead + lag                # frames i+1 .. i+ahead are begun before frame i is completed, and frame i's status is read `lag` frames later

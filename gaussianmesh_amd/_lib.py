@@ -16,7 +16,7 @@ _lib = None
 
 vp, i32, i64, f32, f64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
 
-GM_BATCH_MAX = 4
+GM_BATCH_MAX = 8
 
 
 class BatchFrame(C.Structure):

@@ -294,7 +294,7 @@ struct BinningState {           // per-instance state (R-sized)
 // takes frame 0's pointers plus, per caller-owned buffer kind, the byte distance of frame f's buffer from frame 0's - the scratch layouts
 // depend only on (base address mod 256, sizes), and the batch entry point insists on 256-byte aligned bases, so a field of frame f is the
 // same field of frame 0 moved by that distance.  A single-frame launch passes zeros and gridDim.z == 1.
-#define GM_BATCH_MAX 4
+#define GM_BATCH_MAX 8
 struct FrameOfs { long long d[GM_BATCH_MAX]; };
 template <class T>
 __device__ __forceinline__ T* frame_ptr(T* p, const FrameOfs& o) {       // (pointer arithmetic on p itself: the result keeps p's __restrict__ provenance)

@@ -308,7 +308,7 @@ int gm_forward_status_async(void* geom_buffer, int P, int* status_host, void* st
  * refused in its own status words and rendered again by the caller through the single-frame calls).  1 <= K <= GM_BATCH_MAX; M == 16;
  * emission policies with at most 2048 list tiles (the one-pass tile sort); every scratch buffer base 256-byte aligned; the frames'
  * buffers distinct.  Like every deformed frame: forward only. */
-#define GM_BATCH_MAX 4
+#define GM_BATCH_MAX 8
 #define GM_BATCH_IMAGE_ONLY 1    /* as GM_FWD_IMAGE_ONLY */
 #define GM_BATCH_COV6 2          /* as GM_STREAM_COV6 */
 typedef struct gm_batch_frame {
