@@ -170,7 +170,7 @@ def measured_valu(stage, P, W, H):
     return t["stages"][stage].get("valu")
 
 
-def valu_ceiling(stage, nv, avg_ms):
+def valu_ceiling(stage, nv, avg_ms, frames=1):
     """Vector-ALU time of a kernel against its duration.  With SQ_ACTIVE_INST_VALU in profiles/inst_mix.json (round 5: the blend
     kernels) the busy time is measured; otherwise the instruction count is priced at the mix average of the blend kernels, 4.2 cycles
     (measured: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4.24 forward, 4.17 backward - NOT the 2.3 cycles of a plain v_fma_f32: the mix is
@@ -180,6 +180,8 @@ def valu_ceiling(stage, nv, avg_ms):
         quads = json.load(open(os.path.join(ROOT, "profiles", "inst_mix.json")))["stages"][stage].get("valu_active_quad_cycles")
     except (OSError, KeyError):
         pass
+    if quads:
+        quads *= frames                          # (a launch over `frames` frames: the committed counters are per single-frame launch)
     busy_ms = (4.0 * quads if quads else 4.2 * nv) / (1024 * 2.4e9) * 1e3
     return {"vector_instructions": nv, "valu_busy_ms": busy_ms, "frac_of_kernel_time": busy_ms / avg_ms,
             "cycles_per_instruction": (4.0 * quads / nv) if quads else 4.2,
@@ -1054,8 +1056,7 @@ def main():
                                "single_frame_launch": {k: single[k] for k in ("kernel", "kernel_name", "achieved", "frac", "traffic", "algorithmic_bytes", "avg_ms") if k in single}}
             nvb_ = measured_valu(domb, P, W, H)
             if nvb_ and domb != "deform":           # (the per-frame instruction count of the blend does not depend on how its frames are launched)
-                out["roofline"]["valu_issue"] = valu_ceiling(domb, nvb_ * KB, perb[domb] * KB)
-                out["roofline"]["valu_issue"]["vector_instructions"] = nvb_ * KB
+                out["roofline"]["valu_issue"] = valu_ceiling(domb, nvb_ * KB, perb[domb] * KB, frames=KB)
             out["batch"] = {"frames_per_launch": KB, "launches_per_batch": 12,
                             "stage_ms_per_frame": {k: round(v, 4) for k, v in perb.items()}, "kernel_ms_per_frame_one_stream": round(sum(perb.values()), 4),
                             "stage_roofline": {st: round(bbytes(st) / (perb[st] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for st in perb if st in ("mesh_rs", "deform", "depth_sort", "duplicate", "tile_sort", "render")},
