@@ -56,20 +56,20 @@ def _state(h, P, W, H, policy, nr):
     return out
 
 
-@pytest.mark.parametrize("K,cov6,image_only", [(1, True, True), (2, False, True), (3, True, False), (4, True, True), (4, False, False)])
+@pytest.mark.parametrize("K,cov6,image_only", [(1, True, True), (2, False, True), (3, True, False), (4, True, True), (4, False, False), (8, True, True)])
 def test_batched_frames_equal_the_single_frame_calls(K, cov6, image_only):
     """Each of the K frames of a batch against forward_deformed_begin(...).finish(sync_free=True) of the same (mesh frame, camera) on
     buffers of the same capacity: every byte a later stage or the caller reads is the same."""
     from gaussianmesh_amd import rasterizer as Rz
     from gaussianmesh_amd.deform import mesh_rs_packed, mesh_rs_packed_batch, pack_cov6
-    P, W, H, F = 30000, 480, 270, 8
+    P, W, H, F = (30000 if K < 8 else 29989), 480, 270, 8                       # (K = GM_BATCH_MAX on a row count that fills no wave)
     g, cams = _scene(P, W, H, F)
     policy = Rz.get_default_emission_policy(W, H)
     bg = torch.tensor([0.2, 0.5, 0.7], device="cuda")
     cov = pack_cov6(g["cov"]) if cov6 else g["cov"]
     assert cov is not None
     hint = Rz.new_work_hint(W, H, bg.device)
-    pairs = [(1, 5), (4, 2), (6, 7), (3, 0)][:K]                               # (mesh frame, camera) of the batch's frames
+    pairs = [(1, 5), (4, 2), (6, 7), (3, 0), (0, 1), (2, 3), (5, 4), (7, 6)][:K]   # (mesh frame, camera) of the batch's frames
     # reference: the single-frame path, one workspace per frame; the first (exact) pass learns the capacity
     ref_ws = [Rz.RasterWorkspace() for _ in range(K)]
     ref = []
@@ -151,6 +151,38 @@ def test_a_frame_that_outgrows_the_batch_capacity_is_refused_alone_and_redone():
     assert ws[0].in_flight is None and ws[0].capacity > counts[0]
 
 
+def test_a_frame_that_sees_nothing_inside_a_batch():
+    """An empty frame between two ordinary ones (a camera that looks away from the cloud: every Gaussian culled).  Its launches of the
+    batched chain have nothing to order and nothing to blend: zero instances in its status words, no radius set, the image the background -
+    and its neighbours in the batch are, byte for byte, what they are alone."""
+    from gaussianmesh_amd import rasterizer as Rz, scenes
+    from gaussianmesh_amd.deform import mesh_rs_packed_batch
+    from gpu_utils import T
+    P, W, H, F = 20000, 320, 200, 4
+    g, cams = _scene(P, W, H, F)
+    bg = torch.tensor([0.3, 0.6, 0.1], device="cuda")
+    away = scenes.look_at_camera((8.0, 1.5, 0.0), (16.0, 1.5, 0.0), W, H, 60.0)                    # on the orbit, back to the torus
+    blind = dict(view=T(away["view"]), proj=T(away["proj"]), campos=T(away["campos"]), tanx=away["tanx"], tany=away["tany"])
+    frames = [(1, cams[1]), (2, blind), (3, cams[3])]
+    tables = mesh_rs_packed_batch(g["verts"], [g["v1"][t] for t, _ in frames], g["faces"], g["adjacency"])
+    alone = []
+    for (t, cm), tab in zip(frames, tables):
+        nr, color, radii, *_ = Rz.forward_deformed_begin(bg, g["tri"], g["weights"], tab, g["cov"], g["pos"], g["shs"], g["opac"], cm["view"], cm["proj"],
+                                                         cm["tanx"], cm["tany"], H, W, 3, cm["campos"], False).finish(image_only=True)
+        alone.append((nr, color.clone(), radii.clone()))
+    assert alone[1][0] == 0 and alone[0][0] > 0 and alone[2][0] > 0, [a[0] for a in alone]
+    ws = [Rz.RasterWorkspace() for _ in frames]
+    for w_ in ws:
+        w_.capacity = 2 * max(a[0] for a in alone)
+    hs = Rz.forward_deformed_batch(bg, g["tri"], g["weights"], tables, g["cov"], g["pos"], g["shs"], g["opac"], [cm for _, cm in frames], H, W, 3, ws, image_only=True)
+    for k, h in enumerate(hs):
+        ok, nr = h.check()
+        assert ok and nr == alone[k][0], (k, ok, nr)
+        assert torch.equal(h.color, alone[k][1]) and torch.equal(h.radii, alone[k][2]), k
+    assert int((hs[1].radii != 0).sum()) == 0
+    assert torch.equal(hs[1].color, bg.reshape(3, 1, 1).expand(3, H, W))
+
+
 def test_batch_argument_errors():
     from gaussianmesh_amd import _lib, rasterizer as Rz
     from gaussianmesh_amd.deform import mesh_rs_packed_batch
@@ -171,3 +203,10 @@ def test_batch_argument_errors():
     assert all(w_.in_flight is None for w_ in ws)
     hs = Rz.forward_deformed_batch(bg, g["tri"], g["weights"], tables, g["cov"], g["pos"], g["shs"], g["opac"], cams[:2], H, W, 3, ws)
     assert all(h.check()[0] for h in hs)
+    many = _lib.GM_BATCH_MAX + 1                                                  # more frames than one launch chain carries
+    ws9 = [Rz.RasterWorkspace() for _ in range(many)]
+    for w_ in ws9:
+        w_.capacity = 100000
+    with pytest.raises((ValueError, _lib.GmeshError)):
+        Rz.forward_deformed_batch(bg, g["tri"], g["weights"], [tables[0]] * many, g["cov"], g["pos"], g["shs"], g["opac"], [cams[0]] * many, H, W, 3, ws9)
+    assert all(w_.in_flight is None for w_ in ws9)
