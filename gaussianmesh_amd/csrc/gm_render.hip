@@ -177,12 +177,13 @@ __device__ __forceinline__ Gather issue_gather(const float4* __restrict__ splat,
 // brightest pixel whenever the polynomial came out at +1e-6.  The backward kernel clamps likewise.
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-// The A-operand table of the exponent polynomial, shared by BOTH blend kernels (round 4: the backward evaluates the same polynomial
-// on the matrix core, so that forward and backward take the SAME alpha >= 1/255 decision for every (entry, pixel) - backward.cu repeats
-// forward.cu's expression for exactly that reason).  ct[4 * 6 * 32]: [group of 16 survivors][monomial][MFMA row]; row of (half h,
+// The A-operand table of the exponent polynomial (image-only frames; a training step's two halves take the SAME alpha >= 1/255 decision
+// for every (entry, pixel) - backward.cu repeats forward.cu's expression for exactly that reason - by both using staged_exponent: EXACT
+// below.  The other way round, the backward on this polynomial, was built in round 4 and measured 26 % slower: NOTEBOOK.md section 2,
+// tools/experiments/render_bwd_matrix_exponent_round4.hip.txt).  ct[4 * 6 * 32]: [group of 16 survivors][monomial][MFMA row]; row of (half h,
 // survivor sg of the group) = 8 (sg / 4) + 4 h + sg % 4.  e' = log2(e) power + log2(opacity): the opacity rides in the constant
 // coefficient, so that 2^e' IS opacity * G and the per-survivor opacity product (and its broadcast) is gone from both kernels.
-// Contraction is off and every product is spelled out: the two kernels must produce bit-identical coefficients, whatever the
+// Contraction is off and every product is spelled out: every build of the kernel must produce bit-identical coefficients, whatever the
 // compiler would fuse in one of them.  (ucx, vcy): centre of half 0 of the wave's quadrant; half 1 lies four rows below.
 #define GM_POLY_PAD -1.0e30f      // constant coefficient of a row that holds no survivor: 2^e' = 0, the entry is skipped by every pixel
 __device__ __forceinline__ void stage_poly(float* __restrict__ ct, int slot, float x, float y, float conx, float cony, float conz, float opacity,
