@@ -51,6 +51,51 @@ def test_argument_validation_happens_before_any_gpu_work():
     assert l.gm_sh_colors(5, 4, 16, one, one, None, one, one, None) == 1
 
 
+def test_round6_entry_points_validate_before_any_gpu_work():
+    """gm_forward_deformed_batch_async / gm_mesh_rs_packed_batch / gm_backward_sh_step (ABI 3): every refusal below is decided on the
+    arguments alone - no device is touched, so it holds on a box without one."""
+    from gaussianmesh_amd import _lib
+    l = _lib.lib()
+    one = 1
+    K = _lib.GM_BATCH_MAX
+    frames = (_lib.BatchFrame * (K + 1))()
+    call = lambda k, fr, P=10, deg=3, M=16, W=64, H=64, cap=1000, flags=1, pol=2: l.gm_forward_deformed_batch_async(
+        pol, k, fr, P, deg, M, W, H, one, one, one, one, one, one, one, cap, flags, None, 0, None)
+    assert call(K + 1, frames) == 1 and b"frames" in l.gm_last_error()
+    assert call(0, frames) == 1
+    assert call(2, None) == 1
+    assert call(2, frames, flags=8) == 1 and b"unknown flags" in l.gm_last_error()
+    assert call(2, frames, P=0) == 1 and b"single-frame calls" in l.gm_last_error()
+    assert call(2, frames, M=9) == 1
+    assert call(2, frames, cap=0) == 1 and b"binning_capacity" in l.gm_last_error()
+    assert call(2, frames, W=3840, H=2160, pol=2) == 1 and b"list tiles" in l.gm_last_error()      # 4K under 32-px parents: two tile passes
+    assert call(2, frames, pol=9) == 1 and b"emission policy" in l.gm_last_error()
+    assert call(2, frames) == 1 and b"null pointer" in l.gm_last_error()                            # frames of nulls
+    for k in range(2):                                                                              # unaligned scratch, then a shared buffer
+        for name, _ in _lib.BatchFrame._fields_:
+            if name not in ("tan_fovx", "tan_fovy"):
+                setattr(frames[k], name, 4096 * (k + 1) + 8)
+    assert call(2, frames) == 1 and b"256-byte aligned" in l.gm_last_error()
+    for k in range(2):
+        frames[k].geom_buffer, frames[k].binning_buffer, frames[k].image_buffer = 1 << 20, 2 << 20, 3 << 20
+    assert call(2, frames) == 1 and b"share a buffer" in l.gm_last_error()
+    ptrs = (C.c_void_p * (K + 1))(*([4096] * (K + 1)))
+    assert l.gm_mesh_rs_packed_batch(K + 1, 10, 10, one, ptrs, one, one, one, ptrs, None) == 1
+    assert l.gm_mesh_rs_packed_batch(0, 10, 10, one, ptrs, one, one, one, ptrs, None) == 1
+    assert l.gm_mesh_rs_packed_batch(2, 10, 10, one, None, one, one, one, ptrs, None) == 1
+    odd = (C.c_void_p * 2)(4096, 4100)
+    assert l.gm_mesh_rs_packed_batch(2, 10, 10, one, ptrs, one, one, one, odd, None) == 1 and b"unaligned" in l.gm_last_error()
+    step = lambda M=16, D=3, rows=10, P=10, st=1, m=one, shs=one: l.gm_backward_sh_step(
+        2, P, D, M, 5, one, 64, 64, one, shs, one, 1.0, one, None, one, one, one, 0.5, 0.5, one, one, one, one, one, one, one, one, None, one, one, rows, m, one,
+        1e-3, 1e-4, 0.9, 0.999, 1e-15, st, 0, None)
+    assert step(M=9) == 1 and b"SH operand" in l.gm_last_error()
+    assert step(shs=None) == 1
+    assert step(D=4) == 1
+    assert step(rows=11) == 1 and b"optimizer state" in l.gm_last_error()
+    assert step(st=0) == 1
+    assert step(m=None) == 1
+
+
 def test_no_cpu_fallback():
     from gaussianmesh_amd import GaussianRasterizationSettings, GaussianRasterizer, distCUDA2
     from gaussianmesh_amd._lib import GmeshError
