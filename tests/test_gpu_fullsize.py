@@ -279,6 +279,50 @@ def test_c3_bench_path_full_size_vs_oracle(oracle):
         assert_forward_gate(fw, out[2][1], W, H, 1e-4, "C3 frame %d" % t, plain_tol=5e-5)
 
 
+def test_c3_batch_of_four_full_size_equals_the_single_frame_path():
+    """The launch chain bench.py's headline runs since round 6 - gm_mesh_rs_packed_batch + gm_forward_deformed_batch_async, four frames
+    per chain, packed [N,6] covariances, image-only, work hint - at BASELINE's size (1 M Gaussians, 1920x1080): every frame's image, radii
+    and instance count are, bit for bit, the single-frame path's (gm_mesh_rs_packed + gm_forward_0_deformed_async + gm_forward_1_geom),
+    which test_c3_bench_path_full_size_vs_oracle holds against the oracle for two of these four (mesh frame, camera) pairs."""
+    import bench
+    from gpu_utils import T
+    from gaussianmesh_amd import rasterizer as Rz, scenes
+    from gaussianmesh_amd.deform import mesh_rs_packed, mesh_rs_packed_batch, pack_cov6, vertex_face_adjacency
+    P, W, H, F = 1_000_000, 1920, 1080, 64
+    host = bench.build_scene(P, W, H, F)
+    g = {k: T(host[k]) for k in ("weights", "pos", "cov", "opac", "shs", "verts")}
+    g["tri"] = T(host["tri"], dtype=torch.int32)
+    faces = T(host["faces"], dtype=torch.int32)
+    off, adj = vertex_face_adjacency(host["faces"], host["verts"].shape[0])
+    adjacency = (torch.tensor(off, device="cuda"), torch.tensor(adj, device="cuda"))
+    cov6 = pack_cov6(g["cov"])
+    bg = T(np.ones(3, np.float32))
+    pairs = [(3, 3), (40, 17), (10, 50), (63, 0)]
+    cams = []
+    for _, k in pairs:
+        cam = scenes.orbit_camera(k, F, W, H)
+        cams.append(dict(view=T(cam["view"]), proj=T(cam["proj"]), campos=T(cam["campos"]), tanx=cam["tanx"], tany=cam["tany"]))
+    v1 = [T(np.ascontiguousarray(host["mesh"][t][:, 0:3])) for t, _ in pairs]
+    single = []
+    for (t, _), cm, v in zip(pairs, cams, v1):
+        packed = mesh_rs_packed(g["verts"], v, faces, adjacency)
+        nr, color, radii, *_ = Rz.forward_deformed_begin(bg, g["tri"], g["weights"], packed, cov6, g["pos"], g["shs"], g["opac"], cm["view"], cm["proj"],
+                                                         cm["tanx"], cm["tany"], H, W, 3, cm["campos"], False).finish(image_only=True)
+        single.append((nr, color.clone(), radii.clone(), packed.clone()))
+    ws = [Rz.RasterWorkspace() for _ in pairs]
+    for w_ in ws:
+        w_.capacity = int(1.05 * max(s[0] for s in single))
+    hint = Rz.new_work_hint(W, H, bg.device)
+    for rep in range(2):                                   # the second chain runs with the work hint the first one left
+        tables = mesh_rs_packed_batch(g["verts"], v1, faces, adjacency)
+        hs = Rz.forward_deformed_batch(bg, g["tri"], g["weights"], tables, cov6, g["pos"], g["shs"], g["opac"], cams, H, W, 3, ws, image_only=True, work_hint=hint)
+        for k, h in enumerate(hs):
+            ok, nr = h.check()
+            assert ok and nr == single[k][0], (rep, k, ok, nr, single[k][0])
+            assert torch.equal(tables[k], single[k][3]), (rep, k)
+            assert torch.equal(h.radii, single[k][2]) and torch.equal(h.color, single[k][1]), (rep, k)
+
+
 def test_4k_policy3_lists_image_and_gradients_vs_oracle(oracle):
     """BASELINE config C5's list geometry against the ORACLE, not only through properties (review round 5, item 5c): 200 k Gaussians on
     a 3840x2160 grid, where the product's default emission policy is 3 - instances per 64-px parent tile, 2040 list tiles, one 11-bit
