@@ -237,16 +237,8 @@ struct FwdLds {                  // per wave: 5.1 KiB
 // pixel-relative form of round 2 / of the backward kernel (staged_exponent: |e - e_exact| ~ 5e-7) instead of the matrix core's
 // polynomial (~1e-5).  Everything else - lists, cull, decisions, recurrence - is the same code, so the two builds may differ only
 // where an entry's alpha or a pixel's T sits within the polynomial's error of a threshold (tests/test_gpu_parity.py).
-#ifndef GM_FWD_WAVES_PER_SIMD
-#define GM_FWD_WAVES_PER_SIMD 0     // > 0: cap the register allocation for that many waves per SIMD (6: 80 VGPRs, a handful of spills)
-#endif
-#if GM_FWD_WAVES_PER_SIMD > 0
-#define GM_FWD_OCC __attribute__((amdgpu_waves_per_eu(GM_FWD_WAVES_PER_SIMD, GM_FWD_WAVES_PER_SIMD)))
-#else
-#define GM_FWD_OCC
-#endif
 template <bool STATE, bool TRACE, bool EXACT = false>
-__global__ __launch_bounds__(64) GM_FWD_OCC void render_fwd_kernel(const uint2* __restrict__ ranges, const uint2* __restrict__ pairs,
+__global__ __launch_bounds__(64) void render_fwd_kernel(const uint2* __restrict__ ranges, const uint2* __restrict__ pairs,
                                                         const float4* __restrict__ splat, int W, int H, TileMap tm,
                                                         const float* __restrict__ bg, float* __restrict__ out_color,
                                                         float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
