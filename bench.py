@@ -17,7 +17,9 @@ One JSON line on stdout (rank 0).  Extra objects: "roofline" (dominant kernel of
 on the same cloud through the autograd operator, with its stage times, "roofline" of the backward blend and "iteration_roofline";
 also the iteration with the L1 + SSIM loss, a whole training iteration and BASELINE config C2; N=1 only), "c5" (a bounded leg of
 BASELINE config C5: --c5-iters iterations of the 3 M-Gaussian 4K training loop; `--config c5` runs its 1000 iterations as a line
-of its own), "repeats" (the timed region four more times) and "single_stream" (latency of one frame).
+of its own), "c5_phases" / "c5_fixed" (the same loop at each SH degree / at degree 3 with the topology fixed), "batch" (per-frame stage times
+and traffic of the K-frame launch chain the headline runs), "repeats" (the timed region four more times) and "single_stream" (latency of one
+frame: with the instance count read back by the host, and enqueued sync-free in one go).
 """
 import argparse
 import json
